@@ -1,0 +1,64 @@
+// common.h -- device helpers shared by the gfx950 kernels of libmagma_hip.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include "../../include/magma_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;   // one MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) float f32x4;     // 16x16 MFMA accumulator
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define MG_DEV __device__ __forceinline__
+
+// ---- bf16 <-> f32 (round-to-nearest-even, NaN preserved) --------------------
+MG_DEV float bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+MG_DEV uint16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // quiet NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+MG_DEV uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+MG_DEV float bflo(uint32_t w) { return __uint_as_float(w << 16); }
+MG_DEV float bfhi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+MG_DEV float gelu_new_f(float x) {
+  // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))   (HF NewGELUActivation)
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  float u = k0 * (x + k1 * x * x * x);
+  return 0.5f * x * (1.0f + tanhf(u));
+}
+MG_DEV float apply_act(float v, int act) {
+  if (act == MG_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == MG_ACT_GELU_NEW) return gelu_new_f(v);
+  return v;
+}
+
+// ---- wave / block reductions (wave = 64 lanes) -------------------------------
+MG_DEV float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+MG_DEV float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- host-side error plumbing -------------------------------------------------
+void mg_set_error(const char* fmt, ...);
+#define MG_FAIL(code, ...)      \
+  do {                          \
+    mg_set_error(__VA_ARGS__);  \
+    return (code);              \
+  } while (0)
+#define MG_CHECK_LAUNCH()                                               \
+  do {                                                                  \
+    hipError_t e__ = hipGetLastError();                                 \
+    if (e__ != hipSuccess) MG_FAIL(MG_ERR_HIP, "%s: %s", __func__, hipGetErrorString(e__)); \
+  } while (0)
+#define MG_ALIGNED16(p) ((((uintptr_t)(p)) & 15u) == 0)

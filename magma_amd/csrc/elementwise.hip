@@ -1,0 +1,342 @@
+// elementwise.hip -- the HBM-bound kernels of the MAGMA hot path (gfx950):
+// LayerNorm, embedding gather, NHWC avg-pool, stem im2col, greedy argmax,
+// build_labels (integer, exact) and the shifted cross-entropy pieces.
+// All bf16 traffic is 16 B per lane (guide G13).
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// LayerNorm: one 256-thread workgroup per row, two-pass statistics in fp32 on
+// register-resident data (d <= 256*8*MAXV).
+// ---------------------------------------------------------------------------
+constexpr int LN_MAXV = 8;  // 16-B vectors per thread -> d <= 16384
+
+__global__ __launch_bounds__(256) void layernorm_kernel(const mg_bf16* __restrict__ x, int64_t ldx,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta,
+                                                        mg_bf16* __restrict__ y, int64_t ldy, int d, float eps) {
+  __shared__ float red[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row = blockIdx.x;
+  const int nvec = d >> 3;
+  const mg_bf16* xr = x + (int64_t)row * ldx;
+  float v[LN_MAXV][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int vi = tid + i * 256;
+    if (vi < nvec) {
+      const u32x4 w = *(const u32x4*)(xr + vi * 8);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[i][2 * j] = bflo(w[j]); v[i][2 * j + 1] = bfhi(w[j]); }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[i][j];
+    }
+  }
+  s = wave_sum(s);
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int vi = tid + i * 256;
+    if (vi < nvec) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float t = v[i][j] - mean; q += t * t; }
+    }
+  }
+  q = wave_sum(q);
+  if (lane == 0) red[4 + wave] = q;
+  __syncthreads();
+  const float rstd = rsqrtf((red[4] + red[5] + red[6] + red[7]) / (float)d + eps);
+  mg_bf16* yr = y + (int64_t)row * ldy;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int vi = tid + i * 256;
+    if (vi < nvec) {
+      const float4 g0 = *(const float4*)(gamma + vi * 8), g1 = *(const float4*)(gamma + vi * 8 + 4);
+      const float4 b0 = *(const float4*)(beta + vi * 8), b1 = *(const float4*)(beta + vi * 8 + 4);
+      const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+      const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+      u32x4 w;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        w[j] = pack2bf((v[i][2 * j] - mean) * rstd * g[2 * j] + bb[2 * j],
+                       (v[i][2 * j + 1] - mean) * rstd * g[2 * j + 1] + bb[2 * j + 1]);
+      *(u32x4*)(yr + vi * 8) = w;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// embedding gather: one workgroup per token.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embedding_kernel(const int64_t* __restrict__ ids, int T,
+                                                        const mg_bf16* __restrict__ wte, int vocab, int d,
+                                                        mg_bf16* __restrict__ out, int64_t out_bstride,
+                                                        int row_off) {
+  const int tok = blockIdx.x;
+  const int b = tok / T, t = tok - b * T;
+  int64_t id = ids[tok];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  const u32x4* src = (const u32x4*)(wte + id * (int64_t)d);
+  u32x4* dst = (u32x4*)(out + b * out_bstride + (int64_t)(row_off + t) * d);
+  for (int i = threadIdx.x; i < (d >> 3); i += 256) dst[i] = src[i];
+}
+
+// ---------------------------------------------------------------------------
+// 2x2 average pool, NHWC.  thread = one 16-B channel chunk of one output pixel
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void avgpool2_kernel(const mg_bf16* __restrict__ x, mg_bf16* __restrict__ y,
+                                                       int B, int H, int W, int C) {
+  const int Ho = H >> 1, Wo = W >> 1, cv = C >> 3;
+  const int64_t total = (int64_t)B * Ho * Wo * cv;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % cv);
+    int64_t t = i / cv;
+    const int xo = (int)(t % Wo); t /= Wo;
+    const int yo = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    const mg_bf16* p00 = x + (((int64_t)b * H + 2 * yo) * W + 2 * xo) * C + c * 8;
+    const u32x4 a = *(const u32x4*)p00, bq = *(const u32x4*)(p00 + C);
+    const u32x4 cq = *(const u32x4*)(p00 + (int64_t)W * C), dq = *(const u32x4*)(p00 + (int64_t)W * C + C);
+    u32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      o[j] = pack2bf(0.25f * (bflo(a[j]) + bflo(bq[j]) + bflo(cq[j]) + bflo(dq[j])),
+                     0.25f * (bfhi(a[j]) + bfhi(bq[j]) + bfhi(cq[j]) + bfhi(dq[j])));
+    *(u32x4*)(y + i * 8) = o;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// stem conv1 im2col: NCHW bf16 image -> [B*(H/2)*(W/2), 32], col=(ky*3+kx)*3+c
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stem_im2col_kernel(const mg_bf16* __restrict__ img,
+                                                          mg_bf16* __restrict__ out, int B, int H, int W) {
+  const int Ho = H >> 1, Wo = W >> 1;
+  const int64_t total = (int64_t)B * Ho * Wo;
+  for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < total; m += (int64_t)gridDim.x * 256) {
+    const int xo = (int)(m % Wo);
+    const int64_t t = m / Wo;
+    const int yo = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    uint16_t col[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) col[i] = 0;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int yy = 2 * yo + ky - 1, xx = 2 * xo + kx - 1;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) col[(ky * 3 + kx) * 3 + c] = img[(((int64_t)b * 3 + c) * H + yy) * W + xx];
+        }
+      }
+    u32x4* dst = (u32x4*)(out + m * 32);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      u32x4 w;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w[j] = (uint32_t)col[g * 8 + 2 * j] | ((uint32_t)col[g * 8 + 2 * j + 1] << 16);
+      dst[g] = w;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// greedy argmax over fp32 logits, first maximum wins (torch.argmax on CPU).
+// one 1024-thread workgroup per row.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ logits, int64_t ld, int V,
+                                                      int64_t* __restrict__ token) {
+  __shared__ float bv[16];
+  __shared__ int bi[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* row = logits + (int64_t)blockIdx.x * ld;
+  float best = -INFINITY;
+  int idx = 0x7fffffff;
+  for (int i = tid; i < V; i += 1024) {
+    const float v = row[i];
+    if (v > best || (v == best && i < idx)) { best = v; idx = i; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(idx, o, 64);
+    if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+  }
+  if (lane == 0) { bv[wave] = best; bi[wave] = idx; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 16; ++w)
+      if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+    token[blockIdx.x] = (idx == 0x7fffffff) ? 0 : idx;
+  }
+}
+
+__global__ void advance_pos_kernel(int* d_pos, int delta) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *d_pos += delta;
+}
+
+// ---------------------------------------------------------------------------
+// build_labels (reference magma/utils.py:334-364), integer, exact.
+// one workgroup per row: find the first eos among labels[P..S) with a block
+// min-reduction instead of the reference's per-token host loop.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void build_labels_kernel(const int64_t* __restrict__ cap,
+                                                           int64_t* __restrict__ lab, int S, int P,
+                                                           int64_t eos) {
+  __shared__ int wmin[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t* c = cap + (int64_t)blockIdx.x * S;
+  int64_t* l = lab + (int64_t)blockIdx.x * S;
+  const int T = S - P;  // caption tokens that survive the truncation
+  int first = 0x7fffffff;
+  for (int t = tid; t < T; t += 256)
+    if (c[t] == eos) first = min(first, t);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) first = min(first, __shfl_xor(first, o, 64));
+  if (lane == 0) wmin[wave] = first;
+  __syncthreads();
+  first = min(min(wmin[0], wmin[1]), min(wmin[2], wmin[3]));
+  for (int k = tid; k < S; k += 256) {
+    int64_t v = -100;
+    if (k >= P) {
+      const int t = k - P;
+      if (t <= first) v = c[t];   // eos itself is kept, everything after is masked
+    }
+    l[k] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// cross entropy rows: loss_row[r] = logsumexp(logits[r,:]) - logits[r,tgt]
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ logits, int64_t ld,
+                                                      const int64_t* __restrict__ tgt,
+                                                      float* __restrict__ loss_row, int V) {
+  __shared__ float red[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = blockIdx.x;
+  const int64_t tg = tgt[r];
+  if (tg < 0 || tg >= V) { if (tid == 0) loss_row[r] = 0.f; return; }
+  const float* row = logits + (int64_t)r * ld;
+  float mx = -INFINITY;
+  for (int i = tid; i < V; i += 256) mx = fmaxf(mx, row[i]);
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float s = 0.f;
+  for (int i = tid; i < V; i += 256) s += expf(row[i] - mx);
+  s = wave_sum(s);
+  if (lane == 0) red[4 + wave] = s;
+  __syncthreads();
+  if (tid == 0) loss_row[r] = logf(red[4] + red[5] + red[6] + red[7]) + mx - row[tg];
+}
+
+__global__ __launch_bounds__(256) void ce_reduce_kernel(const float* __restrict__ loss_row,
+                                                        const int64_t* __restrict__ tgt, int R,
+                                                        float* __restrict__ out) {
+  __shared__ float rs[4], rc[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float s = 0.f, c = 0.f;
+  for (int i = tid; i < R; i += 256)
+    if (tgt[i] >= 0) { s += loss_row[i]; c += 1.f; }
+  s = wave_sum(s); c = wave_sum(c);
+  if (lane == 0) { rs[wave] = s; rc[wave] = c; }
+  __syncthreads();
+  if (tid == 0) {
+    const float ts = rs[0] + rs[1] + rs[2] + rs[3], tc = rc[0] + rc[1] + rc[2] + rc[3];
+    out[0] = ts / tc;   // NaN when no valid target, like F.cross_entropy
+    out[1] = tc;
+  }
+}
+
+inline int grid_for(int64_t total) {
+  int64_t g = (total + 255) / 256;
+  return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+}  // namespace
+
+extern "C" int mg_layernorm_bf16(const mg_bf16* x, int64_t ldx, const float* gamma, const float* beta, mg_bf16* y,
+                                 int64_t ldy, int32_t rows, int32_t d, float eps, void* stream) {
+  if (rows <= 0 || d <= 0 || (d & 7) || d > 256 * 8 * LN_MAXV) MG_FAIL(MG_ERR_SHAPE, "mg_layernorm_bf16: need rows>0, d%%8==0, d<=%d (d=%d)", 256 * 8 * LN_MAXV, d);
+  if (!x || !y || !gamma || !beta) MG_FAIL(MG_ERR_SHAPE, "mg_layernorm_bf16: null pointer");
+  if (!MG_ALIGNED16(x) || !MG_ALIGNED16(y) || !MG_ALIGNED16(gamma) || !MG_ALIGNED16(beta) || (ldx & 7) || (ldy & 7))
+    MG_FAIL(MG_ERR_ALIGN, "mg_layernorm_bf16: 16-byte alignment required");
+  hipLaunchKernelGGL(layernorm_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta, y, ldy, d, eps);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
+extern "C" int mg_embedding_bf16(const int64_t* ids, int32_t B, int32_t T, const mg_bf16* wte, int32_t vocab,
+                                 int32_t d, mg_bf16* out, int64_t out_bstride, int32_t row_off, void* stream) {
+  if (B <= 0 || T <= 0 || vocab <= 0 || d <= 0 || (d & 7)) MG_FAIL(MG_ERR_SHAPE, "mg_embedding_bf16: bad shape");
+  if (!ids || !wte || !out) MG_FAIL(MG_ERR_SHAPE, "mg_embedding_bf16: null pointer");
+  if (!MG_ALIGNED16(wte) || !MG_ALIGNED16(out) || (out_bstride & 7)) MG_FAIL(MG_ERR_ALIGN, "mg_embedding_bf16: 16-byte alignment required");
+  hipLaunchKernelGGL(embedding_kernel, dim3(B * T), dim3(256), 0, (hipStream_t)stream, ids, T, wte, vocab, d, out, out_bstride, row_off);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
+extern "C" int mg_avgpool2_nhwc_bf16(const mg_bf16* x, mg_bf16* y, int32_t B, int32_t H, int32_t W, int32_t C, void* stream) {
+  if (B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C <= 0 || (C & 7)) MG_FAIL(MG_ERR_SHAPE, "mg_avgpool2_nhwc_bf16: need even H,W and C%%8==0");
+  if (!x || !y || !MG_ALIGNED16(x) || !MG_ALIGNED16(y)) MG_FAIL(MG_ERR_ALIGN, "mg_avgpool2_nhwc_bf16: null/unaligned pointer");
+  const int64_t total = (int64_t)B * (H / 2) * (W / 2) * (C / 8);
+  hipLaunchKernelGGL(avgpool2_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, B, H, W, C);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
+extern "C" int mg_stem_im2col_bf16(const mg_bf16* img, mg_bf16* out, int32_t B, int32_t H, int32_t W, void* stream) {
+  if (B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) MG_FAIL(MG_ERR_SHAPE, "mg_stem_im2col_bf16: need even H,W");
+  if (!img || !out || !MG_ALIGNED16(out)) MG_FAIL(MG_ERR_ALIGN, "mg_stem_im2col_bf16: null/unaligned pointer");
+  const int64_t total = (int64_t)B * (H / 2) * (W / 2);
+  hipLaunchKernelGGL(stem_im2col_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, img, out, B, H, W);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
+extern "C" int mg_argmax_f32(const float* logits, int64_t ld, int32_t B, int32_t V, int64_t* token, void* stream) {
+  if (B <= 0 || V <= 0 || !logits || !token) MG_FAIL(MG_ERR_SHAPE, "mg_argmax_f32: bad arguments");
+  hipLaunchKernelGGL(argmax_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, logits, ld, V, token);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
+extern "C" int mg_advance_pos(int32_t* d_pos, int32_t delta, void* stream) {
+  if (!d_pos) MG_FAIL(MG_ERR_SHAPE, "mg_advance_pos: null pointer");
+  hipLaunchKernelGGL(advance_pos_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d_pos, delta);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
+extern "C" int mg_build_labels_i64(const int64_t* captions, int64_t* labels, int32_t B, int32_t S, int32_t P,
+                                   int64_t eos, void* stream) {
+  if (B <= 0 || S <= 0 || P < 0 || P > S) MG_FAIL(MG_ERR_SHAPE, "mg_build_labels_i64: captions.shape[1] (%d) must be >= prefix length (%d)", S, P);
+  if (!captions || !labels) MG_FAIL(MG_ERR_SHAPE, "mg_build_labels_i64: null pointer");
+  hipLaunchKernelGGL(build_labels_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, captions, labels, S, P, eos);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
+extern "C" int mg_ce_rows_f32(const float* logits, int64_t ld, const int64_t* tgt, float* loss_row, int32_t R,
+                              int32_t V, void* stream) {
+  if (R <= 0 || V <= 0 || !logits || !tgt || !loss_row) MG_FAIL(MG_ERR_SHAPE, "mg_ce_rows_f32: bad arguments");
+  hipLaunchKernelGGL(ce_rows_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, logits, ld, tgt, loss_row, V);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
+extern "C" int mg_ce_reduce_f32(const float* loss_row, const int64_t* tgt, int32_t R, float* out, void* stream) {
+  if (R <= 0 || !loss_row || !tgt || !out) MG_FAIL(MG_ERR_SHAPE, "mg_ce_reduce_f32: bad arguments");
+  hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, loss_row, tgt, R, out);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}

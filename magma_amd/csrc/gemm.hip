@@ -1,0 +1,442 @@
+// gemm.hip -- bf16 MFMA GEMM family for gfx950 (MI355X).
+//
+//   C[M,N] = A[M,K] * W[N,K]^T  (+ fused epilogue), fp32 accumulate.
+//
+// Two kernels:
+//   gemm128_kernel   128x128x64 workgroup tile, 4 waves (2x2), each wave a 64x64
+//                    sub-tile as 4x4 v_mfma_f32_16x16x32_bf16 accumulators.
+//                    Operand tiles go HBM -> LDS with global_load_lds_dwordx4
+//                    (LDS-DMA, no VGPR round trip), double buffered, one barrier
+//                    per K-tile.  Row-major operands use an XOR chunk swizzle
+//                    applied on the *source* address (the DMA writes LDS
+//                    lane-linearly) and again on the ds_read_b128; fragment-tiled
+//                    weights need no swizzle at all (LDS image == fragment order).
+//                    A-operand loaders: dense rows, or implicit-im2col 3x3 conv
+//                    over an NHWC image (CLIP trunk).
+//   skinny_kernel    M <= 16 (decode): pure weight streaming from fragment-tiled
+//                    weights straight into VGPRs (1 KiB contiguous per wave
+//                    instruction), K split across the waves of a workgroup,
+//                    fp32 cross-wave reduction through LDS.  HBM-bound.
+//
+// MFMA operand roles are swapped (weights as the "A" operand, activations as
+// "B") so that each lane ends up with 4 *consecutive n* of one output row:
+//   acc[r] = C[m0 + (lane&15)][n0 + (lane>>4)*4 + r]
+// which makes the epilogue an 8-byte (bf16) / 16-byte (fp32) vector store and
+// lets bias / residual loads be vectors too.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;        // 16 KiB per operand tile
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;    // A + B
+constexpr int GEMM_LDS = 2 * STAGE_BYTES;      // double buffered: 64 KiB
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+MG_DEV void glds16(const void* g, char* lds_wave_base) {
+  // 64 lanes x 16 B -> 1 KiB at lds_wave_base (wave-uniform) + lane*16
+  __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 0);
+}
+
+// ---------------------------------------------------------------------------
+// shared epilogue: 4 consecutive n of row m
+// ---------------------------------------------------------------------------
+MG_DEV void epilogue_store4(const mg_epilogue& ep, int m, int n, f32x4 v, int N) {
+  if (n >= N) return;
+  const bool full = (n + 3 < N);
+  float sc[4] = {1.f, 1.f, 1.f, 1.f}, bi[4] = {0.f, 0.f, 0.f, 0.f};
+  if (full) {
+    if (ep.scale) { const float4 t = *(const float4*)(ep.scale + n); sc[0] = t.x; sc[1] = t.y; sc[2] = t.z; sc[3] = t.w; }
+    if (ep.bias)  { const float4 t = *(const float4*)(ep.bias + n);  bi[0] = t.x; bi[1] = t.y; bi[2] = t.z; bi[3] = t.w; }
+  } else {
+    for (int r = 0; r < 4; ++r) if (n + r < N) {
+      if (ep.scale) sc[r] = ep.scale[n + r];
+      if (ep.bias) bi[r] = ep.bias[n + r];
+    }
+  }
+  float o[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) o[r] = apply_act(v[r] * sc[r] + bi[r], ep.act);
+  const mg_bf16* rs[3] = {ep.res0, ep.res1, ep.res2};
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    if (rs[t]) {
+      const mg_bf16* rp = rs[t] + (int64_t)m * ep.ldr + n;
+      if (full) {
+        const u32x2 w = *(const u32x2*)rp;
+        o[0] += bflo(w[0]); o[1] += bfhi(w[0]); o[2] += bflo(w[1]); o[3] += bfhi(w[1]);
+      } else {
+        for (int r = 0; r < 4; ++r) if (n + r < N) o[r] += bf2f(rp[r]);
+      }
+    }
+  }
+  if (ep.act_after == MG_ACT_RELU) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = o[r] > 0.f ? o[r] : 0.f;
+  }
+  if (ep.out_f32) {
+    float* cp = (float*)ep.C + (int64_t)m * ep.ldc + n;
+    if (full) *(float4*)cp = make_float4(o[0], o[1], o[2], o[3]);
+    else for (int r = 0; r < 4; ++r) if (n + r < N) cp[r] = o[r];
+  } else {
+    mg_bf16* cp = (mg_bf16*)ep.C + (int64_t)m * ep.ldc + n;
+    if (full) { u32x2 w; w[0] = pack2bf(o[0], o[1]); w[1] = pack2bf(o[2], o[3]); *(u32x2*)cp = w; }
+    else for (int r = 0; r < 4; ++r) if (n + r < N) cp[r] = f2bf(o[r]);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// workgroup id -> output tile.  (1) undo the dispatcher's round-robin over the
+// 8 XCDs so each XCD (private 4 MiB L2) owns a contiguous run of tiles
+// (bijective form, guide 5.5 T1); (2) inside the run walk groups of GROUP_M
+// row-tiles x all column-tiles so the A panels of a group stay L2 resident.
+// ---------------------------------------------------------------------------
+MG_DEV void tile_coords(int bid, int tiles_m, int tiles_n, int& tm, int& tn) {
+  const int nwg = tiles_m * tiles_n;
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  constexpr int GROUP_M = 8;
+  const int per_group = GROUP_M * tiles_n;
+  const int group = wg / per_group;
+  const int first_m = group * GROUP_M;
+  const int gm = min(GROUP_M, tiles_m - first_m);
+  const int in_group = wg - group * per_group;
+  tm = first_m + in_group % gm;
+  tn = in_group / gm;
+}
+
+struct GemmParams {
+  const mg_bf16* A; int64_t lda;
+  const mg_bf16* W; int64_t ldw;
+  int M, N, K;
+  int H, Wd, Cin;
+  const mg_bf16* zero;
+  int tiles_m, tiles_n;
+  mg_epilogue ep;
+};
+
+template <int AMODE, int WLAYOUT>
+__global__ __launch_bounds__(256) void gemm128_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int tm, tn;
+  tile_coords(blockIdx.x, p.tiles_m, p.tiles_n, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int nkt = (p.K + BK - 1) / BK;
+
+  // ---- per-lane staging state: 4 DMA pieces of A and 4 of B per K-tile ----
+  // piece j of wave w fills LDS rows [32w+8j, 32w+8j+8) x 128 B; lane -> (row
+  // r = 32w+8j+(lane>>3), LDS chunk c = lane&7), reads global chunk g = c ^ f(r)
+  // with f(r) = (r>>1)&7  (conflict-free ds_read_b128 for the 16-lane groups).
+  const mg_bf16* a_src[4];
+  int a_k[4];
+  // conv state
+  int cv_y[4], cv_x[4], cv_tap[4], cv_cc[4];
+  bool cv_ok[4];
+  const int cpt = (AMODE == MG_A_CONV3X3) ? (p.Cin >> 3) : 1;  // 16-B chunks per tap
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = wave * 32 + j * 8 + (lane >> 3);
+    const int g = (lane & 7) ^ ((r >> 1) & 7);
+    a_k[j] = g * 8;
+    const int m = m0 + r;
+    if (AMODE == MG_A_DENSE) {
+      const int mc = min(m, p.M - 1);
+      a_src[j] = p.A + (int64_t)mc * p.lda + g * 8;
+    } else {
+      const int mc = min(m, p.M - 1);
+      const int x = mc % p.Wd;
+      const int t = mc / p.Wd;
+      const int y = t % p.H;
+      cv_y[j] = y; cv_x[j] = x;
+      cv_ok[j] = (m < p.M);
+      a_src[j] = p.A + (int64_t)mc * p.Cin;   // centre pixel, channel 0
+      cv_tap[j] = g / cpt;
+      cv_cc[j] = g - cv_tap[j] * cpt;
+    }
+  }
+  const mg_bf16* b_src[4];
+  int b_k[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (WLAYOUT == MG_W_ROWMAJOR) {
+      const int r = wave * 32 + j * 8 + (lane >> 3);
+      const int g = (lane & 7) ^ ((r >> 1) & 7);
+      b_k[j] = g * 8;
+      const int nc = min(n0 + r, p.N - 1);
+      b_src[j] = p.W + (int64_t)nc * p.ldw + g * 8;
+    } else {
+      // fragment-tiled: piece = (n-tile nt_l = (4w+j)>>1, k-step ks_l = (4w+j)&1)
+      const int bi = wave * 4 + j;
+      const int ntiles = (p.N + 15) >> 4;
+      const int nt = min((n0 >> 4) + (bi >> 1), ntiles - 1);
+      const int64_t ksteps = p.ldw >> 5;  // Kp / 32
+      b_src[j] = p.W + ((int64_t)nt * ksteps + (bi & 1)) * 512 + lane * 8;
+      b_k[j] = 0;
+    }
+  }
+
+  auto stage = [&](int kt, int buf) {
+    char* abase = smem + buf * STAGE_BYTES;
+    char* bbase = abase + TILE_BYTES;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const mg_bf16* src;
+      if (AMODE == MG_A_DENSE) {
+        src = (kt * BK + a_k[j] < p.K) ? a_src[j] + kt * BK : p.zero;
+      } else {
+        // implicit im2col: k = tap*Cin + ci, tap = ky*3+kx, pad 1
+        const int tap = cv_tap[j];
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const int yy = cv_y[j] + ky - 1, xx = cv_x[j] + kx - 1;
+        const bool ok = cv_ok[j] && tap < 9 && yy >= 0 && yy < p.H && xx >= 0 && xx < p.Wd;
+        src = ok ? a_src[j] + ((int64_t)(ky - 1) * p.Wd + (kx - 1)) * p.Cin + cv_cc[j] * 8 : p.zero;
+        // advance by one K-tile = 8 chunks
+        int cc = cv_cc[j] + 8, tp = tap;
+        while (cc >= cpt) { cc -= cpt; ++tp; }
+        cv_cc[j] = cc; cv_tap[j] = tp;
+      }
+      glds16(src, abase + (wave * 32 + j * 8) * 128);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const mg_bf16* src;
+      if (WLAYOUT == MG_W_ROWMAJOR) {
+        src = (kt * BK + b_k[j] < p.K) ? b_src[j] + kt * BK : p.zero;
+        glds16(src, bbase + (wave * 32 + j * 8) * 128);
+      } else {
+        src = b_src[j] + (int64_t)kt * 1024;   // 2 k-steps * 512 elements
+        glds16(src, bbase + (wave * 4 + j) * 1024);
+      }
+    }
+  };
+
+  // ---- reader offsets -----------------------------------------------------
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 15, lq = lane >> 4;
+  const int fsw = (li >> 1) & 7;  // f(r) only depends on lane (tile rows are 16-aligned)
+  int a_rd[2], b_rd[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    a_rd[s] = (wm * 64 + li) * 128 + (((s * 4 + lq) ^ fsw) << 4);
+    if (WLAYOUT == MG_W_ROWMAJOR) b_rd[s] = TILE_BYTES + (wn * 64 + li) * 128 + (((s * 4 + lq) ^ fsw) << 4);
+    else b_rd[s] = TILE_BYTES + ((wn * 4) * 2 + s) * 1024 + lane * 16;
+  }
+  constexpr int A_MT_STRIDE = 16 * 128;
+  constexpr int B_NT_STRIDE = (WLAYOUT == MG_W_ROWMAJOR) ? 16 * 128 : 2 * 1024;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  stage(0, 0);
+  __syncthreads();  // hipcc drains the LDS-DMA (vmcnt(0)) in front of the barrier
+  int cur = 0;
+  for (int kt = 0; kt < nkt; ++kt) {
+    if (kt + 1 < nkt) stage(kt + 1, cur ^ 1);
+    const char* sb = smem + cur * STAGE_BYTES;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) af[t] = *(const bf16x8*)(sb + a_rd[s] + t * A_MT_STRIDE);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) bfr[t] = *(const bf16x8*)(sb + b_rd[s] + t * B_NT_STRIDE);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();  // next tile landed (vmcnt(0)) + everyone done reading `cur`
+    cur ^= 1;
+  }
+
+  // ---- epilogue -------------------------------------------------------------
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + li;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + lq * 4;
+      epilogue_store4(p.ep, m, n, acc[i][j], p.N);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// skinny (decode) kernel
+// ---------------------------------------------------------------------------
+struct SkinnyParams {
+  const mg_bf16* X; int64_t ldx;
+  const mg_bf16* W;
+  int M, N, ntiles, ksteps;
+  mg_epilogue ep;
+};
+
+template <int WAVES, int KC, int NT>
+__global__ __launch_bounds__(WAVES * 64) void skinny_kernel(const SkinnyParams p) {
+  __shared__ __attribute__((aligned(16))) float red[WAVES * NT * 256];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int per_wave = p.ksteps / WAVES;
+  const int ks0 = wave * per_wave;
+  const int nt0 = blockIdx.x * NT;
+  const int li = lane & 15, lq = lane >> 4;
+  const bool xok = li < p.M;
+  const mg_bf16* xrow = p.X + (int64_t)(xok ? li : 0) * p.ldx + lq * 8;
+
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int kc = 0; kc < per_wave; kc += KC) {
+    // Issue the whole chunk's loads before the first MFMA (GEMV recipe: loads
+    // straight to VGPRs, deep queue, late wait): weights first (HBM, non-temporal
+    // -- each byte is read exactly once per step), then the x fragments (L2 hits).
+    u32x4 wf[NT][KC];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int nt = min(nt0 + t, p.ntiles - 1);
+      const u32x4* wp = (const u32x4*)p.W + ((int64_t)nt * p.ksteps + ks0 + kc) * 64 + lane;
+#pragma unroll
+      for (int i = 0; i < KC; ++i) wf[t][i] = __builtin_nontemporal_load(wp + i * 64);
+    }
+    bf16x8 xf[KC];
+#pragma unroll
+    for (int i = 0; i < KC; ++i) {
+      u32x4 raw = *(const u32x4*)(xrow + (int64_t)(ks0 + kc + i) * 32);
+      if (!xok) raw = (u32x4){0u, 0u, 0u, 0u};
+      xf[i] = __builtin_bit_cast(bf16x8, raw);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int i = 0; i < KC; ++i)
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[t][i]), xf[i], acc[t], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  // cross-wave (split-K) reduction through LDS, then epilogue by wave t
+#pragma unroll
+  for (int t = 0; t < NT; ++t) *(f32x4*)(red + ((wave * NT + t) * 64 + lane) * 4) = acc[t];
+  __syncthreads();
+  for (int t = wave; t < NT; t += WAVES) {
+    if (nt0 + t >= p.ntiles) break;
+    f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) s += *(const f32x4*)(red + ((w * NT + t) * 64 + lane) * 4);
+    if (xok) epilogue_store4(p.ep, li, (nt0 + t) * 16 + lq * 4, s, p.N);
+  }
+}
+
+int check_epilogue(const mg_epilogue& ep, const char* who) {
+  if (!ep.C) MG_FAIL(MG_ERR_SHAPE, "%s: null output", who);
+  if ((ep.ldc & 3) != 0) MG_FAIL(MG_ERR_ALIGN, "%s: ldc must be a multiple of 4", who);
+  if ((ep.res0 || ep.res1 || ep.res2) && (ep.ldr & 3) != 0) MG_FAIL(MG_ERR_ALIGN, "%s: ldr must be a multiple of 4", who);
+  if (!MG_ALIGNED16(ep.C) || !MG_ALIGNED16(ep.scale) || !MG_ALIGNED16(ep.bias) || !MG_ALIGNED16(ep.res0) ||
+      !MG_ALIGNED16(ep.res1) || !MG_ALIGNED16(ep.res2))
+    MG_FAIL(MG_ERR_ALIGN, "%s: epilogue pointers must be 16-byte aligned", who);
+  if (ep.act < 0 || ep.act > 2 || ep.act_after < 0 || ep.act_after > 1) MG_FAIL(MG_ERR_SHAPE, "%s: bad activation code", who);
+  return MG_OK;
+}
+
+template <int AMODE, int WLAYOUT>
+int launch_gemm(const GemmParams& gp, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm128_kernel<AMODE, WLAYOUT>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+    if (e != hipSuccess) MG_FAIL(MG_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm128_kernel<AMODE, WLAYOUT>), dim3(gp.tiles_m * gp.tiles_n), dim3(256), GEMM_LDS, s, gp);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
+template <int WAVES, int KC, int NT>
+int launch_skinny(const SkinnyParams& sp, hipStream_t s) {
+  const int grid = (sp.ntiles + NT - 1) / NT;
+  hipLaunchKernelGGL((skinny_kernel<WAVES, KC, NT>), dim3(grid), dim3(WAVES * 64), 0, s, sp);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
+}  // namespace
+
+extern "C" int mg_gemm_bf16(const mg_gemm_desc* d, void* stream) {
+  if (!d) MG_FAIL(MG_ERR_SHAPE, "mg_gemm_bf16: null descriptor");
+  if (d->M <= 0 || d->N <= 0 || d->K <= 0) MG_FAIL(MG_ERR_SHAPE, "mg_gemm_bf16: M,N,K must be positive (%d,%d,%d)", d->M, d->N, d->K);
+  if (d->K & 7) MG_FAIL(MG_ERR_SHAPE, "mg_gemm_bf16: K=%d must be a multiple of 8", d->K);
+  if (!d->A || !d->W || !d->zero_page) MG_FAIL(MG_ERR_SHAPE, "mg_gemm_bf16: null A/W/zero_page");
+  if (!MG_ALIGNED16(d->A) || !MG_ALIGNED16(d->W) || !MG_ALIGNED16(d->zero_page)) MG_FAIL(MG_ERR_ALIGN, "mg_gemm_bf16: A/W/zero_page must be 16-byte aligned");
+  if (int rc = check_epilogue(d->ep, "mg_gemm_bf16")) return rc;
+  GemmParams gp;
+  gp.A = d->A; gp.lda = d->lda; gp.W = d->W; gp.ldw = d->ldw;
+  gp.M = d->M; gp.N = d->N; gp.K = d->K;
+  gp.H = d->H; gp.Wd = d->Wd; gp.Cin = d->Cin;
+  gp.zero = d->zero_page;
+  gp.tiles_m = (d->M + BM - 1) / BM; gp.tiles_n = (d->N + BN - 1) / BN;
+  gp.ep = d->ep;
+  if (d->a_mode == MG_A_DENSE) {
+    if (d->lda & 7) MG_FAIL(MG_ERR_ALIGN, "mg_gemm_bf16: lda must be a multiple of 8");
+    if (d->lda < d->K) MG_FAIL(MG_ERR_SHAPE, "mg_gemm_bf16: lda < K");
+  } else if (d->a_mode == MG_A_CONV3X3) {
+    if (d->Cin <= 0 || (d->Cin & 7) || d->K != 9 * d->Cin) MG_FAIL(MG_ERR_SHAPE, "mg_gemm_bf16: conv3x3 needs Cin%%8==0 and K==9*Cin");
+    if (d->H <= 0 || d->Wd <= 0 || d->M % (d->H * d->Wd)) MG_FAIL(MG_ERR_SHAPE, "mg_gemm_bf16: conv3x3 needs M == B*H*W");
+  } else MG_FAIL(MG_ERR_SHAPE, "mg_gemm_bf16: bad a_mode %d", d->a_mode);
+  if (d->w_layout == MG_W_ROWMAJOR) {
+    if ((d->ldw & 7) || d->ldw < d->K) MG_FAIL(MG_ERR_ALIGN, "mg_gemm_bf16: ldw must be >= K and a multiple of 8");
+  } else if (d->w_layout == MG_W_FRAGTILED) {
+    if ((d->ldw & 63) || d->ldw < d->K) MG_FAIL(MG_ERR_ALIGN, "mg_gemm_bf16: tiled weights need Kp (ldw) %%64==0 and >= K");
+  } else MG_FAIL(MG_ERR_SHAPE, "mg_gemm_bf16: bad w_layout %d", d->w_layout);
+  hipStream_t s = (hipStream_t)stream;
+  if (d->a_mode == MG_A_DENSE) {
+    return d->w_layout == MG_W_ROWMAJOR ? launch_gemm<MG_A_DENSE, MG_W_ROWMAJOR>(gp, s)
+                                        : launch_gemm<MG_A_DENSE, MG_W_FRAGTILED>(gp, s);
+  }
+  return d->w_layout == MG_W_ROWMAJOR ? launch_gemm<MG_A_CONV3X3, MG_W_ROWMAJOR>(gp, s)
+                                      : launch_gemm<MG_A_CONV3X3, MG_W_FRAGTILED>(gp, s);
+}
+
+extern "C" int mg_gemm_skinny_bf16(const mg_skinny_desc* d, void* stream) {
+  if (!d) MG_FAIL(MG_ERR_SHAPE, "mg_gemm_skinny_bf16: null descriptor");
+  if (d->M <= 0 || d->M > 16) MG_FAIL(MG_ERR_SHAPE, "mg_gemm_skinny_bf16: M=%d must be in [1,16]", d->M);
+  if (d->N <= 0 || d->Kp <= 0 || (d->Kp & 63)) MG_FAIL(MG_ERR_SHAPE, "mg_gemm_skinny_bf16: need N>0 and Kp%%64==0 (N=%d Kp=%d)", d->N, d->Kp);
+  if (!d->X || !d->W) MG_FAIL(MG_ERR_SHAPE, "mg_gemm_skinny_bf16: null X/W");
+  if (!MG_ALIGNED16(d->X) || !MG_ALIGNED16(d->W) || (d->ldx & 7) || d->ldx < d->Kp) MG_FAIL(MG_ERR_ALIGN, "mg_gemm_skinny_bf16: X/W 16-byte aligned, ldx%%8==0, ldx>=Kp required");
+  if (int rc = check_epilogue(d->ep, "mg_gemm_skinny_bf16")) return rc;
+  SkinnyParams sp;
+  sp.X = d->X; sp.ldx = d->ldx; sp.W = d->W; sp.M = d->M; sp.N = d->N;
+  sp.ntiles = (d->N + 15) / 16; sp.ksteps = d->Kp / 32; sp.ep = d->ep;
+  hipStream_t s = (hipStream_t)stream;
+  // Variant = (waves per workgroup, k-steps per load burst, n-tiles per
+  // workgroup).  nt_hint == 0 -> tuned default for the shape; otherwise
+  // nt_hint = nt | waves<<4 | kc<<8 (bench/tuning sweeps use this).
+  int nt = d->nt_hint & 15, waves = (d->nt_hint >> 4) & 15, kc = (d->nt_hint >> 8) & 255;
+  if (d->nt_hint == 0) {
+    if (sp.ksteps % (8 * 16) == 0) { waves = 8; kc = 16; nt = sp.ntiles >= 768 ? 2 : 1; }
+    else if (sp.ksteps % (8 * 4) == 0) { waves = 8; kc = 4; nt = sp.ntiles >= 512 ? 2 : 1; }
+    else if (sp.ksteps % 4 == 0) { waves = 4; kc = 1; nt = 1; }
+    else { waves = 1; kc = 1; nt = 1; }
+  }
+  if (waves <= 0 || kc <= 0 || nt <= 0 || sp.ksteps % (waves * kc) != 0)
+    MG_FAIL(MG_ERR_SHAPE, "mg_gemm_skinny_bf16: variant (waves=%d,kc=%d,nt=%d) does not divide ksteps=%d", waves, kc, nt, sp.ksteps);
+#define MG_SK(W_, K_, N_) if (waves == W_ && kc == K_ && nt == N_) return launch_skinny<W_, K_, N_>(sp, s)
+  MG_SK(8, 16, 1); MG_SK(8, 16, 2); MG_SK(4, 16, 1); MG_SK(4, 16, 2);
+  MG_SK(8, 8, 1);  MG_SK(8, 8, 2);  MG_SK(8, 8, 4);  MG_SK(4, 8, 2); MG_SK(4, 8, 4);
+  MG_SK(8, 4, 1);  MG_SK(8, 4, 2);  MG_SK(8, 4, 4);
+  MG_SK(4, 1, 1);  MG_SK(1, 1, 1);
+#undef MG_SK
+  MG_FAIL(MG_ERR_UNSUPPORTED, "mg_gemm_skinny_bf16: variant (waves=%d,kc=%d,nt=%d) not instantiated", waves, kc, nt);
+}

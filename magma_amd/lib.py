@@ -1,0 +1,105 @@
+"""ctypes binding of libmagma_hip.so (the C ABI declared in include/magma_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing, or an op
+is asked to run on a non-GPU tensor, we raise.  The CPU restatement in
+``oracle/`` is test infrastructure and is never imported from here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "libmagma_hip.so"
+
+MG_ACT_NONE, MG_ACT_RELU, MG_ACT_GELU_NEW = 0, 1, 2
+MG_W_ROWMAJOR, MG_W_FRAGTILED = 0, 1
+MG_A_DENSE, MG_A_CONV3X3 = 0, 1
+
+
+class MagmaHipError(RuntimeError):
+    pass
+
+
+class Epilogue(C.Structure):
+    _fields_ = [
+        ("scale", C.c_void_p), ("bias", C.c_void_p),
+        ("act", C.c_int32), ("act_after", C.c_int32),
+        ("res0", C.c_void_p), ("res1", C.c_void_p), ("res2", C.c_void_p),
+        ("ldr", C.c_int64),
+        ("C", C.c_void_p), ("ldc", C.c_int64),
+        ("out_f32", C.c_int32), ("_pad", C.c_int32),
+    ]
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("lda", C.c_int64),
+        ("W", C.c_void_p), ("ldw", C.c_int64),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("a_mode", C.c_int32), ("w_layout", C.c_int32),
+        ("H", C.c_int32), ("Wd", C.c_int32), ("Cin", C.c_int32),
+        ("zero_page", C.c_void_p),
+        ("ep", Epilogue),
+    ]
+
+
+class SkinnyDesc(C.Structure):
+    _fields_ = [
+        ("X", C.c_void_p), ("ldx", C.c_int64),
+        ("W", C.c_void_p),
+        ("M", C.c_int32), ("N", C.c_int32), ("Kp", C.c_int32), ("nt_hint", C.c_int32),
+        ("ep", Epilogue),
+    ]
+
+
+# every symbol include/magma_hip.h declares: (name, restype, argtypes)
+_i32, _i64, _f32, _vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+SYMBOLS = {
+    "mg_version": (C.c_char_p, []),
+    "mg_last_error": (C.c_char_p, []),
+    "mg_gemm_bf16": (C.c_int, [C.POINTER(GemmDesc), _vp]),
+    "mg_gemm_skinny_bf16": (C.c_int, [C.POINTER(SkinnyDesc), _vp]),
+    "mg_layernorm_bf16": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp]),
+    "mg_embedding_bf16": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _i64, _i32, _vp]),
+    "mg_rotary_split_bf16": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp]),
+    "mg_attn_prefill_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "mg_attn_decode_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "mg_argmax_f32": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp]),
+    "mg_advance_pos": (C.c_int, [_vp, _i32, _vp]),
+    "mg_avgpool2_nhwc_bf16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "mg_stem_im2col_bf16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
+    "mg_build_labels_i64": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i64, _vp]),
+    "mg_ce_rows_f32": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _i32, _vp]),
+    "mg_ce_reduce_f32": (C.c_int, [_vp, _vp, _i32, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libmagma_hip.so (built in-tree by ``__graft_entry__.build()`` /
+    ``make -C magma_amd/csrc``).  Raises MagmaHipError if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = Path(os.environ.get("MAGMA_HIP_LIB", LIB_PATH))
+    if not path.exists():
+        raise MagmaHipError(
+            f"{path} not found: the MI355X HIP library is required (no CPU fallback). "
+            "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`make -C magma_amd/csrc`.")
+    lib = C.CDLL(str(path))
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().mg_last_error().decode("utf-8", "replace")
+        raise MagmaHipError(f"{what or 'libmagma_hip'} failed (rc={rc}): {msg}")

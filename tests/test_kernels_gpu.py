@@ -1,0 +1,311 @@
+"""Kernel-level parity: every C-ABI entry point against a plain PyTorch fp32
+reference of the same op, on seeded random (never zero-filled, never symmetric)
+inputs.  Tolerances are stated per test.  All calls go through libmagma_hip.so."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+BF16 = torch.bfloat16
+
+
+def rnd(*shape, dev, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dev)
+
+
+def rel_err(a, b):
+    a, b = a.float(), b.float()
+    return float((a - b).norm() / (b.norm() + 1e-12))
+
+
+def assert_close(got, ref, tol, what=""):
+    e = rel_err(got, ref)
+    mx = float((got.float() - ref.float()).abs().max())
+    assert math.isfinite(e) and e < tol, f"{what}: rel-L2 {e:.3e} (max abs {mx:.3e}) >= {tol}"
+
+
+# bf16 output rounding alone is ~2^-9 = 2e-3 rel per element; inputs are exact bf16
+GEMM_TOL = 4e-3
+
+
+@pytest.mark.parametrize("layout", ["rm", "ft"])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 192), (77, 1056, 96), (1216, 512, 4096), (130, 48, 432)])
+def test_gemm_dense(dev, layout, M, N, K):
+    from magma_amd import ops
+    a = rnd(M, K, dev=dev, seed=1).to(BF16)
+    w = rnd(N, K, dev=dev, seed=2, scale=0.05).to(BF16)
+    lin = ops.PackedLinear(w, tiled=True, rowmajor=True)
+    out = ops.gemm(a, lin, layout=layout)
+    ref = a.float() @ w.float().t()
+    assert_close(out, ref, GEMM_TOL, f"gemm {layout} {M}x{N}x{K}")
+
+
+def test_gemm_transpose_detecting(dev):
+    """A = I (rectangular pad) with an asymmetric W catches swapped C layouts."""
+    from magma_amd import ops
+    M = N = K = 128
+    a = torch.eye(M, K, device=dev).to(BF16)
+    w = (torch.arange(N * K, device=dev).float().reshape(N, K) % 251 - 125.0) / 128.0
+    lin = ops.PackedLinear(w.to(BF16), tiled=True, rowmajor=True)
+    for layout in ("rm", "ft"):
+        out = ops.gemm(a, lin, layout=layout)
+        assert torch.equal(out.float(), w.to(BF16).float().t().contiguous()), layout
+
+
+def test_gemm_epilogue(dev):
+    from magma_amd import ops
+    M, N, K = 200, 328, 256
+    a = rnd(M, K, dev=dev, seed=3).to(BF16)
+    w = rnd(N, K, dev=dev, seed=4, scale=0.05).to(BF16)
+    bias = rnd(N, dev=dev, seed=5)
+    scale = rnd(N, dev=dev, seed=6).abs() + 0.5
+    r0, r1, r2 = (rnd(M, N, dev=dev, seed=7 + i).to(BF16) for i in range(3))
+    lin = ops.PackedLinear(w, bias=bias)
+    acc = a.float() @ w.float().t()
+    # bias + gelu_new
+    out = ops.gemm(a, lin, act=ops.MG_ACT_GELU_NEW)
+    x = acc + bias
+    ref = 0.5 * x * (1 + torch.tanh(math.sqrt(2 / math.pi) * (x + 0.044715 * x ** 3)))
+    assert_close(out, ref, GEMM_TOL, "bias+gelu")
+    # scale + bias + relu  (folded BatchNorm)
+    out = ops.gemm(a, lin, act=ops.MG_ACT_RELU, scale=scale)
+    assert_close(out, F.relu(acc * scale + bias), GEMM_TOL, "scale+bias+relu")
+    # bias + 3 residuals (GPT-J block sum), fp32 out
+    out = ops.gemm(a, lin, residuals=(r0, r1, r2), out_dtype=torch.float32)
+    assert out.dtype == torch.float32
+    assert_close(out, acc + bias + r0.float() + r1.float() + r2.float(), 1e-4, "bias+3res f32")
+    # scale+bias, residual, relu after (bottleneck tail)
+    out = ops.gemm(a, lin, scale=scale, residuals=(r0,), act_after=ops.MG_ACT_RELU)
+    assert_close(out, F.relu(acc * scale + bias + r0.float()), GEMM_TOL, "bn+identity+relu")
+    # N not a multiple of 4 (vocab 50258 style), fp32 logits into a padded buffer
+    N2 = 203
+    lin2 = ops.PackedLinear(w[:N2], bias=bias[:N2])
+    buf = torch.full((M, 208), 7.0, dtype=torch.float32, device=dev)
+    ops.gemm(a, lin2, out=buf)
+    assert_close(buf[:, :N2], acc[:, :N2] + bias[:N2], 1e-4, "odd N")
+    assert bool((buf[:, N2:] == 7.0).all()), "wrote past N"
+
+
+@pytest.mark.parametrize("layout", ["rm", "ft"])
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 12, 10, 16, 24), (1, 7, 9, 48, 96), (2, 24, 24, 96, 96)])
+def test_conv3x3(dev, layout, B, H, W, Cin, Cout):
+    from magma_amd import ops
+    x = rnd(B, Cin, H, W, dev=dev, seed=11).to(BF16)
+    w = rnd(Cout, Cin, 3, 3, dev=dev, seed=12, scale=0.1).to(BF16)
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous()
+    lin = ops.PackedLinear(w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous(), tiled=True, rowmajor=True)
+    out = ops.gemm(x_nhwc.view(B * H * W, Cin), lin, conv=(H, W, Cin), layout=layout)
+    ref = F.conv2d(x.float(), w.float(), padding=1).permute(0, 2, 3, 1).reshape(B * H * W, Cout)
+    assert_close(out, ref, GEMM_TOL, f"conv3x3 {layout}")
+
+
+@pytest.mark.parametrize("M", [1, 8, 16])
+@pytest.mark.parametrize("N,K,variant", [
+    (4096, 4096, 0), (1056, 4096, 0), (1024, 1024, 0), (512, 512, 0), (208, 64, 0), (50258, 512, 0),
+    (4096, 4096, 1 | 8 << 4 | 8 << 8), (4096, 4096, 2 | 4 << 4 | 16 << 8), (4096, 16384, 4 | 8 << 4 | 8 << 8),
+    (4096, 4096, 2 | 8 << 4 | 16 << 8), (4096, 4096, 1 | 4 << 4 | 16 << 8), (4096, 4096, 4 | 4 << 4 | 8 << 8),
+    (4096, 4096, 2 | 4 << 4 | 8 << 8), (4096, 4096, 2 | 8 << 4 | 8 << 8), (4096, 1024, 4 | 8 << 4 | 4 << 8),
+])
+def test_gemm_skinny(dev, M, N, K, variant):
+    from magma_amd import ops
+    x = rnd(M, K, dev=dev, seed=21).to(BF16)
+    w = rnd(N, K, dev=dev, seed=22, scale=0.05).to(BF16)
+    bias = rnd(N, dev=dev, seed=23)
+    res = rnd(M, N, dev=dev, seed=24).to(BF16)
+    lin = ops.PackedLinear(w, bias=bias)
+    out = ops.gemm_skinny(x, lin, residuals=(res,), variant=variant)
+    ref = x.float() @ w.float().t() + bias + res.float()
+    assert_close(out, ref, GEMM_TOL, f"skinny M={M} {N}x{K} v={variant}")
+    out32 = ops.gemm_skinny(x, lin, act=ops.MG_ACT_RELU, out_dtype=torch.float32, variant=variant)
+    assert_close(out32, F.relu(x.float() @ w.float().t() + bias), 1e-4, "skinny relu f32")
+
+
+def test_tile_roundtrip(dev):
+    from magma_amd import ops
+    w = rnd(48, 128, dev=dev, seed=31).to(BF16)
+    assert torch.equal(ops.PackedLinear.untile(ops.PackedLinear.tile(w)), w)
+
+
+@pytest.mark.parametrize("rows,d", [(8, 4096), (37, 512), (3, 16384)])
+def test_layernorm(dev, rows, d):
+    from magma_amd import ops
+    x = (rnd(rows, d, dev=dev, seed=41) * 2 + 0.3).to(BF16)
+    g = rnd(d, dev=dev, seed=42) * 0.1 + 1
+    b = rnd(d, dev=dev, seed=43) * 0.1
+    out = ops.layernorm(x, g, b, 1e-5)
+    ref = F.layer_norm(x.float(), (d,), g, b, 1e-5)
+    assert_close(out, ref, 3e-3, "layernorm")
+
+
+def test_embedding(dev):
+    from magma_amd import ops
+    V, d, B, T = 1056, 512, 3, 7
+    wte = rnd(V, d, dev=dev, seed=51).to(BF16)
+    ids = torch.randint(0, V, (B, T), generator=torch.Generator().manual_seed(5)).to(dev)
+    out = torch.zeros(B, 12, d, dtype=BF16, device=dev)
+    ops.embedding(ids, wte, out, row_off=4)
+    assert torch.equal(out[:, 4:11], wte[ids])
+    assert bool((out[:, :4] == 0).all()) and bool((out[:, 11:] == 0).all())
+
+
+def _rotary_ref(x, pos, rot):
+    from oracle.model import apply_rotary
+    return apply_rotary(x.float().cpu(), pos.cpu(), rot)
+
+
+@pytest.mark.parametrize("B,S,H", [(2, 57, 2), (1, 152, 3), (2, 33, 1)])
+def test_rotary_split_and_prefill_attention(dev, B, S, H):
+    """rotary/split vs the oracle's apply_rotary; flash attention vs fp32 softmax(QK^T/16)V."""
+    from magma_amd import ops
+    from oracle.model import rotary_tables
+    d = H * 256
+    Smax = 192
+    qkv = rnd(B * S, 3 * d, dev=dev, seed=61).to(BF16)
+    sin_t, cos_t = rotary_tables(64, Smax)
+    sin_t, cos_t = sin_t.to(dev).contiguous(), cos_t.to(dev).contiguous()
+    q = torch.empty(B, H, S, 256, dtype=BF16, device=dev)
+    kc = torch.zeros(B, H, Smax, 256, dtype=BF16, device=dev)
+    vc = torch.zeros(B, H, Smax, 256, dtype=BF16, device=dev)
+    vt_ld = (S + 31) // 32 * 32
+    vt = torch.full((B, H, 256, vt_ld), float("nan"), dtype=BF16, device=dev)
+    ops.rotary_split(qkv, B, S, H, 64, sin_t, cos_t, q, kc, vc, pos0=0, vt=vt)
+    x = qkv.view(B, S, 3, H, 256).float().cpu()
+    pos = torch.arange(S)
+    q_ref = _rotary_ref(x[:, :, 0], pos, 64).permute(0, 2, 1, 3)
+    k_ref = _rotary_ref(x[:, :, 1], pos, 64).permute(0, 2, 1, 3)
+    v_ref = x[:, :, 2].permute(0, 2, 1, 3)
+    assert_close(q.cpu(), q_ref, 3e-3, "q rotary")
+    assert_close(kc[:, :, :S].cpu(), k_ref, 3e-3, "k rotary")
+    assert torch.equal(vc[:, :, :S].float().cpu(), v_ref)
+    assert torch.equal(vt[:, :, :, :S].float().cpu(), v_ref.transpose(2, 3))
+    assert bool((vt[:, :, :, S:] == 0).all()), "V^T padding must be zero"
+    # flash attention on the kernel's own (bf16-rounded) q,k,v
+    out = torch.empty(B * S, d, dtype=BF16, device=dev)
+    lse = torch.empty(B, H, S, dtype=torch.float32, device=dev)
+    ops.attn_prefill(q, kc, vt, out, B, H, S, lse=lse)
+    qf, kf, vf = q.float(), kc[:, :, :S].float(), vc[:, :, :S].float()
+    sc = qf @ kf.transpose(-1, -2) / 16.0
+    mask = torch.ones(S, S, dtype=torch.bool, device=dev).tril()
+    sc = sc.masked_fill(~mask, float("-inf"))
+    ref = (torch.softmax(sc, -1) @ vf).permute(0, 2, 1, 3).reshape(B * S, d)
+    assert_close(out, ref, 8e-3, "flash attention")   # P is rounded to bf16 like the reference's cast
+    assert_close(lse, torch.logsumexp(sc, -1), 1e-4, "lse")
+
+
+def test_attention_online_softmax_rescale(dev):
+    """Force the running-max rescale branch: one late key dominates (guide rule 26)."""
+    from magma_amd import ops
+    B, H, S, Smax = 1, 1, 128, 128
+    q = rnd(B, H, S, 256, dev=dev, seed=71, scale=0.5).to(BF16)
+    k = rnd(B, H, Smax, 256, dev=dev, seed=72, scale=0.5).to(BF16)
+    v = rnd(B, H, Smax, 256, dev=dev, seed=73).to(BF16)
+    k[0, 0, 100] = (q[0, 0, 120].float() * 4).to(BF16)   # spike for late queries at key 100
+    vt = v.transpose(2, 3).contiguous()
+    out = torch.empty(B * S, 256, dtype=BF16, device=dev)
+    ops.attn_prefill(q, k, vt, out, B, H, S)
+    sc = q.float() @ k.float().transpose(-1, -2) / 16.0
+    sc = sc.masked_fill(~torch.ones(S, S, dtype=torch.bool, device=dev).tril(), float("-inf"))
+    ref = (torch.softmax(sc, -1) @ v.float()).reshape(S, 256)
+    assert_close(out, ref, 8e-3, "rescale branch")
+
+
+@pytest.mark.parametrize("ctx", [1, 57, 152, 184])
+def test_decode_attention(dev, ctx):
+    from magma_amd import ops
+    from oracle.model import rotary_tables
+    B, H, Smax = 3, 2, 192
+    d = H * 256
+    kc = rnd(B, H, Smax, 256, dev=dev, seed=81, scale=0.5).to(BF16)
+    vc = rnd(B, H, Smax, 256, dev=dev, seed=82).to(BF16)
+    qkv = rnd(B, 3 * d, dev=dev, seed=83, scale=0.5).to(BF16)
+    sin_t, cos_t = rotary_tables(64, Smax)
+    sin_t, cos_t = sin_t.to(dev).contiguous(), cos_t.to(dev).contiguous()
+    d_pos = torch.tensor([ctx - 1], dtype=torch.int32, device=dev)
+    q = torch.empty(B, H, 1, 256, dtype=BF16, device=dev)
+    kc0, vc0 = kc.clone(), vc.clone()
+    ops.rotary_split(qkv, B, 1, H, 64, sin_t, cos_t, q, kc, vc, d_pos=d_pos)
+    x = qkv.view(B, 1, 3, H, 256).float().cpu()
+    pos = torch.tensor([ctx - 1])
+    k_new = _rotary_ref(x[:, :, 1], pos, 64).permute(0, 2, 1, 3)
+    assert_close(kc[:, :, ctx - 1:ctx].cpu(), k_new, 3e-3, "appended k")
+    assert torch.equal(vc[:, :, ctx - 1].float().cpu(), x[:, 0, 2])
+    if ctx > 1:
+        assert torch.equal(kc[:, :, :ctx - 1], kc0[:, :, :ctx - 1]) and torch.equal(vc[:, :, ctx:], vc0[:, :, ctx:])
+    out = torch.empty(B, d, dtype=BF16, device=dev)
+    ops.attn_decode(q, kc, vc, out, B, H, d_pos)
+    sc = (q.float() @ kc[:, :, :ctx].float().transpose(-1, -2)) / 16.0
+    ref = (torch.softmax(sc, -1) @ vc[:, :, :ctx].float()).reshape(B, d)
+    assert_close(out, ref, 3e-3, "decode attention")
+
+
+def test_argmax_and_pos(dev):
+    from magma_amd import ops
+    lg = rnd(8, 50258, dev=dev, seed=91)
+    lg[3, 17] = lg[3, 40000] = 100.0     # tie -> first index
+    tok = ops.argmax(lg)
+    ref = torch.argmax(lg.cpu(), dim=-1)
+    assert torch.equal(tok.cpu(), ref) and int(tok[3]) == 17
+    p = torch.tensor([5], dtype=torch.int32, device=dev)
+    ops.advance_pos(p, 2)
+    assert int(p) == 7
+
+
+def test_avgpool_and_stem(dev):
+    from magma_amd import ops
+    x = rnd(2, 24, 6, 8, dev=dev, seed=101).to(BF16)       # NCHW
+    y = ops.avgpool2(x.permute(0, 2, 3, 1).contiguous())
+    ref = F.avg_pool2d(x.float(), 2).permute(0, 2, 3, 1)
+    assert_close(y, ref, 3e-3, "avgpool")
+    img = rnd(2, 3, 20, 16, dev=dev, seed=102).to(BF16)
+    w = rnd(8, 3, 3, 3, dev=dev, seed=103, scale=0.2).to(BF16)
+    cols = ops.stem_im2col(img)
+    wk = torch.zeros(8, 32, dtype=BF16, device=dev)
+    wk[:, :27] = w.permute(0, 2, 3, 1).reshape(8, 27)
+    out = ops.gemm(cols, ops.PackedLinear(wk))
+    ref = F.conv2d(img.float(), w.float(), stride=2, padding=1).permute(0, 2, 3, 1).reshape(-1, 8)
+    assert_close(out, ref, GEMM_TOL, "stem conv via im2col")
+
+
+def test_build_labels_exact(dev):
+    """Integer path: bit-exact against the oracle's literal restatement of reference utils.py:334-364."""
+    from magma_amd import ops
+    from oracle.model import build_labels
+    eos, S, P = 1054, 64, 9
+    g = torch.Generator().manual_seed(7)
+    cap = torch.randint(0, 1000, (6, S), generator=g)
+    cap[0, 20:] = eos            # normal padded caption
+    cap[1, 0] = eos              # eos at position 0
+    cap[2, :] = eos              # all eos
+    # row 3: no eos at all; row 4: eos only inside the truncated tail
+    cap[4, S - P + 2] = eos
+    cap[5, 5] = eos; cap[5, 30] = eos
+    got = ops.build_labels(cap.to(dev), P, eos).cpu()
+    ref = build_labels(P, cap, eos)
+    assert torch.equal(got, ref)
+    with pytest.raises(AssertionError):
+        ops.build_labels(cap[:, :4].contiguous().to(dev), P, eos)
+
+
+def test_cross_entropy(dev):
+    from magma_amd import ops
+    R, V = 37, 1056
+    lg = rnd(R, V, dev=dev, seed=111) * 3
+    tg = torch.randint(0, V, (R,), generator=torch.Generator().manual_seed(3))
+    tg[::5] = -100
+    loss, rows = ops.cross_entropy(lg, tg.to(dev))
+    ref = F.cross_entropy(lg.cpu(), tg, ignore_index=-100)
+    assert abs(float(loss) - float(ref)) < 1e-4 * max(1.0, abs(float(ref)))
+
+
+def test_errors_are_loud(dev):
+    from magma_amd import ops
+    from magma_amd.lib import MagmaHipError
+    a = torch.zeros(4, 12, dtype=BF16, device=dev)      # K not a multiple of 8
+    with pytest.raises((MagmaHipError, ValueError)):
+        ops.gemm(a, ops.PackedLinear(torch.zeros(8, 12, dtype=BF16, device=dev)))
+    with pytest.raises(MagmaHipError):
+        ops.layernorm(torch.zeros(2, 64, dtype=BF16), torch.ones(64), torch.zeros(64))   # CPU tensor

@@ -1,0 +1,97 @@
+"""Kernel micro-benchmarks on one MI355X (run through gpurun).  Random data only
+(zero-filled operands inflate MFMA clocks, guide 5.4 rule 25).  Weight-streaming
+kernels rotate over enough distinct weight copies to defeat the 256 MiB
+Infinity Cache.  Writes JSON lines to gpurun_out/kbench.jsonl."""
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from magma_amd import ops  # noqa: E402
+
+dev = torch.device("cuda:0")
+BF16 = torch.bfloat16
+OUT = os.path.join("gpurun_out", "kbench.jsonl")
+os.makedirs("gpurun_out", exist_ok=True)
+fout = open(OUT, "a")
+
+
+def emit(**kw):
+    line = json.dumps(kw)
+    print(line, flush=True)
+    fout.write(line + "\n")
+    fout.flush()
+
+
+def timeit(fn, iters, warmup=3):
+    for _ in range(warmup):
+        fn(0)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(iters):
+        fn(i)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters  # ms
+
+
+def bench_gemm(M, N, K, layout, act=0, tag=""):
+    a = torch.randn(M, K, device=dev).to(BF16)
+    w = (torch.randn(N, K, device=dev) * 0.05).to(BF16)
+    lin = ops.PackedLinear(w, tiled=(layout == "ft"), rowmajor=(layout == "rm"))
+    out = torch.empty(M, N, dtype=BF16, device=dev)
+    ms = timeit(lambda i: ops.gemm(a, lin, out=out, layout=layout, act=act), 20)
+    emit(kind="gemm", tag=tag, M=M, N=N, K=K, layout=layout, ms=ms, tflops=2.0 * M * N * K / ms / 1e9)
+
+
+def bench_skinny(M, N, K, variants, tag=""):
+    nbytes = N * K * 2
+    ncopy = max(2, int(600e6 // nbytes) + 1)
+    lins = []
+    for c in range(ncopy):
+        w = (torch.randn(N, K, device=dev) * 0.05).to(BF16)
+        lins.append(ops.PackedLinear(w))
+        del w
+    x = torch.randn(M, K, device=dev).to(BF16)
+    out = torch.empty(M, N, dtype=BF16, device=dev)
+    ksteps = lins[0].Kp // 32
+    for (nt, waves, kc) in variants:
+        if ksteps % (waves * kc):
+            continue
+        v = nt | waves << 4 | kc << 8
+        try:
+            ms = timeit(lambda i: ops.gemm_skinny(x, lins[i % ncopy], out=out, variant=v), 4 * ncopy, warmup=ncopy)
+        except Exception as e:  # noqa: BLE001
+            emit(kind="skinny", tag=tag, M=M, N=N, K=K, nt=nt, waves=waves, kc=kc, error=str(e)[:200])
+            continue
+        emit(kind="skinny", tag=tag, M=M, N=N, K=K, nt=nt, waves=waves, kc=kc, ms=ms, gbps=nbytes / ms / 1e6)
+    del lins
+
+
+def main():
+    t0 = time.time()
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which in ("all", "gemm"):
+        for layout in ("ft", "rm"):
+            bench_gemm(4096, 4096, 4096, layout, tag="square4k")
+            bench_gemm(8192, 8192, 8192, layout, tag="square8k")
+            for (N, K, tag) in [(12288, 4096, "qkv"), (16384, 4096, "fc_in"), (4096, 4096, "out_proj"),
+                                (4096, 16384, "fc_out"), (1024, 4096, "adapter_dn"), (4096, 1024, "adapter_up")]:
+                bench_gemm(1216, N, K, layout, tag="prefill152_" + tag)
+            bench_gemm(32768, 16384, 4096, layout, tag="train_fc_in")
+    if which in ("all", "skinny"):
+        variants = [(1, 8, 16), (2, 8, 16), (1, 4, 16), (2, 4, 16), (1, 8, 8), (2, 8, 8), (4, 8, 8), (2, 4, 8),
+                    (4, 4, 8), (1, 8, 4), (2, 8, 4), (4, 8, 4)]
+        for (N, K, tag) in [(12288, 4096, "qkv"), (16384, 4096, "fc_in"), (4096, 4096, "out_proj"),
+                            (4096, 16384, "fc_out"), (1024, 4096, "adapter_dn"), (4096, 1024, "adapter_up"),
+                            (50258, 4096, "lm_head")]:
+            bench_skinny(8, N, K, variants, tag=tag)
+    emit(kind="done", seconds=time.time() - t0)
+
+
+if __name__ == "__main__":
+    main()
