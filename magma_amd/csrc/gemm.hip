@@ -425,8 +425,10 @@ extern "C" int mg_gemm_skinny_bf16(const mg_skinny_desc* d, void* stream) {
   // nt_hint = nt | waves<<4 | kc<<8 (bench/tuning sweeps use this).
   int nt = d->nt_hint & 15, waves = (d->nt_hint >> 4) & 15, kc = (d->nt_hint >> 8) & 255;
   if (d->nt_hint == 0) {
-    if (sp.ksteps % (8 * 16) == 0) { waves = 8; kc = 16; nt = sp.ntiles >= 768 ? 2 : 1; }
-    else if (sp.ksteps % (8 * 4) == 0) { waves = 8; kc = 4; nt = sp.ntiles >= 512 ? 2 : 1; }
+    // measured on MI355X (tools/kbench.py, profiles/r01_kbench_skinny.txt): many
+    // waves with short load bursts beat few waves with deep ones.
+    if (sp.ksteps % (8 * 8) == 0 && sp.ksteps >= 512) { waves = 8; kc = 8; nt = 1; }
+    else if (sp.ksteps % (8 * 4) == 0) { waves = 8; kc = 4; nt = 1; }
     else if (sp.ksteps % 4 == 0) { waves = 4; kc = 1; nt = 1; }
     else { waves = 1; kc = 1; nt = 1; }
   }

@@ -1,0 +1,299 @@
+"""LMEngine -- executes the GPT-J(+adapters) graph on the HIP kernels.
+
+One engine per GPTJForCausalLM.  It owns the device-layout copies of the
+(frozen) weights -- fragment-tiled so that the same bytes feed both the
+128x128 MFMA tile GEMM (prefill / training shapes) and the weight-streaming
+decode GEMM -- the rotary tables, the KV cache objects and, for decode, a
+HIP graph of the whole token step (28 x ~10 launches + head) that is replayed
+per token with the position held in device memory.
+
+Per block (parallel residual, adapters after attention/MLP):
+    ln   = LayerNorm(x)
+    qkv  = ln Wqkv^T                      -> rotary(q,k), K/V scattered into the cache
+    ctx  = causal softmax(q k^T / 16) v   (flash kernel / decode kernel)
+    a    = ctx Wout^T                     [v2: a += Wup relu(Wdn a + b) + b]
+    h    = gelu_new(ln Wfc^T + b)
+    m    = h Wproj^T + b
+    x'   = m + Wup relu(Wdn m + b) + b + a + x     (one GEMM epilogue: bias + 3 residuals)
+"""
+from __future__ import annotations
+
+from typing import Any, List, Optional
+
+import torch
+
+from . import ops
+from .language_model import LMOutput
+
+BF16 = torch.bfloat16
+
+
+def rotary_tables(rotary_dim: int, n_pos: int, device):
+    """sin/cos of pos * 10000^(-2i/rotary_dim) in fp32, computed with the same
+    torch expression as HF/GPT-J's create_sinusoidal_positions so the table is
+    bit-identical to what the reference graph multiplies by."""
+    inv_freq = 1.0 / (10000 ** (torch.arange(0, rotary_dim, 2, dtype=torch.int64).float() / rotary_dim))
+    ang = torch.einsum("i,j->ij", torch.arange(n_pos, dtype=torch.int64).float(), inv_freq)
+    return torch.sin(ang).to(device).contiguous(), torch.cos(ang).to(device).contiguous()
+
+
+class KVCache:
+    """Opaque ``past_key_values`` (reference sampling.py:81-93 only hands it back)."""
+
+    def __init__(self, n_layer: int, B: int, H: int, Smax: int, device):
+        self.k = torch.empty(n_layer, B, H, Smax, 256, dtype=BF16, device=device)
+        self.v = torch.empty(n_layer, B, H, Smax, 256, dtype=BF16, device=device)
+        self.d_pos = torch.zeros(1, dtype=torch.int32, device=device)   # next write position
+        self.pos = 0                                                     # host mirror
+        self.B, self.Smax = B, Smax
+        self.decode_state = None
+
+    def __len__(self):
+        return self.k.shape[0]
+
+
+class _Layer:
+    pass
+
+
+class LMEngine:
+    def __init__(self, lm):
+        cfg = lm.config
+        self.cfg = cfg
+        dev = lm.lm_head.weight.device
+        if dev.type != "cuda":
+            raise ops.L.MagmaHipError("the MAGMA LM runs on MI355X only: move the model to a GPU (no CPU fallback)")
+        self.device = dev
+        self.d, self.H, self.L = cfg.hidden_size, cfg.num_heads, cfg.num_layers
+        if self.d != self.H * 256:
+            raise ValueError("the attention kernels are specialised for head_dim = 256 (GPT-J)")
+        self.eps = cfg.layer_norm_epsilon
+        self.wte = lm.transformer.wte.weight.detach()
+        if self.wte.dtype != BF16:
+            self.wte = self.wte.to(BF16)
+        self.wte = self.wte.contiguous()
+        self.V = lm.lm_head.weight.shape[0]
+        self.layers: List[_Layer] = []
+        f32 = lambda t: t.detach().float().contiguous()  # noqa: E731
+        for blk in lm.transformer.h:
+            ly = _Layer()
+            attn = blk.attn
+            ly.attn_adapter = None
+            if hasattr(attn, "attn_block"):          # AdapterWrapper (v2)
+                ad = attn.adapter
+                ly.attn_adapter = (ops.PackedLinear(ad[0].weight, ad[0].bias), ops.PackedLinear(ad[2].weight, ad[2].bias))
+                attn = attn.attn_block
+            a = attn.attention
+            ly.qkv = ops.PackedLinear(torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], dim=0))
+            ly.out = ops.PackedLinear(a.out_proj.weight)
+            mlp = blk.mlp
+            ly.mlp_adapter = None
+            if isinstance(mlp, torch.nn.Sequential):  # Sequential(mlp, Adapter)  (reference magma.py:143-149)
+                ad = mlp[1].adapter
+                ly.mlp_adapter = (ops.PackedLinear(ad[0].weight, ad[0].bias), ops.PackedLinear(ad[2].weight, ad[2].bias))
+                mlp = mlp[0]
+            ly.fc_in = ops.PackedLinear(mlp.c_fc.weight, mlp.c_fc.bias)
+            ly.fc_out = ops.PackedLinear(mlp.c_proj.weight, mlp.c_proj.bias)
+            ly.ln_g, ly.ln_b = f32(blk.ln_1.weight), f32(blk.ln_1.bias)
+            self.layers.append(ly)
+        self.lnf_g, self.lnf_b = f32(lm.transformer.ln_f.weight), f32(lm.transformer.ln_f.bias)
+        self.head = ops.PackedLinear(lm.lm_head.weight, lm.lm_head.bias)
+        self.Vp = ops.ceil_to(self.V, 8)
+        self.sin_t, self.cos_t = rotary_tables(cfg.rotary_dim, cfg.max_position_embeddings, dev)
+        self.rot = cfg.rotary_dim
+
+    # ------------------------------------------------------------------ API
+    def forward(self, input_ids=None, inputs_embeds=None, labels=None, use_cache=False, past_key_values=None,
+                output_hidden_states=False, cache_hint: Optional[int] = None) -> LMOutput:
+        if labels is not None:
+            if inputs_embeds is None:
+                inputs_embeds = self.embed_ids(input_ids)
+            return self.forward_loss(inputs_embeds, labels, output_hidden_states)
+        if past_key_values is not None:
+            if input_ids is None or input_ids.shape[1] != 1:
+                raise NotImplementedError("cached decoding takes one new token id per sequence (reference sampling.py:88-90)")
+            logits, tok = self.decode(input_ids, past_key_values)
+            return LMOutput(logits=logits.unsqueeze(1), past_key_values=past_key_values, next_token=tok, loss=None)
+        if inputs_embeds is None:
+            inputs_embeds = self.embed_ids(input_ids)
+        if use_cache:
+            logits, cache, hs = self.prefill(inputs_embeds, cache_hint, output_hidden_states)
+            # generate() only reads the last position, so only that row is computed
+            return LMOutput(logits=logits.unsqueeze(1), past_key_values=cache, hidden_states=hs, loss=None)
+        x, hs = self._blocks_prefill(inputs_embeds, None, output_hidden_states)
+        B, S, _ = inputs_embeds.shape
+        logits = self._full_logits(x, B * S).view(B, S, self.V)
+        return LMOutput(logits=logits, past_key_values=None, hidden_states=hs, loss=None)
+
+    def embed_ids(self, ids: torch.Tensor) -> torch.Tensor:
+        ids = ids.to(self.device).contiguous()
+        out = torch.empty(ids.shape[0], ids.shape[1], self.d, dtype=BF16, device=self.device)
+        return ops.embedding(ids, self.wte, out)
+
+    # -------------------------------------------------------------- prefill
+    def _blocks_prefill(self, embeds: torch.Tensor, cache: Optional[KVCache], want_hidden=False, lse_out=None):
+        B, S, d = embeds.shape
+        assert d == self.d
+        if S > self.cfg.max_position_embeddings:
+            raise ValueError(f"sequence length {S} exceeds max_position_embeddings")
+        dev = self.device
+        x = embeds.to(BF16).contiguous().view(B * S, d)
+        M = B * S
+        vt_ld = ops.ceil_to(S, 32)
+        q = torch.empty(B, self.H, S, 256, dtype=BF16, device=dev)
+        vt = torch.empty(B, self.H, 256, vt_ld, dtype=BF16, device=dev)
+        if cache is None:   # no cache requested: one scratch K/V shared by all layers
+            kscr = torch.empty(B, self.H, S, 256, dtype=BF16, device=dev)
+            vscr = torch.empty(B, self.H, S, 256, dtype=BF16, device=dev)
+        ctx = torch.empty(M, d, dtype=BF16, device=dev)
+        hs = [x.view(B, S, d)] if want_hidden else None
+        for li, ly in enumerate(self.layers):
+            ln = ops.layernorm(x, ly.ln_g, ly.ln_b, self.eps)
+            qkv = ops.gemm(ln, ly.qkv)
+            kc, vc = (cache.k[li], cache.v[li]) if cache is not None else (kscr, vscr)
+            ops.rotary_split(qkv, B, S, self.H, self.rot, self.sin_t, self.cos_t, q, kc, vc, pos0=0, vt=vt)
+            ops.attn_prefill(q, kc, vt, ctx, B, self.H, S, lse=None if lse_out is None else lse_out[li])
+            a = ops.gemm(ctx, ly.out)
+            if ly.attn_adapter is not None:
+                t = ops.gemm(a, ly.attn_adapter[0], act=ops.MG_ACT_RELU)
+                a = ops.gemm(t, ly.attn_adapter[1], residuals=(a,))
+            h = ops.gemm(ln, ly.fc_in, act=ops.MG_ACT_GELU_NEW)
+            if ly.mlp_adapter is not None:
+                m = ops.gemm(h, ly.fc_out)
+                t = ops.gemm(m, ly.mlp_adapter[0], act=ops.MG_ACT_RELU)
+                x = ops.gemm(t, ly.mlp_adapter[1], residuals=(m, a, x))
+            else:
+                x = ops.gemm(h, ly.fc_out, residuals=(a, x))
+            if want_hidden:
+                hs.append(x.view(B, S, d))
+        return x, hs
+
+    def prefill(self, embeds: torch.Tensor, cache_hint: Optional[int] = None, want_hidden=False):
+        B, S, _ = embeds.shape
+        n_pos = self.cfg.max_position_embeddings
+        Smax = min(n_pos, ops.ceil_to(S + (cache_hint if cache_hint else 256), 64))
+        cache = KVCache(self.L, B, self.H, Smax, self.device)
+        x, hs = self._blocks_prefill(embeds, cache, want_hidden)
+        cache.pos = S
+        cache.d_pos.fill_(S)
+        last = x.view(B, S, self.d)[:, S - 1, :]                 # strided rows, no copy
+        xl = ops.layernorm(last, self.lnf_g, self.lnf_b, self.eps)
+        logits = self._head(xl)
+        return logits, cache, hs
+
+    def _head(self, xl: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        M = xl.shape[0]
+        if out is None:
+            out = torch.empty(M, self.Vp, dtype=torch.float32, device=self.device)
+        if M <= 16:
+            ops.gemm_skinny(xl, self.head, out=out)
+        else:
+            ops.gemm(xl, self.head, out=out)
+        return out[:, : self.V]
+
+    def _full_logits(self, x: torch.Tensor, M: int) -> torch.Tensor:
+        xl = ops.layernorm(x, self.lnf_g, self.lnf_b, self.eps)
+        out = torch.empty(M, self.Vp, dtype=BF16, device=self.device)
+        ops.gemm(xl, self.head, out=out)
+        return out[:, : self.V]
+
+    # --------------------------------------------------------------- decode
+    def _alloc_decode_state(self, cache: KVCache):
+        B, d, dev = cache.B, self.d, self.device
+        ff = self.layers[0].fc_in.N
+        st = _Layer()
+        e = lambda *s, dt=BF16: torch.empty(*s, dtype=dt, device=dev)  # noqa: E731
+        st.ids = torch.zeros(B, 1, dtype=torch.int64, device=dev)
+        st.xa, st.xb = e(B, d), e(B, d)
+        st.ln, st.qkv, st.q = e(B, d), e(B, 3 * d), e(B, self.H, 1, 256)
+        st.ctx, st.a, st.a2, st.h, st.m = e(B, d), e(B, d), e(B, d), e(B, ff), e(B, d)
+        r_mlp = max([ly.mlp_adapter[0].N for ly in self.layers if ly.mlp_adapter] + [8])
+        r_att = max([ly.attn_adapter[0].N for ly in self.layers if ly.attn_adapter] + [8])
+        st.t, st.ta = e(B, r_mlp), e(B, r_att)
+        st.lnf = e(B, d)
+        st.logits = e(B, self.Vp, dt=torch.float32)
+        st.token = torch.zeros(B, dtype=torch.int64, device=dev)
+        st.graph = None
+        st.steps = 0
+        return st
+
+    def _decode_step(self, cache: KVCache, st):
+        """Enqueue one token step for all B sequences (graph-capturable: no
+        allocation, no sync, position read from cache.d_pos on the device)."""
+        B = cache.B
+        ops.embedding(st.ids, self.wte, st.xa.view(B, 1, self.d))
+        x, xn = st.xa, st.xb
+        for li, ly in enumerate(self.layers):
+            ops.layernorm(x, ly.ln_g, ly.ln_b, self.eps, out=st.ln)
+            ops.gemm_skinny(st.ln, ly.qkv, out=st.qkv)
+            ops.gemm_skinny(st.ln, ly.fc_in, out=st.h, act=ops.MG_ACT_GELU_NEW)
+            ops.rotary_split(st.qkv, B, 1, self.H, self.rot, self.sin_t, self.cos_t, st.q, cache.k[li], cache.v[li],
+                             d_pos=cache.d_pos)
+            ops.attn_decode(st.q, cache.k[li], cache.v[li], st.ctx, B, self.H, cache.d_pos)
+            a = ops.gemm_skinny(st.ctx, ly.out, out=st.a)
+            if ly.attn_adapter is not None:
+                ta = st.ta[:, : ly.attn_adapter[0].N]
+                ops.gemm_skinny(a, ly.attn_adapter[0], out=ta, act=ops.MG_ACT_RELU)
+                a = ops.gemm_skinny(ta, ly.attn_adapter[1], out=st.a2, residuals=(a,))
+            if ly.mlp_adapter is not None:
+                ops.gemm_skinny(st.h, ly.fc_out, out=st.m)
+                t = st.t[:, : ly.mlp_adapter[0].N]
+                ops.gemm_skinny(st.m, ly.mlp_adapter[0], out=t, act=ops.MG_ACT_RELU)
+                ops.gemm_skinny(t, ly.mlp_adapter[1], out=xn, residuals=(st.m, a, x))
+            else:
+                ops.gemm_skinny(st.h, ly.fc_out, out=xn, residuals=(a, x))
+            x, xn = xn, x
+        ops.layernorm(x, self.lnf_g, self.lnf_b, self.eps, out=st.lnf)
+        ops.gemm_skinny(st.lnf, self.head, out=st.logits)
+        ops.argmax(st.logits[:, : self.V], out=st.token)
+        ops.advance_pos(cache.d_pos, 1)
+
+    def decode(self, input_ids: torch.Tensor, cache: KVCache, use_graph: bool = True):
+        """One cached step.  Returns (fp32 logits (B,V) view, greedy token (B,) view);
+        both are overwritten by the next step."""
+        if cache.pos >= cache.Smax:
+            raise ValueError(f"KV cache full (Smax={cache.Smax}); pass a larger cache_hint / max_steps")
+        if cache.B > 16:
+            raise NotImplementedError("decode batch > 16 per GPU is not implemented (weight-streaming kernel is M<=16)")
+        st = cache.decode_state
+        if st is None:
+            st = cache.decode_state = self._alloc_decode_state(cache)
+        st.ids.copy_(input_ids.reshape(cache.B, 1))
+        if not use_graph:
+            self._decode_step(cache, st)
+        elif st.graph is not None:
+            st.graph.replay()
+        elif st.steps == 0:
+            self._decode_step(cache, st)          # first step eager (loads code objects)
+        else:
+            g = torch.cuda.CUDAGraph()            # hipGraph on ROCm
+            with torch.cuda.graph(g):
+                self._decode_step(cache, st)
+            st.graph = g
+            g.replay()
+        st.steps += 1
+        cache.pos += 1
+        return st.logits[:, : self.V], st.token
+
+    # ------------------------------------------------- loss (eval) forward
+    def forward_loss(self, embeds: torch.Tensor, labels: torch.Tensor, want_hidden=False) -> LMOutput:
+        """Shifted cross-entropy of the full sequence (reference magma.py:270-274).
+        lm_head + CE are evaluated only on rows that carry a target (the others
+        contribute nothing to the loss); inference-mode forward, see train engine
+        for the autograd version."""
+        B, S, _ = embeds.shape
+        x, hs = self._blocks_prefill(embeds, None, want_hidden)
+        labels = labels.to(self.device)
+        tgt = labels[:, 1:].reshape(-1)
+        rows = (torch.arange(B, device=self.device)[:, None] * S + torch.arange(S - 1, device=self.device)[None, :]).reshape(-1)
+        keep = (tgt != -100).nonzero().squeeze(1)           # host sync: index plumbing only
+        if keep.numel() == 0:
+            return LMOutput(loss=torch.full((), float("nan"), device=self.device), logits=None, hidden_states=hs,
+                            past_key_values=None)
+        xr = x.index_select(0, rows[keep])
+        xl = ops.layernorm(xr, self.lnf_g, self.lnf_b, self.eps)
+        logits = torch.empty(xl.shape[0], self.Vp, dtype=torch.float32, device=self.device)
+        ops.gemm(xl, self.head, out=logits)
+        loss, _ = ops.cross_entropy(logits[:, : self.V], tgt[keep].contiguous())
+        return LMOutput(loss=loss, logits=None, hidden_states=hs, past_key_values=None,
+                        target_rows=rows[keep], target_logits=logits[:, : self.V])

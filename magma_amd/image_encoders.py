@@ -1,0 +1,165 @@
+"""Image encoders for the MAGMA path (reference magma/image_encoders.py:48-91).
+
+Only ``clip_resnet_large`` (CLIP RN50x16 trunk with the attention pool replaced
+by ``b d h w -> b (h w) d``) is selected by the shipped YAMLs and is in scope;
+the others raise.  The module tree carries openai/CLIP's
+parameter names (conv1..3, bn1..3, layer{1..4}.{j}.{conv,bn}{1..3},
+downsample.{0,1}) so reference checkpoints load by name, but the arithmetic is
+NOT torch: forward() drives the HIP kernels -- NHWC activations, every conv an
+MFMA GEMM (1x1: plain, 3x3: implicit im2col, stem: explicit im2col) with the
+eval-mode BatchNorm folded into the epilogue's per-channel scale/shift, ReLU
+and the bottleneck's residual add fused as well."""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+CLIP_RESNETS = {
+    # name: (layers, width, input_resolution)
+    "clip_resnet_large": ((6, 8, 18, 8), 96, 384),  # RN50x16
+}
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, **kw):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False, **kw)
+        self.bn1 = nn.BatchNorm2d(planes, **kw)
+        self.conv2 = nn.Conv2d(planes, planes, 3, padding=1, bias=False, **kw)
+        self.bn2 = nn.BatchNorm2d(planes, **kw)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False, **kw)
+        self.bn3 = nn.BatchNorm2d(planes * 4, **kw)
+        self.stride = stride
+        self.downsample = None
+        if stride > 1 or inplanes != planes * 4:
+            self.downsample = nn.Sequential(OrderedDict([
+                ("-1", nn.AvgPool2d(stride)),
+                ("0", nn.Conv2d(inplanes, planes * 4, 1, stride=1, bias=False, **kw)),
+                ("1", nn.BatchNorm2d(planes * 4, **kw)),
+            ]))
+
+
+class ModifiedResNetTrunk(nn.Module):
+    """CLIP ModifiedResNet without attnpool: (B,3,H,W) -> (B, H/32*W/32, 32*width)."""
+
+    def __init__(self, layers=(6, 8, 18, 8), width=96, input_resolution=384, device=None, dtype=None):
+        super().__init__()
+        kw = dict(device=device, dtype=dtype)
+        self.input_resolution = input_resolution
+        self.width = width
+        self.conv1 = nn.Conv2d(3, width // 2, 3, stride=2, padding=1, bias=False, **kw)
+        self.bn1 = nn.BatchNorm2d(width // 2, **kw)
+        self.conv2 = nn.Conv2d(width // 2, width // 2, 3, padding=1, bias=False, **kw)
+        self.bn2 = nn.BatchNorm2d(width // 2, **kw)
+        self.conv3 = nn.Conv2d(width // 2, width, 3, padding=1, bias=False, **kw)
+        self.bn3 = nn.BatchNorm2d(width, **kw)
+        self._inplanes = width
+        self.layer1 = self._make_layer(width, layers[0], 1, kw)
+        self.layer2 = self._make_layer(width * 2, layers[1], 2, kw)
+        self.layer3 = self._make_layer(width * 4, layers[2], 2, kw)
+        self.layer4 = self._make_layer(width * 8, layers[3], 2, kw)
+        self.out_dim = width * 32
+        self._packed = None
+        self.eval()  # clip.load(...) returns the tower in eval mode
+
+    def _make_layer(self, planes, blocks, stride, kw):
+        mods = [Bottleneck(self._inplanes, planes, stride, **kw)]
+        self._inplanes = planes * 4
+        for _ in range(1, blocks):
+            mods.append(Bottleneck(self._inplanes, planes, **kw))
+        return nn.Sequential(*mods)
+
+    # ---- weight packing (one-off re-layout; invalidated when params change) ----
+    def invalidate_packed(self):
+        self._packed = None
+
+    def _pack_conv(self, conv: nn.Conv2d, bn: nn.BatchNorm2d):
+        w = conv.weight.detach()
+        cout, cin, kh, _ = w.shape
+        if kh == 1:
+            w2 = w.reshape(cout, cin)
+        elif cin == 3:  # stem conv1: explicit im2col columns (ky,kx,c), padded to 32
+            w2 = torch.zeros(cout, 32, dtype=w.dtype, device=w.device)
+            w2[:, :27] = w.permute(0, 2, 3, 1).reshape(cout, 27)
+        else:
+            w2 = w.permute(0, 2, 3, 1).reshape(cout, 9 * cin)
+        scale = (bn.weight.detach().float() / torch.sqrt(bn.running_var.float() + bn.eps)).contiguous()
+        shift = (bn.bias.detach().float() - bn.running_mean.float() * scale).contiguous()
+        return ops.PackedLinear(w2, bias=shift), scale
+
+    def _ensure_packed(self):
+        if self._packed is not None:
+            return self._packed
+        if self.training:
+            raise NotImplementedError("batch-statistics BatchNorm is not implemented; the reference runs the tower "
+                                      "in eval mode until its first eval phase (SURVEY Q5)")
+        pk = {"conv1": self._pack_conv(self.conv1, self.bn1), "conv2": self._pack_conv(self.conv2, self.bn2),
+              "conv3": self._pack_conv(self.conv3, self.bn3)}
+        for li in range(1, 5):
+            for j, blk in enumerate(getattr(self, f"layer{li}")):
+                pre = f"layer{li}.{j}."
+                pk[pre + "conv1"] = self._pack_conv(blk.conv1, blk.bn1)
+                pk[pre + "conv2"] = self._pack_conv(blk.conv2, blk.bn2)
+                pk[pre + "conv3"] = self._pack_conv(blk.conv3, blk.bn3)
+                if blk.downsample is not None:
+                    pk[pre + "down"] = self._pack_conv(blk.downsample[1], blk.downsample[2])
+        self._packed = pk
+        return pk
+
+    # ---- forward on the HIP kernels ----
+    @staticmethod
+    def _conv(a, packed, relu=True, conv=None, residual=None):
+        lin, scale = packed
+        if residual is None:
+            return ops.gemm(a, lin, scale=scale, act=ops.MG_ACT_RELU if relu else ops.MG_ACT_NONE, conv=conv)
+        return ops.gemm(a, lin, scale=scale, residuals=(residual,), act_after=ops.MG_ACT_RELU, conv=conv)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        pk = self._ensure_packed()
+        if x.ndim != 4 or x.shape[1] != 3 or x.shape[2] % 32 or x.shape[3] % 32:
+            raise ValueError(f"expected (B,3,H,W) with H,W multiples of 32, got {tuple(x.shape)}")
+        x = x.to(torch.bfloat16).contiguous()
+        B, _, H, W = x.shape
+        h, w = H // 2, W // 2
+        y = self._conv(ops.stem_im2col(x), pk["conv1"])                       # [B*h*w, width/2]
+        y = self._conv(y, pk["conv2"], conv=(h, w, y.shape[1]))
+        y = self._conv(y, pk["conv3"], conv=(h, w, y.shape[1]))
+        y = ops.avgpool2(y.view(B, h, w, -1))
+        h, w = h // 2, w // 2
+        y = y.view(B * h * w, -1)
+        for li in range(1, 5):
+            for j, blk in enumerate(getattr(self, f"layer{li}")):
+                pre = f"layer{li}.{j}."
+                identity = y
+                out = self._conv(y, pk[pre + "conv1"])
+                out = self._conv(out, pk[pre + "conv2"], conv=(h, w, out.shape[1]))
+                if blk.stride > 1:
+                    out = ops.avgpool2(out.view(B, h, w, -1)).view(B * (h // 2) * (w // 2), -1)
+                if blk.downsample is not None:
+                    if blk.stride > 1:
+                        identity = ops.avgpool2(identity.view(B, h, w, -1)).view(B * (h // 2) * (w // 2), -1)
+                    identity = self._conv(identity, pk[pre + "down"], relu=False)
+                if blk.stride > 1:
+                    h, w = h // 2, w // 2
+                y = self._conv(out, pk[pre + "conv3"], residual=identity)
+        return y.view(B, h * w, -1)   # NHWC rows == "b (h w) d": the rearrange is free
+
+
+def clip_encoder(device=None, name: str = "clip_resnet_large", dtype=None) -> nn.Module:
+    if name in ("clip_resnet_large", "RN50x16"):
+        layers, width, res = CLIP_RESNETS["clip_resnet_large"]
+        return ModifiedResNetTrunk(layers, width, res, device=device, dtype=dtype)
+    raise NotImplementedError(f"encoder {name!r} is out of scope for the MI355X path (SURVEY 8f row 4); "
+                              "only clip_resnet_large (RN50x16) is implemented")
+
+
+def get_image_encoder(name: str, device=None, pretrained: bool = False, dtype=None) -> nn.Module:
+    if "clip" in name:
+        return clip_encoder(device=device, name=name, dtype=dtype)
+    raise NotImplementedError(f"image encoder {name!r} is out of scope for the MI355X path (SURVEY 8f row 4)")

@@ -1,0 +1,245 @@
+"""Magma -- drop-in for reference magma/magma.py on MI355X.
+
+Same public surface: ``Magma(config, device)``, ``from_checkpoint``,
+``preprocess_inputs``, ``embed``, ``forward``, ``generate``, ``add_adapters``
+and the attributes callers read (tokenizer, config, transforms, seq_len,
+image_prefix, lm, word_embedding, transformer, image_token, eos_token, device).
+The module tree keeps the reference's parameter names; the arithmetic runs in
+libmagma_hip.so.  Differences: weights are created directly on the
+GPU in bf16 (the reference builds fp32 on the CPU, then .half()); ``device``
+must be a GPU -- there is no CPU execution path; SURVEY Q2 ("freeze_lm" as the
+paper intends: only adapters, the image encoder and the prefix train)."""
+from __future__ import annotations
+
+from copy import deepcopy
+from os.path import exists
+from pathlib import Path
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from .adapters import Adapter, AdapterWrapper
+from .config import MultimodalConfig
+from .image_input import ImageInput
+from .image_prefix import ImagePrefix
+from .language_model import GPTJConfig, LMOutput, get_gptj
+from .sampling import generate
+from .transforms import get_transforms
+from .utils import build_labels, get_tokenizer, print_main
+
+
+class Magma(nn.Module):
+    def __init__(self, config, device=None, lm_config: Optional[GPTJConfig] = None, enc: nn.Module = None,
+                 dtype=torch.bfloat16, init_seed: Optional[int] = None):
+        super().__init__()
+        if isinstance(config, (str, Path)):
+            config = MultimodalConfig.from_yml(config)
+        else:
+            assert isinstance(config, MultimodalConfig)
+        self.device = torch.device(device) if device is not None else torch.device(
+            "cuda" if torch.cuda.is_available() else "cpu")
+        if self.device.type != "cuda":
+            from .lib import MagmaHipError
+            raise MagmaHipError("magma_amd.Magma runs on MI355X only (device=%s requested); there is no CPU "
+                                "execution path -- the CPU restatement lives in oracle/ and is test-only" % self.device)
+        self.config = config
+        self.dtype = dtype
+        self.lm = get_gptj(device=self.device, dtype=dtype, config=lm_config, init=True)
+        if init_seed is not None:
+            self.lm.init_weights(init_seed)
+        self.seq_len = self.lm.config.max_position_embeddings
+        self.tokenizer = get_tokenizer("gpt2", sequence_length=self.seq_len)
+        self.image_token = self.tokenizer.cls_token_id
+        self.eos_token = self.tokenizer.eos_token_id
+        if lm_config is None:   # full-size model: len(tokenizer) = 50258
+            self.lm.resize_token_embeddings(len(self.tokenizer))
+        elif self.lm.config.vocab_size < len(self.tokenizer):
+            # reduced test vocabularies: keep the special ids in range (eos = V-2, image = V-1)
+            self.eos_token, self.image_token = self.lm.config.vocab_size - 2, self.lm.config.vocab_size - 1
+        self.lm.config.pad_token_id = self.tokenizer.eos_token_id
+        self.word_embedding = self.lm.transformer.wte
+        self.transformer = self.lm.transformer.h
+        self.mlp_adapter_added, self.attn_adapter_added = False, False
+        self.image_prefix = ImagePrefix(config=config, out_dim=self.lm.config.hidden_size, device=self.device,
+                                        dtype=dtype, enc=enc)
+        self.image_prefix_seq_len = self.image_prefix.out_seq_len
+        self.transforms = get_transforms(config.image_size, config.encoder_name,
+                                         input_resolution=self.image_prefix.enc.input_resolution)
+        if config.adapter_config:
+            mlp_config = deepcopy(config.adapter_config.get("mlp", None))
+            if mlp_config:
+                assert mlp_config.get("adapter_type") is not None
+                self.add_adapters(location="mlp", adapter_type=mlp_config.pop("adapter_type"),
+                                  downsample_factor=mlp_config.pop("downsample_factor", 4), **mlp_config)
+            attn_config = deepcopy(config.adapter_config.get("attention", None))
+            if attn_config:
+                assert attn_config.get("adapter_type") is not None
+                self.add_adapters(location="attention", adapter_type=attn_config.pop("adapter_type"), **attn_config)
+        # trainable set: adapters + image encoder + proj/ln; LM frozen
+        if config.freeze_lm:
+            for name, p in self.lm.named_parameters():
+                p.requires_grad = bool(config.adapter_config) and "adapter" in name
+        if config.freeze_img_encoder:
+            for p in self.image_prefix.enc.parameters():
+                p.requires_grad = False
+
+    # ------------------------------------------------------------ adapters
+    def add_adapters(self, downsample_factor: int = 4, adapter_type: str = "normal", location: str = "mlp",
+                     ff_attr: str = "mlp", attn_attr: str = "attn", **adapter_kwargs):
+        assert adapter_type in ["normal", "parallel", "scaled_parallel"], \
+            "adapter_type must be one of 'normal', 'parallel', or 'scaled_parallel'"
+        assert location in ["mlp", "attention"], "location must be one of 'mlp' or 'attention'"
+        if adapter_type != "normal":
+            raise NotImplementedError("parallel adapters are not used by MAGMA_v1/v2 and are out of scope (SURVEY 8f row 4)")
+        if (location == "mlp" and self.mlp_adapter_added) or (location == "attention" and self.attn_adapter_added):
+            raise ValueError("Adapter layer already added")
+        dim = self.lm.config.hidden_size
+        kw = dict(device=self.device, dtype=self.dtype)
+        for blk in self.transformer:
+            if location == "mlp":
+                adpt = Adapter(dim=dim, downsample_factor=downsample_factor, **adapter_kwargs, **kw)
+                setattr(blk, ff_attr, nn.Sequential(getattr(blk, ff_attr), adpt))
+            else:
+                setattr(blk, attn_attr, AdapterWrapper(attn_block=getattr(blk, attn_attr), dim=dim,
+                                                       downsample_factor=downsample_factor, **adapter_kwargs, **kw))
+        if location == "mlp":
+            self.mlp_adapter_added = True
+        else:
+            self.attn_adapter_added = True
+        self.lm.invalidate_packed()
+
+    def invalidate_packed(self):
+        self.lm.invalidate_packed()
+        self.image_prefix.invalidate_packed()
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        r = super().load_state_dict(state_dict, strict=strict)
+        self.invalidate_packed()
+        return r
+
+    # -------------------------------------------------------------- inputs
+    def preprocess_inputs(self, input_list: list, embed=True) -> List[torch.Tensor]:
+        """Strings -> token ids, ImageInput -> normalised image tensor; mutates the
+        caller's list in place exactly like the reference (magma.py:181-186)."""
+        for i in range(len(input_list)):
+            inp = input_list[i]
+            if isinstance(inp, str):
+                input_list[i] = self.tokenizer.encode(inp, return_tensors="pt")
+            elif isinstance(inp, ImageInput):
+                input_list[i] = inp.get_transformed_image(transform_fn=self.transforms)
+            else:
+                raise Exception(f"Invalid input type:{type(inp)}")
+        return self.embed(input_list) if embed else input_list
+
+    @torch.no_grad()
+    def embed(self, inputs: List[torch.Tensor]) -> torch.Tensor:
+        """2-D -> word embeddings, 4-D -> image prefix; written straight into one
+        (b, s, d) buffer (replaces the torch.cat at reference magma.py:212)."""
+        from . import ops
+        parts, total, B = [], 0, None
+        for x in inputs:
+            if x.ndim == 2:
+                n = x.shape[1]
+            elif x.ndim == 4:
+                n = None
+            else:
+                raise ValueError(f"Expected 2d or 4d tensor, got {x.ndim}d")
+            parts.append(n)
+            B = x.shape[0] if B is None else B
+            assert x.shape[0] == B, "all inputs must share the batch size"
+        d = self.lm.config.hidden_size
+        embs = []
+        for x, n in zip(inputs, parts):
+            if n is None:
+                embs.append(self.image_prefix(x.to(self.device)))
+                total += embs[-1].shape[1]
+            else:
+                embs.append(None)
+                total += n
+        out = torch.empty(B, total, d, dtype=self.dtype, device=self.device)
+        off = 0
+        for x, n, e in zip(inputs, parts, embs):
+            if e is None:
+                ops.embedding(x.to(self.device).contiguous(), self.lm.engine.wte, out, row_off=off)
+                off += n
+            else:
+                out[:, off:off + e.shape[1]] = e
+                off += e.shape[1]
+        return out
+
+    @torch.no_grad()
+    def generate(self, embeddings, max_steps: int = 100, temperature: float = 0.7, top_k: int = 0,
+                 top_p: float = 0.9, decode: bool = True, stop_on_eos: bool = True):
+        return generate(self, embeddings=embeddings, max_steps=max_steps, temperature=temperature, top_k=top_k,
+                        top_p=top_p, decode=decode, stop_on_eos=stop_on_eos)
+
+    # ------------------------------------------------------------- forward
+    def forward(self, images=None, captions=None, output_hidden_states: bool = False, input_embeddings=None,
+                dropout_mask=None) -> LMOutput:
+        assert captions is not None, "Must provide captions in training"
+        assert (images is None) != (input_embeddings is None), "Pass in either images, or input embeddings, not both."
+        assert captions.shape[1] == self.seq_len, \
+            f"in training, captions should be padded to sequence length ({self.seq_len}), but are length {captions.shape[1]}"
+        from . import ops
+        captions = captions.to(self.device).contiguous()
+        if input_embeddings is None:
+            input_embeddings = self.image_prefix(images.to(self.device), dropout_mask=dropout_mask)
+        P = input_embeddings.shape[1]
+        labels = build_labels(input_embeddings, captions, self.eos_token, self.device)
+        B, S = captions.shape
+        emb = torch.empty(B, S, self.lm.config.hidden_size, dtype=self.dtype, device=self.device)
+        emb[:, :P] = input_embeddings
+        ops.embedding(captions[:, : S - P].contiguous(), self.lm.engine.wte, emb, row_off=P)
+        out = self.lm(inputs_embeds=emb, labels=labels, output_hidden_states=output_hidden_states)
+        out["labels"] = labels
+        return out
+
+    # ---------------------------------------------------------- checkpoints
+    @classmethod
+    def from_checkpoint(cls, config_path, checkpoint_path, device="cuda"):
+        """Load a (DeepSpeed-layout) MAGMA checkpoint: a torch-saved dict, optionally
+        wrapped in "module" (reference magma.py:292-297).  The download fallback of
+        the reference needs the network and is not reproduced."""
+        if not exists(checkpoint_path):
+            raise FileNotFoundError(f"checkpoint {checkpoint_path} does not exist (no network download in this build)")
+        model = cls(config=config_path, device=device)
+        sd = torch.load(checkpoint_path, map_location=torch.device("cpu"))
+        if "module" in sd.keys():
+            sd = sd["module"]
+        print_main(f"loading magma checkpoint from: {checkpoint_path}")
+        model.load_checkpoint_state(sd)
+        print_main("magma successfully loaded")
+        model.eval()
+        return model
+
+    def load_checkpoint_state(self, sd: dict):
+        """strict=False load that tolerates the reference's aliases (SURVEY Q8:
+        ``transformer.N...`` / ``word_embedding.weight`` duplicate ``lm.transformer...``),
+        skips buffers of the fork (attention.bias / masked_bias) and sniffs the
+        vocabulary rows of wte / lm_head (Q1)."""
+        own = self.state_dict()
+        fixed = {}
+        for k, v in sd.items():
+            if k.endswith("attention.bias") or k.endswith("masked_bias"):
+                continue
+            if k.startswith("transformer."):
+                k = "lm." + k
+            elif k == "word_embedding.weight":
+                k = "lm.transformer.wte.weight"
+            fixed[k] = v
+        for name in ("lm.transformer.wte.weight", "lm.lm_head.weight"):
+            if name in fixed and name in own and fixed[name].shape[0] != own[name].shape[0]:
+                self.lm.resize_token_embeddings(fixed[name].shape[0])
+                self.word_embedding = self.lm.transformer.wte
+                own = self.state_dict()
+        missing, unexpected = [], []
+        with torch.no_grad():
+            for k, v in fixed.items():
+                if k in own and own[k].shape == v.shape:
+                    own[k].copy_(v.to(own[k].dtype))
+                else:
+                    unexpected.append(k)
+        missing = [k for k in own if k not in fixed]
+        self.invalidate_packed()
+        return missing, unexpected

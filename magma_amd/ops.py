@@ -119,8 +119,8 @@ def gemm(a: torch.Tensor, w: PackedLinear, out: Optional[torch.Tensor] = None, *
     _need_gpu(a)
     assert a.dtype == BF16 and a.ndim == 2 and a.stride(1) == 1
     M = a.shape[0]
-    if out is None:
-        out = torch.empty(M, w.N, dtype=out_dtype, device=a.device)
+    if out is None:  # row stride padded to 8 elements (the C ABI wants ldc % 4 == 0)
+        out = torch.empty(M, ceil_to(w.N, 8), dtype=out_dtype, device=a.device)[:, : w.N]
     assert out.ndim == 2 and out.shape[0] == M and out.shape[1] >= w.N and out.stride(1) == 1
     d = GemmDesc()
     d.A, d.lda = a.data_ptr(), a.stride(0)
@@ -153,7 +153,7 @@ def gemm_skinny(x: torch.Tensor, w: PackedLinear, out: Optional[torch.Tensor] = 
     assert x.shape[1] == w.Kp, "decode activations must span the padded K"
     M = x.shape[0]
     if out is None:
-        out = torch.empty(M, w.N, dtype=out_dtype, device=x.device)
+        out = torch.empty(M, ceil_to(w.N, 8), dtype=out_dtype, device=x.device)[:, : w.N]
     d = SkinnyDesc()
     d.X, d.ldx, d.W = x.data_ptr(), x.stride(0), w.ft.data_ptr()
     d.M, d.N, d.Kp, d.nt_hint = M, w.N, w.Kp, variant

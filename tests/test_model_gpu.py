@@ -1,0 +1,155 @@
+"""Model-level parity: the HIP path (through the Magma drop-in API and the C ABI)
+against the CPU oracle on the same seeded weights and inputs.
+
+Tolerance: err(HIP bf16, oracle fp32) <= 2 x err(oracle run in bf16
+with PyTorch CPU kernels, oracle fp32) + a small floor; integer outputs (labels,
+greedy ids where the oracle's own top-1/top-2 margin exceeds bf16 noise) exact."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-12))
+
+
+def bf16_params(p):
+    return {k: (v.to(torch.bfloat16) if v.is_floating_point() else v) for k, v in p.items()}
+
+
+def check(err_hip, err_bf16, what, floor=2e-3):
+    assert err_hip <= 2.0 * err_bf16 + floor, f"{what}: HIP err {err_hip:.3e} vs eager-bf16 err {err_bf16:.3e}"
+
+
+@pytest.fixture(scope="module", params=["v1", "v2"])
+def setup(request, dev):
+    from magma_amd.testing import build_reduced_magma
+    from oracle.model import OracleConfig, init_params
+    v2 = request.param == "v2"
+    cfg = OracleConfig.tiny(mlp_adapter_hidden=64 if v2 else 128, attn_adapter_hidden=64 if v2 else 0)
+    params = init_params(cfg, seed=11)
+    # larger adapter weights than the 1e-3 init so adapter arithmetic is visible in the outputs
+    for k in params:
+        if ".adapter." in k:
+            params[k] = params[k] * 20
+    model = build_reduced_magma(dev, mlp_factor=8 if v2 else 4, attn_factor=8 if v2 else None)
+    missing, unexpected = model.load_checkpoint_state(params)
+    assert not unexpected, unexpected
+    assert all(k.endswith("num_batches_tracked") or k.startswith(("transformer.", "word_embedding.")) for k in missing), missing
+    model.eval()
+    g = torch.Generator().manual_seed(5)
+    images = torch.randn(2, 3, 64, 64, generator=g)
+    ids = torch.randint(0, 1000, (2, 6), generator=g)
+    return cfg, params, model, images, ids
+
+
+def test_encoder_and_prefix(setup):
+    from oracle.model import encoder_fwd, image_prefix_fwd
+    cfg, p, model, images, _ = setup
+    pb = bf16_params(p)
+    ref = encoder_fwd(p, cfg, images)
+    got = model.image_prefix.enc(images.cuda())
+    eb = rel(encoder_fwd(pb, cfg, images.to(torch.bfloat16)), ref)
+    check(rel(got, ref), eb, "CLIP trunk", floor=5e-3)
+    ref2 = image_prefix_fwd(p, cfg, images)
+    got2 = model.image_prefix(images.cuda())
+    eb2 = rel(image_prefix_fwd(pb, cfg, images.to(torch.bfloat16)), ref2)
+    check(rel(got2, ref2), eb2, "ImagePrefix", floor=5e-3)
+    assert got2.shape == (2, 4, cfg.d_model)
+
+
+def test_embed_matches_reference_layout(setup):
+    from oracle.model import embed
+    cfg, p, model, images, ids = setup
+    got = model.embed([images, ids])
+    ref = embed(p, cfg, [images, ids])
+    assert got.shape == ref.shape == (2, 4 + 6, cfg.d_model)
+    assert rel(got[:, 4:], ref[:, 4:]) < 4e-3          # text rows: pure gather (bf16 rounding of the table)
+    # preprocess_inputs plumbing (string + already-transformed image), in-place list mutation like the reference
+    lst = [images[:1].clone(), "hi"]
+    out = model.preprocess_inputs(lst, embed=False)
+    assert out is lst and lst[1].ndim == 2 and lst[1].dtype == torch.int64
+
+
+def test_prefill_and_decode_logits(setup):
+    from oracle.model import embed, generate_greedy
+    cfg, p, model, images, ids = setup
+    pb = bf16_params(p)
+    emb_ref = embed(p, cfg, [images, ids])
+    steps = 5
+    ref_toks, ref_logits = generate_greedy(p, cfg, emb_ref, steps, stop_on_eos=False)
+    # eager bf16 baseline of the same graph, teacher-forced on the oracle's tokens
+    bf_toks, bf_logits = generate_greedy(pb, cfg, emb_ref.to(torch.bfloat16), steps, stop_on_eos=False)
+    emb = emb_ref.to(torch.bfloat16).cuda()       # same inputs into the LM
+    out = model.lm(inputs_embeds=emb, use_cache=True, cache_hint=steps)
+    check(rel(out.logits[:, -1], ref_logits[0]), rel(bf_logits[0], ref_logits[0]), "prefill logits")
+    past = out.past_key_values
+    S0 = emb.shape[1]
+    for i in range(1, steps):
+        tok = ref_toks[:, S0 + i - 1: S0 + i].cuda()       # teacher forcing with the oracle's token
+        out = model.lm(input_ids=tok, use_cache=True, past_key_values=past)
+        if bool((bf_toks[:, :S0 + i] == ref_toks[:, :S0 + i]).all()):
+            eb = rel(bf_logits[i], ref_logits[i])
+        else:
+            eb = 1e-2
+        check(rel(out.logits[:, -1], ref_logits[i]), eb, f"decode step {i} logits")
+        # greedy id exact wherever the oracle's margin is above bf16 noise
+        top2 = torch.topk(ref_logits[i], 2, dim=-1).values
+        safe = (top2[:, 0] - top2[:, 1]) > 0.05 * ref_logits[i].std()
+        assert bool((out.next_token.cpu()[safe] == ref_logits[i].argmax(-1)[safe]).all())
+
+
+def test_generate_api_and_graph_equals_eager(setup):
+    cfg, p, model, images, ids = setup
+    emb = model.embed([images, ids])
+    a = model.generate(emb, max_steps=6, temperature=0.0, decode=False, stop_on_eos=False)
+    assert a.shape == (2, emb.shape[1] + 6) and bool((a[:, : emb.shape[1]] == model.image_token).all())
+    # same thing with the decode graph disabled
+    eng = model.lm.engine
+    out = model.lm(inputs_embeds=emb, use_cache=True, cache_hint=6)
+    toks = [out.logits[:, -1].argmax(-1)]
+    cache = out.past_key_values
+    for _ in range(5):
+        lg, tk = eng.decode(toks[-1][:, None], cache, use_graph=False)
+        toks.append(tk.clone())
+    assert torch.equal(a[:, emb.shape[1]:], torch.stack(toks, 1))
+    strs = model.generate(emb, max_steps=3, temperature=0.7, top_k=5, top_p=0.9)
+    assert isinstance(strs, list) and len(strs) == 2 and all(isinstance(s, str) for s in strs)
+
+
+def test_forward_loss(setup):
+    from oracle.model import magma_forward
+    cfg, p, model, images, _ = setup
+    pb = bf16_params(p)
+    S = model.seq_len
+    g = torch.Generator().manual_seed(9)
+    caps = torch.full((2, S), cfg.eos_token, dtype=torch.int64)
+    caps[0, :20] = torch.randint(0, 1000, (20,), generator=g)
+    caps[1, :9] = torch.randint(0, 1000, (9,), generator=g)
+    ref = magma_forward(p, cfg, images, caps)
+    bf = magma_forward(pb, cfg, images.to(torch.bfloat16), caps)
+    out = model(images.cuda(), caps.cuda())
+    assert torch.equal(out.labels.cpu(), ref["labels"])                       # integer path: exact
+    e_hip = abs(float(out.loss) - float(ref["loss"])) / abs(float(ref["loss"]))
+    e_bf = abs(float(bf["loss"]) - float(ref["loss"])) / abs(float(ref["loss"]))
+    check(e_hip, e_bf, "loss", floor=2e-3)
+    with pytest.raises(AssertionError):
+        model(images.cuda(), caps[:, :100].cuda())                           # reference magma.py:249-251
+
+
+def test_full_logits_path(setup):
+    from oracle.model import lm_forward
+    cfg, p, model, images, ids = setup
+    ids = ids.cuda()
+    out = model.lm(input_ids=ids)
+    ref = lm_forward(p, cfg, input_ids=ids.cpu())
+    bf = lm_forward(bf16_params(p), cfg, input_ids=ids.cpu())
+    assert out.logits.shape == ref["logits"].shape
+    check(rel(out.logits, ref["logits"]), rel(bf["logits"], ref["logits"]), "full logits", floor=4e-3)
+
+
+def test_smoke_entry():
+    import __graft_entry__ as g
+    g.smoke()

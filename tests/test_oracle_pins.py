@@ -1,0 +1,90 @@
+"""Pins the oracle (and the host-side sampling logic) to outputs of the
+reference's own code, captured by tests/golden/make_golden.py (which ran
+/root/reference/magma/{adapters,sampling,utils}.py in place).  CPU only."""
+import os
+import types
+
+import torch
+
+from oracle import model as O
+
+PINS = torch.load(os.path.join(os.path.dirname(__file__), "golden", "reference_pins.pt"), weights_only=False)
+
+
+def test_adapter_matches_reference():
+    pin = PINS["adapter"]
+    p = {"a." + k.replace("adapter.", ""): v for k, v in pin["sd"].items()}
+    y = O.adapter_fwd(p, "a.", pin["x"])
+    assert torch.allclose(y, pin["y"], atol=1e-6, rtol=1e-6)
+    assert PINS["adapter_init_absmax"] <= 2e-3 + 1e-9      # reference adapters.py:28-33 clamp
+    q = O.init_params(O.OracleConfig.tiny(), 0)
+    assert float(q["lm.transformer.h.0.mlp.1.adapter.0.weight"].abs().max()) <= 2e-3 + 1e-9
+
+
+def test_adapter_wrapper_matches_reference():
+    pin = PINS["adapter_wrapper"]
+    p = {"a." + k.replace("adapter.", ""): v for k, v in pin["sd"].items() if k.startswith("adapter.")}
+    attn_out = pin["x"] * 0.5 + 1.0                     # the toy attention block used by make_golden.py
+    assert torch.allclose(O.adapter_fwd(p, "a.", attn_out), pin["y"], atol=1e-6, rtol=1e-6)
+    assert pin["rest"] == ["present", "weights"]        # tuple tail is passed through untouched
+
+
+def test_sampling_filters_match_reference():
+    from magma_amd import sampling as S
+    for mod in (O, S):
+        for thr, key in ((0.9, "out_0.9"), (0.5, "out_0.5")):
+            got = mod.top_p_filter(PINS["top_p"]["logits"].clone(), thr)
+            assert torch.equal(got, PINS["top_p"][key]), (mod.__name__, thr)
+        assert torch.equal(mod.top_k_filter(PINS["top_k"]["logits"].clone(), 5), PINS["top_k"]["out_5"])
+    assert S.remove_tokens_after_eos(PINS["remove_eos"]["in"].clone(), 1, 7) == PINS["remove_eos"]["out"]
+    assert S.remove_tokens_after_eos(PINS["remove_eos_none"]["in"].clone(), 1, 7) == PINS["remove_eos_none"]["out"]
+
+
+def test_build_labels_matches_reference():
+    pin = PINS["build_labels"]
+    got = O.build_labels(pin["P"], pin["captions"], pin["eos"])
+    assert torch.equal(got, pin["labels"])
+
+
+def test_generate_loop_matches_reference():
+    """Our sampling.generate driven by the same toy LM must emit the same token
+    ids, strings and (prefill, then one-id-per-step) call pattern."""
+    from magma_amd import sampling as S
+    pin = PINS["generate_toy"]
+
+    class ToyLM:
+        def __init__(self, V):
+            self.V, self.calls = V, []
+
+        def __call__(self, inputs_embeds=None, input_ids=None, use_cache=None, past_key_values=None, cache_hint=None):
+            from magma_amd.language_model import LMOutput
+            if inputs_embeds is not None:
+                last = (inputs_embeds[:, -1, :].sum(-1) * 7).long() % self.V
+                seen = inputs_embeds.shape[1]
+            else:
+                last, seen = input_ids[:, -1], past_key_values + 1
+            self.calls.append(("embeds" if inputs_embeds is not None else "ids", seen))
+            idx = torch.arange(self.V)[None, :]
+            logits = (-((idx - (last[:, None] * 3 + seen) % self.V) ** 2).float())[:, None, :]
+            return LMOutput(logits=logits, past_key_values=seen, next_token=logits[:, -1].argmax(-1))
+
+    class ToyModel:
+        training = False
+
+        def __init__(self):
+            self.lm = ToyLM(17)
+            self.eos_token, self.image_token = 16, 15
+            self.device = torch.device("cpu")
+            self.tokenizer = types.SimpleNamespace(decode=lambda ids: " ".join(map(str, ids)))
+
+        def eval(self):
+            return self
+
+        def train(self, mode=True):
+            return self
+
+    tm = ToyModel()
+    toks = S.generate(tm, pin["emb"], max_steps=6, temperature=0.0, decode=False)
+    assert torch.equal(toks, pin["tokens"])
+    assert tm.lm.calls == pin["calls"]
+    assert S.generate(ToyModel(), pin["emb"], max_steps=6, temperature=0.0, decode=True) == pin["strings"]
