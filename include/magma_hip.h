@@ -41,6 +41,12 @@ extern "C" {
 #define MG_ACT_RELU 1
 #define MG_ACT_GELU_NEW 2
 
+/* auxiliary-operand modes of the epilogue (backward passes, dropout) */
+#define MG_AUX_NONE 0
+#define MG_AUX_RELU_GATE 1 /* v *= (aux > 0)            -- ReLU backward            */
+#define MG_AUX_GELU_GRAD 2 /* v *= gelu_new'(aux)       -- aux = saved pre-activation */
+#define MG_AUX_MUL 3       /* v *= aux                  -- dropout mask (pre-scaled)  */
+
 /* weight layouts for the B operand of the GEMMs */
 #define MG_W_ROWMAJOR 0 /* W[n*ldw + k], k zero-padded to a multiple of 64   */
 #define MG_W_FRAGTILED 1 /* [N/16][Kp/32][64 lanes][8]: lane=(kq*16+n%16) holds \
@@ -55,10 +61,14 @@ const char* mg_version(void);
 const char* mg_last_error(void);
 
 /* Fused epilogue shared by both GEMM kernels:
- *   v = acc * scale[n] + bias[n];  v = act(v);  v += res0 + res1 + res2;
- *   v = act_after(v);  C[m*ldc + n] = v  (bf16, or fp32 when out_f32)
+ *   v = acc * scale[n] + bias[n];  C2[m*ldc2+n] = v (optional, bf16: the
+ *   pre-activation a later backward pass needs);  v = act(v);
+ *   v = aux_op(v, aux[m*ldaux+n]) (unless aux_after);  v += res0 + res1 + res2;
+ *   v = aux_op(v, aux) (if aux_after);  v = act_after(v);
+ *   C[m*ldc + n] = v  (bf16, or fp32 when out_f32)
  * Covers: Linear(+bias) / gelu_new / adapter ReLU / 3-way GPT-J residual /
- * folded BatchNorm + ReLU / bottleneck "relu(bn3(conv3)+identity)".          */
+ * folded BatchNorm + ReLU / bottleneck "relu(bn3(conv3)+identity)" / dropout /
+ * and, in backward, ReLU and GELU gradients fused into the dgrad GEMMs.      */
 typedef struct mg_epilogue {
   const float* scale; /* [N] or NULL */
   const float* bias;  /* [N] or NULL */
@@ -71,7 +81,13 @@ typedef struct mg_epilogue {
   void* C;
   int64_t ldc;
   int32_t out_f32;
+  int32_t aux_mode;   /* MG_AUX_* */
+  const mg_bf16* aux;
+  int64_t ldaux;
+  int32_t aux_after;  /* apply the aux op after the residual adds */
   int32_t _pad;
+  mg_bf16* C2;        /* optional second output (value before `act`), bf16 */
+  int64_t ldc2;
 } mg_epilogue;
 
 /* K9/K11/K12/K13/K14/K18 (GPT-J + adapter GEMMs, prefill/training shapes),
@@ -152,7 +168,8 @@ int mg_avgpool2_nhwc_bf16(const mg_bf16* x, mg_bf16* y, int32_t B, int32_t H, in
 
 /* K1 stem conv1 (3->C, 3x3, stride 2, pad 1): explicit im2col of the NCHW
  * bf16 image into [B*(H/2)*(W/2), 32] (27 taps*channels + 5 zero columns,
- * column = (ky*3+kx)*3 + c) for mg_gemm_bf16.                                */
+ * column = c*9 + ky*3 + kx, i.e. the conv weight's own
+ * [cout, 3, 3, 3] flattening) for mg_gemm_bf16.                                */
 int mg_stem_im2col_bf16(const mg_bf16* img_nchw, mg_bf16* out, int32_t B, int32_t H, int32_t W,
                         void* stream);
 
@@ -170,6 +187,60 @@ int mg_ce_rows_f32(const float* logits, int64_t ld, const int64_t* tgt, float* l
                    int32_t R, int32_t V, void* stream);
 int mg_ce_reduce_f32(const float* loss_row, const int64_t* tgt, int32_t R, float* out,
                      void* stream);
+
+/* ===================== training path (backward + optimizer) ===================== */
+
+/* out[C,R] = in[R,C]^T (batched).  Feeds the wgrad GEMMs, which contract over the
+ * row index M of activations: dW[N,K] = dY^T[N,M] * (X^T[K,M])^T.                 */
+int mg_transpose_bf16(const mg_bf16* in, int64_t ld_in, int64_t bs_in, mg_bf16* out, int64_t ld_out,
+                      int64_t bs_out, int32_t R, int32_t C, int32_t batch, void* stream);
+
+/* dst[((b*H+h)*256+d)*ld + s] = src[b*sb + s*ss + h*sh + d]; zero fill to round_up(S,32). */
+int mg_head_transpose_bf16(const mg_bf16* src, int64_t sb, int64_t ss, int64_t sh, mg_bf16* dst, int32_t ld,
+                           int32_t B, int32_t H, int32_t S, void* stream);
+
+/* out[n] += sum_m x[m][n] * (y ? y[m][n] : 1)  (bias / affine gradients, fp32 atomics). */
+int mg_colsum_f32(const mg_bf16* x, int64_t ldx, const mg_bf16* y, int64_t ldy, float* out, int32_t M,
+                  int32_t N, void* stream);
+
+/* LayerNorm input gradient (+ optional residual add, optional xhat output).         */
+int mg_layernorm_bwd_bf16(const mg_bf16* dy, int64_t lddy, const mg_bf16* x, int64_t ldx, const float* gamma,
+                          const mg_bf16* res, int64_t ldr, mg_bf16* dx, int64_t lddx, mg_bf16* xhat,
+                          int64_t ldxh, int32_t rows, int32_t d, float eps, void* stream);
+
+/* dlogits = (softmax(logits) - onehot(tgt)) / n_valid, bf16, zero padded to ldo.
+ * stats = output of mg_ce_reduce_f32 (stats[1] = number of valid targets).          */
+int mg_ce_bwd_bf16(const float* logits, int64_t ld, const int64_t* tgt, const float* stats, mg_bf16* out,
+                   int64_t ldo, int32_t R, int32_t V, void* stream);
+
+/* inverse rotary on dq,dk and merge dq|dk|dv [B,H,S,256] -> dqkv [B*S, 3*H*256].    */
+int mg_rotary_merge_bwd_bf16(const mg_bf16* dq, const mg_bf16* dk, const mg_bf16* dv, int32_t B, int32_t S,
+                             int32_t H, int32_t rot_dim, const float* sin_t, const float* cos_t,
+                             mg_bf16* dqkv, void* stream);
+
+/* causal flash-attention backward, head dim 256 (recomputes P from q,k,lse).
+ * q,k,v [B,H,S,256]; qt,kt,dOt [B,H,256,ld_t]; dO,O [B*S,H*256]; lse,D [B,H,S].      */
+int mg_attn_bwd_bf16(const mg_bf16* q, const mg_bf16* k, const mg_bf16* v, const mg_bf16* qt,
+                     const mg_bf16* kt, const mg_bf16* dO, const mg_bf16* dOt, const mg_bf16* O,
+                     const float* lse, float* D, mg_bf16* dq, mg_bf16* dk, mg_bf16* dv, int32_t B,
+                     int32_t H, int32_t S, int32_t ld_t, void* stream);
+
+/* CLIP trunk backward helpers */
+int mg_avgpool2_bwd_nhwc_bf16(const mg_bf16* dy, const mg_bf16* gate, mg_bf16* dx, int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
+int mg_mul_bf16(const mg_bf16* a, const mg_bf16* b, mg_bf16* out, int64_t n, void* stream);
+int mg_scale_rows_acc_f32(float* dst, const float* src, int64_t ld_src, const float* row_scale, int32_t rows,
+                          int32_t cols, void* stream);
+int mg_add_gate_bf16(const mg_bf16* a, const mg_bf16* b, const mg_bf16* gate, mg_bf16* out, int64_t n, void* stream);
+int mg_bn_param_grad_f32(const mg_bf16* g, const mg_bf16* y, const mg_bf16* sub, const float* gamma,
+                         const float* beta, float* dgamma, float* dbeta, int32_t M, int32_t C, void* stream);
+int mg_im2col_t_bf16(const mg_bf16* x, mg_bf16* out, int64_t ldo, int32_t B, int32_t H, int32_t W, int32_t Cin, void* stream);
+
+/* optimizer (replaces DeepSpeed's fp16 ZeRO-2 step: global-norm clip + AdamW on fp32
+ * master copies, reference train.py:96-101, config.py:124-134).                     */
+int mg_sumsq_f32(const float* g, int64_t n, float* out, void* stream);
+int mg_adamw_f32(float* p, float* m, float* v, const float* g, mg_bf16* p_bf16, int64_t n, float lr,
+                 float beta1, float beta2, float eps, float weight_decay, int32_t step, float max_norm,
+                 const float* norm_sq, float grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

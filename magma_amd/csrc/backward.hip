@@ -1,0 +1,614 @@
+// backward.hip -- HBM-bound kernels of the training path (gfx950): transposes
+// feeding the wgrad GEMMs, column sums (bias / affine gradients), LayerNorm
+// backward, cross-entropy backward, inverse rotary merge, avg-pool backward,
+// BatchNorm (frozen statistics) affine gradients, and the fused clip + AdamW.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// transpose: in [R, C] (ld_in) -> out [C, R] (ld_out); 64x64 tiles through LDS.
+// R, C multiples of 8.  batched through blockIdx.z.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_kernel(const mg_bf16* __restrict__ in, int64_t ld_in,
+                                                        int64_t bs_in, mg_bf16* __restrict__ out,
+                                                        int64_t ld_out, int64_t bs_out, int R, int C) {
+  __shared__ mg_bf16 tile[64][64 + 2];
+  const int tid = threadIdx.x;
+  in += (int64_t)blockIdx.z * bs_in;
+  out += (int64_t)blockIdx.z * bs_out;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int ci = tid + it * 256;
+    const int r = ci >> 3, cc = (ci & 7) * 8;
+    u32x4 v = (u32x4){0u, 0u, 0u, 0u};
+    if (r0 + r < R && c0 + cc < C) v = *(const u32x4*)(in + (int64_t)(r0 + r) * ld_in + c0 + cc);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      tile[r][cc + 2 * j] = (mg_bf16)(v[j] & 0xffffu);
+      tile[r][cc + 2 * j + 1] = (mg_bf16)(v[j] >> 16);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int ci = tid + it * 256;
+    const int c = ci >> 3, rr = (ci & 7) * 8;   // output row c, 8 consecutive input rows
+    if (c0 + c < C && r0 + rr < R) {
+      u32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        o[j] = (uint32_t)tile[rr + 2 * j][c] | ((uint32_t)tile[rr + 2 * j + 1][c] << 16);
+      *(u32x4*)(out + (int64_t)(c0 + c) * ld_out + r0 + rr) = o;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// head transpose: element (b, s, h, d) at src + b*sb + s*ss + h*sh + d  ->
+// dst[((b*H + h)*256 + d)*ld + s]; columns s in [S, round_up(S,32)) zero filled.
+// grid (ceil(S/32), B*H), 256 threads.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_transpose_kernel(const mg_bf16* __restrict__ src, int64_t sb,
+                                                             int64_t ss, int64_t sh, mg_bf16* __restrict__ dst,
+                                                             int ld, int H, int S) {
+  __shared__ __attribute__((aligned(16))) mg_bf16 tile[32 * 256];
+  const int tid = threadIdx.x;
+  const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+  const int s0 = blockIdx.x * 32;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int ci = tid + it * 256;
+    const int row = ci >> 5, c = ci & 31;
+    u32x4 v = (u32x4){0u, 0u, 0u, 0u};
+    if (s0 + row < S) v = *(const u32x4*)(src + b * sb + (int64_t)(s0 + row) * ss + h * sh + c * 8);
+    *(u32x4*)(tile + row * 256 + c * 8) = v;
+  }
+  __syncthreads();
+  mg_bf16* d = dst + ((int64_t)bh * 256 + tid) * ld + s0;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    u32x4 o;
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+      o[w] = (uint32_t)tile[(g * 8 + w * 2) * 256 + tid] | ((uint32_t)tile[(g * 8 + w * 2 + 1) * 256 + tid] << 16);
+    *(u32x4*)(d + g * 8) = o;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// column sums: out[n] += sum_m x[m][n] * (y ? y[m][n] : 1)   (fp32 atomics)
+// grid (ceil(N/512), ceil(M/rows_per_block))
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colsum_kernel(const mg_bf16* __restrict__ x, int64_t ldx,
+                                                     const mg_bf16* __restrict__ y, int64_t ldy,
+                                                     float* __restrict__ out, int M, int N, int rows_per_block) {
+  __shared__ float red[4][64][8];
+  const int tid = threadIdx.x, cl = tid & 63, rl = tid >> 6;
+  const int n = blockIdx.x * 512 + cl * 8;
+  const int m0 = blockIdx.y * rows_per_block, m1 = min(M, m0 + rows_per_block);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (n < N) {
+    for (int m = m0 + rl; m < m1; m += 4) {
+      const u32x4 a = *(const u32x4*)(x + (int64_t)m * ldx + n);
+      if (y) {
+        const u32x4 b = *(const u32x4*)(y + (int64_t)m * ldy + n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc[2 * j] += bflo(a[j]) * bflo(b[j]); acc[2 * j + 1] += bfhi(a[j]) * bfhi(b[j]); }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc[2 * j] += bflo(a[j]); acc[2 * j + 1] += bfhi(a[j]); }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[rl][cl][j] = acc[j];
+  __syncthreads();
+  if (rl == 0 && n < N) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (n + j < N) atomicAdd(out + n + j, red[0][cl][j] + red[1][cl][j] + red[2][cl][j] + red[3][cl][j]);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// LayerNorm backward (input gradient), one workgroup per row:
+//   xh = (x-mu)*rstd ; g = dy*gamma ; dx = rstd*(g - mean(g) - xh*mean(g*xh)) (+ res)
+// optionally writes xh (bf16) for the affine-gradient column sums.
+// ---------------------------------------------------------------------------
+constexpr int LNB_MAXV = 4;  // d <= 8192
+
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const mg_bf16* __restrict__ dy, int64_t lddy,
+                                                            const mg_bf16* __restrict__ x, int64_t ldx,
+                                                            const float* __restrict__ gamma,
+                                                            const mg_bf16* __restrict__ res, int64_t ldr,
+                                                            mg_bf16* __restrict__ dx, int64_t lddx,
+                                                            mg_bf16* __restrict__ xhat, int64_t ldxh, int d,
+                                                            float eps) {
+  __shared__ float red[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row = blockIdx.x, nvec = d >> 3;
+  float xv[LNB_MAXV][8], gv[LNB_MAXV][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LNB_MAXV; ++i) {
+    const int vi = tid + i * 256;
+    if (vi < nvec) {
+      const u32x4 w = *(const u32x4*)(x + (int64_t)row * ldx + vi * 8);
+      const u32x4 g = *(const u32x4*)(dy + (int64_t)row * lddy + vi * 8);
+      const float4 g0 = *(const float4*)(gamma + vi * 8), g1 = *(const float4*)(gamma + vi * 8 + 4);
+      const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        xv[i][2 * j] = bflo(w[j]); xv[i][2 * j + 1] = bfhi(w[j]);
+        gv[i][2 * j] = bflo(g[j]) * gm[2 * j]; gv[i][2 * j + 1] = bfhi(g[j]) * gm[2 * j + 1];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += xv[i][j];
+    }
+  }
+  s = wave_sum(s);
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LNB_MAXV; ++i)
+    if (tid + i * 256 < nvec)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float t = xv[i][j] - mean; q += t * t; }
+  q = wave_sum(q);
+  if (lane == 0) red[4 + wave] = q;
+  __syncthreads();
+  const float rstd = rsqrtf((red[4] + red[5] + red[6] + red[7]) / (float)d + eps);
+  float sg = 0.f, sgx = 0.f;
+#pragma unroll
+  for (int i = 0; i < LNB_MAXV; ++i)
+    if (tid + i * 256 < nvec)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        xv[i][j] = (xv[i][j] - mean) * rstd;   // xhat
+        sg += gv[i][j];
+        sgx += gv[i][j] * xv[i][j];
+      }
+  sg = wave_sum(sg); sgx = wave_sum(sgx);
+  if (lane == 0) { red[8 + wave] = sg; red[12 + wave] = sgx; }
+  __syncthreads();
+  const float mg_ = (red[8] + red[9] + red[10] + red[11]) / (float)d;
+  const float mgx = (red[12] + red[13] + red[14] + red[15]) / (float)d;
+#pragma unroll
+  for (int i = 0; i < LNB_MAXV; ++i) {
+    const int vi = tid + i * 256;
+    if (vi < nvec) {
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = rstd * (gv[i][j] - mg_ - xv[i][j] * mgx);
+      if (res) {
+        const u32x4 r = *(const u32x4*)(res + (int64_t)row * ldr + vi * 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { o[2 * j] += bflo(r[j]); o[2 * j + 1] += bfhi(r[j]); }
+      }
+      u32x4 w;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w[j] = pack2bf(o[2 * j], o[2 * j + 1]);
+      *(u32x4*)(dx + (int64_t)row * lddx + vi * 8) = w;
+      if (xhat) {
+        u32x4 h;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) h[j] = pack2bf(xv[i][2 * j], xv[i][2 * j + 1]);
+        *(u32x4*)(xhat + (int64_t)row * ldxh + vi * 8) = h;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// cross-entropy backward: dlogits[r][v] = (softmax(logits[r])[v] - [v==tgt]) * inv_n
+// inv_n = 1 / stats[1] (valid-target count written by ce_reduce).  bf16 out,
+// columns [V, ldo) zero filled (they are the K padding of the dgrad GEMM).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits, int64_t ld,
+                                                     const int64_t* __restrict__ tgt,
+                                                     const float* __restrict__ stats,
+                                                     mg_bf16* __restrict__ out, int64_t ldo, int V) {
+  __shared__ float red[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = blockIdx.x;
+  const int64_t tg = tgt[r];
+  const float* row = logits + (int64_t)r * ld;
+  mg_bf16* orow = out + (int64_t)r * ldo;
+  if (tg < 0 || tg >= V) {
+    for (int i = tid; i < ldo; i += 256) orow[i] = 0;
+    return;
+  }
+  float mx = -INFINITY;
+  for (int i = tid; i < V; i += 256) mx = fmaxf(mx, row[i]);
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float s = 0.f;
+  for (int i = tid; i < V; i += 256) s += expf(row[i] - mx);
+  s = wave_sum(s);
+  if (lane == 0) red[4 + wave] = s;
+  __syncthreads();
+  const float inv_sum = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+  const float inv_n = 1.0f / stats[1];
+  for (int i = tid; i < ldo; i += 256) {
+    float v = 0.f;
+    if (i < V) v = (expf(row[i] - mx) * inv_sum - (i == tg ? 1.f : 0.f)) * inv_n;
+    orow[i] = f2bf(v);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// inverse rotary + merge: dq,dk,dv [B,H,S,256] -> dqkv [B*S, 3*H*256]
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rotary_merge_bwd_kernel(const mg_bf16* __restrict__ dq,
+                                                               const mg_bf16* __restrict__ dk,
+                                                               const mg_bf16* __restrict__ dv, int B, int S, int H,
+                                                               int rot_dim, const float* __restrict__ sin_t,
+                                                               const float* __restrict__ cos_t,
+                                                               mg_bf16* __restrict__ dqkv) {
+  const int tid = threadIdx.x;
+  const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+  const int s0 = blockIdx.x * 32;
+  const int dmodel = H * 256, half_rot = rot_dim >> 1;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int ci = tid + it * 256;
+    const int row = ci >> 5, c = ci & 31, s = s0 + row, d0 = c * 8;
+    if (s >= S) continue;
+    const int64_t src = ((int64_t)bh * S + s) * 256 + d0;
+    u32x4 qv = *(const u32x4*)(dq + src), kv = *(const u32x4*)(dk + src);
+    const u32x4 vv = *(const u32x4*)(dv + src);
+    if (d0 < rot_dim) {
+      const float* sp = sin_t + (int64_t)s * half_rot + (d0 >> 1);
+      const float* cp = cos_t + (int64_t)s * half_rot + (d0 >> 1);
+#pragma unroll
+      for (int pi = 0; pi < 4; ++pi) {
+        const float sn = sp[pi], cs = cp[pi];
+        const float q0 = bflo(qv[pi]), q1 = bfhi(qv[pi]), k0 = bflo(kv[pi]), k1 = bfhi(kv[pi]);
+        qv[pi] = pack2bf(q0 * cs + q1 * sn, q1 * cs - q0 * sn);   // R(-theta)
+        kv[pi] = pack2bf(k0 * cs + k1 * sn, k1 * cs - k0 * sn);
+      }
+    }
+    mg_bf16* base = dqkv + (int64_t)(b * S + s) * (3 * dmodel) + h * 256 + d0;
+    *(u32x4*)base = qv;
+    *(u32x4*)(base + dmodel) = kv;
+    *(u32x4*)(base + 2 * dmodel) = vv;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// avg-pool 2x2 backward (NHWC): dx[b,2y+i,2x+j,c] = 0.25*dy[b,y,x,c] (optionally
+// gated by aux > 0 and accumulated with add)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const mg_bf16* __restrict__ dy,
+                                                           const mg_bf16* __restrict__ gate,
+                                                           mg_bf16* __restrict__ dx, int B, int H, int W, int C) {
+  const int Ho = H >> 1, Wo = W >> 1, cv = C >> 3;
+  const int64_t total = (int64_t)B * H * W * cv;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % cv);
+    int64_t t = i / cv;
+    const int x = (int)(t % W); t /= W;
+    const int y = (int)(t % H);
+    const int b = (int)(t / H);
+    const u32x4 g = *(const u32x4*)(dy + ((((int64_t)b * Ho + (y >> 1)) * Wo + (x >> 1)) * C + c * 8));
+    u32x4 gt = (u32x4){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+    if (gate) gt = *(const u32x4*)(gate + i * 8);
+    u32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      o[j] = pack2bf(bflo(gt[j]) > 0.f ? 0.25f * bflo(g[j]) : 0.f, bfhi(gt[j]) > 0.f ? 0.25f * bfhi(g[j]) : 0.f);
+    *(u32x4*)(dx + i * 8) = o;
+  }
+}
+
+// elementwise helpers ------------------------------------------------------------
+// out = a (+ b) gated by (gate > 0) when gate != null   (bf16, 16-B vectors)
+__global__ __launch_bounds__(256) void add_gate_kernel(const mg_bf16* __restrict__ a, const mg_bf16* __restrict__ b,
+                                                       const mg_bf16* __restrict__ gate, mg_bf16* __restrict__ out,
+                                                       int64_t nvec) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+    const u32x4 x = ((const u32x4*)a)[i];
+    u32x4 y = (u32x4){0u, 0u, 0u, 0u}, g = (u32x4){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+    if (b) y = ((const u32x4*)b)[i];
+    if (gate) g = ((const u32x4*)gate)[i];
+    u32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float lo = (bflo(g[j]) > 0.f) ? bflo(x[j]) + bflo(y[j]) : 0.f;
+      const float hi = (bfhi(g[j]) > 0.f) ? bfhi(x[j]) + bfhi(y[j]) : 0.f;
+      o[j] = pack2bf(lo, hi);
+    }
+    ((u32x4*)out)[i] = o;
+  }
+}
+
+// BatchNorm with frozen statistics: y = conv*scale + shift (scale = gamma*rstd).
+// dgamma[c] += sum_m g[m][c] * (ybn[m][c] - beta[c]) / gamma[c] ; dbeta[c] += sum_m g[m][c]
+// where ybn = y - (sub ? sub : 0) (the pre-residual BN output) and g is already
+// gated by the ReLU.  grid (ceil(C/512), row blocks)
+__global__ __launch_bounds__(256) void bn_param_grad_kernel(const mg_bf16* __restrict__ g, const mg_bf16* __restrict__ y,
+                                                            const mg_bf16* __restrict__ sub,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            int M, int C, int rows_per_block) {
+  __shared__ float red[2][4][64][8];
+  const int tid = threadIdx.x, cl = tid & 63, rl = tid >> 6;
+  const int n = blockIdx.x * 512 + cl * 8;
+  const int m0 = blockIdx.y * rows_per_block, m1 = min(M, m0 + rows_per_block);
+  float ag[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ab[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (n < C) {
+    float bt[8], ig[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { bt[j] = beta[n + j]; const float gm = gamma[n + j]; ig[j] = gm != 0.f ? 1.f / gm : 0.f; }
+    for (int m = m0 + rl; m < m1; m += 4) {
+      const u32x4 gv = *(const u32x4*)(g + (int64_t)m * C + n);
+      const u32x4 yv = *(const u32x4*)(y + (int64_t)m * C + n);
+      u32x4 sv = (u32x4){0u, 0u, 0u, 0u};
+      if (sub) sv = *(const u32x4*)(sub + (int64_t)m * C + n);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float g0 = bflo(gv[j]), g1 = bfhi(gv[j]);
+        ab[2 * j] += g0; ab[2 * j + 1] += g1;
+        ag[2 * j] += g0 * (bflo(yv[j]) - bflo(sv[j]) - bt[2 * j]) * ig[2 * j];
+        ag[2 * j + 1] += g1 * (bfhi(yv[j]) - bfhi(sv[j]) - bt[2 * j + 1]) * ig[2 * j + 1];
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { red[0][rl][cl][j] = ag[j]; red[1][rl][cl][j] = ab[j]; }
+  __syncthreads();
+  if (rl == 0 && n < C) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      atomicAdd(dgamma + n + j, red[0][0][cl][j] + red[0][1][cl][j] + red[0][2][cl][j] + red[0][3][cl][j]);
+      atomicAdd(dbeta + n + j, red[1][0][cl][j] + red[1][1][cl][j] + red[1][2][cl][j] + red[1][3][cl][j]);
+    }
+  }
+}
+
+// im2col^T for the 3x3 wgrad: out[(ci*9 + tap)][m] = x[(b,y+ky-1,x+kx-1)][ci]  (row order =
+// the conv weight's own [cin,3,3] flattening, so dW needs no re-layout)
+// (zero outside), out row stride ldo >= M.  grid (ceil(M/64), Cin/64.. , 9)
+__global__ __launch_bounds__(256) void im2col_t_kernel(const mg_bf16* __restrict__ x, mg_bf16* __restrict__ out,
+                                                       int64_t ldo, int B, int H, int W, int Cin) {
+  __shared__ mg_bf16 tile[64][64 + 2];
+  const int tid = threadIdx.x;
+  const int tap = blockIdx.z, ky = tap / 3, kx = tap - ky * 3;
+  const int m0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int M = B * H * W;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int ci = tid + it * 256;
+    const int r = ci >> 3, cc = (ci & 7) * 8;
+    const int m = m0 + r;
+    u32x4 v = (u32x4){0u, 0u, 0u, 0u};
+    if (m < M && c0 + cc < Cin) {
+      const int xx = m % W, t = m / W, yy = t % H;
+      const int y2 = yy + ky - 1, x2 = xx + kx - 1;
+      if (y2 >= 0 && y2 < H && x2 >= 0 && x2 < W)
+        v = *(const u32x4*)(x + ((int64_t)m + (int64_t)(ky - 1) * W + (kx - 1)) * Cin + c0 + cc);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      tile[r][cc + 2 * j] = (mg_bf16)(v[j] & 0xffffu);
+      tile[r][cc + 2 * j + 1] = (mg_bf16)(v[j] >> 16);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int ci = tid + it * 256;
+    const int c = ci >> 3, rr = (ci & 7) * 8;
+    if (c0 + c < Cin && m0 + rr < M) {
+      u32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        o[j] = (uint32_t)tile[rr + 2 * j][c] | ((uint32_t)tile[rr + 2 * j + 1][c] << 16);
+      *(u32x4*)(out + ((int64_t)(c0 + c) * 9 + tap) * ldo + m0 + rr) = o;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// optimizer: sum of squares (global grad norm) and fused clip + AdamW
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) { const float v = g[i]; s += v * v; }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+// p (fp32 master), m, v, g (fp32 grads, already averaged over ranks); writes the
+// bf16 model copy.  clip = min(1, max_norm / (sqrt(*norm_sq) + 1e-6)).
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                                    const float* __restrict__ g, mg_bf16* __restrict__ p_bf16,
+                                                    int64_t n, float lr, float beta1, float beta2, float eps,
+                                                    float wd, float bc1, float bc2, float max_norm,
+                                                    const float* __restrict__ norm_sq, float grad_scale) {
+  float clip = grad_scale;
+  if (norm_sq && max_norm > 0.f) {
+    const float nrm = sqrtf(*norm_sq) * grad_scale;
+    clip = grad_scale * fminf(1.0f, max_norm / (nrm + 1e-6f));
+  }
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float gi = g[i] * clip;
+    float pi = p[i];
+    pi -= lr * wd * pi;                                  // decoupled weight decay (torch.optim.AdamW)
+    const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    pi -= lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
+    p[i] = pi;
+    if (p_bf16) p_bf16[i] = f2bf(pi);
+  }
+}
+
+// out = a * b (bf16) -- dropout backward
+__global__ __launch_bounds__(256) void mul_kernel(const mg_bf16* __restrict__ a, const mg_bf16* __restrict__ b,
+                                                  mg_bf16* __restrict__ out, int64_t nvec) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+    const u32x4 x = ((const u32x4*)a)[i], y = ((const u32x4*)b)[i];
+    u32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = pack2bf(bflo(x[j]) * bflo(y[j]), bfhi(x[j]) * bfhi(y[j]));
+    ((u32x4*)out)[i] = o;
+  }
+}
+
+// dst[r*cols + c] += src[r*lds + c] * (row_scale ? row_scale[r] : 1)   (fp32 gradient accumulation)
+__global__ __launch_bounds__(256) void scale_rows_acc_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                                             int64_t lds_, const float* __restrict__ row_scale,
+                                                             int rows, int cols) {
+  const int64_t total = (int64_t)rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
+    dst[i] += src[(int64_t)r * lds_ + c] * (row_scale ? row_scale[r] : 1.0f);
+  }
+}
+
+inline int grid_for(int64_t total) {
+  int64_t g = (total + 255) / 256;
+  return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+}  // namespace
+
+extern "C" int mg_transpose_bf16(const mg_bf16* in, int64_t ld_in, int64_t bs_in, mg_bf16* out, int64_t ld_out,
+                                 int64_t bs_out, int32_t R, int32_t C, int32_t batch, void* stream) {
+  if (R <= 0 || C <= 0 || batch <= 0 || (C & 7) || ld_out < ((R + 7) & ~7)) MG_FAIL(MG_ERR_SHAPE, "mg_transpose_bf16: C%%8==0 and ld_out >= round_up(R,8) required (padding columns are zero filled)");
+  if (!in || !out || !MG_ALIGNED16(in) || !MG_ALIGNED16(out) || (ld_in & 7) || (ld_out & 7) || (bs_in & 7) || (bs_out & 7))
+    MG_FAIL(MG_ERR_ALIGN, "mg_transpose_bf16: 16-byte alignment required");
+  dim3 grid((C + 63) / 64, (R + 63) / 64, batch);
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, ld_in, bs_in, out, ld_out, bs_out, R, C);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
+extern "C" int mg_head_transpose_bf16(const mg_bf16* src, int64_t sb, int64_t ss, int64_t sh, mg_bf16* dst, int32_t ld,
+                                      int32_t B, int32_t H, int32_t S, void* stream) {
+  if (B <= 0 || H <= 0 || S <= 0 || (ld & 7) || ld < ((S + 31) & ~31)) MG_FAIL(MG_ERR_SHAPE, "mg_head_transpose_bf16: ld must be a multiple of 8 and >= round_up(S,32)");
+  if (!src || !dst || !MG_ALIGNED16(src) || !MG_ALIGNED16(dst) || (sb & 7) || (ss & 7) || (sh & 7)) MG_FAIL(MG_ERR_ALIGN, "mg_head_transpose_bf16: 16-byte alignment required");
+  hipLaunchKernelGGL(head_transpose_kernel, dim3((S + 31) / 32, B * H), dim3(256), 0, (hipStream_t)stream, src, sb, ss, sh, dst, ld, H, S);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
+extern "C" int mg_colsum_f32(const mg_bf16* x, int64_t ldx, const mg_bf16* y, int64_t ldy, float* out, int32_t M,
+                             int32_t N, void* stream) {
+  if (M <= 0 || N <= 0 || (N & 7)) MG_FAIL(MG_ERR_SHAPE, "mg_colsum_f32: N must be a positive multiple of 8");
+  if (!x || !out || !MG_ALIGNED16(x) || !MG_ALIGNED16(y) || (ldx & 7) || (y && (ldy & 7))) MG_FAIL(MG_ERR_ALIGN, "mg_colsum_f32: 16-byte alignment required");
+  const int rpb = 256;
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 511) / 512, (M + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, out, M, N, rpb);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
+extern "C" int mg_layernorm_bwd_bf16(const mg_bf16* dy, int64_t lddy, const mg_bf16* x, int64_t ldx, const float* gamma,
+                                     const mg_bf16* res, int64_t ldr, mg_bf16* dx, int64_t lddx, mg_bf16* xhat,
+                                     int64_t ldxh, int32_t rows, int32_t d, float eps, void* stream) {
+  if (rows <= 0 || d <= 0 || (d & 7) || d > 256 * 8 * LNB_MAXV) MG_FAIL(MG_ERR_SHAPE, "mg_layernorm_bwd_bf16: need d%%8==0 and d<=%d", 256 * 8 * LNB_MAXV);
+  if (!dy || !x || !gamma || !dx) MG_FAIL(MG_ERR_SHAPE, "mg_layernorm_bwd_bf16: null pointer");
+  if (!MG_ALIGNED16(dy) || !MG_ALIGNED16(x) || !MG_ALIGNED16(gamma) || !MG_ALIGNED16(res) || !MG_ALIGNED16(dx) || !MG_ALIGNED16(xhat) ||
+      (lddy & 7) || (ldx & 7) || (lddx & 7) || (res && (ldr & 7)) || (xhat && (ldxh & 7)))
+    MG_FAIL(MG_ERR_ALIGN, "mg_layernorm_bwd_bf16: 16-byte alignment required");
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, dy, lddy, x, ldx, gamma, res, ldr, dx, lddx, xhat, ldxh, d, eps);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
+extern "C" int mg_ce_bwd_bf16(const float* logits, int64_t ld, const int64_t* tgt, const float* stats, mg_bf16* out,
+                              int64_t ldo, int32_t R, int32_t V, void* stream) {
+  if (R <= 0 || V <= 0 || ldo < V || !logits || !tgt || !stats || !out) MG_FAIL(MG_ERR_SHAPE, "mg_ce_bwd_bf16: bad arguments");
+  hipLaunchKernelGGL(ce_bwd_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, logits, ld, tgt, stats, out, ldo, V);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
+extern "C" int mg_rotary_merge_bwd_bf16(const mg_bf16* dq, const mg_bf16* dk, const mg_bf16* dv, int32_t B, int32_t S,
+                                        int32_t H, int32_t rot_dim, const float* sin_t, const float* cos_t,
+                                        mg_bf16* dqkv, void* stream) {
+  if (B <= 0 || S <= 0 || H <= 0 || rot_dim < 0 || rot_dim > 256 || (rot_dim & 7)) MG_FAIL(MG_ERR_SHAPE, "mg_rotary_merge_bwd_bf16: bad shape");
+  if (!dq || !dk || !dv || !dqkv || !MG_ALIGNED16(dq) || !MG_ALIGNED16(dk) || !MG_ALIGNED16(dv) || !MG_ALIGNED16(dqkv)) MG_FAIL(MG_ERR_ALIGN, "mg_rotary_merge_bwd_bf16: null/unaligned pointer");
+  hipLaunchKernelGGL(rotary_merge_bwd_kernel, dim3((S + 31) / 32, B * H), dim3(256), 0, (hipStream_t)stream, dq, dk, dv, B, S, H, rot_dim, sin_t, cos_t, dqkv);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
+extern "C" int mg_avgpool2_bwd_nhwc_bf16(const mg_bf16* dy, const mg_bf16* gate, mg_bf16* dx, int32_t B, int32_t H, int32_t W, int32_t C, void* stream) {
+  if (B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C <= 0 || (C & 7)) MG_FAIL(MG_ERR_SHAPE, "mg_avgpool2_bwd_nhwc_bf16: need even H,W (input size) and C%%8==0");
+  if (!dy || !dx || !MG_ALIGNED16(dy) || !MG_ALIGNED16(dx) || !MG_ALIGNED16(gate)) MG_FAIL(MG_ERR_ALIGN, "mg_avgpool2_bwd_nhwc_bf16: null/unaligned pointer");
+  hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3(grid_for((int64_t)B * H * W * (C / 8))), dim3(256), 0, (hipStream_t)stream, dy, gate, dx, B, H, W, C);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
+extern "C" int mg_add_gate_bf16(const mg_bf16* a, const mg_bf16* b, const mg_bf16* gate, mg_bf16* out, int64_t n, void* stream) {
+  if (n <= 0 || (n & 7) || !a || !out) MG_FAIL(MG_ERR_SHAPE, "mg_add_gate_bf16: n must be a positive multiple of 8");
+  if (!MG_ALIGNED16(a) || !MG_ALIGNED16(b) || !MG_ALIGNED16(gate) || !MG_ALIGNED16(out)) MG_FAIL(MG_ERR_ALIGN, "mg_add_gate_bf16: 16-byte alignment required");
+  hipLaunchKernelGGL(add_gate_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, a, b, gate, out, n / 8);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
+extern "C" int mg_bn_param_grad_f32(const mg_bf16* g, const mg_bf16* y, const mg_bf16* sub, const float* gamma,
+                                    const float* beta, float* dgamma, float* dbeta, int32_t M, int32_t C, void* stream) {
+  if (M <= 0 || C <= 0 || (C & 7)) MG_FAIL(MG_ERR_SHAPE, "mg_bn_param_grad_f32: C must be a positive multiple of 8");
+  if (!g || !y || !gamma || !beta || !dgamma || !dbeta || !MG_ALIGNED16(g) || !MG_ALIGNED16(y) || !MG_ALIGNED16(sub)) MG_FAIL(MG_ERR_ALIGN, "mg_bn_param_grad_f32: null/unaligned pointer");
+  const int rpb = 256;
+  hipLaunchKernelGGL(bn_param_grad_kernel, dim3((C + 511) / 512, (M + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream, g, y, sub, gamma, beta, dgamma, dbeta, M, C, rpb);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
+extern "C" int mg_im2col_t_bf16(const mg_bf16* x, mg_bf16* out, int64_t ldo, int32_t B, int32_t H, int32_t W, int32_t Cin, void* stream) {
+  const int64_t M = (int64_t)B * H * W;
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 7) || ldo < ((M + 7) & ~7) || (ldo & 7)) MG_FAIL(MG_ERR_SHAPE, "mg_im2col_t_bf16: need Cin%%8==0, ldo>=round_up(M,8), ldo%%8==0");
+  if (!x || !out || !MG_ALIGNED16(x) || !MG_ALIGNED16(out)) MG_FAIL(MG_ERR_ALIGN, "mg_im2col_t_bf16: null/unaligned pointer");
+  hipLaunchKernelGGL(im2col_t_kernel, dim3((unsigned)((M + 63) / 64), (Cin + 63) / 64, 9), dim3(256), 0, (hipStream_t)stream, x, out, ldo, B, H, W, Cin);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
+extern "C" int mg_sumsq_f32(const float* g, int64_t n, float* out, void* stream) {
+  if (n <= 0 || !g || !out) MG_FAIL(MG_ERR_SHAPE, "mg_sumsq_f32: bad arguments");
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n) > 1024 ? 1024 : grid_for(n)), dim3(256), 0, (hipStream_t)stream, g, n, out);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
+extern "C" int mg_adamw_f32(float* p, float* m, float* v, const float* g, mg_bf16* p_bf16, int64_t n, float lr,
+                            float beta1, float beta2, float eps, float weight_decay, int32_t step, float max_norm,
+                            const float* norm_sq, float grad_scale, void* stream) {
+  if (n <= 0 || step <= 0 || !p || !m || !v || !g) MG_FAIL(MG_ERR_SHAPE, "mg_adamw_f32: bad arguments");
+  const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, m, v, g, p_bf16, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, max_norm, norm_sq, grad_scale);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
+extern "C" int mg_mul_bf16(const mg_bf16* a, const mg_bf16* b, mg_bf16* out, int64_t n, void* stream) {
+  if (n <= 0 || (n & 7) || !a || !b || !out) MG_FAIL(MG_ERR_SHAPE, "mg_mul_bf16: n must be a positive multiple of 8");
+  if (!MG_ALIGNED16(a) || !MG_ALIGNED16(b) || !MG_ALIGNED16(out)) MG_FAIL(MG_ERR_ALIGN, "mg_mul_bf16: 16-byte alignment required");
+  hipLaunchKernelGGL(mul_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, a, b, out, n / 8);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
+extern "C" int mg_scale_rows_acc_f32(float* dst, const float* src, int64_t ld_src, const float* row_scale, int32_t rows,
+                                     int32_t cols, void* stream) {
+  if (rows <= 0 || cols <= 0 || !dst || !src || ld_src < cols) MG_FAIL(MG_ERR_SHAPE, "mg_scale_rows_acc_f32: bad arguments");
+  hipLaunchKernelGGL(scale_rows_acc_kernel, dim3(grid_for((int64_t)rows * cols)), dim3(256), 0, (hipStream_t)stream, dst, src, ld_src, row_scale, rows, cols);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}

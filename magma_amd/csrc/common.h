@@ -31,6 +31,11 @@ MG_DEV float gelu_new_f(float x) {
   float u = k0 * (x + k1 * x * x * x);
   return 0.5f * x * (1.0f + tanhf(u));
 }
+MG_DEV float gelu_new_grad_f(float x) {
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  const float t = tanhf(k0 * (x + k1 * x * x * x));
+  return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * k0 * (1.0f + 3.0f * k1 * x * x);
+}
 MG_DEV float apply_act(float v, int act) {
   if (act == MG_ACT_RELU) return v > 0.f ? v : 0.f;
   if (act == MG_ACT_GELU_NEW) return gelu_new_f(v);

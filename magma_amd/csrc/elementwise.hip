@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void avgpool2_kernel(const mg_bf16* __restrict
 }
 
 // ---------------------------------------------------------------------------
-// stem conv1 im2col: NCHW bf16 image -> [B*(H/2)*(W/2), 32], col=(ky*3+kx)*3+c
+// stem conv1 im2col: NCHW bf16 image -> [B*(H/2)*(W/2), 32], col = c*9 + ky*3 + kx
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void stem_im2col_kernel(const mg_bf16* __restrict__ img,
                                                           mg_bf16* __restrict__ out, int B, int H, int W) {
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void stem_im2col_kernel(const mg_bf16* __restr
         const int yy = 2 * yo + ky - 1, xx = 2 * xo + kx - 1;
         if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
 #pragma unroll
-          for (int c = 0; c < 3; ++c) col[(ky * 3 + kx) * 3 + c] = img[(((int64_t)b * 3 + c) * H + yy) * W + xx];
+          for (int c = 0; c < 3; ++c) col[c * 9 + ky * 3 + kx] = img[(((int64_t)b * 3 + c) * H + yy) * W + xx];
         }
       }
     u32x4* dst = (u32x4*)(out + m * 32);

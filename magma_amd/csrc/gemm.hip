@@ -58,7 +58,29 @@ MG_DEV void epilogue_store4(const mg_epilogue& ep, int m, int n, f32x4 v, int N)
   }
   float o[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) o[r] = apply_act(v[r] * sc[r] + bi[r], ep.act);
+  for (int r = 0; r < 4; ++r) o[r] = v[r] * sc[r] + bi[r];
+  if (ep.C2) {  // pre-activation copy for the backward pass
+    mg_bf16* cp = ep.C2 + (int64_t)m * ep.ldc2 + n;
+    if (full) { u32x2 w; w[0] = pack2bf(o[0], o[1]); w[1] = pack2bf(o[2], o[3]); *(u32x2*)cp = w; }
+    else for (int r = 0; r < 4; ++r) if (n + r < N) cp[r] = f2bf(o[r]);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) o[r] = apply_act(o[r], ep.act);
+  float ax[4] = {1.f, 1.f, 1.f, 1.f};
+  if (ep.aux_mode != MG_AUX_NONE) {
+    const mg_bf16* ap = ep.aux + (int64_t)m * ep.ldaux + n;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    if (full) { const u32x2 w = *(const u32x2*)ap; a[0] = bflo(w[0]); a[1] = bfhi(w[0]); a[2] = bflo(w[1]); a[3] = bfhi(w[1]); }
+    else for (int r = 0; r < 4; ++r) if (n + r < N) a[r] = bf2f(ap[r]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      ax[r] = ep.aux_mode == MG_AUX_RELU_GATE ? (a[r] > 0.f ? 1.f : 0.f)
+            : ep.aux_mode == MG_AUX_GELU_GRAD ? gelu_new_grad_f(a[r]) : a[r];
+    if (!ep.aux_after) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] *= ax[r];
+    }
+  }
   const mg_bf16* rs[3] = {ep.res0, ep.res1, ep.res2};
 #pragma unroll
   for (int t = 0; t < 3; ++t) {
@@ -71,6 +93,10 @@ MG_DEV void epilogue_store4(const mg_epilogue& ep, int m, int n, f32x4 v, int N)
         for (int r = 0; r < 4; ++r) if (n + r < N) o[r] += bf2f(rp[r]);
       }
     }
+  }
+  if (ep.aux_mode != MG_AUX_NONE && ep.aux_after) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] *= ax[r];
   }
   if (ep.act_after == MG_ACT_RELU) {
 #pragma unroll
@@ -347,6 +373,9 @@ int check_epilogue(const mg_epilogue& ep, const char* who) {
       !MG_ALIGNED16(ep.res1) || !MG_ALIGNED16(ep.res2))
     MG_FAIL(MG_ERR_ALIGN, "%s: epilogue pointers must be 16-byte aligned", who);
   if (ep.act < 0 || ep.act > 2 || ep.act_after < 0 || ep.act_after > 1) MG_FAIL(MG_ERR_SHAPE, "%s: bad activation code", who);
+  if (ep.aux_mode < 0 || ep.aux_mode > 3) MG_FAIL(MG_ERR_SHAPE, "%s: bad aux_mode", who);
+  if (ep.aux_mode != MG_AUX_NONE && (!ep.aux || (ep.ldaux & 3) || !MG_ALIGNED16(ep.aux))) MG_FAIL(MG_ERR_ALIGN, "%s: aux operand must be 16-byte aligned with ldaux %% 4 == 0", who);
+  if (ep.C2 && ((ep.ldc2 & 3) || !MG_ALIGNED16(ep.C2))) MG_FAIL(MG_ERR_ALIGN, "%s: C2 must be 16-byte aligned with ldc2 %% 4 == 0", who);
   return MG_OK;
 }
 

@@ -102,6 +102,17 @@ class LMEngine:
         self.sin_t, self.cos_t = rotary_tables(cfg.rotary_dim, cfg.max_position_embeddings, dev)
         self.rot = cfg.rotary_dim
 
+    def repack_adapters(self, lm):
+        """Refresh only the (trainable) adapter operands after optimizer steps; the
+        12 GB of frozen weights keep their packed copies."""
+        for ly, blk in zip(self.layers, lm.transformer.h):
+            if ly.attn_adapter is not None:
+                ad = blk.attn.adapter
+                ly.attn_adapter = (ops.PackedLinear(ad[0].weight, ad[0].bias), ops.PackedLinear(ad[2].weight, ad[2].bias))
+            if ly.mlp_adapter is not None:
+                ad = blk.mlp[1].adapter
+                ly.mlp_adapter = (ops.PackedLinear(ad[0].weight, ad[0].bias), ops.PackedLinear(ad[2].weight, ad[2].bias))
+
     # ------------------------------------------------------------------ API
     def forward(self, input_ids=None, inputs_embeds=None, labels=None, use_cache=False, past_key_values=None,
                 output_hidden_states=False, cache_hint: Optional[int] = None) -> LMOutput:

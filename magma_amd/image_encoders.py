@@ -84,9 +84,9 @@ class ModifiedResNetTrunk(nn.Module):
         cout, cin, kh, _ = w.shape
         if kh == 1:
             w2 = w.reshape(cout, cin)
-        elif cin == 3:  # stem conv1: explicit im2col columns (ky,kx,c), padded to 32
+        elif cin == 3:  # stem conv1: explicit im2col columns (c,ky,kx), padded to 32
             w2 = torch.zeros(cout, 32, dtype=w.dtype, device=w.device)
-            w2[:, :27] = w.permute(0, 2, 3, 1).reshape(cout, 27)
+            w2[:, :27] = w.reshape(cout, 27)
         else:
             w2 = w.permute(0, 2, 3, 1).reshape(cout, 9 * cin)
         scale = (bn.weight.detach().float() / torch.sqrt(bn.running_var.float() + bn.eps)).contiguous()

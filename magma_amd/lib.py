@@ -16,6 +16,7 @@ LIB_PATH = _HERE / "libmagma_hip.so"
 MG_ACT_NONE, MG_ACT_RELU, MG_ACT_GELU_NEW = 0, 1, 2
 MG_W_ROWMAJOR, MG_W_FRAGTILED = 0, 1
 MG_A_DENSE, MG_A_CONV3X3 = 0, 1
+MG_AUX_NONE, MG_AUX_RELU_GATE, MG_AUX_GELU_GRAD, MG_AUX_MUL = 0, 1, 2, 3
 
 
 class MagmaHipError(RuntimeError):
@@ -29,7 +30,10 @@ class Epilogue(C.Structure):
         ("res0", C.c_void_p), ("res1", C.c_void_p), ("res2", C.c_void_p),
         ("ldr", C.c_int64),
         ("C", C.c_void_p), ("ldc", C.c_int64),
-        ("out_f32", C.c_int32), ("_pad", C.c_int32),
+        ("out_f32", C.c_int32), ("aux_mode", C.c_int32),
+        ("aux", C.c_void_p), ("ldaux", C.c_int64),
+        ("aux_after", C.c_int32), ("_pad", C.c_int32),
+        ("C2", C.c_void_p), ("ldc2", C.c_int64),
     ]
 
 
@@ -73,6 +77,22 @@ SYMBOLS = {
     "mg_build_labels_i64": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i64, _vp]),
     "mg_ce_rows_f32": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _i32, _vp]),
     "mg_ce_reduce_f32": (C.c_int, [_vp, _vp, _i32, _vp, _vp]),
+    # training path
+    "mg_transpose_bf16": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
+    "mg_head_transpose_bf16": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "mg_colsum_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _i32, _vp]),
+    "mg_layernorm_bwd_bf16": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _f32, _vp]),
+    "mg_ce_bwd_bf16": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "mg_rotary_merge_bwd_bf16": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "mg_attn_bwd_bf16": (C.c_int, [_vp] * 13 + [_i32, _i32, _i32, _i32, _vp]),
+    "mg_avgpool2_bwd_nhwc_bf16": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "mg_mul_bf16": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
+    "mg_scale_rows_acc_f32": (C.c_int, [_vp, _vp, _i64, _vp, _i32, _i32, _vp]),
+    "mg_add_gate_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
+    "mg_bn_param_grad_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
+    "mg_im2col_t_bf16": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
+    "mg_sumsq_f32": (C.c_int, [_vp, _i64, _vp, _vp]),
+    "mg_adamw_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _vp, _f32, _vp]),
 }
 
 _lib = None

@@ -9,8 +9,9 @@ from typing import Optional, Sequence
 import torch
 
 from . import lib as L
-from .lib import (MG_A_CONV3X3, MG_A_DENSE, MG_ACT_GELU_NEW, MG_ACT_NONE, MG_ACT_RELU,
-                  MG_W_FRAGTILED, MG_W_ROWMAJOR, Epilogue, GemmDesc, SkinnyDesc, check)
+from .lib import (MG_A_CONV3X3, MG_A_DENSE, MG_ACT_GELU_NEW, MG_ACT_NONE, MG_ACT_RELU, MG_AUX_GELU_GRAD,
+                  MG_AUX_MUL, MG_AUX_NONE, MG_AUX_RELU_GATE, MG_W_FRAGTILED, MG_W_ROWMAJOR, Epilogue, GemmDesc,
+                  SkinnyDesc, check)
 
 BF16 = torch.bfloat16
 _zero_pages = {}
@@ -89,7 +90,8 @@ class PackedLinear:
         return ft.view(nt, ks, 4, 16, 8).permute(0, 3, 1, 2, 4).reshape(nt * 16, ks * 32)
 
 
-def _epilogue(out: torch.Tensor, N: int, bias, scale, act, residuals, act_after) -> Epilogue:
+def _epilogue(out: torch.Tensor, N: int, bias, scale, act, residuals, act_after, aux=None, aux_mode=MG_AUX_NONE,
+              aux_after=False, out2=None) -> Epilogue:
     ep = Epilogue()
     ep.scale = _p(scale)
     ep.bias = _p(bias)
@@ -107,13 +109,21 @@ def _epilogue(out: torch.Tensor, N: int, bias, scale, act, residuals, act_after)
     ep.C = out.data_ptr()
     ep.ldc = out.stride(0)
     ep.out_f32 = 1 if out.dtype == torch.float32 else 0
+    if aux is not None and aux_mode != MG_AUX_NONE:
+        _need_gpu(aux)
+        assert aux.dtype == BF16 and aux.ndim == 2 and aux.stride(1) == 1 and aux.shape[1] >= N
+        ep.aux, ep.ldaux, ep.aux_mode, ep.aux_after = aux.data_ptr(), aux.stride(0), aux_mode, int(bool(aux_after))
+    if out2 is not None:
+        assert out2.dtype == BF16 and out2.ndim == 2 and out2.stride(1) == 1 and out2.shape[1] >= N
+        ep.C2, ep.ldc2 = out2.data_ptr(), out2.stride(0)
     return ep
 
 
 def gemm(a: torch.Tensor, w: PackedLinear, out: Optional[torch.Tensor] = None, *, act: int = MG_ACT_NONE,
          residuals: Sequence[torch.Tensor] = (), act_after: int = MG_ACT_NONE, scale=None,
          use_bias: bool = True, out_dtype=BF16, layout: Optional[str] = None,
-         conv: Optional[tuple] = None) -> torch.Tensor:
+         conv: Optional[tuple] = None, aux=None, aux_mode: int = MG_AUX_NONE, aux_after: bool = False,
+         out2: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[M,N] = epilogue(a[M,K] @ w^T).  ``conv=(H, W, Cin)`` switches the A
     loader to implicit-im2col 3x3 over an NHWC image (a = [B*H*W, Cin])."""
     _need_gpu(a)
@@ -129,7 +139,7 @@ def gemm(a: torch.Tensor, w: PackedLinear, out: Optional[torch.Tensor] = None, *
     if layout == "ft":
         d.W, d.ldw, d.w_layout = w.ft.data_ptr(), w.Kp, MG_W_FRAGTILED
     else:
-        d.W, d.ldw, d.w_layout = w.rm.data_ptr(), w.Kp, MG_W_ROWMAJOR
+        d.W, d.ldw, d.w_layout = w.rm.data_ptr(), w.rm.stride(0), MG_W_ROWMAJOR
     d.M, d.N, d.K = M, w.N, w.K
     if conv is None:
         assert a.shape[1] == w.K, f"A has K={a.shape[1]}, weight has K={w.K}"
@@ -139,9 +149,24 @@ def gemm(a: torch.Tensor, w: PackedLinear, out: Optional[torch.Tensor] = None, *
         d.H, d.Wd, d.Cin = conv
         assert a.shape[1] == conv[2] and a.is_contiguous() and w.K == 9 * conv[2]
     d.zero_page = zero_page(a.device).data_ptr()
-    d.ep = _epilogue(out, w.N, w.bias if use_bias else None, scale, act, residuals, act_after)
+    d.ep = _epilogue(out, w.N, w.bias if use_bias else None, scale, act, residuals, act_after, aux, aux_mode,
+                     aux_after, out2)
     check(L.load().mg_gemm_bf16(C.byref(d), _stream()), "mg_gemm_bf16")
     return out
+
+
+class RawWeight:
+    """Row-major [N, K] bf16 tensor used directly as the GEMM B operand (no copy):
+    trainable weights, and the transposed activations of the wgrad GEMMs."""
+
+    def __init__(self, w: torch.Tensor, bias: Optional[torch.Tensor] = None, K: Optional[int] = None):
+        _need_gpu(w)
+        assert w.dtype == BF16 and w.ndim == 2 and w.stride(1) == 1 and w.stride(0) % 8 == 0
+        self.N = w.shape[0]
+        self.K = w.shape[1] if K is None else K
+        self.Kp = w.stride(0)
+        self.rm, self.ft = w, None
+        self.bias = bias
 
 
 def gemm_skinny(x: torch.Tensor, w: PackedLinear, out: Optional[torch.Tensor] = None, *, act: int = MG_ACT_NONE,
@@ -270,3 +295,147 @@ def cross_entropy(logits: torch.Tensor, targets: torch.Tensor):
     check(L.load().mg_ce_reduce_f32(rows.data_ptr(), targets.data_ptr(), R, out.data_ptr(), _stream()),
           "mg_ce_reduce_f32")
     return out[0], rows
+
+
+# ======================= training path (backward + optimizer) =======================
+
+def transpose(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[R, C] -> [C, round_up(R,8)]; the padding columns are zero (they are the K
+    padding of the wgrad GEMM that consumes the result)."""
+    _need_gpu(x)
+    assert x.dtype == BF16 and x.ndim == 2 and x.stride(1) == 1
+    R, Cc = x.shape
+    if out is None:
+        out = torch.empty(Cc, ceil_to(R, 8), dtype=BF16, device=x.device)
+    check(L.load().mg_transpose_bf16(x.data_ptr(), x.stride(0), 0, out.data_ptr(), out.stride(0), 0, R, Cc, 1, _stream()),
+          "mg_transpose_bf16")
+    return out
+
+
+def head_transpose(src: torch.Tensor, B: int, H: int, S: int, sb: int, ss: int, sh: int,
+                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """-> [B, H, 256, round_up(S,32)] with zero padding."""
+    _need_gpu(src)
+    ld = ceil_to(S, 32)
+    if out is None:
+        out = torch.empty(B, H, 256, ld, dtype=BF16, device=src.device)
+    check(L.load().mg_head_transpose_bf16(src.data_ptr(), sb, ss, sh, out.data_ptr(), ld, B, H, S, _stream()),
+          "mg_head_transpose_bf16")
+    return out
+
+
+def colsum(x: torch.Tensor, out: torch.Tensor, y: Optional[torch.Tensor] = None):
+    """out[n] += sum_m x[m,n] * (y[m,n] if y else 1); out fp32 [N]."""
+    _need_gpu(x, out)
+    assert x.dtype == BF16 and x.ndim == 2 and x.stride(1) == 1 and out.dtype == torch.float32
+    check(L.load().mg_colsum_f32(x.data_ptr(), x.stride(0), _p(y), 0 if y is None else y.stride(0), out.data_ptr(),
+                                 x.shape[0], x.shape[1], _stream()), "mg_colsum_f32")
+    return out
+
+
+def layernorm_bwd(dy, x, gamma, eps=1e-5, res=None, want_xhat=False):
+    _need_gpu(dy, x)
+    assert dy.dtype == BF16 and x.dtype == BF16 and dy.shape == x.shape and dy.stride(1) == 1 and x.stride(1) == 1
+    dx = torch.empty(x.shape, dtype=BF16, device=x.device)
+    xhat = torch.empty(x.shape, dtype=BF16, device=x.device) if want_xhat else None
+    check(L.load().mg_layernorm_bwd_bf16(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), gamma.data_ptr(),
+                                         _p(res), 0 if res is None else res.stride(0), dx.data_ptr(), dx.stride(0),
+                                         _p(xhat), 0 if xhat is None else xhat.stride(0), x.shape[0], x.shape[1], eps,
+                                         _stream()), "mg_layernorm_bwd_bf16")
+    return (dx, xhat) if want_xhat else dx
+
+
+def cross_entropy_fwd_bwd(logits: torch.Tensor, targets: torch.Tensor, ld_out: int):
+    """loss + dlogits (bf16 [R, ld_out], zero padded) for rows already shifted."""
+    _need_gpu(logits, targets)
+    R, V = logits.shape
+    rows = torch.empty(R, dtype=torch.float32, device=logits.device)
+    stats = torch.empty(2, dtype=torch.float32, device=logits.device)
+    lib = L.load()
+    check(lib.mg_ce_rows_f32(logits.data_ptr(), logits.stride(0), targets.data_ptr(), rows.data_ptr(), R, V, _stream()), "mg_ce_rows_f32")
+    check(lib.mg_ce_reduce_f32(rows.data_ptr(), targets.data_ptr(), R, stats.data_ptr(), _stream()), "mg_ce_reduce_f32")
+    dl = torch.empty(R, ld_out, dtype=BF16, device=logits.device)
+    check(lib.mg_ce_bwd_bf16(logits.data_ptr(), logits.stride(0), targets.data_ptr(), stats.data_ptr(), dl.data_ptr(),
+                             ld_out, R, V, _stream()), "mg_ce_bwd_bf16")
+    return stats[0], dl
+
+
+def rotary_merge_bwd(dq, dk, dv, B, S, H, rot_dim, sin_t, cos_t):
+    _need_gpu(dq)
+    out = torch.empty(B * S, 3 * H * 256, dtype=BF16, device=dq.device)
+    check(L.load().mg_rotary_merge_bwd_bf16(dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, S, H, rot_dim,
+                                            sin_t.data_ptr(), cos_t.data_ptr(), out.data_ptr(), _stream()),
+          "mg_rotary_merge_bwd_bf16")
+    return out
+
+
+def attn_bwd(q, k, v, qt, kt, dO, dOt, O, lse, B, H, S):
+    """q,k,v [B,H,S,256]; qt,kt,dOt [B,H,256,ld]; dO,O [B*S,H*256]; lse [B,H,S] -> dq,dk,dv [B,H,S,256]."""
+    _need_gpu(q)
+    dev = q.device
+    D = torch.empty(B, H, S, dtype=torch.float32, device=dev)
+    dq, dk, dv = (torch.empty(B, H, S, 256, dtype=BF16, device=dev) for _ in range(3))
+    check(L.load().mg_attn_bwd_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), qt.data_ptr(), kt.data_ptr(),
+                                    dO.data_ptr(), dOt.data_ptr(), O.data_ptr(), lse.data_ptr(), D.data_ptr(),
+                                    dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, H, S, qt.shape[3], _stream()),
+          "mg_attn_bwd_bf16")
+    return dq, dk, dv
+
+
+def avgpool2_bwd(dy: torch.Tensor, B, H, W, Cc, gate: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dy [B,H/2,W/2,C] -> dx [B,H,W,C] (zeroed where gate <= 0 when a gate is given)."""
+    _need_gpu(dy)
+    dx = torch.empty(B, H, W, Cc, dtype=BF16, device=dy.device)
+    check(L.load().mg_avgpool2_bwd_nhwc_bf16(dy.data_ptr(), _p(gate), dx.data_ptr(), B, H, W, Cc, _stream()), "mg_avgpool2_bwd_nhwc_bf16")
+    return dx
+
+
+def mul(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    _need_gpu(a, b)
+    out = torch.empty_like(a)
+    check(L.load().mg_mul_bf16(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream()), "mg_mul_bf16")
+    return out
+
+
+def scale_rows_acc(dst: torch.Tensor, src: torch.Tensor, row_scale: Optional[torch.Tensor] = None):
+    """dst[r,c] += src[r,c] * row_scale[r]; dst fp32 contiguous view of a flat gradient buffer."""
+    _need_gpu(dst, src)
+    assert dst.dtype == torch.float32 and src.dtype == torch.float32 and src.stride(1) == 1 and dst.is_contiguous()
+    rows, cols = dst.shape
+    check(L.load().mg_scale_rows_acc_f32(dst.data_ptr(), src.data_ptr(), src.stride(0), _p(row_scale), rows, cols, _stream()),
+          "mg_scale_rows_acc_f32")
+
+
+def add_gate(a, b=None, gate=None, out=None):
+    """out = (a + b) * (gate > 0); b, gate optional; flat bf16 tensors of equal numel (multiple of 8)."""
+    _need_gpu(a)
+    if out is None:
+        out = torch.empty_like(a)
+    check(L.load().mg_add_gate_bf16(a.data_ptr(), _p(b), _p(gate), out.data_ptr(), a.numel(), _stream()), "mg_add_gate_bf16")
+    return out
+
+
+def bn_param_grad(g, y, sub, gamma, beta, dgamma, dbeta):
+    _need_gpu(g)
+    M, Cc = g.shape
+    check(L.load().mg_bn_param_grad_f32(g.data_ptr(), y.data_ptr(), _p(sub), gamma.data_ptr(), beta.data_ptr(),
+                                        dgamma.data_ptr(), dbeta.data_ptr(), M, Cc, _stream()), "mg_bn_param_grad_f32")
+
+
+def im2col_t(x_nhwc: torch.Tensor, B, H, W, Cin) -> torch.Tensor:
+    """-> [Cin*9, round_up(M,8)] (row = ci*9 + tap, zero padded columns) for the 3x3 wgrad GEMM."""
+    _need_gpu(x_nhwc)
+    M = B * H * W
+    ldo = ceil_to(M, 8)
+    out = torch.empty(9 * Cin, ldo, dtype=BF16, device=x_nhwc.device)
+    check(L.load().mg_im2col_t_bf16(x_nhwc.data_ptr(), out.data_ptr(), ldo, B, H, W, Cin, _stream()), "mg_im2col_t_bf16")
+    return out
+
+
+def sumsq(g: torch.Tensor, out: torch.Tensor):
+    check(L.load().mg_sumsq_f32(g.data_ptr(), g.numel(), out.data_ptr(), _stream()), "mg_sumsq_f32")
+
+
+def adamw(p, m, v, g, p_bf16, lr, beta1, beta2, eps, wd, step, max_norm=0.0, norm_sq=None, grad_scale=1.0):
+    check(L.load().mg_adamw_f32(p.data_ptr(), m.data_ptr(), v.data_ptr(), g.data_ptr(), _p(p_bf16), p.numel(), lr,
+                                beta1, beta2, eps, wd, step, max_norm, _p(norm_sq), grad_scale, _stream()), "mg_adamw_f32")

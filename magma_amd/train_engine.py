@@ -1,0 +1,620 @@
+"""Training engine: explicit forward/backward of the MAGMA graph on the HIP
+kernels + fused clip/AdamW + RCCL gradient all-reduce.  Replaces the DeepSpeed
+engine the reference trains with (reference train.py:103-111,
+train_loop.py:7-21, config.py:124-134) behind the same object protocol:
+
+    engine(images, captions) -> .loss ; engine.backward(loss) ; engine.step()
+    engine.train() / .eval() ; .save_checkpoint / .load_checkpoint ; .lr_scheduler.get_lr()
+
+No torch.autograd: every gradient is produced by a C-ABI kernel (dgrad = the
+same MFMA GEMM on a transposed weight copy; wgrad = the same GEMM on transposed
+activations; ReLU/GELU gradients fused into GEMM epilogues; flash-attention
+backward; LayerNorm / CE / rotary / pool backward kernels).  Trainable set
+(SURVEY Q2): adapters, CLIP trunk (conv + BN affine, BN statistics frozen, Q5),
+ImagePrefix proj + LayerNorm.  288 GB of HBM: activations are kept, nothing is
+recomputed -- "no recompute" policy for every reported number.
+"""
+from __future__ import annotations
+
+import math
+import os
+from pathlib import Path
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+from .language_model import LMOutput
+from .ops import BF16, PackedLinear, RawWeight
+
+F32 = torch.float32
+
+
+# ----------------------------------------------------------------------------
+# flat fp32 optimizer state, one block per (lr, weight_decay) group
+# ----------------------------------------------------------------------------
+class FlatGroup:
+    def __init__(self, params: List[torch.nn.Parameter], lr: float, weight_decay: float, device):
+        self.params = params
+        self.lr_max, self.wd = lr, weight_decay
+        self.offsets, n = [], 0
+        for p in params:
+            self.offsets.append(n)
+            n += (p.numel() + 3) // 4 * 4          # keep every view 16-byte aligned
+        self.n = n
+        self.master = torch.zeros(n, dtype=F32, device=device)
+        self.m = torch.zeros(n, dtype=F32, device=device)
+        self.v = torch.zeros(n, dtype=F32, device=device)
+        self.grad = torch.zeros(n, dtype=F32, device=device)
+        self.model = torch.zeros(n, dtype=BF16, device=device)     # bf16 copy the kernels read
+        for p, o in zip(params, self.offsets):
+            self.master[o:o + p.numel()].copy_(p.data.reshape(-1).float())
+        self.model.copy_(self.master)
+        # re-point the module parameters at the flat bf16 buffer (zero-copy operands)
+        for p, o in zip(params, self.offsets):
+            p.data = self.model[o:o + p.numel()].view(p.shape)
+
+    def view(self, buf: torch.Tensor, p: torch.nn.Parameter) -> torch.Tensor:
+        i = next(k for k, q in enumerate(self.params) if q is p)
+        o = self.offsets[i]
+        return buf[o:o + p.numel()].view(p.shape)
+
+
+class LRScheduler:
+    """WarmupDecayLR / WarmupLR of DeepSpeed [UNVENDORED]: log-shaped warm-up from
+    min_lr to max_lr over warmup_num_steps, then linear decay to 0 at total_num_steps."""
+
+    def __init__(self, cfg_params: dict, kind: str, max_lrs: List[float]):
+        self.kind = kind
+        self.warmup = max(2, int(cfg_params.get("warmup_num_steps", 100)))
+        self.total = cfg_params.get("total_num_steps")
+        mins = cfg_params.get("warmup_min_lr", 0.0)
+        self.min_lrs = list(mins) if isinstance(mins, (list, tuple)) else [mins] * len(max_lrs)
+        self.max_lrs = list(max_lrs)
+        self.last_step = 0
+        self.inv_log = 1.0 / math.log(self.warmup)
+
+    def _gamma(self, step: int) -> float:
+        if step < self.warmup:
+            return self.inv_log * math.log(step + 1)
+        if self.kind == "WarmupDecayLR" and self.total:
+            return max(0.0, (self.total - step) / max(1.0, self.total - self.warmup))
+        return 1.0
+
+    def get_lr(self) -> List[float]:
+        g = self._gamma(self.last_step)
+        if self.last_step < self.warmup:
+            return [mn + (mx - mn) * g for mn, mx in zip(self.min_lrs, self.max_lrs)]
+        return [mx * g for mx in self.max_lrs]
+
+    def step(self):
+        self.last_step += 1
+
+    def state_dict(self):
+        return {"last_step": self.last_step}
+
+    def load_state_dict(self, sd):
+        self.last_step = sd["last_step"]
+
+
+def _t(x: torch.Tensor) -> RawWeight:
+    """Transposed copy of a [R, C] activation/weight as a GEMM B operand [C, R]."""
+    return RawWeight(ops.transpose(x))       # [C, round_up(R,8)], zero padded
+
+
+class MagmaEngine:
+    """DeepSpeed-engine shim over a ``Magma`` model."""
+
+    def __init__(self, model, config=None, param_groups: Optional[List[dict]] = None, betas=(0.9, 0.95),
+                 eps: float = 1e-8, truncate: bool = False):
+        self.module = model
+        self.config = config or model.config
+        self.device = model.device
+        self.betas, self.eps = betas, eps
+        self.truncate = truncate or os.environ.get("MAGMA_TRUNCATE", "0") == "1"
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.gas = max(1, int(self.config.gradient_accumulation_steps))
+        self.clip = float(self.config.gradient_clipping or 0.0)
+        if param_groups is None:
+            from .utils import configure_param_groups
+            param_groups = configure_param_groups(model, self.config)
+        self.groups: List[FlatGroup] = []
+        for g in param_groups:
+            self.groups.append(FlatGroup(list(g["params"]), g.get("lr", self.config.lr),
+                                         g.get("weight_decay", self.config.weight_decay), self.device))
+        self._where: Dict[int, tuple] = {}
+        for gi, g in enumerate(self.groups):
+            for p in g.params:
+                self._where[id(p)] = (gi, p)
+        sched = self.config.deepspeed_config_params["scheduler"]
+        self.lr_scheduler = LRScheduler(sched["params"], sched["type"], [g.lr_max for g in self.groups])
+        self.micro_steps = 0
+        self.global_steps = 0
+        self.training = True
+        self._tape = None
+        self._norm_sq = torch.zeros(1, dtype=F32, device=self.device)
+        self._comm_stream = torch.cuda.Stream(device=self.device) if self.world > 1 else None
+        model.invalidate_packed()
+        self._lm_train_packs = None
+        self._adapters_dirty = False
+
+    # ---- helpers -------------------------------------------------------------
+    def grad_of(self, p: torch.nn.Parameter) -> torch.Tensor:
+        gi, _ = self._where[id(p)]
+        return self.groups[gi].view(self.groups[gi].grad, p)
+
+    def master_of(self, p: torch.nn.Parameter) -> torch.Tensor:
+        gi, _ = self._where[id(p)]
+        return self.groups[gi].view(self.groups[gi].master, p)
+
+    def is_trainable(self, p) -> bool:
+        return id(p) in self._where
+
+    def train(self, mode: bool = True):
+        self.training = mode
+        self.module.train(mode)
+        self.module.image_prefix.enc.eval()     # BN statistics stay frozen (first-eval_every-steps behaviour)
+        if not mode and self._adapters_dirty:   # inference path reads packed copies of the adapters
+            self.module.lm.engine.repack_adapters(self.module.lm)
+            self._adapters_dirty = False
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    # ---- forward ---------------------------------------------------------------
+    def __call__(self, images, captions, dropout_mask=None) -> LMOutput:
+        if not self.training:
+            with torch.no_grad():
+                return self.module(images, captions)
+        return self.forward_train(images, captions, dropout_mask)
+
+    def _lm_packs(self):
+        """Transposed copies of the frozen LM weights for the dgrad GEMMs (one-off, 12 GB)."""
+        if self._lm_train_packs is None:
+            eng = self.module.lm.engine
+            packs = []
+            for ly, blk in zip(eng.layers, self.module.lm.transformer.h):
+                attn = blk.attn.attn_block if hasattr(blk.attn, "attn_block") else blk.attn
+                a = attn.attention
+                mlp = blk.mlp[0] if isinstance(blk.mlp, torch.nn.Sequential) else blk.mlp
+                pk = {
+                    "qkv_t": PackedLinear(torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0).t().contiguous()),
+                    "out_t": PackedLinear(a.out_proj.weight.t().contiguous()),
+                    "fc_in_t": PackedLinear(mlp.c_fc.weight.t().contiguous()),
+                    "fc_out_t": PackedLinear(mlp.c_proj.weight.t().contiguous()),
+                }
+                packs.append(pk)
+            V, d = eng.V, eng.d
+            wt = torch.zeros(d, ops.ceil_to(V, 8), dtype=BF16, device=self.device)
+            wt[:, :V] = self.module.lm.lm_head.weight.t()
+            self._lm_train_packs = (packs, PackedLinear(wt))
+        return self._lm_train_packs
+
+    def _adapter_ops(self, ad):
+        """(down, up) RawWeights on the live bf16 parameters, biases = fp32 master views."""
+        dn, up = ad[0], ad[2]
+        return (RawWeight(dn.weight.data, bias=self.master_of(dn.bias)),
+                RawWeight(up.weight.data, bias=self.master_of(up.bias)))
+
+    def forward_train(self, images, captions, dropout_mask=None) -> LMOutput:
+        model = self.module
+        eng = model.lm.engine
+        dev = self.device
+        captions = captions.to(dev).contiguous()
+        B, S_full = captions.shape
+        assert S_full == model.seq_len, "captions must be padded to the sequence length (reference magma.py:249-251)"
+        tape = {"B": B}
+        # ---- image prefix (encoder tape inside) ----
+        prefix, ptape = self._prefix_forward(images.to(dev), dropout_mask)
+        tape["prefix"] = ptape
+        P = prefix.shape[1]
+        labels = ops.build_labels(captions, P, model.eos_token)
+        S = S_full
+        if self.truncate:     # causal attention + masked loss => identical loss/grads
+            first_eos = (captions[:, : S_full - P] == model.eos_token).int().argmax(1)
+            has = (captions[:, : S_full - P] == model.eos_token).any(1)
+            last = torch.where(has, first_eos, torch.full_like(first_eos, S_full - P - 1))
+            S = min(S_full, ops.ceil_to(int(last.max()) + 1 + P + 1, 64))
+        tape["S"], tape["P"] = S, P
+        emb = torch.empty(B, S, eng.d, dtype=BF16, device=dev)
+        emb[:, :P] = prefix
+        ops.embedding(captions[:, : S - P].contiguous(), eng.wte, emb, row_off=P)
+        loss = self._lm_forward(emb, labels[:, :S].contiguous(), tape)
+        self._tape = tape
+        return LMOutput(loss=loss, logits=None, labels=labels)
+
+    def _lm_forward(self, emb, labels, tape):
+        eng = self.module.lm.engine
+        dev = self.device
+        B, S, d = emb.shape
+        M, H = B * S, eng.H
+        x = emb.view(M, d)
+        vt_ld = ops.ceil_to(S, 32)
+        vt = torch.empty(B, H, 256, vt_ld, dtype=BF16, device=dev)
+        saved = []
+        for ly, blk in zip(eng.layers, self.module.lm.transformer.h):
+            sv = {"x": x}
+            ln = ops.layernorm(x, ly.ln_g, ly.ln_b, eng.eps)
+            qkv = ops.gemm(ln, ly.qkv)
+            q = torch.empty(B, H, S, 256, dtype=BF16, device=dev)
+            k = torch.empty(B, H, S, 256, dtype=BF16, device=dev)
+            v = torch.empty(B, H, S, 256, dtype=BF16, device=dev)
+            ops.rotary_split(qkv, B, S, H, eng.rot, eng.sin_t, eng.cos_t, q, k, v, pos0=0, vt=vt)
+            ctx = torch.empty(M, d, dtype=BF16, device=dev)
+            lse = torch.empty(B, H, S, dtype=F32, device=dev)
+            ops.attn_prefill(q, k, vt, ctx, B, H, S, lse=lse)
+            sv.update(q=q, k=k, v=v, ctx=ctx, lse=lse)
+            a = ops.gemm(ctx, ly.out)
+            if ly.attn_adapter is not None:
+                dn, up = self._adapter_ops(blk.attn.adapter)
+                ta = ops.gemm(a, dn, act=ops.MG_ACT_RELU, layout="rm")
+                a2 = ops.gemm(ta, up, residuals=(a,), layout="rm")
+                sv.update(a=a, ta=ta)
+                a = a2
+            hpre = torch.empty(M, ly.fc_in.N, dtype=BF16, device=dev)
+            h = ops.gemm(ln, ly.fc_in, act=ops.MG_ACT_GELU_NEW, out2=hpre)
+            sv["hpre"] = hpre
+            if ly.mlp_adapter is not None:
+                dn, up = self._adapter_ops(blk.mlp[1].adapter)
+                m = ops.gemm(h, ly.fc_out)
+                t = ops.gemm(m, dn, act=ops.MG_ACT_RELU, layout="rm")
+                x = ops.gemm(t, up, residuals=(m, a, x), layout="rm")
+                sv.update(m=m, t=t)
+            else:
+                x = ops.gemm(h, ly.fc_out, residuals=(a, x))
+            del h, qkv, ln
+            saved.append(sv)
+        tape["layers"] = saved
+        # ---- head + loss on rows that carry a target ----
+        tgt = labels[:, 1:].reshape(-1)
+        rows = (torch.arange(B, device=dev)[:, None] * S + torch.arange(S - 1, device=dev)[None, :]).reshape(-1)
+        keep = (tgt != -100).nonzero().squeeze(1)       # index plumbing (one host sync per micro-step)
+        rows, tgt = rows[keep], tgt[keep].contiguous()
+        xr = x.index_select(0, rows)
+        xl = ops.layernorm(xr, eng.lnf_g, eng.lnf_b, eng.eps)
+        logits = torch.empty(xl.shape[0], eng.Vp, dtype=F32, device=dev)
+        ops.gemm(xl, eng.head, out=logits)
+        _, head_t = self._lm_packs()
+        loss, dlogits = ops.cross_entropy_fwd_bwd(logits[:, : eng.V], tgt, head_t.K)
+        tape.update(rows=rows, xr=xr, dlogits=dlogits, M=M)
+        return loss
+
+    # ---- backward ----------------------------------------------------------------
+    def backward(self, loss=None):
+        tape = self._tape
+        assert tape is not None, "backward() without a training forward"
+        scale_note = 1.0 / self.gas     # applied at step() through grad_scale (DeepSpeed divides the loss by gas)
+        del scale_note
+        d_emb = self._lm_backward(tape)
+        B, S, P = tape["B"], tape["S"], tape["P"]
+        d_prefix = d_emb.view(B, S, -1)[:, :P].contiguous()
+        self._prefix_backward(tape["prefix"], d_prefix)
+        self._tape = None
+        self.micro_steps += 1
+
+    def _acc_wgrad(self, param, gT: RawWeight, xT: RawWeight, row_scale=None):
+        """grad(param)[N,K] += gT[N,M] . xT[K,M]^T  (fp32), optional per-row scale."""
+        tmp = ops.gemm(gT.rm, xT, out_dtype=F32, layout="rm", use_bias=False)
+        gview = self.grad_of(param).view(param.shape[0], -1)
+        ops.scale_rows_acc(gview, tmp[:, : gview.shape[1]], row_scale)
+
+    def _adapter_backward(self, ad, g, x_in, t):
+        """y = x_in + Wup relu(Wdn x_in + bdn) + bup.  Given g = dL/dy returns dL/dx_in
+        WITHOUT the identity term (caller adds g through the residual epilogue)."""
+        dn, up = ad[0], ad[2]
+        ops.colsum(g, self.grad_of(up.bias))
+        gT = _t(g)
+        self._acc_wgrad(up.weight, gT, _t(t))
+        dt = ops.gemm(g, _t(up.weight.data), aux=t, aux_mode=ops.MG_AUX_RELU_GATE, layout="rm", use_bias=False)
+        ops.colsum(dt, self.grad_of(dn.bias))
+        self._acc_wgrad(dn.weight, _t(dt), _t(x_in))
+        return dt, _t(dn.weight.data)
+
+    def _lm_backward(self, tape):
+        eng = self.module.lm.engine
+        dev = self.device
+        packs, head_t = self._lm_packs()
+        B, S, M = tape["B"], tape["S"], tape["M"]
+        H, d = eng.H, eng.d
+        # loss head: dlogits -> dxl -> ln_f backward -> scatter to the target rows
+        dxl = ops.gemm(tape["dlogits"], head_t)
+        dxr = ops.layernorm_bwd(dxl, tape["xr"], eng.lnf_g, eng.eps)
+        g = torch.zeros(M, d, dtype=BF16, device=dev)
+        g.index_copy_(0, tape["rows"], dxr)
+        for li in range(len(eng.layers) - 1, -1, -1):
+            ly, blk, pk, sv = eng.layers[li], self.module.lm.transformer.h[li], packs[li], tape["layers"][li]
+            # ---- MLP branch ----
+            if ly.mlp_adapter is not None:
+                dt, dn_t = self._adapter_backward(blk.mlp[1].adapter, g, sv["m"], sv["t"])
+                dm = ops.gemm(dt, dn_t, residuals=(g,), layout="rm", use_bias=False)
+            else:
+                dm = g
+            dhpre = ops.gemm(dm, pk["fc_out_t"], aux=sv["hpre"], aux_mode=ops.MG_AUX_GELU_GRAD)
+            dln_mlp = ops.gemm(dhpre, pk["fc_in_t"])
+            del dhpre, dm
+            # ---- attention branch ----
+            if ly.attn_adapter is not None:
+                dta, dn_t = self._adapter_backward(blk.attn.adapter, g, sv["a"], sv["ta"])
+                da = ops.gemm(dta, dn_t, residuals=(g,), layout="rm", use_bias=False)
+            else:
+                da = g
+            dctx = ops.gemm(da, pk["out_t"])
+            q, k, v = sv["q"], sv["k"], sv["v"]
+            hs = H * S * 256
+            qt = ops.head_transpose(q, B, H, S, sb=hs, ss=256, sh=S * 256)
+            kt = ops.head_transpose(k, B, H, S, sb=hs, ss=256, sh=S * 256)
+            dOt = ops.head_transpose(dctx, B, H, S, sb=S * d, ss=d, sh=256)
+            dq, dk, dv = ops.attn_bwd(q, k, v, qt, kt, dctx, dOt, sv["ctx"], sv["lse"], B, H, S)
+            dqkv = ops.rotary_merge_bwd(dq, dk, dv, B, S, H, eng.rot, eng.sin_t, eng.cos_t)
+            dln = ops.gemm(dqkv, pk["qkv_t"], residuals=(dln_mlp,))
+            g = ops.layernorm_bwd(dln, sv["x"], ly.ln_g, eng.eps, res=g)
+            tape["layers"][li] = None     # free this layer's activations
+        return g
+
+    # ---- image prefix + CLIP trunk -------------------------------------------------
+    def _prefix_forward(self, images, dropout_mask):
+        ip = self.module.image_prefix
+        feats, etape = self._encoder_forward(images)
+        B, P, E = feats.shape
+        proj = RawWeight(ip.proj.weight.data, bias=self.master_of(ip.proj.bias)) if self.is_trainable(ip.proj.weight) \
+            else PackedLinear(ip.proj.weight, ip.proj.bias)
+        f2 = feats.reshape(B * P, E)
+        keep = 1.0 - ip.dropout.p
+        mask = None
+        if ip.dropout.p > 0:
+            if dropout_mask is None:
+                dropout_mask = (torch.rand(B * P, ip.out_dim, device=self.device) < keep).to(BF16) / keep
+            mask = dropout_mask.reshape(B * P, ip.out_dim).to(BF16).contiguous()
+        y1 = ops.gemm(f2, proj, layout="rm" if isinstance(proj, RawWeight) else None,
+                      aux=mask, aux_mode=ops.MG_AUX_MUL if mask is not None else ops.MG_AUX_NONE)
+        if ip.use_layernorm:
+            y2 = ops.layernorm(y1, self.master_of(ip.ln.weight), self.master_of(ip.ln.bias), ip.ln.eps)
+        else:
+            y2 = y1
+        return y2.view(B, P, ip.out_dim), {"enc": etape, "feats": f2, "mask": mask, "y1": y1, "B": B, "P": P}
+
+    def _prefix_backward(self, pt, d_prefix):
+        ip = self.module.image_prefix
+        B, P = pt["B"], pt["P"]
+        g = d_prefix.reshape(B * P, ip.out_dim)
+        if ip.use_layernorm:
+            dx, xhat = ops.layernorm_bwd(g, pt["y1"], self.master_of(ip.ln.weight), ip.ln.eps, want_xhat=True)
+            ops.colsum(g, self.grad_of(ip.ln.weight), xhat)
+            ops.colsum(g, self.grad_of(ip.ln.bias))
+            g = dx
+        if pt["mask"] is not None:
+            g = ops.mul(g, pt["mask"])
+        ops.colsum(g, self.grad_of(ip.proj.bias))
+        self._acc_wgrad(ip.proj.weight, _t(g), _t(pt["feats"]))
+        if pt["enc"] is None:
+            return
+        # gradient wrt the trunk output (a post-ReLU tensor): gate fused in the epilogue
+        d_feats = ops.gemm(g, _t(ip.proj.weight.data), aux=pt["feats"], aux_mode=ops.MG_AUX_RELU_GATE, layout="rm",
+                           use_bias=False)
+        self._encoder_backward(pt["enc"], d_feats)
+
+    # The trunk is executed unit by unit; a unit = conv (+ frozen-statistics BN) (+ ReLU).
+    def _bn_vectors(self, bn):
+        gamma, beta = self.master_of(bn.weight), self.master_of(bn.bias)
+        scale = (gamma / torch.sqrt(bn.running_var.float() + bn.eps)).contiguous()
+        shift = (beta - bn.running_mean.float() * scale).contiguous()
+        return gamma, beta, scale, shift
+
+    def _unit_fwd(self, conv, bn, a, geom, relu, residual=None, kind=None):
+        w = conv.weight.data
+        cout, cin, kh, _ = w.shape
+        gamma, beta, scale, shift = self._bn_vectors(bn)
+        if kind == "stem":
+            w2 = torch.zeros(cout, 64, dtype=BF16, device=w.device)
+            w2[:, :27] = w.reshape(cout, 27)
+            wop, convarg = RawWeight(w2, bias=shift, K=32), None
+        elif kh == 1:
+            wop, convarg = RawWeight(self._pad_k(w.reshape(cout, cin)), bias=shift, K=cin), None
+        else:
+            wop = RawWeight(self._pad_k(w.permute(0, 2, 3, 1).reshape(cout, 9 * cin)), bias=shift, K=9 * cin)
+            convarg = (geom[1], geom[2], cin)
+        if residual is None:
+            y = ops.gemm(a, wop, scale=scale, act=ops.MG_ACT_RELU if relu else ops.MG_ACT_NONE, conv=convarg, layout="rm")
+        else:
+            y = ops.gemm(a, wop, scale=scale, residuals=(residual,), act_after=ops.MG_ACT_RELU, conv=convarg, layout="rm")
+        rec = {"conv": conv, "bn": bn, "a": a, "y": y, "geom": geom, "kind": kind or ("1x1" if kh == 1 else "3x3"),
+               "scale": scale, "gamma": gamma, "beta": beta, "sub": residual}
+        return y, rec
+
+    @staticmethod
+    def _pad_k(w2):
+        n, k = w2.shape
+        kp = ops.ceil_to(k, 64)
+        if kp == k:
+            return w2.contiguous()
+        out = torch.zeros(n, kp, dtype=w2.dtype, device=w2.device)
+        out[:, :k] = w2
+        return out
+
+    def _encoder_forward(self, images):
+        enc = self.module.image_prefix.enc
+        if not any(self.is_trainable(p) for p in enc.parameters()):
+            return enc(images), None           # frozen trunk: inference path, nothing taped
+        x = images.to(BF16).contiguous()
+        B, _, H, W = x.shape
+        h, w = H // 2, W // 2
+        units = []
+        cols = ops.stem_im2col(x)
+        y, r = self._unit_fwd(enc.conv1, enc.bn1, cols, (B, h, w), True, kind="stem"); units.append(r)
+        y, r = self._unit_fwd(enc.conv2, enc.bn2, y, (B, h, w), True); units.append(r)
+        y, r = self._unit_fwd(enc.conv3, enc.bn3, y, (B, h, w), True); units.append(r)
+        stem_out = y
+        y = ops.avgpool2(y.view(B, h, w, -1))
+        h, w = h // 2, w // 2
+        y = y.view(B * h * w, -1)
+        blocks = []
+        for li in range(1, 5):
+            for blk in getattr(enc, f"layer{li}"):
+                br = {"x": y, "geom": (B, h, w), "stride": blk.stride}
+                o1, br["u1"] = self._unit_fwd(blk.conv1, blk.bn1, y, (B, h, w), True)
+                o2, br["u2"] = self._unit_fwd(blk.conv2, blk.bn2, o1, (B, h, w), True)
+                p, xi = o2, y
+                if blk.stride > 1:
+                    p = ops.avgpool2(o2.view(B, h, w, -1)).view(B * (h // 2) * (w // 2), -1)
+                    xi = ops.avgpool2(y.view(B, h, w, -1)).view(B * (h // 2) * (w // 2), -1)
+                    h, w = h // 2, w // 2
+                identity = y if blk.downsample is None else None
+                if blk.downsample is not None:
+                    identity, br["ud"] = self._unit_fwd(blk.downsample[1], blk.downsample[2], xi, (B, h, w), False)
+                y, br["u3"] = self._unit_fwd(blk.conv3, blk.bn3, p, (B, h, w), False, residual=identity)
+                br["out_geom"] = (B, h, w)
+                blocks.append(br)
+        feats = y.view(B, h * w, -1)
+        return feats, {"units": units, "stem_out": stem_out, "blocks": blocks, "B": B}
+
+    def _unit_bwd(self, rec, g, need_dgrad=True, gate=None, residuals=(), gate_after=False):
+        """g: gradient wrt the unit's BN output, already ReLU-gated, [M, Cout].
+        Accumulates conv / BN-affine gradients; returns the gradient wrt the unit's
+        input, gated by ``gate`` (> 0) and with ``residuals`` added in the epilogue."""
+        conv, bn = rec["conv"], rec["bn"]
+        w = conv.weight.data
+        cout, cin, kh, _ = w.shape
+        Bq, hh, ww = rec["geom"]
+        a, scale = rec["a"], rec["scale"]
+        ops.bn_param_grad(g, rec["y"], rec["sub"], rec["gamma"], rec["beta"], self.grad_of(bn.weight), self.grad_of(bn.bias))
+        gT = _t(g)
+        if rec["kind"] == "3x3":
+            # im2col^T rows come in the weight's own (ci, ky, kx) order -> dW needs no re-layout
+            self._acc_wgrad(conv.weight, gT, RawWeight(ops.im2col_t(a, Bq, hh, ww, cin)), row_scale=scale)
+        else:   # 1x1, or the stem's explicit im2col matrix (columns already in (c, ky, kx) order)
+            self._acc_wgrad(conv.weight, gT, _t(a), row_scale=scale)
+        if not need_dgrad:
+            return None
+        aux_kw = {}
+        if gate is not None:
+            aux_kw = dict(aux=gate, aux_mode=ops.MG_AUX_RELU_GATE, aux_after=gate_after)
+        if rec["kind"] == "3x3":
+            # dX = conv3x3(g, W') with W'[ci][(ky,kx),co] = W[co][ci][2-ky][2-kx] * scale[co]
+            wf = (w.float() * scale.view(cout, 1, 1, 1)).flip(2, 3).permute(1, 2, 3, 0).reshape(cin, 9 * cout).to(BF16)
+            wop = RawWeight(self._pad_k(wf), K=9 * cout)
+            return ops.gemm(g, wop, conv=(hh, ww, cout), layout="rm", use_bias=False, residuals=residuals, **aux_kw)
+        wf = (w.reshape(cout, cin).float() * scale.view(cout, 1)).t().contiguous().to(BF16)    # [cin, cout]
+        wop = RawWeight(self._pad_k(wf), K=cout)
+        return ops.gemm(g, wop, layout="rm", use_bias=False, residuals=residuals, **aux_kw)
+
+    def _encoder_backward(self, et, g_out):
+        """g_out: gradient wrt the trunk output, already gated by (out > 0)."""
+        blocks = et["blocks"]
+        g3 = g_out
+        for bi in range(len(blocks) - 1, -1, -1):
+            br = blocks[bi]
+            B, h, w = br["geom"]
+            x = br["x"]
+            prev_is_relu = bi > 0            # block input is the previous block's ReLU output (not for layer1.0)
+            # identity path
+            if "ud" in br:
+                dxi = self._unit_bwd(br["ud"], g3)
+                d_id = ops.avgpool2_bwd(dxi.view(B, h // 2, w // 2, -1), B, h, w, dxi.shape[1]).view(B * h * w, -1) \
+                    if br["stride"] > 1 else dxi
+            else:
+                d_id = g3
+            # main path: conv3 -> (pool) -> conv2 -> conv1
+            u2y = br["u2"]["y"]
+            if br["stride"] > 1:
+                dp = self._unit_bwd(br["u3"], g3)
+                g2 = ops.avgpool2_bwd(dp.view(B, h // 2, w // 2, -1), B, h, w, dp.shape[1], gate=u2y).view(B * h * w, -1)
+            else:
+                g2 = self._unit_bwd(br["u3"], g3, gate=u2y)
+            g1 = self._unit_bwd(br["u2"], g2, gate=br["u1"]["y"])
+            g3 = self._unit_bwd(br["u1"], g1, gate=x if prev_is_relu else None, residuals=(d_id,), gate_after=True)
+            blocks[bi] = None
+        # stem: avgpool -> conv3 -> conv2 -> conv1
+        units = et["units"]
+        B, h, w = units[2]["geom"]
+        g = ops.avgpool2_bwd(g3.view(B, h // 2, w // 2, -1), B, h, w, g3.shape[1], gate=et["stem_out"]).view(B * h * w, -1)
+        g = self._unit_bwd(units[2], g, gate=units[1]["y"])
+        g = self._unit_bwd(units[1], g, gate=units[0]["y"])
+        self._unit_bwd(units[0], g, need_dgrad=False)
+
+    # ---- optimizer step ----------------------------------------------------------------
+    def step(self):
+        if self.micro_steps % self.gas != 0:
+            return
+        self.global_steps += 1
+        lrs = self.lr_scheduler.get_lr()
+        grad_scale = 1.0 / self.gas
+        if self.world > 1:
+            # gradient average over ranks (DeepSpeed ZeRO-2 reduce-scatter semantics: mean), RCCL over xGMI
+            from .comm import allreduce_grads
+            allreduce_grads([g.grad for g in self.groups])
+            grad_scale /= self.world
+        self._norm_sq.zero_()
+        for g in self.groups:
+            ops.sumsq(g.grad, self._norm_sq)
+        for g, lr in zip(self.groups, lrs):
+            ops.adamw(g.master, g.m, g.v, g.grad, g.model, lr, self.betas[0], self.betas[1], self.eps, g.wd,
+                      self.global_steps, max_norm=self.clip, norm_sq=self._norm_sq, grad_scale=grad_scale)
+            g.grad.zero_()
+        self.lr_scheduler.step()
+        self.module.image_prefix.invalidate_packed()
+        self._adapters_dirty = True
+
+    def grad_norm(self) -> float:
+        return float(torch.sqrt(self._norm_sq)) / self.gas / self.world
+
+    # ---- DeepSpeed-protocol odds and ends -------------------------------------------------
+    def deepspeed_io(self, dataset, batch_size=None, collate_fn=None):
+        from torch.utils.data import DataLoader
+        from torch.utils.data.distributed import DistributedSampler
+        bs = batch_size or max(1, self.config.batch_size // (self.gas * self.world))
+        sampler = DistributedSampler(dataset) if self.world > 1 else None
+        from .datasets import collate_fn as default_collate
+        from functools import partial
+        return DataLoader(dataset, batch_size=bs, sampler=sampler, shuffle=False,
+                          collate_fn=collate_fn or partial(default_collate, seq_len=self.module.seq_len))
+
+    def save_checkpoint(self, save_dir, client_state=None, tag=None):
+        """DeepSpeed layout: <dir>/<tag>/mp_rank_00_model_states.pt with {"module": state_dict, ...} + <dir>/latest."""
+        tag = tag or f"global_step{self.global_steps}"
+        if (not dist.is_initialized()) or dist.get_rank() == 0:
+            path = Path(save_dir) / tag
+            path.mkdir(parents=True, exist_ok=True)
+            sd = {"module": {k: v.detach().cpu() for k, v in self.module.state_dict().items()},
+                  "optimizer": [{"master": g.master.cpu(), "m": g.m.cpu(), "v": g.v.cpu()} for g in self.groups],
+                  "lr_scheduler": self.lr_scheduler.state_dict(), "global_steps": self.global_steps,
+                  "micro_steps": self.micro_steps}
+            sd.update(client_state or {})
+            torch.save(sd, path / "mp_rank_00_model_states.pt")
+            (Path(save_dir) / "latest").write_text(tag)
+        if dist.is_initialized():
+            dist.barrier()
+
+    def load_checkpoint(self, load_dir, load_optimizer_states=True, load_lr_scheduler_states=True, tag=None):
+        latest = Path(load_dir) / "latest"
+        if tag is None:
+            if not latest.exists():
+                return None, None
+            tag = latest.read_text().strip()
+        path = Path(load_dir) / tag / "mp_rank_00_model_states.pt"
+        if not path.exists():
+            return None, None
+        sd = torch.load(path, map_location="cpu", weights_only=False)
+        self.module.load_checkpoint_state(sd["module"])
+        for g in self.groups:       # parameters were re-pointed at the flat buffers; refresh masters from the loaded values
+            for p, o in zip(g.params, g.offsets):
+                g.master[o:o + p.numel()].copy_(p.data.reshape(-1).float())
+        if load_optimizer_states and "optimizer" in sd:
+            for g, s in zip(self.groups, sd["optimizer"]):
+                g.master.copy_(s["master"]); g.m.copy_(s["m"]); g.v.copy_(s["v"])
+                g.model.copy_(g.master)
+            self.global_steps = sd.get("global_steps", 0)
+            self.micro_steps = sd.get("micro_steps", 0)
+        if load_lr_scheduler_states and "lr_scheduler" in sd:
+            self.lr_scheduler.load_state_dict(sd["lr_scheduler"])
+        self.module.invalidate_packed()
+        self._lm_train_packs = None if False else self._lm_train_packs
+        return str(path), sd
+
+
+def initialize(model, config=None, model_parameters=None, training_data=None, collate_fn=None, **unused):
+    """deepspeed.initialize(...) look-alike: returns (engine, optimizer, train_loader, lr_scheduler)."""
+    engine = MagmaEngine(model, config, param_groups=model_parameters)
+    loader = engine.deepspeed_io(training_data, collate_fn=collate_fn) if training_data is not None else None
+    return engine, engine, loader, engine.lr_scheduler

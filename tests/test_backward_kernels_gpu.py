@@ -1,0 +1,191 @@
+"""Backward / optimizer kernels against torch autograd (fp32) on the same inputs."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+BF16 = torch.bfloat16
+
+
+def rnd(*shape, dev, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dev)
+
+
+def rel(a, b):
+    a, b = a.float(), b.float()
+    return float((a - b).norm() / (b.norm() + 1e-12))
+
+
+def test_transposes(dev):
+    from magma_amd import ops
+    x = rnd(200, 136, dev=dev, seed=1).to(BF16)
+    assert torch.equal(ops.transpose(x), x.t().contiguous())
+    y = rnd(13, 16, dev=dev, seed=1).to(BF16)                       # R not a multiple of 8 -> zero padded columns
+    yt = ops.transpose(y)
+    assert yt.shape == (16, 16) and torch.equal(yt[:, :13], y.t()) and bool((yt[:, 13:] == 0).all())
+    B, H, S = 2, 3, 57
+    src = rnd(B * S, H * 256, dev=dev, seed=2).to(BF16)          # [M, d] activation -> per-head transposed
+    out = ops.head_transpose(src, B, H, S, sb=S * H * 256, ss=H * 256, sh=256)
+    ref = src.view(B, S, H, 256).permute(0, 2, 3, 1)
+    assert torch.equal(out[..., :S], ref) and bool((out[..., S:] == 0).all())
+    q = rnd(B, H, S, 256, dev=dev, seed=3).to(BF16)               # [B,H,S,256] -> [B,H,256,S]
+    out = ops.head_transpose(q, B, H, S, sb=H * S * 256, ss=256, sh=S * 256)
+    assert torch.equal(out[..., :S], q.transpose(2, 3))
+
+
+def test_colsum(dev):
+    from magma_amd import ops
+    x = rnd(1000, 520, dev=dev, seed=4).to(BF16)
+    y = rnd(1000, 520, dev=dev, seed=5).to(BF16)
+    out = torch.zeros(520, device=dev)
+    ops.colsum(x, out)
+    assert rel(out, x.float().sum(0)) < 1e-5
+    ops.colsum(x, out, y)                                         # accumulates
+    assert rel(out, x.float().sum(0) + (x.float() * y.float()).sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("rows,d", [(9, 4096), (33, 512)])
+def test_layernorm_bwd(dev, rows, d):
+    from magma_amd import ops
+    x = (rnd(rows, d, dev=dev, seed=6) * 2 + 0.5).to(BF16)
+    dy = rnd(rows, d, dev=dev, seed=7).to(BF16)
+    res = rnd(rows, d, dev=dev, seed=8).to(BF16)
+    g = rnd(d, dev=dev, seed=9) * 0.1 + 1
+    xf = x.float().requires_grad_(True)
+    yref = F.layer_norm(xf, (d,), g, torch.zeros(d, device=dev), 1e-5)
+    yref.backward(dy.float())
+    dx, xh = ops.layernorm_bwd(dy, x, g, 1e-5, res=res, want_xhat=True)
+    assert rel(dx, xf.grad + res.float()) < 4e-3
+    assert rel(xh, F.layer_norm(x.float(), (d,))) < 4e-3
+
+
+def test_ce_fwd_bwd(dev):
+    from magma_amd import ops
+    R, V = 21, 1053
+    lg = (rnd(R, V, dev=dev, seed=10) * 3)
+    tg = torch.randint(0, V, (R,), generator=torch.Generator().manual_seed(1))
+    tg[::4] = -100
+    lgr = lg.clone().requires_grad_(True)
+    ref = F.cross_entropy(lgr, tg.to(dev), ignore_index=-100)
+    ref.backward()
+    loss, dl = ops.cross_entropy_fwd_bwd(lg, tg.to(dev), 1056)
+    assert abs(float(loss) - float(ref)) < 1e-4
+    assert rel(dl[:, :V], lgr.grad) < 4e-3 and bool((dl[:, V:] == 0).all())
+
+
+def test_epilogue_aux_modes(dev):
+    from magma_amd import ops
+    M, N, K = 130, 264, 128
+    a = rnd(M, K, dev=dev, seed=11).to(BF16)
+    w = rnd(N, K, dev=dev, seed=12, scale=0.1).to(BF16)
+    aux = rnd(M, N, dev=dev, seed=13).to(BF16)
+    r0 = rnd(M, N, dev=dev, seed=14).to(BF16)
+    lin = ops.PackedLinear(w, bias=rnd(N, dev=dev, seed=15))
+    acc = a.float() @ w.float().t() + lin.bias
+    out = ops.gemm(a, lin, aux=aux, aux_mode=ops.MG_AUX_RELU_GATE, residuals=(r0,))
+    assert rel(out, acc * (aux.float() > 0) + r0.float()) < 4e-3
+    out = ops.gemm(a, lin, aux=aux, aux_mode=ops.MG_AUX_RELU_GATE, residuals=(r0,), aux_after=True)
+    assert rel(out, (acc + r0.float()) * (aux.float() > 0)) < 4e-3
+    xa = aux.float().requires_grad_(True)
+    gl = 0.5 * xa * (1 + torch.tanh(math.sqrt(2 / math.pi) * (xa + 0.044715 * xa ** 3)))
+    gl.sum().backward()
+    out = ops.gemm(a, lin, aux=aux, aux_mode=ops.MG_AUX_GELU_GRAD)
+    assert rel(out, acc * xa.grad) < 4e-3
+    out = ops.gemm(a, lin, aux=aux, aux_mode=ops.MG_AUX_MUL)
+    assert rel(out, acc * aux.float()) < 4e-3
+    pre = torch.empty(M, N, dtype=BF16, device=dev)
+    out = ops.gemm(a, lin, act=ops.MG_ACT_GELU_NEW, out2=pre)
+    assert rel(pre, acc) < 4e-3 and rel(out, F.gelu(acc, approximate="tanh")) < 4e-3
+
+
+@pytest.mark.parametrize("B,H,S", [(1, 1, 64), (2, 2, 57), (1, 2, 152)])
+def test_attention_backward(dev, B, H, S):
+    from magma_amd import ops
+    d = H * 256
+    q = rnd(B, H, S, 256, dev=dev, seed=20, scale=0.5).to(BF16)
+    k = rnd(B, H, S, 256, dev=dev, seed=21, scale=0.5).to(BF16)
+    v = rnd(B, H, S, 256, dev=dev, seed=22).to(BF16)
+    dO = rnd(B * S, d, dev=dev, seed=23).to(BF16)
+    vt = ops.head_transpose(v, B, H, S, sb=H * S * 256, ss=256, sh=S * 256)
+    out = torch.empty(B * S, d, dtype=BF16, device=dev)
+    lse = torch.empty(B, H, S, dtype=torch.float32, device=dev)
+    ops.attn_prefill(q, k, vt, out, B, H, S, lse=lse)
+    qt = ops.head_transpose(q, B, H, S, sb=H * S * 256, ss=256, sh=S * 256)
+    kt = ops.head_transpose(k, B, H, S, sb=H * S * 256, ss=256, sh=S * 256)
+    dOt = ops.head_transpose(dO, B, H, S, sb=S * d, ss=d, sh=256)
+    dq, dk, dv = ops.attn_bwd(q, k, v, qt, kt, dO, dOt, out, lse, B, H, S)
+    qf, kf, vf = (t.float().requires_grad_(True) for t in (q, k, v))
+    sc = qf @ kf.transpose(-1, -2) / 16.0
+    sc = sc.masked_fill(~torch.ones(S, S, dtype=torch.bool, device=dev).tril(), float("-inf"))
+    o = (torch.softmax(sc, -1) @ vf).permute(0, 2, 1, 3).reshape(B * S, d)
+    o.backward(dO.float())
+    assert rel(dq, qf.grad) < 1.5e-2, rel(dq, qf.grad)
+    assert rel(dk, kf.grad) < 1.5e-2, rel(dk, kf.grad)
+    assert rel(dv, vf.grad) < 1.5e-2, rel(dv, vf.grad)
+
+
+def test_rotary_merge_bwd(dev):
+    from magma_amd import ops
+    from oracle.model import apply_rotary, rotary_tables
+    B, S, H = 2, 37, 2
+    sin_t, cos_t = rotary_tables(64, 64)
+    dq, dk, dv = (rnd(B, H, S, 256, dev=dev, seed=30 + i).to(BF16) for i in range(3))
+    out = ops.rotary_merge_bwd(dq, dk, dv, B, S, H, 64, sin_t.to(dev).contiguous(), cos_t.to(dev).contiguous())
+    x = torch.zeros(B, S, H, 256, requires_grad=True)
+    y = apply_rotary(x, torch.arange(S), 64)
+    y.backward(dq.float().cpu().permute(0, 2, 1, 3))
+    got = out.view(B, S, 3, H, 256).float().cpu()
+    assert rel(got[:, :, 0], x.grad) < 4e-3
+    assert torch.equal(got[:, :, 2], dv.float().cpu().permute(0, 2, 1, 3))
+
+
+def test_conv_backward_helpers(dev):
+    from magma_amd import ops
+    B, H, W, C = 2, 6, 8, 16
+    dy = rnd(B, H // 2, W // 2, C, dev=dev, seed=40).to(BF16)
+    dx = ops.avgpool2_bwd(dy, B, H, W, C)
+    xr = torch.zeros(B, C, H, W, device=dev, requires_grad=True)
+    F.avg_pool2d(xr, 2).backward(dy.float().permute(0, 3, 1, 2))
+    assert rel(dx, xr.grad.permute(0, 2, 3, 1)) < 4e-3
+    a, b, gt = (rnd(64, 24, dev=dev, seed=41 + i).to(BF16) for i in range(3))
+    assert rel(ops.add_gate(a, b, gt), (a.float() + b.float()) * (gt.float() > 0)) < 4e-3
+    assert torch.equal(ops.add_gate(a), a)
+    # im2col^T x dY^T == conv weight gradient
+    x = rnd(B, H, W, C, dev=dev, seed=44).to(BF16)
+    cols_t = ops.im2col_t(x, B, H, W, C)
+    ref = F.unfold(x.float().permute(0, 3, 1, 2), 3, padding=1)          # [B, C*9, HW], row = c*9 + tap
+    ref = ref.permute(1, 0, 2).reshape(9 * C, B * H * W)
+    assert torch.equal(cols_t.float()[:, : B * H * W], ref)
+    # frozen-stat BN affine grads
+    M = B * H * W
+    g = rnd(M, C, dev=dev, seed=45).to(BF16)
+    y = rnd(M, C, dev=dev, seed=46).to(BF16)
+    sub = rnd(M, C, dev=dev, seed=47).to(BF16)
+    gamma, beta = rnd(C, dev=dev, seed=48) + 2, rnd(C, dev=dev, seed=49)
+    dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    ops.bn_param_grad(g, y, sub, gamma, beta, dg, db)
+    assert rel(db, g.float().sum(0)) < 1e-4
+    assert rel(dg, (g.float() * (y.float() - sub.float() - beta) / gamma).sum(0)) < 1e-4
+
+
+def test_adamw_and_clip(dev):
+    from magma_amd import ops
+    n = 10007
+    p0 = rnd(n, dev=dev, seed=50)
+    g = rnd(n, dev=dev, seed=51) * 3
+    ref_p = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([ref_p], lr=1e-2, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1)
+    p, m, v = p0.clone(), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    pb = torch.empty(n, dtype=BF16, device=dev)
+    for step in (1, 2, 3):
+        ref_p.grad = g.clone()
+        torch.nn.utils.clip_grad_norm_([ref_p], 1.0)
+        opt.step()
+        nsq = torch.zeros(1, device=dev)
+        ops.sumsq(g, nsq)
+        ops.adamw(p, m, v, g, pb, 1e-2, 0.9, 0.95, 1e-8, 0.1, step, max_norm=1.0, norm_sq=nsq)
+    assert rel(p, ref_p.detach()) < 1e-5
+    assert torch.equal(pb, p.to(BF16))

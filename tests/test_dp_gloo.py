@@ -1,0 +1,70 @@
+"""world_size-2 data-parallel logic on CPU (gloo): the bucketed gradient
+all-reduce and the loss reduction give every rank the same mean, and averaging
+the gradients of two half batches equals the full-batch gradient."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from magma_amd import comm
+    from magma_amd.utils import reduce_losses
+    comm.BUCKET_ELEMS = 1000                     # force several buckets
+    torch.manual_seed(0)
+    w = torch.randn(37, 11)
+    x = torch.randn(8, 11)
+    xs = x[rank * 4:(rank + 1) * 4]              # this rank's shard of the global batch
+    w_r = w.clone().requires_grad_(True)
+    loss = (xs @ w_r.t()).pow(2).mean()          # per-rank mean loss (DeepSpeed semantics: mean of means)
+    loss.backward()
+    flat = [w_r.grad.reshape(-1).clone(), torch.full((2500,), float(rank + 1))]
+    comm.allreduce_grads(flat)
+    grad_mean = flat[0] / world
+    w_f = w.clone().requires_grad_(True)
+    (x @ w_f.t()).pow(2).mean().backward()
+    ok = torch.allclose(grad_mean, w_f.grad.reshape(-1), atol=1e-6)
+    ok &= bool((flat[1] == 3.0).all())
+    red = reduce_losses(loss.detach())
+    q.put((rank, bool(ok), float(red)))
+    dist.destroy_process_group()
+
+
+def test_dp_allreduce_two_ranks():
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+    assert all(r[1] for r in res), res
+    assert abs(res[0][2] - res[1][2]) < 1e-7          # every rank logs the same reduced loss
+
+
+def test_lr_schedule_shape():
+    from magma_amd.train_engine import LRScheduler
+    s = LRScheduler({"warmup_min_lr": [0.0, 0.0], "warmup_num_steps": 100, "total_num_steps": 1000}, "WarmupDecayLR",
+                    [8e-4, 2e-6])
+    lr0 = s.get_lr()
+    assert lr0 == [0.0, 0.0]
+    for _ in range(100):
+        s.step()
+    assert abs(s.get_lr()[0] - 8e-4) < 1e-12 and abs(s.get_lr()[1] - 2e-6) < 1e-15
+    for _ in range(450):
+        s.step()
+    assert abs(s.get_lr()[0] - 4e-4) < 1e-9          # half way down the linear decay

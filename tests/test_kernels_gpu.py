@@ -115,7 +115,7 @@ def test_gemm_skinny(dev, M, N, K, variant):
     x = rnd(M, K, dev=dev, seed=21).to(BF16)
     w = rnd(N, K, dev=dev, seed=22, scale=0.05).to(BF16)
     bias = rnd(N, dev=dev, seed=23)
-    res = rnd(M, N, dev=dev, seed=24).to(BF16)
+    res = rnd(M, (N + 7) // 8 * 8, dev=dev, seed=24).to(BF16)[:, :N]   # padded row stride (ldr % 4 == 0)
     lin = ops.PackedLinear(w, bias=bias)
     out = ops.gemm_skinny(x, lin, residuals=(res,), variant=variant)
     ref = x.float() @ w.float().t() + bias + res.float()
@@ -264,7 +264,7 @@ def test_avgpool_and_stem(dev):
     w = rnd(8, 3, 3, 3, dev=dev, seed=103, scale=0.2).to(BF16)
     cols = ops.stem_im2col(img)
     wk = torch.zeros(8, 32, dtype=BF16, device=dev)
-    wk[:, :27] = w.permute(0, 2, 3, 1).reshape(8, 27)
+    wk[:, :27] = w.reshape(8, 27)
     out = ops.gemm(cols, ops.PackedLinear(wk))
     ref = F.conv2d(img.float(), w.float(), stride=2, padding=1).permute(0, 2, 3, 1).reshape(-1, 8)
     assert_close(out, ref, GEMM_TOL, "stem conv via im2col")

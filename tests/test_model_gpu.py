@@ -68,9 +68,19 @@ def test_embed_matches_reference_layout(setup):
     assert got.shape == ref.shape == (2, 4 + 6, cfg.d_model)
     assert rel(got[:, 4:], ref[:, 4:]) < 4e-3          # text rows: pure gather (bf16 rounding of the table)
     # preprocess_inputs plumbing (string + already-transformed image), in-place list mutation like the reference
-    lst = [images[:1].clone(), "hi"]
+    import numpy as np
+    import PIL.Image as I
+    from magma_amd import ImageInput
+    path = "/tmp/_magma_test_img.png"
+    I.fromarray((np.random.RandomState(0).rand(90, 70, 3) * 255).astype("uint8")).save(path)
+    lst = [ImageInput(path), "hi"]
     out = model.preprocess_inputs(lst, embed=False)
     assert out is lst and lst[1].ndim == 2 and lst[1].dtype == torch.int64
+    assert lst[0].shape == (1, 3, 64, 64)                       # resized + center-cropped to the encoder resolution
+    e = model.preprocess_inputs([ImageInput(path), "hi"])      # embed=True path
+    assert e.shape == (1, 4 + lst[1].shape[1], cfg.d_model)
+    with pytest.raises(Exception):
+        model.preprocess_inputs([images[:1]])                   # raw tensors are rejected, as in the reference
 
 
 def test_prefill_and_decode_logits(setup):
