@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--config", default="MAGMA_v1")
     ap.add_argument("--layers", type=int, default=None, help="debug: fewer LM layers (result is then NOT the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--train-steps", type=int, default=2, help="timed training steps for the extra 'train' object (0 = skip)")
+    ap.add_argument("--train-batch", type=int, default=16, help="per-GPU micro-batch of the training step (BASELINE config[2])")
+    ap.add_argument("--train-truncate", action="store_true", help="also time the exact-truncation variant (SURVEY Q3)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     return ap.parse_args()
 
@@ -58,31 +61,42 @@ def cpu_baseline(args, budget_s):
     cores = os.cpu_count()
     cfg = O.OracleConfig.magma_v1()
     cfg.n_layer = 1
-    g = torch.Generator().manual_seed(0)
     d = cfg.d_model
-    p = {}
-    h = "lm.transformer.h.0."
-    mk = lambda *s: (torch.randn(*s, generator=g) * 0.02).to(torch.bfloat16)  # noqa: E731
-    p[h + "ln_1.weight"], p[h + "ln_1.bias"] = torch.ones(d, dtype=torch.bfloat16), torch.zeros(d, dtype=torch.bfloat16)
-    for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
-        p[O.attn_prefix(cfg, 0) + n + ".weight"] = mk(d, d)
-    mp = O.mlp_prefix(cfg, 0)
-    p[mp + "c_fc.weight"], p[mp + "c_fc.bias"] = mk(cfg.d_ff, d), mk(cfg.d_ff)
-    p[mp + "c_proj.weight"], p[mp + "c_proj.bias"] = mk(d, cfg.d_ff), mk(d)
-    a = h + "mlp.1.adapter."
-    p[a + "0.weight"], p[a + "0.bias"] = mk(1024, d), mk(1024)
-    p[a + "2.weight"], p[a + "2.bias"] = mk(d, 1024), mk(d)
     B, P = args.batch, (args.res // 32) ** 2
     S0 = P + args.prompt
-    x = mk(B, S0, d) * 50
+    h = "lm.transformer.h.0."
+    a = h + "mlp.1.adapter."
     t_used = time.time()
+
+    def build(dtype):
+        g = torch.Generator().manual_seed(0)
+        mk = lambda *s: (torch.randn(*s, generator=g) * 0.02).to(dtype)  # noqa: E731
+        p = {h + "ln_1.weight": torch.ones(d, dtype=dtype), h + "ln_1.bias": torch.zeros(d, dtype=dtype)}
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            p[O.attn_prefix(cfg, 0) + n + ".weight"] = mk(d, d)
+        mp = O.mlp_prefix(cfg, 0)
+        p[mp + "c_fc.weight"], p[mp + "c_fc.bias"] = mk(cfg.d_ff, d), mk(cfg.d_ff)
+        p[mp + "c_proj.weight"], p[mp + "c_proj.bias"] = mk(d, cfg.d_ff), mk(d)
+        p[a + "0.weight"], p[a + "0.bias"] = mk(1024, d), mk(1024)
+        p[a + "2.weight"], p[a + "2.bias"] = mk(d, 1024), mk(d)
+        return p, mk
+
+    best = None
     with torch.no_grad():
-        O.block_fwd(p, cfg, 0, x, None, 0)                       # warm
-        t0 = time.time(); _, past = O.block_fwd(p, cfg, 0, x, None, 0); t_prefill_layer = time.time() - t0
+        for dtype in (torch.float32, torch.bfloat16):      # report whichever the host runs faster
+            p, mk = build(dtype)
+            x = mk(B, S0, d) * 50
+            O.block_fwd(p, cfg, 0, x, None, 0)
+            t0 = time.time(); _, past = O.block_fwd(p, cfg, 0, x, None, 0); tp = time.time() - t0
+            if best is None or tp < best[0]:
+                best = (tp, dtype, p, mk, past)
+            if time.time() - t_used > budget_s * 0.5:
+                break
+        t_prefill_layer, dtype, p, mk, past = best
         x1 = mk(B, 1, d) * 50
         t0 = time.time()
         n_dec = 0
-        while n_dec < 3 or (time.time() - t0 < budget_s * 0.4 and n_dec < 8):
+        while n_dec < 2 or (time.time() - t0 < budget_s * 0.3 and n_dec < 8):
             O.block_fwd(p, cfg, 0, x1, past, S0); n_dec += 1
         t_decode_layer = (time.time() - t0) / n_dec
         head_w, head_b = mk(cfg.vocab_out, d), mk(cfg.vocab_out)
@@ -91,9 +105,68 @@ def cpu_baseline(args, budget_s):
     total = L * t_prefill_layer + args.gen * (L * t_decode_layer + t_head)
     toks = B * args.gen
     return {"value": toks / total, "unit": "tokens/s", "cores": cores, "kind": "port",
-            "sample": f"oracle (PyTorch CPU bf16) one full-size GPT-J block+adapter timed at prefill B={B},S={S0} "
-                      f"({t_prefill_layer*1e3:.0f} ms) and decode ({t_decode_layer*1e3:.0f} ms), x{L} layers + lm_head "
-                      f"({t_head*1e3:.0f} ms) x {args.gen} steps; image encoder excluded; measured in {time.time()-t_used:.0f} s"}
+            "sample": f"oracle (PyTorch CPU {str(dtype).split('.')[-1]}, {cores} threads) one full-size GPT-J block+adapter timed at "
+                      f"prefill B={B},S={S0} ({t_prefill_layer*1e3:.0f} ms) and decode ({t_decode_layer*1e3:.0f} ms), x{L} layers + "
+                      f"lm_head ({t_head*1e3:.0f} ms) x {args.gen} steps; image encoder excluded; measured in {time.time()-t_used:.0f} s"}
+
+
+def train_flops_per_image(model, res, S):
+    """SURVEY 8d, 'no recompute' policy: T = 2G + 3A + W + 3E per image."""
+    L, d, ff, V = model.lm.config.num_layers, model.lm.config.hidden_size, model.lm.config.intermediate_size, model.lm.config.vocab_size
+    r = sum(ad.N for ad in (model.lm.engine.layers[0].mlp_adapter or ())[:1]) + sum(ad.N for ad in (model.lm.engine.layers[0].attn_adapter or ())[:1])
+    G = S * (L * (8 * d * d + 4 * d * ff + 4 * d * r))            # block GEMMs fwd (head runs on target rows only)
+    A = 4 * L * d * S * S                                          # attention fwd, full S^2 as the reference computes
+    Wg = 4 * S * L * d * r                                         # adapter wgrad
+    E = 47.72e9 * (res / 224.0) ** 2                               # CLIP trunk fwd per image
+    return 2 * G + 3 * A + Wg + 3 * E
+
+
+def bench_train(model, args, rank, world, dev):
+    """Config[2]: MAGMA_v1 training step, synthetic img-caption pairs, per-GPU batch 16,
+    S = 2048, trainable = adapters + CLIP trunk + prefix; no recompute; AdamW + clip inside
+    the timed region; DP all-reduce when world > 1."""
+    from magma_amd.datasets import synthetic_batch
+    from magma_amd.train_engine import MagmaEngine
+    model.config.gradient_accumulation_steps = 1
+    out = {}
+    eng = MagmaEngine(model)
+    eng.train()
+    B, S = args.train_batch, model.seq_len
+    images, caps = synthetic_batch(B, args.res, S, model.eos_token, 50256, 1234 + rank, device=dev, dtype=torch.bfloat16)
+
+    def step():
+        o = eng(images, caps)
+        eng.backward(o.loss)
+        eng.step()
+        return o.loss
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for trunc in ([False, True] if args.train_truncate else [False]):
+        eng.truncate = trunc
+        step()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.train_steps):
+            loss = step()
+        sync()
+        dt = (time.perf_counter() - t0) / args.train_steps
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t)
+        key = "truncated" if trunc else "full_S2048"
+        fl = train_flops_per_image(model, args.res, S) * B
+        out[key] = {"images_per_s": world * B / dt, "ms_per_step": dt * 1e3, "loss": float(loss),
+                    "algorithmic_tflops_per_gpu": None if trunc else fl / dt / 1e12,
+                    "mfma_frac_of_2.5PF": None if trunc else fl / dt / 2.5e15}
+    out["policy"] = "no recompute; bf16; adapters+CLIP trunk+prefix trainable; clip 1.0 + AdamW in the timed region"
+    out["per_gpu_batch"], out["seq_len"] = B, S
+    return out
 
 
 def main():
@@ -185,6 +258,15 @@ def main():
                            "parallelism": f"replicas x{world}", "layers": model.lm.config.num_layers,
                            "prefill_len": int(toks.shape[1] - gen)},
                 "roofline": roof}
+        line["train"] = None
+    train = None
+    if args.train_steps > 0:
+        try:
+            train = bench_train(model, args, rank, world, dev)
+        except Exception as e:  # noqa: BLE001
+            train = {"error": repr(e)[:300]}
+    if rank == 0:
+        line["train"] = train
         if not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
