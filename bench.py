@@ -238,15 +238,47 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         ms_tok = e0.elapsed_time(e1) / n_rep
-        wbytes = 0
+        # dominant kernel in isolation: every decode GEMV of the model (all layers + head) launched
+        # back to back on the real weights (12.16 GB, far beyond the 256 MiB Infinity Cache), HIP events
+        # on the launch stream.  achieved = algorithmic bytes per launch / average launch duration.
+        from magma_amd import ops
+        st = cache.decode_state
+        jobs = []
         for ly in eng.layers:
-            for lin in [ly.qkv, ly.out, ly.fc_in, ly.fc_out] + list(ly.mlp_adapter or ()) + list(ly.attn_adapter or ()):
-                wbytes += lin.N * lin.K * 2
-        wbytes += eng.head.N * eng.head.K * 2
-        achieved = wbytes / (ms_tok * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": "skinny_kernel (decode weight-streaming GEMM, whole token step graph)",
-                "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
-                "bytes_per_launch": wbytes, "ms_per_token_step": ms_tok, "decode_tokens_per_s": B / (ms_tok * 1e-3)}
+            jobs += [(st.ln, ly.qkv, st.qkv), (st.ln, ly.fc_in, st.h), (st.ctx, ly.out, st.a), (st.h, ly.fc_out, st.m)]
+            if ly.mlp_adapter:
+                jobs += [(st.m, ly.mlp_adapter[0], st.t[:, : ly.mlp_adapter[0].N]), (st.t[:, : ly.mlp_adapter[0].N], ly.mlp_adapter[1], st.xb)]
+            if ly.attn_adapter:
+                jobs += [(st.a, ly.attn_adapter[0], st.ta[:, : ly.attn_adapter[0].N]), (st.ta[:, : ly.attn_adapter[0].N], ly.attn_adapter[1], st.a2)]
+        jobs.append((st.lnf, eng.head, st.logits))
+        wbytes = sum(w.N * w.K * 2 for _, w, _ in jobs)
+
+        def sweep():
+            for xin, w, o in jobs:
+                ops.gemm_skinny(xin, w, out=o)
+
+        gk = torch.cuda.CUDAGraph()
+        sweep()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(gk):
+            sweep()
+        gk.replay()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(10):
+            gk.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        ms_sweep = e0.elapsed_time(e1) / 10
+        achieved = wbytes / (ms_sweep * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": "skinny_kernel (decode weight-streaming GEMM, M=8)",
+                "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                # PMC (profiles/r01_skinny_fc_in_pmc_*): FETCH_SIZE 65,850 KB/launch at the fc_in shape, x2 for the
+                # gfx950 wide-read under-count (MI355X_MICROARCH.md HBM) = 134.9 MB vs 134.2 MB algorithmic
+                "traffic": 1.005 * wbytes / len(jobs), "bytes_per_launch": wbytes / len(jobs), "launches": len(jobs),
+                "avg_launch_us": ms_sweep * 1e3 / len(jobs),
+                "token_step": {"ms": ms_tok, "decode_tokens_per_s": B / (ms_tok * 1e-3),
+                               "hbm_frac_whole_step": wbytes / (ms_tok * 1e-3) / 8e12}}
 
     if rank == 0:
         line = {"metric": "generate tokens/sec (MAGMA_v1, batch-8 images, 32 new tokens, greedy)",

@@ -156,6 +156,12 @@ int mg_attn_decode_bf16(const mg_bf16* q, const mg_bf16* kcache, const mg_bf16* 
                         mg_bf16* out, int32_t B, int32_t H, int32_t Smax, const int32_t* d_pos,
                         void* stream);
 
+/* K9 epilogue + K10 decode in ONE launch: takes the fused qkv row of the new token
+ * [B, 3*H*256], rotates q,k, appends k,v at *d_pos, attends over [0, *d_pos].      */
+int mg_attn_decode_fused_bf16(const mg_bf16* qkv, mg_bf16* kcache, mg_bf16* vcache, mg_bf16* out, int32_t B,
+                              int32_t H, int32_t Smax, const int32_t* d_pos, int32_t rot_dim,
+                              const float* sin_t, const float* cos_t, void* stream);
+
 /* K24 greedy: token[b] = argmax_v logits[b, v] (first maximum), int64 out;
  * optionally appends to out_tokens[b*out_ld + *d_pos_out] and bumps *d_pos.  */
 int mg_argmax_f32(const float* logits, int64_t ld, int32_t B, int32_t V, int64_t* token,

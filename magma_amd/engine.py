@@ -238,9 +238,8 @@ class LMEngine:
             ops.layernorm(x, ly.ln_g, ly.ln_b, self.eps, out=st.ln)
             ops.gemm_skinny(st.ln, ly.qkv, out=st.qkv)
             ops.gemm_skinny(st.ln, ly.fc_in, out=st.h, act=ops.MG_ACT_GELU_NEW)
-            ops.rotary_split(st.qkv, B, 1, self.H, self.rot, self.sin_t, self.cos_t, st.q, cache.k[li], cache.v[li],
-                             d_pos=cache.d_pos)
-            ops.attn_decode(st.q, cache.k[li], cache.v[li], st.ctx, B, self.H, cache.d_pos)
+            ops.attn_decode_fused(st.qkv, cache.k[li], cache.v[li], st.ctx, B, self.H, cache.d_pos, self.rot,
+                                  self.sin_t, self.cos_t)
             a = ops.gemm_skinny(st.ctx, ly.out, out=st.a)
             if ly.attn_adapter is not None:
                 ta = st.ta[:, : ly.attn_adapter[0].N]

@@ -236,6 +236,15 @@ def attn_decode(q, kcache, vcache, out, B, H, d_pos):
     return out
 
 
+def attn_decode_fused(qkv, kcache, vcache, out, B, H, d_pos, rot_dim, sin_t, cos_t):
+    """rotary(q,k) + KV append at *d_pos + attention over [0, *d_pos], one launch."""
+    _need_gpu(qkv)
+    check(L.load().mg_attn_decode_fused_bf16(qkv.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), out.data_ptr(), B, H,
+                                             kcache.shape[2], d_pos.data_ptr(), rot_dim, sin_t.data_ptr(),
+                                             cos_t.data_ptr(), _stream()), "mg_attn_decode_fused_bf16")
+    return out
+
+
 def argmax(logits: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _need_gpu(logits)
     assert logits.dtype == torch.float32 and logits.ndim == 2 and logits.stride(1) == 1

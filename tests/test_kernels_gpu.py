@@ -240,6 +240,12 @@ def test_decode_attention(dev, ctx):
     sc = (q.float() @ kc[:, :, :ctx].float().transpose(-1, -2)) / 16.0
     ref = (torch.softmax(sc, -1) @ vc[:, :, :ctx].float()).reshape(B, d)
     assert_close(out, ref, 3e-3, "decode attention")
+    # fused variant: rotary + append + attention in one launch, from the same qkv row
+    kc2, vc2 = kc0.clone(), vc0.clone()
+    out2 = torch.empty(B, d, dtype=BF16, device=dev)
+    ops.attn_decode_fused(qkv, kc2, vc2, out2, B, H, d_pos, 64, sin_t, cos_t)
+    assert torch.equal(kc2, kc) and torch.equal(vc2, vc), "fused append must write the same cache rows"
+    assert_close(out2, ref, 3e-3, "fused decode attention")
 
 
 def test_argmax_and_pos(dev):
