@@ -118,8 +118,20 @@ typedef struct mg_skinny_desc {
   int64_t ldx;
   const mg_bf16* W;
   int32_t M, N, Kp;  /* Kp = padded K of the tiled weight (multiple of 64)    */
-  int32_t nt_hint;   /* 0 = auto; else n-tiles (of 16 rows) per workgroup     */
+  int32_t nt_hint;   /* 0 = auto; else variant nt | waves<<4 | kc<<8          */
   mg_epilogue ep;
+  /* LayerNorm folded into the GEMV: W must already be W*gamma and ep.bias must be
+   * b + W.beta; ln_colsum[n] = sum_k W'[n][k].  The kernel derives mean/rstd of each
+   * x row from the fragments it streams:  y = rstd*(acc - mean*ln_colsum[n]) + bias[n].
+   * NULL = plain GEMV.  (Saves the separate LayerNorm launch of every decode layer.)   */
+  const float* ln_colsum;
+  float ln_inv_d, ln_eps;
+  /* two output segments in one launch (fused qkv | fc_in of a GPT-J block, which share
+   * their input): columns [split_n, N) use ep_b (pointers/vectors indexed from column
+   * split_n = 0).  0 = single segment.                                                 */
+  int32_t split_n;
+  int32_t _pad;
+  mg_epilogue ep_b;
 } mg_skinny_desc;
 
 int mg_gemm_skinny_bf16(const mg_skinny_desc* d, void* stream);

@@ -305,7 +305,14 @@ struct SkinnyParams {
   const mg_bf16* X; int64_t ldx;
   const mg_bf16* W;
   int M, N, ntiles, ksteps;
+  // LayerNorm folded into the GEMV (decode): W' = W*gamma, bias' = b + W.beta are baked
+  // into the operands; the kernel gets the row statistics from the x fragments it already
+  // streams and applies  y = rstd*(acc - mean*colsum[n]) + bias'[n]  in the epilogue.
+  const float* ln_colsum; float ln_inv_d, ln_eps;
+  // two output segments (fused qkv | fc_in): columns >= split_n go to ep_b
+  int split_n;
   mg_epilogue ep;
+  mg_epilogue ep_b;
 };
 
 template <int WAVES, int KC, int NT>
@@ -323,6 +330,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_kernel(const SkinnyParams p
   f32x4 acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float xs = 0.f, xss = 0.f;   // row statistics of x (LayerNorm fold)
 
   for (int kc = 0; kc < per_wave; kc += KC) {
     // Issue the whole chunk's loads before the first MFMA (GEMV recipe: loads
@@ -343,6 +351,18 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_kernel(const SkinnyParams p
       if (!xok) raw = (u32x4){0u, 0u, 0u, 0u};
       xf[i] = __builtin_bit_cast(bf16x8, raw);
     }
+    if (p.ln_colsum) {
+#pragma unroll
+      for (int i = 0; i < KC; ++i) {
+        const u32x4 raw = __builtin_bit_cast(u32x4, xf[i]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float a = bflo(raw[j]), b = bfhi(raw[j]);
+          xs += a + b;
+          xss += a * a + b * b;
+        }
+      }
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -353,15 +373,36 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_kernel(const SkinnyParams p
   }
 
   // cross-wave (split-K) reduction through LDS, then epilogue by wave t
+  __shared__ float rstat[WAVES][16][2];
 #pragma unroll
   for (int t = 0; t < NT; ++t) *(f32x4*)(red + ((wave * NT + t) * 64 + lane) * 4) = acc[t];
+  if (p.ln_colsum) {   // lanes li, li+16, li+32, li+48 hold the same row: fold the 4 k-slots
+    xs += __shfl_xor(xs, 16, 64); xs += __shfl_xor(xs, 32, 64);
+    xss += __shfl_xor(xss, 16, 64); xss += __shfl_xor(xss, 32, 64);
+    if (lq == 0) { rstat[wave][li][0] = xs; rstat[wave][li][1] = xss; }
+  }
   __syncthreads();
+  float mean = 0.f, rstd = 1.f;
+  if (p.ln_colsum) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) { a += rstat[w][li][0]; b += rstat[w][li][1]; }
+    mean = a * p.ln_inv_d;
+    rstd = rsqrtf(fmaxf(b * p.ln_inv_d - mean * mean, 0.f) + p.ln_eps);
+  }
   for (int t = wave; t < NT; t += WAVES) {
     if (nt0 + t >= p.ntiles) break;
     f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int w = 0; w < WAVES; ++w) s += *(const f32x4*)(red + ((w * NT + t) * 64 + lane) * 4);
-    if (xok) epilogue_store4(p.ep, li, (nt0 + t) * 16 + lq * 4, s, p.N);
+    if (!xok) continue;
+    const int n = (nt0 + t) * 16 + lq * 4;
+    if (p.ln_colsum && n < p.N) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[r] = rstd * (s[r] - mean * (n + r < p.N ? p.ln_colsum[n + r] : 0.f));
+    }
+    if (p.split_n > 0 && n >= p.split_n) epilogue_store4(p.ep_b, li, n - p.split_n, s, p.N - p.split_n);
+    else epilogue_store4(p.ep, li, n, s, p.split_n > 0 ? p.split_n : p.N);
   }
 }
 
@@ -448,6 +489,14 @@ extern "C" int mg_gemm_skinny_bf16(const mg_skinny_desc* d, void* stream) {
   SkinnyParams sp;
   sp.X = d->X; sp.ldx = d->ldx; sp.W = d->W; sp.M = d->M; sp.N = d->N;
   sp.ntiles = (d->N + 15) / 16; sp.ksteps = d->Kp / 32; sp.ep = d->ep;
+  sp.ln_colsum = d->ln_colsum; sp.ln_inv_d = d->ln_inv_d; sp.ln_eps = d->ln_eps;
+  sp.split_n = d->split_n; sp.ep_b = d->ep_b;
+  if (d->split_n != 0) {
+    if (d->split_n < 0 || d->split_n >= d->N || (d->split_n & 15)) MG_FAIL(MG_ERR_SHAPE, "mg_gemm_skinny_bf16: split_n must be a multiple of 16 inside (0, N)");
+    if (int rc = check_epilogue(d->ep_b, "mg_gemm_skinny_bf16(ep_b)")) return rc;
+    // per-column vectors of the second segment are indexed from its own column 0
+  }
+  if (d->ln_colsum && (!MG_ALIGNED16(d->ln_colsum) || d->ln_inv_d <= 0.f)) MG_FAIL(MG_ERR_ALIGN, "mg_gemm_skinny_bf16: bad LayerNorm-fold arguments");
   hipStream_t s = (hipStream_t)stream;
   // Variant = (waves per workgroup, k-steps per load burst, n-tiles per
   // workgroup).  nt_hint == 0 -> tuned default for the shape; otherwise
@@ -456,7 +505,7 @@ extern "C" int mg_gemm_skinny_bf16(const mg_skinny_desc* d, void* stream) {
   if (d->nt_hint == 0) {
     // measured on MI355X (tools/kbench.py, profiles/r01_kbench_skinny.txt): many
     // waves with short load bursts beat few waves with deep ones.
-    if (sp.ksteps % (8 * 8) == 0 && sp.ksteps >= 512) { waves = 8; kc = 8; nt = 1; }
+    if (sp.ksteps % (4 * 16) == 0 && sp.ksteps >= 512) { waves = 4; kc = 16; nt = 1; }   // K=16384 (fc_out): 5.57 TB/s
     else if (sp.ksteps % (8 * 4) == 0) { waves = 8; kc = 4; nt = 1; }
     else if (sp.ksteps % 4 == 0) { waves = 4; kc = 1; nt = 1; }
     else { waves = 1; kc = 1; nt = 1; }
@@ -467,6 +516,7 @@ extern "C" int mg_gemm_skinny_bf16(const mg_skinny_desc* d, void* stream) {
   MG_SK(8, 16, 1); MG_SK(8, 16, 2); MG_SK(4, 16, 1); MG_SK(4, 16, 2);
   MG_SK(8, 8, 1);  MG_SK(8, 8, 2);  MG_SK(8, 8, 4);  MG_SK(4, 8, 2); MG_SK(4, 8, 4);
   MG_SK(8, 4, 1);  MG_SK(8, 4, 2);  MG_SK(8, 4, 4);
+  MG_SK(16, 8, 1); MG_SK(16, 4, 1); MG_SK(16, 2, 1); MG_SK(16, 4, 2);
   MG_SK(4, 1, 1);  MG_SK(1, 1, 1);
 #undef MG_SK
   MG_FAIL(MG_ERR_UNSUPPORTED, "mg_gemm_skinny_bf16: variant (waves=%d,kc=%d,nt=%d) not instantiated", waves, kc, nt);

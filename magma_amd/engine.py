@@ -18,6 +18,7 @@ Per block (parallel residual, adapters after attention/MLP):
 """
 from __future__ import annotations
 
+import os
 from typing import Any, List, Optional
 
 import torch
@@ -95,12 +96,40 @@ class LMEngine:
             ly.fc_in = ops.PackedLinear(mlp.c_fc.weight, mlp.c_fc.bias)
             ly.fc_out = ops.PackedLinear(mlp.c_proj.weight, mlp.c_proj.bias)
             ly.ln_g, ly.ln_b = f32(blk.ln_1.weight), f32(blk.ln_1.bias)
+            ly.dec_in = None      # decode-only fused [qkv | fc_in] operand with ln_1 folded in (built lazily)
+            ly._src = (a, mlp)
             self.layers.append(ly)
         self.lnf_g, self.lnf_b = f32(lm.transformer.ln_f.weight), f32(lm.transformer.ln_f.bias)
         self.head = ops.PackedLinear(lm.lm_head.weight, lm.lm_head.bias)
         self.Vp = ops.ceil_to(self.V, 8)
         self.sin_t, self.cos_t = rotary_tables(cfg.rotary_dim, cfg.max_position_embeddings, dev)
         self.rot = cfg.rotary_dim
+        self.head_dec = None
+        self._lm_head = lm.lm_head
+        self._cache_pool = {}
+        self._side_stream = torch.cuda.Stream(device=dev)
+        self.two_streams = os.environ.get("MAGMA_DECODE_STREAMS", "1") == "2"   # measured slower (3.07 vs 2.94 ms/step): off
+
+    def _ensure_decode_packs(self):
+        """Decode operands with the LayerNorms folded in (frozen gamma/beta): per layer one
+        fused [3d+ff, d] matrix W' = [Wqkv;Wfc]*gamma whose single weight-streaming launch
+        produces qkv and gelu(fc_in) from the raw residual stream (no LayerNorm launch, one
+        GEMV instead of two); ln_f is folded into lm_head the same way."""
+        if self.head_dec is not None:
+            return
+        d3 = 3 * self.d
+        for ly in self.layers:
+            a, mlp = ly._src
+            w = torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight, mlp.c_fc.weight], dim=0)
+            b = torch.cat([torch.zeros(d3, device=self.device), mlp.c_fc.bias.detach().float()])
+            w2, b2, cs = ops.fold_layernorm(w, b, ly.ln_g, ly.ln_b)
+            lin = ops.PackedLinear(w2, bias=b2[:d3])
+            lin.bias_b, lin.colsum = b2[d3:].contiguous(), cs
+            ly.dec_in = lin
+            del w, w2
+        w2, b2, cs = ops.fold_layernorm(self._lm_head.weight, self._lm_head.bias, self.lnf_g, self.lnf_b)
+        self.head_dec = ops.PackedLinear(w2, bias=b2)
+        self.head_dec.colsum = cs
 
     def repack_adapters(self, lm):
         """Refresh only the (trainable) adapter operands after optimizer steps; the
@@ -115,7 +144,7 @@ class LMEngine:
 
     # ------------------------------------------------------------------ API
     def forward(self, input_ids=None, inputs_embeds=None, labels=None, use_cache=False, past_key_values=None,
-                output_hidden_states=False, cache_hint: Optional[int] = None) -> LMOutput:
+                output_hidden_states=False, cache_hint: Optional[int] = None, reuse_cache: bool = False) -> LMOutput:
         if labels is not None:
             if inputs_embeds is None:
                 inputs_embeds = self.embed_ids(input_ids)
@@ -128,7 +157,7 @@ class LMEngine:
         if inputs_embeds is None:
             inputs_embeds = self.embed_ids(input_ids)
         if use_cache:
-            logits, cache, hs = self.prefill(inputs_embeds, cache_hint, output_hidden_states)
+            logits, cache, hs = self.prefill(inputs_embeds, cache_hint, output_hidden_states, reuse_cache)
             # generate() only reads the last position, so only that row is computed
             return LMOutput(logits=logits.unsqueeze(1), past_key_values=cache, hidden_states=hs, loss=None)
         x, hs = self._blocks_prefill(inputs_embeds, None, output_hidden_states)
@@ -179,11 +208,20 @@ class LMEngine:
                 hs.append(x.view(B, S, d))
         return x, hs
 
-    def prefill(self, embeds: torch.Tensor, cache_hint: Optional[int] = None, want_hidden=False):
+    def prefill(self, embeds: torch.Tensor, cache_hint: Optional[int] = None, want_hidden=False,
+                reuse_cache: bool = False):
         B, S, _ = embeds.shape
         n_pos = self.cfg.max_position_embeddings
         Smax = min(n_pos, ops.ceil_to(S + (cache_hint if cache_hint else 256), 64))
-        cache = KVCache(self.L, B, self.H, Smax, self.device)
+        if reuse_cache:
+            # generate() owns the cache for the duration of one call: keep one KV cache (and the
+            # hipGraph of the token step captured on it) per shape instead of re-allocating and
+            # re-capturing for every call
+            cache = self._cache_pool.get((B, Smax))
+            if cache is None:
+                cache = self._cache_pool[(B, Smax)] = KVCache(self.L, B, self.H, Smax, self.device)
+        else:
+            cache = KVCache(self.L, B, self.H, Smax, self.device)
         x, hs = self._blocks_prefill(embeds, cache, want_hidden)
         cache.pos = S
         cache.d_pos.fill_(S)
@@ -234,10 +272,18 @@ class LMEngine:
         B = cache.B
         ops.embedding(st.ids, self.wte, st.xa.view(B, 1, self.d))
         x, xn = st.xa, st.xb
+        d3 = 3 * self.d
+        main = torch.cuda.current_stream()
+        side = self._side_stream if self.two_streams else None
         for li, ly in enumerate(self.layers):
-            ops.layernorm(x, ly.ln_g, ly.ln_b, self.eps, out=st.ln)
-            ops.gemm_skinny(st.ln, ly.qkv, out=st.qkv)
-            ops.gemm_skinny(st.ln, ly.fc_in, out=st.h, act=ops.MG_ACT_GELU_NEW)
+            # ln_1 + qkv + fc_in(+gelu) in ONE weight-streaming launch
+            ops.gemm_skinny(x, ly.dec_in, out=st.qkv, ln_fold=(ly.dec_in.colsum, self.d, self.eps),
+                            split=(d3, st.h, ops.MG_ACT_GELU_NEW, ly.dec_in.bias_b))
+            # attention branch (latency-bound, 128 workgroups) runs on a second HIP stream
+            # underneath the MLP branch's weight streaming; both join at the adapter-up GEMV
+            if side is not None:
+                side.wait_stream(main)
+                torch.cuda.set_stream(side)
             ops.attn_decode_fused(st.qkv, cache.k[li], cache.v[li], st.ctx, B, self.H, cache.d_pos, self.rot,
                                   self.sin_t, self.cos_t)
             a = ops.gemm_skinny(st.ctx, ly.out, out=st.a)
@@ -245,16 +291,21 @@ class LMEngine:
                 ta = st.ta[:, : ly.attn_adapter[0].N]
                 ops.gemm_skinny(a, ly.attn_adapter[0], out=ta, act=ops.MG_ACT_RELU)
                 a = ops.gemm_skinny(ta, ly.attn_adapter[1], out=st.a2, residuals=(a,))
+            if side is not None:
+                torch.cuda.set_stream(main)
             if ly.mlp_adapter is not None:
                 ops.gemm_skinny(st.h, ly.fc_out, out=st.m)
                 t = st.t[:, : ly.mlp_adapter[0].N]
                 ops.gemm_skinny(st.m, ly.mlp_adapter[0], out=t, act=ops.MG_ACT_RELU)
+                if side is not None:
+                    main.wait_stream(side)
                 ops.gemm_skinny(t, ly.mlp_adapter[1], out=xn, residuals=(st.m, a, x))
             else:
+                if side is not None:
+                    main.wait_stream(side)
                 ops.gemm_skinny(st.h, ly.fc_out, out=xn, residuals=(a, x))
             x, xn = xn, x
-        ops.layernorm(x, self.lnf_g, self.lnf_b, self.eps, out=st.lnf)
-        ops.gemm_skinny(st.lnf, self.head, out=st.logits)
+        ops.gemm_skinny(x, self.head_dec, out=st.logits, ln_fold=(self.head_dec.colsum, self.d, self.eps))
         ops.argmax(st.logits[:, : self.V], out=st.token)
         ops.advance_pos(cache.d_pos, 1)
 
@@ -267,6 +318,7 @@ class LMEngine:
             raise NotImplementedError("decode batch > 16 per GPU is not implemented (weight-streaming kernel is M<=16)")
         st = cache.decode_state
         if st is None:
+            self._ensure_decode_packs()
             st = cache.decode_state = self._alloc_decode_state(cache)
         st.ids.copy_(input_ids.reshape(cache.B, 1))
         if not use_graph:

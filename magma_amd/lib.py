@@ -55,6 +55,9 @@ class SkinnyDesc(C.Structure):
         ("W", C.c_void_p),
         ("M", C.c_int32), ("N", C.c_int32), ("Kp", C.c_int32), ("nt_hint", C.c_int32),
         ("ep", Epilogue),
+        ("ln_colsum", C.c_void_p), ("ln_inv_d", C.c_float), ("ln_eps", C.c_float),
+        ("split_n", C.c_int32), ("_pad", C.c_int32),
+        ("ep_b", Epilogue),
     ]
 
 

@@ -171,8 +171,12 @@ class RawWeight:
 
 def gemm_skinny(x: torch.Tensor, w: PackedLinear, out: Optional[torch.Tensor] = None, *, act: int = MG_ACT_NONE,
                 residuals: Sequence[torch.Tensor] = (), act_after: int = MG_ACT_NONE, scale=None,
-                use_bias: bool = True, out_dtype=BF16, variant: int = 0) -> torch.Tensor:
-    """Decode-shape (M <= 16) weight-streaming GEMM; needs the fragment-tiled layout."""
+                use_bias: bool = True, out_dtype=BF16, variant: int = 0, ln_fold: Optional[tuple] = None,
+                split: Optional[tuple] = None) -> torch.Tensor:
+    """Decode-shape (M <= 16) weight-streaming GEMM; needs the fragment-tiled layout.
+    ``ln_fold=(colsum fp32 [N], d, eps)``: LayerNorm of x folded into the GEMV (weights and
+    bias must be pre-folded, see fold_layernorm).  ``split=(split_n, out_b, act_b, bias_b)``:
+    columns >= split_n are written to ``out_b`` with their own activation / bias vector."""
     _need_gpu(x)
     assert x.dtype == BF16 and x.ndim == 2 and x.stride(1) == 1 and w.ft is not None
     assert x.shape[1] == w.Kp, "decode activations must span the padded K"
@@ -182,9 +186,29 @@ def gemm_skinny(x: torch.Tensor, w: PackedLinear, out: Optional[torch.Tensor] = 
     d = SkinnyDesc()
     d.X, d.ldx, d.W = x.data_ptr(), x.stride(0), w.ft.data_ptr()
     d.M, d.N, d.Kp, d.nt_hint = M, w.N, w.Kp, variant
-    d.ep = _epilogue(out, w.N, w.bias if use_bias else None, scale, act, residuals, act_after)
+    n_a = w.N if split is None else split[0]
+    d.ep = _epilogue(out, n_a, w.bias if use_bias else None, scale, act, residuals, act_after)
+    if ln_fold is not None:
+        cs, dd, eps = ln_fold
+        d.ln_colsum, d.ln_inv_d, d.ln_eps = cs.data_ptr(), 1.0 / dd, eps
+    if split is not None:
+        split_n, out_b, act_b, bias_b = split
+        d.split_n = split_n
+        d.ep_b = _epilogue(out_b, w.N - split_n, bias_b, None, act_b, (), MG_ACT_NONE)
     check(L.load().mg_gemm_skinny_bf16(C.byref(d), _stream()), "mg_gemm_skinny_bf16")
     return out
+
+
+def fold_layernorm(weight: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor):
+    """LN(x) W^T + b  ==  rstd*(x W'^T - mean*colsum) + b'  with  W' = W*gamma (bf16),
+    colsum[n] = sum_k W'[n][k] (of the rounded W'), b' = b + W beta.  One-off weight prep."""
+    wf = weight.detach().float()
+    w2 = (wf * gamma.float()[None, :]).to(BF16)
+    colsum = w2.float().sum(1).contiguous()
+    b2 = wf @ beta.float()
+    if bias is not None:
+        b2 = b2 + bias.detach().float()
+    return w2, b2.contiguous(), colsum
 
 
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,

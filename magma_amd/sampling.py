@@ -55,7 +55,8 @@ def generate(model, embeddings, max_steps: int = 100, temperature: float = 0.7, 
     greedy = temperature == 0.0
     for i in range(max_steps):
         if i == 0:
-            outputs = model.lm(inputs_embeds=embeddings, use_cache=True, past_key_values=None, cache_hint=max_steps)
+            outputs = model.lm(inputs_embeds=embeddings, use_cache=True, past_key_values=None, cache_hint=max_steps,
+                               reuse_cache=True)
         else:
             outputs = model.lm(input_ids=out[:, n - 1:n], use_cache=True, past_key_values=past)
         past = outputs.past_key_values

@@ -315,3 +315,27 @@ def test_errors_are_loud(dev):
         ops.gemm(a, ops.PackedLinear(torch.zeros(8, 12, dtype=BF16, device=dev)))
     with pytest.raises(MagmaHipError):
         ops.layernorm(torch.zeros(2, 64, dtype=BF16), torch.ones(64), torch.zeros(64))   # CPU tensor
+
+
+def test_skinny_layernorm_fold_and_split(dev):
+    """Decode fusion: LayerNorm folded into the GEMV + two output segments (qkv | gelu(fc_in))."""
+    from magma_amd import ops
+    M, K, N1, N2 = 8, 512, 96, 160
+    x = (rnd(M, K, dev=dev, seed=201) * 3 + 0.7).to(BF16)
+    w = rnd(N1 + N2, K, dev=dev, seed=202, scale=0.05).to(BF16)
+    b = rnd(N1 + N2, dev=dev, seed=203)
+    g = rnd(K, dev=dev, seed=204) * 0.2 + 1
+    be = rnd(K, dev=dev, seed=205) * 0.2
+    w2, b2, cs = ops.fold_layernorm(w, b, g, be)
+    lin = ops.PackedLinear(w2, bias=b2[:N1].contiguous())
+    out_a = torch.empty(M, N1, dtype=BF16, device=dev)
+    out_b = torch.empty(M, N2, dtype=BF16, device=dev)
+    ops.gemm_skinny(x, lin, out=out_a, ln_fold=(cs, K, 1e-5), split=(N1, out_b, ops.MG_ACT_GELU_NEW, b2[N1:].contiguous()))
+    ln = F.layer_norm(x.float(), (K,), g, be, 1e-5)
+    ref = ln @ w.float().t() + b
+    assert_close(out_a, ref[:, :N1], 1e-2, "ln-fold segment a")
+    assert_close(out_b, F.gelu(ref[:, N1:], approximate="tanh"), 1e-2, "ln-fold segment b (gelu)")
+    # single segment, fp32 out (lm_head with ln_f folded)
+    lin2 = ops.PackedLinear(w2, bias=b2)
+    o32 = ops.gemm_skinny(x, lin2, out_dtype=torch.float32, ln_fold=(cs, K, 1e-5))
+    assert_close(o32, ref, 1e-2, "ln-fold fp32")

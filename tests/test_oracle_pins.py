@@ -56,7 +56,8 @@ def test_generate_loop_matches_reference():
         def __init__(self, V):
             self.V, self.calls = V, []
 
-        def __call__(self, inputs_embeds=None, input_ids=None, use_cache=None, past_key_values=None, cache_hint=None):
+        def __call__(self, inputs_embeds=None, input_ids=None, use_cache=None, past_key_values=None, cache_hint=None,
+                     reuse_cache=False):
             from magma_amd.language_model import LMOutput
             if inputs_embeds is not None:
                 last = (inputs_embeds[:, -1, :].sum(-1) * 7).long() % self.V

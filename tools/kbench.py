@@ -85,7 +85,7 @@ def main():
             bench_gemm(32768, 16384, 4096, layout, tag="train_fc_in")
     if which in ("all", "skinny"):
         variants = [(1, 8, 16), (2, 8, 16), (1, 4, 16), (2, 4, 16), (1, 8, 8), (2, 8, 8), (4, 8, 8), (2, 4, 8),
-                    (4, 4, 8), (1, 8, 4), (2, 8, 4), (4, 8, 4)]
+                    (4, 4, 8), (1, 8, 4), (2, 8, 4), (4, 8, 4), (1, 16, 8), (1, 16, 4), (1, 16, 2), (2, 16, 4)]
         for (N, K, tag) in [(12288, 4096, "qkv"), (16384, 4096, "fc_in"), (4096, 4096, "out_proj"),
                             (4096, 16384, "fc_out"), (1024, 4096, "adapter_dn"), (4096, 1024, "adapter_up"),
                             (50258, 4096, "lm_head")]:
