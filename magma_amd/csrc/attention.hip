@@ -94,11 +94,14 @@ __global__ __launch_bounds__(256) void rotary_split_kernel(
 // accumulator registers of a lane exactly the 8 consecutive keys it must
 // supply as the P^T operand of the PV product -- no cross-lane movement.
 // ---------------------------------------------------------------------------
-constexpr int K_STRIDE = DH * 2 + 16;   // bytes per K row in LDS (528)
-constexpr int VT_STRIDE = 32 * 2 + 16;  // bytes per V^T row in LDS (80)
+// conflict-free LDS images for the ds_read_b128 lane groups (searched offline): K rows
+// unpadded with the 16-B chunk index XORed by f(row) = (row&3)|((row>>3)<<2); V^T rows 96 B.
+constexpr int K_STRIDE = DH * 2;        // bytes per K row in LDS (512)
+constexpr int VT_STRIDE = 32 * 2 + 32;  // bytes per V^T row in LDS (96)
+MG_DEV int krow_swz(int row) { return (row & 3) | ((row >> 3) << 2); }
 constexpr int FA_LDS = 32 * K_STRIDE + DH * VT_STRIDE;  // 16896 + 20480
 
-__global__ __launch_bounds__(256) void attn_prefill_kernel(
+__global__ __launch_bounds__(256, 2) void attn_prefill_kernel(
     const mg_bf16* __restrict__ q, const mg_bf16* __restrict__ kcache,
     const mg_bf16* __restrict__ vt, mg_bf16* __restrict__ out, float* __restrict__ lse,
     int B, int H, int S, int Smax, int vt_ld) {
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int ci = tid + it * 256;
-      *(u32x4*)(k_lds + (ci >> 5) * K_STRIDE + (ci & 31) * 16) = kreg[it];
+      *(u32x4*)(k_lds + (ci >> 5) * K_STRIDE + (((ci & 31) ^ krow_swz(ci >> 5)) << 4)) = kreg[it];
       *(u32x4*)(v_lds + (ci >> 2) * VT_STRIDE + (ci & 3) * 16) = vreg[it];
     }
   };
@@ -168,10 +171,11 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(
     for (int tt = 0; tt < 2; ++tt) {
       st[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
       const int krow = (li >> 2) * 8 + tt * 4 + (li & 3);
-      const char* kp = k_lds + krow * K_STRIDE + lq * 16;
+      const int sw = krow_swz(krow);
+      const char* kp = k_lds + krow * K_STRIDE;
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
-        const bf16x8 kf = *(const bf16x8*)(kp + ks * 64);
+        const bf16x8 kf = *(const bf16x8*)(kp + (((ks * 4 + lq) ^ sw) << 4));
         st[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], st[tt], 0, 0, 0);
       }
     }

@@ -12,6 +12,7 @@
 //                         loops over query tiles of 32 from the diagonal down:
 //                           S  = Q K^T          dP = dO V^T
 //                           dV^T += dO^T P      dK^T += Q^T dS
+//                         (two instantiations: <false> = dV, <true> = dK)
 //
 // MFMA contracts over 8 consecutive elements per lane, so every operand is
 // needed with its contraction index contiguous: K,V,Q,dO row-major [s][256] for
@@ -24,8 +25,14 @@
 namespace {
 
 constexpr int DH = 256;
-constexpr int ROW_STRIDE = DH * 2 + 16;  // [32][256] tiles, padded rows (528 B)
-constexpr int T_STRIDE = 32 * 2 + 16;    // [256][32] tiles, padded rows (80 B)
+// LDS images chosen conflict-free for the ds_read_b128 lane groups of gfx950 (searched
+// offline over the fragment access patterns below):
+//   row tiles [32][256]: unpadded 512-B rows, 16-B chunk index XORed with
+//                        f(row) = (row&3) | ((row>>3)<<2)
+//   T tiles  [256][32]:  96-B row stride (6 x 16 B)
+constexpr int ROW_STRIDE = DH * 2;       // 512 B
+constexpr int T_STRIDE = 32 * 2 + 32;    // 96 B
+MG_DEV int row_swz(int row) { return (row & 3) | ((row >> 3) << 2); }
 constexpr int ROW_TILE = 32 * ROW_STRIDE;  // 16896
 constexpr int T_TILE = DH * T_STRIDE;      // 20480
 
@@ -48,28 +55,42 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const mg_bf16* __res
   }
 }
 
-MG_DEV void stage_rows(char* lds, const mg_bf16* base, int64_t row_stride_elems, int r0, int rmax, int tid) {
-  // 32 rows x 256 -> padded LDS tile; rows clamped to rmax-1
+// Staging is split into "issue the global loads" and "write the registers to LDS" so the
+// loads of tile t+1 are in flight while tile t is being multiplied (both kernels run at one
+// or two waves per SIMD: there is no other latency hiding).
+MG_DEV void load_rows(u32x4 (&r)[4], const mg_bf16* base, int64_t row_stride_elems, int r0, int rmax, int tid) {
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int ci = tid + it * 256;
-    const int row = ci >> 5, c = ci & 31;
-    const int rr = min(r0 + row, rmax - 1);
-    *(u32x4*)(lds + row * ROW_STRIDE + c * 16) = *(const u32x4*)(base + (int64_t)rr * row_stride_elems + c * 8);
+    const int rr = min(r0 + (ci >> 5), rmax - 1);            // 32 rows x 32 chunks, rows clamped
+    r[it] = *(const u32x4*)(base + (int64_t)rr * row_stride_elems + (ci & 31) * 8);
   }
 }
-MG_DEV void stage_cols(char* lds, const mg_bf16* base_t, int ld, int c0, int tid) {
-  // [256][32] slice of a transposed [256][ld] matrix starting at column c0 (c0+32 <= ld)
+MG_DEV void store_rows(char* lds, const u32x4 (&r)[4], int tid) {
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int ci = tid + it * 256;
-    const int dr = ci >> 2, vc = ci & 3;
-    *(u32x4*)(lds + dr * T_STRIDE + vc * 16) = *(const u32x4*)(base_t + (int64_t)dr * ld + c0 + vc * 8);
+    const int row = ci >> 5;
+    *(u32x4*)(lds + row * ROW_STRIDE + (((ci & 31) ^ row_swz(row)) << 4)) = r[it];
+  }
+}
+MG_DEV void load_cols(u32x4 (&r)[4], const mg_bf16* base_t, int ld, int c0, int tid) {
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int ci = tid + it * 256;                            // [256][32] slice at column c0
+    r[it] = *(const u32x4*)(base_t + (int64_t)(ci >> 2) * ld + c0 + (ci & 3) * 8);
+  }
+}
+MG_DEV void store_cols(char* lds, const u32x4 (&r)[4], int tid) {
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int ci = tid + it * 256;
+    *(u32x4*)(lds + (ci >> 2) * T_STRIDE + (ci & 3) * 16) = r[it];
   }
 }
 
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
     const mg_bf16* __restrict__ q, const mg_bf16* __restrict__ k, const mg_bf16* __restrict__ v,
     const mg_bf16* __restrict__ kt, const mg_bf16* __restrict__ dO, const float* __restrict__ lse,
     const float* __restrict__ Dv, mg_bf16* __restrict__ dq, int B, int H, int S, int ld_t) {
@@ -105,25 +126,36 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
 
   const int kv_end = min(S, qt0 + 64);
   const int ntiles = (kv_end + 31) >> 5;
+  u32x4 rk[4], rv[4], rkt[4];
+  load_rows(rk, kb, DH, 0, S, tid);
+  load_rows(rv, vb, DH, 0, S, tid);
+  load_cols(rkt, ktb, ld_t, 0, tid);
   for (int t = 0; t < ntiles; ++t) {
     const int kv0 = t * 32;
     __syncthreads();
-    stage_rows(k_lds, kb, DH, kv0, S, tid);
-    stage_rows(v_lds, vb, DH, kv0, S, tid);
-    stage_cols(kt_lds, ktb, ld_t, kv0, tid);
+    store_rows(k_lds, rk, tid);
+    store_rows(v_lds, rv, tid);
+    store_cols(kt_lds, rkt, tid);
     __syncthreads();
+    if (t + 1 < ntiles) {
+      load_rows(rk, kb, DH, kv0 + 32, S, tid);
+      load_rows(rv, vb, DH, kv0 + 32, S, tid);
+      load_cols(rkt, ktb, ld_t, kv0 + 32, tid);
+    }
     f32x4 st[2], dp[2];
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
       st[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
       dp[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
       const int krow = (li >> 2) * 8 + tt * 4 + (li & 3);
-      const char* kp = k_lds + krow * ROW_STRIDE + lq * 16;
-      const char* vp = v_lds + krow * ROW_STRIDE + lq * 16;
+      const int sw = row_swz(krow);
+      const char* kp = k_lds + krow * ROW_STRIDE;
+      const char* vp = v_lds + krow * ROW_STRIDE;
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
-        st[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(kp + ks * 64), qf[ks], st[tt], 0, 0, 0);
-        dp[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(vp + ks * 64), dof[ks], dp[tt], 0, 0, 0);
+        const int off = ((ks * 4 + lq) ^ sw) << 4;
+        st[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(kp + off), qf[ks], st[tt], 0, 0, 0);
+        dp[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(vp + off), dof[ks], dp[tt], 0, 0, 0);
       }
     }
     float ds[8];
@@ -155,17 +187,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
 }
 
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(
+// DK = false: dV only (needs S -> P and dO^T);  DK = true: dK only (needs S, dP, dS and Q^T).
+// One accumulator set (64 VGPRs) per instantiation instead of two keeps the kernel at two
+// waves per SIMD / two workgroups per CU, which is what hides the LDS and HBM latency here;
+// the price is recomputing S once more (80 instead of 64 MFMAs per key-tile x query-tile).
+template <bool DK>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(
     const mg_bf16* __restrict__ q, const mg_bf16* __restrict__ k, const mg_bf16* __restrict__ v,
     const mg_bf16* __restrict__ qt, const mg_bf16* __restrict__ dO, const mg_bf16* __restrict__ dOt,
-    const float* __restrict__ lse, const float* __restrict__ Dv, mg_bf16* __restrict__ dk,
-    mg_bf16* __restrict__ dv, int B, int H, int S, int ld_t) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * ROW_TILE + 2 * T_TILE + 256];
+    const float* __restrict__ lse, const float* __restrict__ Dv, mg_bf16* __restrict__ dout,
+    int B, int H, int S, int ld_t) {
+  // LDS: Q rows (+ dO rows for dK) + one transposed tile (Q^T for dK, dO^T for dV) + lse/D
+  __shared__ __attribute__((aligned(16))) char smem[(DK ? 2 : 1) * ROW_TILE + T_TILE + 256];
   char* q_lds = smem;
-  char* do_lds = smem + ROW_TILE;
-  char* qt_lds = smem + 2 * ROW_TILE;
-  char* dot_lds = qt_lds + T_TILE;
-  float* ls_lds = (float*)(dot_lds + T_TILE);   // 32 lse2 + 32 D
+  char* do_lds = smem + ROW_TILE;                         // DK only
+  char* t_lds = smem + (DK ? 2 : 1) * ROW_TILE;
+  float* ls_lds = (float*)(t_lds + T_TILE);               // 32 lse2 + 32 D
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lq = lane >> 4;
@@ -174,83 +211,90 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(
   const int key = k0 + wave * 16 + li, key_c = min(key, S - 1);
   const int dmodel = H * DH;
   const mg_bf16* qb = q + (int64_t)bh * S * DH;
-  const mg_bf16* qtb = qt + (int64_t)bh * DH * ld_t;
-  const mg_bf16* dotb = dOt + (int64_t)bh * DH * ld_t;
+  const mg_bf16* tb = (DK ? qt : dOt) + (int64_t)bh * DH * ld_t;
   const mg_bf16* dob = dO + (int64_t)b * S * dmodel + h * DH;   // row stride dmodel
 
-  bf16x8 kf[8], vf[8];
+  bf16x8 kf[8], vf[DK ? 8 : 1];
   {
     const mg_bf16* kp = k + ((int64_t)bh * S + key_c) * DH + lq * 8;
-    const mg_bf16* vp = v + ((int64_t)bh * S + key_c) * DH + lq * 8;
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) { kf[ks] = *(const bf16x8*)(kp + ks * 32); vf[ks] = *(const bf16x8*)(vp + ks * 32); }
+    for (int ks = 0; ks < 8; ++ks) kf[ks] = *(const bf16x8*)(kp + ks * 32);
+    if (DK) {
+      const mg_bf16* vp = v + ((int64_t)bh * S + key_c) * DH + lq * 8;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) vf[ks] = *(const bf16x8*)(vp + ks * 32);
+    }
   }
-  f32x4 dkt[16], dvt[16];
+  f32x4 acc[16];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) { dkt[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; dvt[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  for (int i = 0; i < 16; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const float L2E = 1.4426950408889634f;
   const float sc2 = 0.0625f * L2E;
 
   const int q_begin = k0 & ~31;               // first query tile that can see key k0
   const int q_tiles_end = (S + 31) >> 5;
+  u32x4 rq[4], rdo[DK ? 4 : 1], rt[4];
+  float r_ls = 0.f;
+  auto load_all = [&](int q0) {
+    load_rows(rq, qb, DH, q0, S, tid);
+    if constexpr (DK) load_rows(rdo, dob, dmodel, q0, S, tid);
+    load_cols(rt, tb, ld_t, q0, tid);
+    if (tid < 64) {
+      const int qq = min(q0 + (tid & 31), S - 1);
+      r_ls = tid < 32 ? lse[(int64_t)bh * S + qq] * L2E : Dv[(int64_t)bh * S + qq];
+    }
+  };
+  load_all(q_begin);
   for (int t = q_begin >> 5; t < q_tiles_end; ++t) {
     const int q0 = t * 32;
     __syncthreads();
-    stage_rows(q_lds, qb, DH, q0, S, tid);
-    stage_rows(do_lds, dob, dmodel, q0, S, tid);
-    stage_cols(qt_lds, qtb, ld_t, q0, tid);
-    stage_cols(dot_lds, dotb, ld_t, q0, tid);
-    if (tid < 32) {
-      const int qq = min(q0 + tid, S - 1);
-      ls_lds[tid] = lse[(int64_t)bh * S + qq] * L2E;
-      ls_lds[32 + tid] = Dv[(int64_t)bh * S + qq];
-    }
+    store_rows(q_lds, rq, tid);
+    if constexpr (DK) store_rows(do_lds, rdo, tid);
+    store_cols(t_lds, rt, tid);
+    if (tid < 64) ls_lds[tid] = r_ls;
     __syncthreads();
+    if (t + 1 < q_tiles_end) load_all(q0 + 32);
     f32x4 s[2], dp[2];
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
       s[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
       dp[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
       const int qr = (li >> 2) * 8 + tt * 4 + (li & 3);   // row permutation: acc regs -> 8 consecutive queries
-      const char* qp = q_lds + qr * ROW_STRIDE + lq * 16;
-      const char* dop = do_lds + qr * ROW_STRIDE + lq * 16;
+      const int sw = row_swz(qr);
+      const char* qp = q_lds + qr * ROW_STRIDE;
+      const char* dop = do_lds + qr * ROW_STRIDE;
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
-        s[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(qp + ks * 64), kf[ks], s[tt], 0, 0, 0);
-        dp[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(dop + ks * 64), vf[ks], dp[tt], 0, 0, 0);
+        const int off = ((ks * 4 + lq) ^ sw) << 4;
+        s[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(qp + off), kf[ks], s[tt], 0, 0, 0);
+        if constexpr (DK)
+          dp[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(dop + off), vf[ks], dp[tt], 0, 0, 0);
       }
     }
     // lane holds queries q0 + lq*8 + j (j = tt*4 + r) for its key
-    float pv[8], dsv[8];
+    float val[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int ql = lq * 8 + j, qg = q0 + ql;
       const float p = (key > qg || qg >= S || key >= S) ? 0.f : exp2f(s[j >> 2][j & 3] * sc2 - ls_lds[ql]);
-      pv[j] = p;
-      dsv[j] = p * (dp[j >> 2][j & 3] - ls_lds[32 + ql]) * 0.0625f;
+      val[j] = DK ? p * (dp[j >> 2][j & 3] - ls_lds[32 + ql]) * 0.0625f : p;
     }
-    u32x4 pw, dw;
+    u32x4 pw;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { pw[j] = pack2bf(pv[2 * j], pv[2 * j + 1]); dw[j] = pack2bf(dsv[2 * j], dsv[2 * j + 1]); }
-    const bf16x8 pf = __builtin_bit_cast(bf16x8, pw), dsf = __builtin_bit_cast(bf16x8, dw);
-    const char* qtp = qt_lds + li * T_STRIDE + lq * 16;
-    const char* dtp = dot_lds + li * T_STRIDE + lq * 16;
+    for (int j = 0; j < 4; ++j) pw[j] = pack2bf(val[2 * j], val[2 * j + 1]);
+    const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
+    const char* tp = t_lds + li * T_STRIDE + lq * 16;
 #pragma unroll
-    for (int dt = 0; dt < 16; ++dt) {
-      dvt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(dtp + dt * 16 * T_STRIDE), pf, dvt[dt], 0, 0, 0);
-      dkt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(qtp + dt * 16 * T_STRIDE), dsf, dkt[dt], 0, 0, 0);
-    }
+    for (int dt = 0; dt < 16; ++dt)
+      acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(tp + dt * 16 * T_STRIDE), pf, acc[dt], 0, 0, 0);
   }
   if (key < S) {
-    mg_bf16* kp = dk + ((int64_t)bh * S + key) * DH + lq * 4;
-    mg_bf16* vp = dv + ((int64_t)bh * S + key) * DH + lq * 4;
+    mg_bf16* op = dout + ((int64_t)bh * S + key) * DH + lq * 4;
 #pragma unroll
     for (int dt = 0; dt < 16; ++dt) {
       u32x2 w;
-      w[0] = pack2bf(dkt[dt][0], dkt[dt][1]); w[1] = pack2bf(dkt[dt][2], dkt[dt][3]);
-      *(u32x2*)(kp + dt * 16) = w;
-      w[0] = pack2bf(dvt[dt][0], dvt[dt][1]); w[1] = pack2bf(dvt[dt][2], dvt[dt][3]);
-      *(u32x2*)(vp + dt * 16) = w;
+      w[0] = pack2bf(acc[dt][0], acc[dt][1]); w[1] = pack2bf(acc[dt][2], acc[dt][3]);
+      *(u32x2*)(op + dt * 16) = w;
     }
   }
 }
@@ -273,7 +317,8 @@ extern "C" int mg_attn_bwd_bf16(const mg_bf16* q, const mg_bf16* k, const mg_bf1
   const int64_t rows = (int64_t)B * S * H;
   hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, dO, O, D, B, H, S);
   hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((S + 63) / 64, B * H), dim3(256), 0, s, q, k, v, kt, dO, lse, D, dq, B, H, S, ld_t);
-  hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3((S + 63) / 64, B * H), dim3(256), 0, s, q, k, v, qt, dO, dOt, lse, D, dk, dv, B, H, S, ld_t);
+  hipLaunchKernelGGL(attn_bwd_dkdv_kernel<false>, dim3((S + 63) / 64, B * H), dim3(256), 0, s, q, k, v, qt, dO, dOt, lse, D, dv, B, H, S, ld_t);
+  hipLaunchKernelGGL(attn_bwd_dkdv_kernel<true>, dim3((S + 63) / 64, B * H), dim3(256), 0, s, q, k, v, qt, dO, dOt, lse, D, dk, B, H, S, ld_t);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }

@@ -223,8 +223,8 @@ class Magma(nn.Module):
         for k, v in sd.items():
             if k.endswith("attention.bias") or k.endswith("masked_bias"):
                 continue
-            if k.startswith("transformer."):
-                k = "lm." + k
+            if k.startswith("transformer."):       # alias of lm.transformer.h (reference magma.py:53)
+                k = "lm.transformer.h." + k[len("transformer."):]
             elif k == "word_embedding.weight":
                 k = "lm.transformer.wte.weight"
             fixed[k] = v

@@ -50,6 +50,9 @@ def parse_args(argv=None):
                         help="local rank passed from distributed launcher")
     parser.add_argument("--synthetic_steps", type=int, default=None,
                         help="override train_steps (synthetic-data smoke runs)")
+    parser.add_argument("--micro_batch", type=int, default=None,
+                        help="per-GPU micro-batch (default: batch_size / (grad-accum * world), as DeepSpeed derives it)")
+    parser.add_argument("--grad_accum", type=int, default=None, help="override gradient_accumulation_steps")
     args, _ = parser.parse_known_args(argv)
     args.deepspeed = False
     return args

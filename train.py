@@ -23,6 +23,9 @@ if __name__ == "__main__":
     tokenizer, config, transforms = model.tokenizer, model.config, model.transforms
     if args.synthetic_steps is not None:
         config.train_steps = args.synthetic_steps
+    if args.grad_accum is not None:
+        config.gradient_accumulation_steps = args.grad_accum
+        config.deepspeed_config_params["gradient_accumulation_steps"] = args.grad_accum
     trainable_parameters = configure_param_groups(model, config)
 
     def make_dataset(directory, n, seed):
@@ -37,8 +40,9 @@ if __name__ == "__main__":
     print_main(f"Loaded eval dataset with {len(eval_dataset)} samples")
 
     model_engine, opt, train_loader, lr_scheduler = initialize(
-        model=model, config=config, model_parameters=trainable_parameters, training_data=train_dataset)
-    eval_loader = cycle(model_engine.deepspeed_io(eval_dataset))
+        model=model, config=config, model_parameters=trainable_parameters, training_data=None)
+    train_loader = model_engine.deepspeed_io(train_dataset, batch_size=args.micro_batch)
+    eval_loader = cycle(model_engine.deepspeed_io(eval_dataset, batch_size=args.micro_batch))
     train_loader = cycle(train_loader)
 
     global_step = 0
