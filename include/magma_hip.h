@@ -106,6 +106,8 @@ typedef struct mg_gemm_desc {
   int32_t H, Wd, Cin; /* conv3x3 only: A is [B,H,Wd,Cin], M = B*H*Wd, K=9*Cin */
   const mg_bf16* zero_page; /* >= 16 zero bytes, 16-B aligned (K/halo padding) */
   mg_epilogue ep;
+  int32_t tile_hint; /* 0 = auto; 128 / 256 force the workgroup-tile kernel        */
+  int32_t _pad;
 } mg_gemm_desc;
 
 int mg_gemm_bf16(const mg_gemm_desc* d, void* stream);

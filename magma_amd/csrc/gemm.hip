@@ -299,6 +299,190 @@ __global__ __launch_bounds__(256) void gemm128_kernel(const GemmParams p) {
 }
 
 // ---------------------------------------------------------------------------
+// gemm256_kernel: 256x256x64 workgroup tile, 8 waves (2 x 4), each wave a 128x64
+// sub-tile as 8x4 MFMA accumulators (128 VGPRs).  Deep-pipelined K loop in the
+// style of the 8-phase structure of the CDNA4 guide:
+//   * LDS holds two K-tiles (2 x 64 KiB); each is staged as four 16-KiB half-tiles
+//     (W rows 0-127 / 128-255, A rows 0-127 / 128-255) by LDS-DMA, ONE half-tile per
+//     phase, started right after the last read of the buffer it overwrites (5 to 2
+//     phases before its first read).  The only wait is a COUNTED s_waitcnt vmcnt(2)
+//     once per K-tile, so loads stay in flight across the workgroup barriers.
+//   * a K-tile is multiplied in four phases of 16 MFMAs (one 64x32 quadrant of the
+//     wave's tile x K=64):  [ds_read the quadrant's new fragments | issue one DMA
+//     half-tile] - barrier - [16 MFMA under s_setprio 1] - barrier.
+//   * the two wave groups (waves 0-3 / 4-7: one wave of each per SIMD) run the same
+//     program shifted by ONE barrier, so that while one group is in its MFMA segment
+//     the other is in its read/DMA segment: the matrix pipe of every SIMD always has
+//     a wave to issue from.
+// Phase q of K-tile t (buffer t&1); registers: A 4 m-tiles x 2, W both n-halves:
+//   q0: read A(mh0), W(nh0) | DMA W_hi(t+1) | MFMA (mh0,nh0)
+//   q1: read W(nh1)         | DMA A_lo(t+1) | MFMA (mh0,nh1)
+//   q2: read A(mh1)         | DMA A_hi(t+1) | MFMA (mh1,nh1)
+//   q3:                     | DMA W_lo(t+2) , vmcnt(2): tile t+1 landed | MFMA (mh1,nh0)
+// Hazards (slots = intervals between consecutive barriers; group 1 is one slot late):
+//   WAR  buffer t is last read (lgkmcnt(0) before the barrier) in q2 of group 1; the
+//        first DMA into it is W_lo(t+2) at q3 of group 0, one barrier later.
+//   RAW  every wave retires its own pieces of tile t+1 (vmcnt(2)) in q3 before that
+//        phase's first barrier; the first reader (group 0, q0 of t+1) has passed the
+//        barrier that group 1 reaches after ITS q3 wait.
+// Requirements: dense A, K % 128 == 0.  Operand layouts, swizzle, swapped MFMA roles
+// and epilogue as in gemm128_kernel.
+// ---------------------------------------------------------------------------
+constexpr int G256_TILE = 256 * 64 * 2;          // 32 KiB per operand per K-tile
+constexpr int G256_BUF = 2 * G256_TILE;          // A + W
+constexpr int G256_LDS = 2 * G256_BUF;           // 128 KiB
+
+#define MG_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define MG_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+template <int WLAYOUT>
+__global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int tm, tn;
+  tile_coords(blockIdx.x, p.tiles_m, p.tiles_n, tm, tn);
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int nkt = p.K >> 6;                       // even (K % 128 == 0)
+  const int wr = wave >> 2, wc = wave & 3;        // wr is also the wave group
+  const int li = lane & 15, lq = lane >> 4;
+
+  // ---- DMA sources: per half-tile this wave moves 2 pieces of 1 KiB ----
+  int a_off[2][2], b_off[2][2];                   // element offsets (< 2^31 on this path)
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = h * 128 + wave * 16 + j * 8 + (lane >> 3);
+      const int gch = (lane & 7) ^ ((r >> 1) & 7);
+      a_off[h][j] = (int)(min(m0 + r, p.M - 1) * p.lda + gch * 8);
+      if (WLAYOUT == MG_W_ROWMAJOR) {
+        b_off[h][j] = (int)(min(n0 + r, p.N - 1) * p.ldw + gch * 8);
+      } else {
+        const int ntiles = (p.N + 15) >> 4;
+        const int nt = min((n0 >> 4) + h * 8 + wave, ntiles - 1);
+        b_off[h][j] = (int)(((int64_t)nt * (p.ldw >> 5) + j) * 512 + lane * 8);   // j = k-step inside the tile
+      }
+    }
+#define MG_DMA_A(kt, h)                                                                                  \
+  {                                                                                                      \
+    char* dst_ = smem + ((kt) & 1) * G256_BUF + ((h) * 128 + wave * 16) * 128;                           \
+    glds16(p.A + (int64_t)(kt) * 64 + a_off[h][0], dst_);                                                \
+    glds16(p.A + (int64_t)(kt) * 64 + a_off[h][1], dst_ + 1024);                                         \
+  }
+#define MG_DMA_B(kt, h)                                                                                  \
+  {                                                                                                      \
+    char* base_ = smem + ((kt) & 1) * G256_BUF + G256_TILE;                                              \
+    if (WLAYOUT == MG_W_ROWMAJOR) {                                                                      \
+      glds16(p.W + (int64_t)(kt) * 64 + b_off[h][0], base_ + ((h) * 128 + wave * 16) * 128);             \
+      glds16(p.W + (int64_t)(kt) * 64 + b_off[h][1], base_ + ((h) * 128 + wave * 16 + 8) * 128);         \
+    } else {                                                                                             \
+      glds16(p.W + (int64_t)(kt) * 1024 + b_off[h][0], base_ + (((h) * 8 + wave) * 2) * 1024);           \
+      glds16(p.W + (int64_t)(kt) * 1024 + b_off[h][1], base_ + (((h) * 8 + wave) * 2 + 1) * 1024);       \
+    }                                                                                                    \
+  }
+
+  // ---- fragment readers (single register set) ----
+  const int fsw = (li >> 1) & 7;
+  const int a_rd0 = (wr * 128 + li) * 128 + ((lq ^ fsw) << 4);          // k-substep 0; substep 1 = ^ 64
+  const int b_rd0 = (WLAYOUT == MG_W_ROWMAJOR) ? G256_TILE + (wc * 64 + li) * 128 + ((lq ^ fsw) << 4)
+                                                : G256_TILE + (wc * 8) * 1024 + lane * 16;
+  constexpr int B_NT = (WLAYOUT == MG_W_ROWMAJOR) ? 16 * 128 : 2 * 1024;
+  constexpr int B_KS = (WLAYOUT == MG_W_ROWMAJOR) ? 0 : 1024;           // row-major: substep via XOR 64
+  bf16x8 af[4][2];                 // current m-half: [m-tile][k-substep]
+  bf16x8 bw[2][2][2];              // both n-halves:  [n-half][n-tile][k-substep]
+#define MG_READ_A(par, mh)                                                                               \
+  {                                                                                                      \
+    const char* sb_ = smem + (par) * G256_BUF;                                                           \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                   \
+      af[i_][0] = *(const bf16x8*)(sb_ + a_rd0 + ((mh) * 4 + i_) * 2048);                                \
+      af[i_][1] = *(const bf16x8*)(sb_ + (a_rd0 ^ 64) + ((mh) * 4 + i_) * 2048);                         \
+    }                                                                                                    \
+  }
+#define MG_READ_B(par, nh)                                                                               \
+  {                                                                                                      \
+    const char* sb_ = smem + (par) * G256_BUF;                                                           \
+    _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                                   \
+      bw[nh][j_][0] = *(const bf16x8*)(sb_ + b_rd0 + ((nh) * 2 + j_) * B_NT);                            \
+      bw[nh][j_][1] = *(const bf16x8*)(sb_ + ((WLAYOUT == MG_W_ROWMAJOR) ? (b_rd0 ^ 64) : (b_rd0 + B_KS)) + ((nh) * 2 + j_) * B_NT); \
+    }                                                                                                    \
+  }
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#define MG_MMA(mh, nh)                                                                                   \
+  {                                                                                                      \
+    __builtin_amdgcn_s_setprio(1);                                                                       \
+    _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)                                                     \
+      _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                   \
+        _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                 \
+          acc[(mh) * 4 + i_][(nh) * 2 + j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                   \
+              bw[nh][j_][s_], af[i_][s_], acc[(mh) * 4 + i_][(nh) * 2 + j_], 0, 0, 0);                   \
+    __builtin_amdgcn_s_setprio(0);                                                                       \
+  }
+#define MG_BAR() __builtin_amdgcn_s_barrier()
+  // one phase: read segment (with the DMA issue / wait given as statements), barrier, MFMA segment, barrier
+#define MG_PHASE(READS, DMA, MH, NH)                                                                     \
+  {                                                                                                      \
+    READS;                                                                                               \
+    DMA;                                                                                                 \
+    MG_WAIT_LGKM0();                                                                                     \
+    MG_BAR();                                                                                            \
+    MG_MMA(MH, NH);                                                                                      \
+    MG_BAR();                                                                                            \
+  }
+  // K-tile t with buffer parity PAR; NXT: tile t+1 exists, NXT2: tile t+2 exists
+#define MG_G256_TILE(t, PAR, NXT, NXT2)                                                                  \
+  {                                                                                                      \
+    MG_PHASE({ MG_READ_A(PAR, 0); MG_READ_B(PAR, 0); }, { if (NXT) MG_DMA_B((t) + 1, 1); }, 0, 0);       \
+    MG_PHASE({ MG_READ_B(PAR, 1); }, { if (NXT) MG_DMA_A((t) + 1, 0); }, 0, 1);                           \
+    MG_PHASE({ MG_READ_A(PAR, 1); }, { if (NXT) MG_DMA_A((t) + 1, 1); }, 1, 1);                           \
+    MG_PHASE({}, { if (NXT2) { MG_DMA_B((t) + 2, 0); MG_WAIT_VM(2); } else { MG_WAIT_VM(0); } }, 1, 0);   \
+  }
+
+  // ---- prologue: tile 0 complete, W_lo(1) in flight; group 1 starts one barrier late ----
+  MG_DMA_B(0, 0); MG_DMA_B(0, 1); MG_DMA_A(0, 0); MG_DMA_A(0, 1);
+  MG_DMA_B(1, 0);
+  MG_WAIT_VM(2);
+  MG_BAR();
+  if (wr == 1) MG_BAR();
+
+  int t = 0;
+  for (; t + 2 < nkt; t += 2) {
+    MG_G256_TILE(t, 0, true, true)
+    MG_G256_TILE(t + 1, 1, true, true)
+  }
+  MG_G256_TILE(t, 0, true, false)
+  MG_G256_TILE(t + 1, 1, false, false)
+  if (wr == 0) MG_BAR();
+#undef MG_G256_TILE
+#undef MG_PHASE
+#undef MG_MMA
+#undef MG_READ_A
+#undef MG_READ_B
+#undef MG_DMA_A
+#undef MG_DMA_B
+
+  // ---- epilogue (expanded by hand: a rolled loop would index acc dynamically -> scratch) ----
+#define MG_EPI(i)                                                                                        \
+  {                                                                                                      \
+    const int m_ = m0 + wr * 128 + (i) * 16 + li;                                                        \
+    if (m_ < p.M) {                                                                                      \
+      epilogue_store4(p.ep, m_, n0 + wc * 64 + 0 * 16 + lq * 4, acc[i][0], p.N);                         \
+      epilogue_store4(p.ep, m_, n0 + wc * 64 + 1 * 16 + lq * 4, acc[i][1], p.N);                         \
+      epilogue_store4(p.ep, m_, n0 + wc * 64 + 2 * 16 + lq * 4, acc[i][2], p.N);                         \
+      epilogue_store4(p.ep, m_, n0 + wc * 64 + 3 * 16 + lq * 4, acc[i][3], p.N);                         \
+    }                                                                                                    \
+  }
+  MG_EPI(0) MG_EPI(1) MG_EPI(2) MG_EPI(3) MG_EPI(4) MG_EPI(5) MG_EPI(6) MG_EPI(7)
+#undef MG_EPI
+}
+
+// ---------------------------------------------------------------------------
 // skinny (decode) kernel
 // ---------------------------------------------------------------------------
 struct SkinnyParams {
@@ -434,6 +618,20 @@ int launch_gemm(const GemmParams& gp, hipStream_t s) {
   return MG_OK;
 }
 
+template <int WLAYOUT>
+int launch_gemm256(GemmParams gp, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<WLAYOUT>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS);
+    if (e != hipSuccess) MG_FAIL(MG_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  gp.tiles_m = (gp.M + 255) / 256; gp.tiles_n = (gp.N + 255) / 256;
+  hipLaunchKernelGGL((gemm256_kernel<WLAYOUT>), dim3(gp.tiles_m * gp.tiles_n), dim3(512), G256_LDS, s, gp);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
 template <int WAVES, int KC, int NT>
 int launch_skinny(const SkinnyParams& sp, hipStream_t s) {
   const int grid = (sp.ntiles + NT - 1) / NT;
@@ -471,6 +669,13 @@ extern "C" int mg_gemm_bf16(const mg_gemm_desc* d, void* stream) {
     if ((d->ldw & 63) || d->ldw < d->K) MG_FAIL(MG_ERR_ALIGN, "mg_gemm_bf16: tiled weights need Kp (ldw) %%64==0 and >= K");
   } else MG_FAIL(MG_ERR_SHAPE, "mg_gemm_bf16: bad w_layout %d", d->w_layout);
   hipStream_t s = (hipStream_t)stream;
+  // large dense shapes go to the deep-pipelined 256x256 kernel (tile_hint: 0 auto, 128 / 256 force)
+  const int64_t wgs256 = (int64_t)((d->M + 255) / 256) * ((d->N + 255) / 256);
+  const bool can256 = d->a_mode == MG_A_DENSE && (d->K % 128) == 0;
+  const bool want256 = d->tile_hint == 256 || (d->tile_hint == 0 && wgs256 >= 192 && d->M >= 1024 && d->N >= 512);
+  if (can256 && want256)
+    return d->w_layout == MG_W_ROWMAJOR ? launch_gemm256<MG_W_ROWMAJOR>(gp, s) : launch_gemm256<MG_W_FRAGTILED>(gp, s);
+  if (d->tile_hint == 256 && !can256) MG_FAIL(MG_ERR_UNSUPPORTED, "mg_gemm_bf16: the 256x256 kernel needs dense A and K %% 128 == 0");
   if (d->a_mode == MG_A_DENSE) {
     return d->w_layout == MG_W_ROWMAJOR ? launch_gemm<MG_A_DENSE, MG_W_ROWMAJOR>(gp, s)
                                         : launch_gemm<MG_A_DENSE, MG_W_FRAGTILED>(gp, s);

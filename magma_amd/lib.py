@@ -46,6 +46,7 @@ class GemmDesc(C.Structure):
         ("H", C.c_int32), ("Wd", C.c_int32), ("Cin", C.c_int32),
         ("zero_page", C.c_void_p),
         ("ep", Epilogue),
+        ("tile_hint", C.c_int32), ("_pad", C.c_int32),
     ]
 
 

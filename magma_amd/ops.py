@@ -123,7 +123,7 @@ def gemm(a: torch.Tensor, w: PackedLinear, out: Optional[torch.Tensor] = None, *
          residuals: Sequence[torch.Tensor] = (), act_after: int = MG_ACT_NONE, scale=None,
          use_bias: bool = True, out_dtype=BF16, layout: Optional[str] = None,
          conv: Optional[tuple] = None, aux=None, aux_mode: int = MG_AUX_NONE, aux_after: bool = False,
-         out2: Optional[torch.Tensor] = None) -> torch.Tensor:
+         out2: Optional[torch.Tensor] = None, tile: int = 0) -> torch.Tensor:
     """out[M,N] = epilogue(a[M,K] @ w^T).  ``conv=(H, W, Cin)`` switches the A
     loader to implicit-im2col 3x3 over an NHWC image (a = [B*H*W, Cin])."""
     _need_gpu(a)
@@ -149,6 +149,7 @@ def gemm(a: torch.Tensor, w: PackedLinear, out: Optional[torch.Tensor] = None, *
         d.H, d.Wd, d.Cin = conv
         assert a.shape[1] == conv[2] and a.is_contiguous() and w.K == 9 * conv[2]
     d.zero_page = zero_page(a.device).data_ptr()
+    d.tile_hint = tile
     d.ep = _epilogue(out, w.N, w.bias if use_bias else None, scale, act, residuals, act_after, aux, aux_mode,
                      aux_after, out2)
     check(L.load().mg_gemm_bf16(C.byref(d), _stream()), "mg_gemm_bf16")

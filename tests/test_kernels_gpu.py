@@ -339,3 +339,22 @@ def test_skinny_layernorm_fold_and_split(dev):
     lin2 = ops.PackedLinear(w2, bias=b2)
     o32 = ops.gemm_skinny(x, lin2, out_dtype=torch.float32, ln_fold=(cs, K, 1e-5))
     assert_close(o32, ref, 1e-2, "ln-fold fp32")
+
+
+@pytest.mark.parametrize("layout", ["rm", "ft"])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (1000, 520, 256), (512, 1056, 1024), (2048, 4096, 4096)])
+def test_gemm256_deep_pipeline(dev, layout, M, N, K):
+    """The 256x256 staggered / counted-vmcnt kernel against fp32 and against the 128x128 kernel;
+    repeated launches on fresh data to screen for LDS-DMA races."""
+    from magma_amd import ops
+    for rep in range(3):
+        a = rnd(M, K, dev=dev, seed=300 + rep).to(BF16)
+        w = rnd(N, K, dev=dev, seed=310 + rep, scale=0.05).to(BF16)
+        bias = rnd(N, dev=dev, seed=320 + rep)
+        res = rnd(M, N, dev=dev, seed=330 + rep).to(BF16)
+        lin = ops.PackedLinear(w, bias=bias, tiled=True, rowmajor=True)
+        out = ops.gemm(a, lin, layout=layout, residuals=(res,), tile=256)
+        ref = a.float() @ w.float().t() + bias + res.float()
+        assert_close(out, ref, GEMM_TOL, f"gemm256 {layout} {M}x{N}x{K} rep{rep}")
+        out128 = ops.gemm(a, lin, layout=layout, residuals=(res,), tile=128)
+        assert float((out.float() - out128.float()).abs().max()) <= 2e-2 * float(ref.abs().max())
