@@ -152,6 +152,22 @@ def bench_train(model, args, rank, world, dev):
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    # forward only (eval mode, same batch): the north-star's "GPT-J + adapter forward" MFMA fraction
+    eng.eval()
+    with torch.no_grad():
+        model(images, caps)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            model(images, caps)
+        sync()
+    dtf = (time.perf_counter() - t0) / 2
+    L, d, ff = model.lm.config.num_layers, model.lm.config.hidden_size, model.lm.config.intermediate_size
+    r = sum(ad.N for ad in (model.lm.engine.layers[0].mlp_adapter or ())[:1]) + sum(ad.N for ad in (model.lm.engine.layers[0].attn_adapter or ())[:1])
+    f_fwd = B * (S * L * (8 * d * d + 4 * d * ff + 4 * d * r) + 4 * L * d * S * S + 47.72e9 * (args.res / 224.0) ** 2)
+    out["forward_only"] = {"ms": dtf * 1e3, "algorithmic_tflops": f_fwd / dtf / 1e12, "mfma_frac_of_2.5PF": f_fwd / dtf / 2.5e15,
+                           "note": "image prefix + 28 blocks at S=2048 (full-S^2 attention flops, as the reference computes) + loss on target rows"}
+    eng.train()
     for trunc in ([False, True] if args.train_truncate else [False]):
         eng.truncate = trunc
         step()
@@ -172,6 +188,7 @@ def bench_train(model, args, rank, world, dev):
                     "mfma_frac_of_2.5PF": None if trunc else fl / dt / 2.5e15}
     out["policy"] = "no recompute; bf16; adapters+CLIP trunk+prefix trainable; clip 1.0 + AdamW in the timed region"
     out["per_gpu_batch"], out["seq_len"] = B, S
+    out["max_memory_allocated_GB"] = torch.cuda.max_memory_allocated() / 2 ** 30
     return out
 
 
@@ -314,7 +331,7 @@ def main():
             train = {"error": repr(e)[:300]}
     if rank == 0:
         line["train"] = train
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # reported on rank 0 at N=1 only
             try:
                 line["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
             except Exception as e:  # noqa: BLE001

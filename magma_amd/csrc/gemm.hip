@@ -335,7 +335,7 @@ constexpr int G256_LDS = 2 * G256_BUF;           // 128 KiB
 #define MG_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define MG_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
-template <int WLAYOUT>
+template <int WLAYOUT, bool LATE_LGKM>
 __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -430,8 +430,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   {                                                                                                      \
     READS;                                                                                               \
     DMA;                                                                                                 \
-    MG_WAIT_LGKM0();                                                                                     \
+    if (!LATE_LGKM) MG_WAIT_LGKM0();                                                                     \
     MG_BAR();                                                                                            \
+    if (LATE_LGKM) MG_WAIT_LGKM0();                                                                      \
     MG_MMA(MH, NH);                                                                                      \
     MG_BAR();                                                                                            \
   }
@@ -618,16 +619,16 @@ int launch_gemm(const GemmParams& gp, hipStream_t s) {
   return MG_OK;
 }
 
-template <int WLAYOUT>
+template <int WLAYOUT, bool LATE_LGKM>
 int launch_gemm256(GemmParams gp, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<WLAYOUT>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<WLAYOUT, LATE_LGKM>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS);
     if (e != hipSuccess) MG_FAIL(MG_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_set = true;
   }
   gp.tiles_m = (gp.M + 255) / 256; gp.tiles_n = (gp.N + 255) / 256;
-  hipLaunchKernelGGL((gemm256_kernel<WLAYOUT>), dim3(gp.tiles_m * gp.tiles_n), dim3(512), G256_LDS, s, gp);
+  hipLaunchKernelGGL((gemm256_kernel<WLAYOUT, LATE_LGKM>), dim3(gp.tiles_m * gp.tiles_n), dim3(512), G256_LDS, s, gp);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }
@@ -672,9 +673,12 @@ extern "C" int mg_gemm_bf16(const mg_gemm_desc* d, void* stream) {
   // large dense shapes go to the deep-pipelined 256x256 kernel (tile_hint: 0 auto, 128 / 256 force)
   const int64_t wgs256 = (int64_t)((d->M + 255) / 256) * ((d->N + 255) / 256);
   const bool can256 = d->a_mode == MG_A_DENSE && (d->K % 128) == 0;
-  const bool want256 = d->tile_hint == 256 || (d->tile_hint == 0 && wgs256 >= 192 && d->M >= 1024 && d->N >= 512);
-  if (can256 && want256)
-    return d->w_layout == MG_W_ROWMAJOR ? launch_gemm256<MG_W_ROWMAJOR>(gp, s) : launch_gemm256<MG_W_FRAGTILED>(gp, s);
+  const bool want256 = d->tile_hint == 256 || d->tile_hint == 257 || (d->tile_hint == 0 && wgs256 >= 192 && d->M >= 1024 && d->N >= 512);
+  if (can256 && want256) {
+    if (d->tile_hint == 257)   // experiment: LDS-read wait after the barrier
+      return d->w_layout == MG_W_ROWMAJOR ? launch_gemm256<MG_W_ROWMAJOR, true>(gp, s) : launch_gemm256<MG_W_FRAGTILED, true>(gp, s);
+    return d->w_layout == MG_W_ROWMAJOR ? launch_gemm256<MG_W_ROWMAJOR, false>(gp, s) : launch_gemm256<MG_W_FRAGTILED, false>(gp, s);
+  }
   if (d->tile_hint == 256 && !can256) MG_FAIL(MG_ERR_UNSUPPORTED, "mg_gemm_bf16: the 256x256 kernel needs dense A and K %% 128 == 0");
   if (d->a_mode == MG_A_DENSE) {
     return d->w_layout == MG_W_ROWMAJOR ? launch_gemm<MG_A_DENSE, MG_W_ROWMAJOR>(gp, s)

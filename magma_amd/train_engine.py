@@ -134,10 +134,68 @@ class MagmaEngine:
         self.training = True
         self._tape = None
         self._norm_sq = torch.zeros(1, dtype=F32, device=self.device)
-        self._comm_stream = torch.cuda.Stream(device=self.device) if self.world > 1 else None
+        self._dist = dist.is_initialized()            # a 1-rank process group still exercises the overlap path
+        self._comm_stream = torch.cuda.Stream(device=self.device) if self._dist else None
+        self._reduced = [[] for _ in self.groups]     # per group: (lo, hi) ranges already handed to RCCL this step
+        self._works = []
         model.invalidate_packed()
         self._lm_train_packs = None
         self._adapters_dirty = False
+
+    # ---- gradient exchange overlapped with backward --------------------------------
+    def _is_boundary(self) -> bool:
+        """True while the micro-step being back-propagated completes an accumulation window."""
+        return (self.micro_steps + 1) % self.gas == 0
+
+    def _reduce_params_async(self, params):
+        """All-reduce (SUM) the flat-gradient range covering ``params`` on the comm stream as soon as
+        their gradients are final: buckets leave in reverse-backward order (block 27 ... 0, then the
+        prefix, then the trunk) while the earlier blocks are still being back-propagated."""
+        if not self._dist or not self._is_boundary():
+            return
+        spans, sizes = {}, {}
+        for p in params:
+            if id(p) not in self._where:
+                continue
+            gi, _ = self._where[id(p)]
+            g = self.groups[gi]
+            i = next(k for k, q in enumerate(g.params) if q is p)
+            lo = g.offsets[i]
+            hi = g.offsets[i + 1] if i + 1 < len(g.offsets) else g.n
+            a, b = spans.get(gi, (lo, hi))
+            spans[gi] = (min(a, lo), max(b, hi))
+            sizes[gi] = sizes.get(gi, 0) + (hi - lo)
+        spans = {gi: s for gi, s in spans.items() if s[1] - s[0] == sizes[gi]}   # contiguous buckets only
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        for gi, (lo, hi) in spans.items():
+            if any(not (hi <= a or lo >= b) for a, b in self._reduced[gi]):
+                continue                                  # overlaps a range already in flight: leave it to step()
+            with torch.cuda.stream(self._comm_stream):
+                self._comm_stream.wait_event(ev)
+                self._works.append(dist.all_reduce(self.groups[gi].grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+            self._reduced[gi].append((lo, hi))
+
+    def _finish_reduce(self):
+        """Reduce whatever backward did not hand over, then join the comm stream."""
+        if not self._dist:
+            return
+        from .comm import allreduce_grads
+        for gi, g in enumerate(self.groups):
+            done = sorted(self._reduced[gi])
+            pos, rest = 0, []
+            for a, b in done:
+                if a > pos:
+                    rest.append(g.grad[pos:a])
+                pos = max(pos, b)
+            if pos < g.n:
+                rest.append(g.grad[pos:g.n])
+            allreduce_grads(rest)
+            self._reduced[gi] = []
+        for w in self._works:
+            w.wait()
+        self._works = []
+        torch.cuda.current_stream().wait_stream(self._comm_stream)
 
     # ---- helpers -------------------------------------------------------------
     def grad_of(self, p: torch.nn.Parameter) -> torch.Tensor:
@@ -351,6 +409,7 @@ class MagmaEngine:
             dln = ops.gemm(dqkv, pk["qkv_t"], residuals=(dln_mlp,))
             g = ops.layernorm_bwd(dln, sv["x"], ly.ln_g, eng.eps, res=g)
             tape["layers"][li] = None     # free this layer's activations
+            self._reduce_params_async([p for p in blk.parameters() if p.requires_grad])
         return g
 
     # ---- image prefix + CLIP trunk -------------------------------------------------
@@ -388,6 +447,7 @@ class MagmaEngine:
             g = ops.mul(g, pt["mask"])
         ops.colsum(g, self.grad_of(ip.proj.bias))
         self._acc_wgrad(ip.proj.weight, _t(g), _t(pt["feats"]))
+        self._reduce_params_async([p for n, p in ip.named_parameters() if not n.startswith("enc.")])
         if pt["enc"] is None:
             return
         # gradient wrt the trunk output (a post-ReLU tensor): gate fused in the epilogue
@@ -540,10 +600,10 @@ class MagmaEngine:
         self.global_steps += 1
         lrs = self.lr_scheduler.get_lr()
         grad_scale = 1.0 / self.gas
-        if self.world > 1:
-            # gradient average over ranks (DeepSpeed ZeRO-2 reduce-scatter semantics: mean), RCCL over xGMI
-            from .comm import allreduce_grads
-            allreduce_grads([g.grad for g in self.groups])
+        if self._dist:
+            # gradient average over ranks (DeepSpeed ZeRO-2 reduce-scatter semantics: mean), RCCL over xGMI;
+            # most buckets were launched from backward() and have been running under it
+            self._finish_reduce()
             grad_scale /= self.world
         self._norm_sq.zero_()
         for g in self.groups:

@@ -44,8 +44,8 @@ def bench_gemm(M, N, K, layout, act=0, tag=""):
     w = (torch.randn(N, K, device=dev) * 0.05).to(BF16)
     lin = ops.PackedLinear(w, tiled=(layout == "ft"), rowmajor=(layout == "rm"))
     out = torch.empty(M, N, dtype=BF16, device=dev)
-    for tile in (128, 256):
-        if tile == 256 and K % 128:
+    for tile in (128, 256, 257):
+        if tile >= 256 and K % 128:
             continue
         ms = timeit(lambda i: ops.gemm(a, lin, out=out, layout=layout, act=act, tile=tile), 20)
         emit(kind="gemm", tag=tag, M=M, N=N, K=K, layout=layout, tile=tile, ms=ms, tflops=2.0 * M * N * K / ms / 1e9)
