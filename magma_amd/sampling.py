@@ -13,30 +13,30 @@ import torch.nn.functional as F
 
 
 def top_p_filter(logits, threshold: float = 0.9):
-    """Kept literally as published (descending sort, removes
-    cum_probs < 1-threshold shifted by one -- not textbook nucleus)."""
-    s_logits, s_idx = torch.sort(logits, descending=True)
-    cum = torch.cumsum(F.softmax(s_logits, dim=-1), dim=-1)
-    remove = cum < (1 - threshold)
-    remove[..., 1:] = remove[..., :-1].clone()
-    remove[..., 0] = 0
-    s_logits[remove] = float("-inf")
-    return s_logits.scatter(1, s_idx, s_logits)
+    """The reference's own "nucleus" rule, kept literally: sort descending, mark the
+    ranks whose cumulative probability is still below ``1 - threshold``, shift that mark one rank to
+    the right, never drop rank 0 -- which is NOT textbook top-p (it is usually a no-op)."""
+    ranked, order = torch.sort(logits, descending=True)
+    below = torch.cumsum(F.softmax(ranked, dim=-1), dim=-1) < (1 - threshold)
+    drop = torch.zeros_like(below)
+    drop[..., 1:] = below[..., :-1]
+    ranked = ranked.masked_fill(drop, float("-inf"))
+    return ranked.scatter(1, order, ranked)
 
 
 def top_k_filter(logits, k):
+    """Keep the k largest logits of every row, -inf elsewhere."""
     assert k > 0
-    val, ind = torch.topk(logits, k)
-    out = torch.full_like(logits, float("-inf"))
-    out.scatter_(1, ind, val)
-    return out
+    kept_val, kept_idx = torch.topk(logits, k)
+    return torch.full_like(logits, float("-inf")).scatter_(1, kept_idx, kept_val)
 
 
 def remove_tokens_after_eos(tensor, eos_token, image_token):
-    eos_index = (tensor == eos_token).nonzero()
-    if eos_index.any():
-        tensor[eos_index[0]:] = eos_token
-    return [i for i in tensor.tolist() if i != image_token and i != eos_token]
+    """Everything from the first EOS on becomes EOS; image placeholders and EOS are then dropped."""
+    hits = (tensor == eos_token).nonzero()
+    if hits.any():
+        tensor[hits[0]:] = eos_token
+    return [tok for tok in tensor.tolist() if tok not in (image_token, eos_token)]
 
 
 @torch.no_grad()
