@@ -138,6 +138,17 @@ typedef struct mg_skinny_desc {
 
 int mg_gemm_skinny_bf16(const mg_skinny_desc* d, void* stream);
 
+/* Two independent decode GEMVs in ONE launch (out_proj || adapter-down of a GPT-J block:
+ * the 64-workgroup adapter GEMV hides under the other one's weight stream).           */
+int mg_gemm_skinny2_bf16(const mg_skinny_desc* a, const mg_skinny_desc* b, void* stream);
+
+/* mg_attn_decode_fused_bf16 co-launched with one GEMV that does not depend on it (fc_out of
+ * the parallel block): attention workgroups first, GEMV workgroups behind them, one grid.  */
+int mg_decode_attn_gemv_bf16(const mg_bf16* qkv, mg_bf16* kcache, mg_bf16* vcache, mg_bf16* attn_out,
+                             int32_t B, int32_t H, int32_t Smax, const int32_t* d_pos, int32_t rot_dim,
+                             const float* sin_t, const float* cos_t, const mg_skinny_desc* gemv,
+                             void* stream);
+
 /* K8/K17 + ImagePrefix LN: y = (x-mean)/sqrt(var+eps)*gamma+beta, fp32 stats */
 int mg_layernorm_bf16(const mg_bf16* x, int64_t ldx, const float* gamma, const float* beta,
                       mg_bf16* y, int64_t ldy, int32_t rows, int32_t d, float eps, void* stream);

@@ -25,6 +25,9 @@
 // lets bias / residual loads be vectors too.
 #include "common.h"
 
+#include "gemm_device.h"
+#include "attn_decode_device.h"
+
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -38,79 +41,6 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 MG_DEV void glds16(const void* g, char* lds_wave_base) {
   // 64 lanes x 16 B -> 1 KiB at lds_wave_base (wave-uniform) + lane*16
   __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 0);
-}
-
-// ---------------------------------------------------------------------------
-// shared epilogue: 4 consecutive n of row m
-// ---------------------------------------------------------------------------
-MG_DEV void epilogue_store4(const mg_epilogue& ep, int m, int n, f32x4 v, int N) {
-  if (n >= N) return;
-  const bool full = (n + 3 < N);
-  float sc[4] = {1.f, 1.f, 1.f, 1.f}, bi[4] = {0.f, 0.f, 0.f, 0.f};
-  if (full) {
-    if (ep.scale) { const float4 t = *(const float4*)(ep.scale + n); sc[0] = t.x; sc[1] = t.y; sc[2] = t.z; sc[3] = t.w; }
-    if (ep.bias)  { const float4 t = *(const float4*)(ep.bias + n);  bi[0] = t.x; bi[1] = t.y; bi[2] = t.z; bi[3] = t.w; }
-  } else {
-    for (int r = 0; r < 4; ++r) if (n + r < N) {
-      if (ep.scale) sc[r] = ep.scale[n + r];
-      if (ep.bias) bi[r] = ep.bias[n + r];
-    }
-  }
-  float o[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) o[r] = v[r] * sc[r] + bi[r];
-  if (ep.C2) {  // pre-activation copy for the backward pass
-    mg_bf16* cp = ep.C2 + (int64_t)m * ep.ldc2 + n;
-    if (full) { u32x2 w; w[0] = pack2bf(o[0], o[1]); w[1] = pack2bf(o[2], o[3]); *(u32x2*)cp = w; }
-    else for (int r = 0; r < 4; ++r) if (n + r < N) cp[r] = f2bf(o[r]);
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) o[r] = apply_act(o[r], ep.act);
-  float ax[4] = {1.f, 1.f, 1.f, 1.f};
-  if (ep.aux_mode != MG_AUX_NONE) {
-    const mg_bf16* ap = ep.aux + (int64_t)m * ep.ldaux + n;
-    float a[4] = {0.f, 0.f, 0.f, 0.f};
-    if (full) { const u32x2 w = *(const u32x2*)ap; a[0] = bflo(w[0]); a[1] = bfhi(w[0]); a[2] = bflo(w[1]); a[3] = bfhi(w[1]); }
-    else for (int r = 0; r < 4; ++r) if (n + r < N) a[r] = bf2f(ap[r]);
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      ax[r] = ep.aux_mode == MG_AUX_RELU_GATE ? (a[r] > 0.f ? 1.f : 0.f)
-            : ep.aux_mode == MG_AUX_GELU_GRAD ? gelu_new_grad_f(a[r]) : a[r];
-    if (!ep.aux_after) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) o[r] *= ax[r];
-    }
-  }
-  const mg_bf16* rs[3] = {ep.res0, ep.res1, ep.res2};
-#pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    if (rs[t]) {
-      const mg_bf16* rp = rs[t] + (int64_t)m * ep.ldr + n;
-      if (full) {
-        const u32x2 w = *(const u32x2*)rp;
-        o[0] += bflo(w[0]); o[1] += bfhi(w[0]); o[2] += bflo(w[1]); o[3] += bfhi(w[1]);
-      } else {
-        for (int r = 0; r < 4; ++r) if (n + r < N) o[r] += bf2f(rp[r]);
-      }
-    }
-  }
-  if (ep.aux_mode != MG_AUX_NONE && ep.aux_after) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) o[r] *= ax[r];
-  }
-  if (ep.act_after == MG_ACT_RELU) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) o[r] = o[r] > 0.f ? o[r] : 0.f;
-  }
-  if (ep.out_f32) {
-    float* cp = (float*)ep.C + (int64_t)m * ep.ldc + n;
-    if (full) *(float4*)cp = make_float4(o[0], o[1], o[2], o[3]);
-    else for (int r = 0; r < 4; ++r) if (n + r < N) cp[r] = o[r];
-  } else {
-    mg_bf16* cp = (mg_bf16*)ep.C + (int64_t)m * ep.ldc + n;
-    if (full) { u32x2 w; w[0] = pack2bf(o[0], o[1]); w[1] = pack2bf(o[2], o[3]); *(u32x2*)cp = w; }
-    else for (int r = 0; r < 4; ++r) if (n + r < N) cp[r] = f2bf(o[r]);
-  }
 }
 
 // ---------------------------------------------------------------------------
@@ -483,112 +413,19 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
 #undef MG_EPI
 }
 
-// ---------------------------------------------------------------------------
-// skinny (decode) kernel
-// ---------------------------------------------------------------------------
-struct SkinnyParams {
-  const mg_bf16* X; int64_t ldx;
-  const mg_bf16* W;
-  int M, N, ntiles, ksteps;
-  // LayerNorm folded into the GEMV (decode): W' = W*gamma, bias' = b + W.beta are baked
-  // into the operands; the kernel gets the row statistics from the x fragments it already
-  // streams and applies  y = rstd*(acc - mean*colsum[n]) + bias'[n]  in the epilogue.
-  const float* ln_colsum; float ln_inv_d, ln_eps;
-  // two output segments (fused qkv | fc_in): columns >= split_n go to ep_b
-  int split_n;
-  mg_epilogue ep;
-  mg_epilogue ep_b;
-};
-
 template <int WAVES, int KC, int NT>
 __global__ __launch_bounds__(WAVES * 64) void skinny_kernel(const SkinnyParams p) {
-  __shared__ __attribute__((aligned(16))) float red[WAVES * NT * 256];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int per_wave = p.ksteps / WAVES;
-  const int ks0 = wave * per_wave;
-  const int nt0 = blockIdx.x * NT;
-  const int li = lane & 15, lq = lane >> 4;
-  const bool xok = li < p.M;
-  const mg_bf16* xrow = p.X + (int64_t)(xok ? li : 0) * p.ldx + lq * 8;
+  __shared__ __attribute__((aligned(16))) char lds[skinny_lds_bytes<WAVES, NT>()];
+  skinny_body<WAVES, KC, NT>(p, blockIdx.x, lds);
+}
 
-  f32x4 acc[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float xs = 0.f, xss = 0.f;   // row statistics of x (LayerNorm fold)
-
-  for (int kc = 0; kc < per_wave; kc += KC) {
-    // Issue the whole chunk's loads before the first MFMA (GEMV recipe: loads
-    // straight to VGPRs, deep queue, late wait): weights first (HBM, non-temporal
-    // -- each byte is read exactly once per step), then the x fragments (L2 hits).
-    u32x4 wf[NT][KC];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int nt = min(nt0 + t, p.ntiles - 1);
-      const u32x4* wp = (const u32x4*)p.W + ((int64_t)nt * p.ksteps + ks0 + kc) * 64 + lane;
-#pragma unroll
-      for (int i = 0; i < KC; ++i) wf[t][i] = __builtin_nontemporal_load(wp + i * 64);
-    }
-    bf16x8 xf[KC];
-#pragma unroll
-    for (int i = 0; i < KC; ++i) {
-      u32x4 raw = *(const u32x4*)(xrow + (int64_t)(ks0 + kc + i) * 32);
-      if (!xok) raw = (u32x4){0u, 0u, 0u, 0u};
-      xf[i] = __builtin_bit_cast(bf16x8, raw);
-    }
-    if (p.ln_colsum) {
-#pragma unroll
-      for (int i = 0; i < KC; ++i) {
-        const u32x4 raw = __builtin_bit_cast(u32x4, xf[i]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float a = bflo(raw[j]), b = bfhi(raw[j]);
-          xs += a + b;
-          xss += a * a + b * b;
-        }
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int i = 0; i < KC; ++i)
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[t][i]), xf[i], acc[t], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-
-  // cross-wave (split-K) reduction through LDS, then epilogue by wave t
-  __shared__ float rstat[WAVES][16][2];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) *(f32x4*)(red + ((wave * NT + t) * 64 + lane) * 4) = acc[t];
-  if (p.ln_colsum) {   // lanes li, li+16, li+32, li+48 hold the same row: fold the 4 k-slots
-    xs += __shfl_xor(xs, 16, 64); xs += __shfl_xor(xs, 32, 64);
-    xss += __shfl_xor(xss, 16, 64); xss += __shfl_xor(xss, 32, 64);
-    if (lq == 0) { rstat[wave][li][0] = xs; rstat[wave][li][1] = xss; }
-  }
-  __syncthreads();
-  float mean = 0.f, rstd = 1.f;
-  if (p.ln_colsum) {
-    float a = 0.f, b = 0.f;
-#pragma unroll
-    for (int w = 0; w < WAVES; ++w) { a += rstat[w][li][0]; b += rstat[w][li][1]; }
-    mean = a * p.ln_inv_d;
-    rstd = rsqrtf(fmaxf(b * p.ln_inv_d - mean * mean, 0.f) + p.ln_eps);
-  }
-  for (int t = wave; t < NT; t += WAVES) {
-    if (nt0 + t >= p.ntiles) break;
-    f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int w = 0; w < WAVES; ++w) s += *(const f32x4*)(red + ((w * NT + t) * 64 + lane) * 4);
-    if (!xok) continue;
-    const int n = (nt0 + t) * 16 + lq * 4;
-    if (p.ln_colsum && n < p.N) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) s[r] = rstd * (s[r] - mean * (n + r < p.N ? p.ln_colsum[n + r] : 0.f));
-    }
-    if (p.split_n > 0 && n >= p.split_n) epilogue_store4(p.ep_b, li, n - p.split_n, s, p.N - p.split_n);
-    else epilogue_store4(p.ep, li, n, s, p.split_n > 0 ? p.split_n : p.N);
-  }
+// two independent GEMVs (same variant) in ONE launch: blocks [0, g0) work on p0, the rest on p1.
+// Decode uses it for out_proj || adapter-down: the 64-workgroup adapter GEMV hides under the other.
+template <int WAVES, int KC, int NT>
+__global__ __launch_bounds__(WAVES * 64) void skinny2_kernel(const SkinnyParams p0, const SkinnyParams p1, int g0) {
+  __shared__ __attribute__((aligned(16))) char lds[skinny_lds_bytes<WAVES, NT>()];
+  if ((int)blockIdx.x < g0) skinny_body<WAVES, KC, NT>(p0, blockIdx.x, lds);
+  else skinny_body<WAVES, KC, NT>(p1, blockIdx.x - g0, lds);
 }
 
 int check_epilogue(const mg_epilogue& ep, const char* who) {
@@ -688,31 +525,49 @@ extern "C" int mg_gemm_bf16(const mg_gemm_desc* d, void* stream) {
                                       : launch_gemm<MG_A_CONV3X3, MG_W_FRAGTILED>(gp, s);
 }
 
-extern "C" int mg_gemm_skinny_bf16(const mg_skinny_desc* d, void* stream) {
-  if (!d) MG_FAIL(MG_ERR_SHAPE, "mg_gemm_skinny_bf16: null descriptor");
-  if (d->M <= 0 || d->M > 16) MG_FAIL(MG_ERR_SHAPE, "mg_gemm_skinny_bf16: M=%d must be in [1,16]", d->M);
-  if (d->N <= 0 || d->Kp <= 0 || (d->Kp & 63)) MG_FAIL(MG_ERR_SHAPE, "mg_gemm_skinny_bf16: need N>0 and Kp%%64==0 (N=%d Kp=%d)", d->N, d->Kp);
-  if (!d->X || !d->W) MG_FAIL(MG_ERR_SHAPE, "mg_gemm_skinny_bf16: null X/W");
-  if (!MG_ALIGNED16(d->X) || !MG_ALIGNED16(d->W) || (d->ldx & 7) || d->ldx < d->Kp) MG_FAIL(MG_ERR_ALIGN, "mg_gemm_skinny_bf16: X/W 16-byte aligned, ldx%%8==0, ldx>=Kp required");
-  if (int rc = check_epilogue(d->ep, "mg_gemm_skinny_bf16")) return rc;
-  SkinnyParams sp;
+namespace {
+// validate a skinny descriptor and turn it into kernel parameters
+int fill_skinny(const mg_skinny_desc* d, SkinnyParams& sp, const char* who) {
+  if (!d) MG_FAIL(MG_ERR_SHAPE, "%s: null descriptor", who);
+  if (d->M <= 0 || d->M > 16) MG_FAIL(MG_ERR_SHAPE, "%s: M=%d must be in [1,16]", who, d->M);
+  if (d->N <= 0 || d->Kp <= 0 || (d->Kp & 63)) MG_FAIL(MG_ERR_SHAPE, "%s: need N>0 and Kp%%64==0 (N=%d Kp=%d)", who, d->N, d->Kp);
+  if (!d->X || !d->W) MG_FAIL(MG_ERR_SHAPE, "%s: null X/W", who);
+  if (!MG_ALIGNED16(d->X) || !MG_ALIGNED16(d->W) || (d->ldx & 7) || d->ldx < d->Kp) MG_FAIL(MG_ERR_ALIGN, "%s: X/W 16-byte aligned, ldx%%8==0, ldx>=Kp required", who);
+  if (int rc = check_epilogue(d->ep, who)) return rc;
   sp.X = d->X; sp.ldx = d->ldx; sp.W = d->W; sp.M = d->M; sp.N = d->N;
   sp.ntiles = (d->N + 15) / 16; sp.ksteps = d->Kp / 32; sp.ep = d->ep;
   sp.ln_colsum = d->ln_colsum; sp.ln_inv_d = d->ln_inv_d; sp.ln_eps = d->ln_eps;
   sp.split_n = d->split_n; sp.ep_b = d->ep_b;
   if (d->split_n != 0) {
-    if (d->split_n < 0 || d->split_n >= d->N || (d->split_n & 15)) MG_FAIL(MG_ERR_SHAPE, "mg_gemm_skinny_bf16: split_n must be a multiple of 16 inside (0, N)");
-    if (int rc = check_epilogue(d->ep_b, "mg_gemm_skinny_bf16(ep_b)")) return rc;
-    // per-column vectors of the second segment are indexed from its own column 0
+    if (d->split_n < 0 || d->split_n >= d->N || (d->split_n & 15)) MG_FAIL(MG_ERR_SHAPE, "%s: split_n must be a multiple of 16 inside (0, N)", who);
+    if (int rc = check_epilogue(d->ep_b, who)) return rc;
   }
-  if (d->ln_colsum && (!MG_ALIGNED16(d->ln_colsum) || d->ln_inv_d <= 0.f)) MG_FAIL(MG_ERR_ALIGN, "mg_gemm_skinny_bf16: bad LayerNorm-fold arguments");
+  if (d->ln_colsum && (!MG_ALIGNED16(d->ln_colsum) || d->ln_inv_d <= 0.f)) MG_FAIL(MG_ERR_ALIGN, "%s: bad LayerNorm-fold arguments", who);
+  return MG_OK;
+}
+
+// decode attention workgroups and the workgroups of one weight-streaming GEMV in ONE launch: the
+// attention part (B*H workgroups, latency-bound, a few hundred KB of KV) runs underneath the GEMV's
+// HBM stream instead of leaving most of the chip idle for ~10 us per layer.
+template <int KC>
+__global__ __launch_bounds__(256) void decode_attn_gemv_kernel(const AttnDecodeParams ap, int n_attn, const SkinnyParams sp) {
+  constexpr int LDS = ATTN_DEC_LDS > skinny_lds_bytes<4, 1>() ? ATTN_DEC_LDS : skinny_lds_bytes<4, 1>();
+  __shared__ __attribute__((aligned(16))) char lds[LDS];
+  if ((int)blockIdx.x < n_attn) attn_decode_body<true>(ap, blockIdx.x, lds);
+  else skinny_body<4, KC, 1>(sp, blockIdx.x - n_attn, lds);
+}
+}  // namespace
+
+extern "C" int mg_gemm_skinny_bf16(const mg_skinny_desc* d, void* stream) {
+  SkinnyParams sp;
+  if (int rc = fill_skinny(d, sp, "mg_gemm_skinny_bf16")) return rc;
   hipStream_t s = (hipStream_t)stream;
   // Variant = (waves per workgroup, k-steps per load burst, n-tiles per
   // workgroup).  nt_hint == 0 -> tuned default for the shape; otherwise
   // nt_hint = nt | waves<<4 | kc<<8 (bench/tuning sweeps use this).
   int nt = d->nt_hint & 15, waves = (d->nt_hint >> 4) & 15, kc = (d->nt_hint >> 8) & 255;
   if (d->nt_hint == 0) {
-    // measured on MI355X (tools/kbench.py, profiles/r01_kbench_skinny.txt): many
+    // measured on MI355X (tools/kbench.py, profiles/r01_kbench_*.jsonl): many
     // waves with short load bursts beat few waves with deep ones.
     if (sp.ksteps % (4 * 16) == 0 && sp.ksteps >= 512) { waves = 4; kc = 16; nt = 1; }   // K=16384 (fc_out): 5.57 TB/s
     else if (sp.ksteps % (8 * 4) == 0) { waves = 8; kc = 4; nt = 1; }
@@ -729,4 +584,46 @@ extern "C" int mg_gemm_skinny_bf16(const mg_skinny_desc* d, void* stream) {
   MG_SK(4, 1, 1);  MG_SK(1, 1, 1);
 #undef MG_SK
   MG_FAIL(MG_ERR_UNSUPPORTED, "mg_gemm_skinny_bf16: variant (waves=%d,kc=%d,nt=%d) not instantiated", waves, kc, nt);
+}
+
+// Two independent decode GEMVs in one launch (out_proj || adapter-down).  Both K must be
+// multiples of 1024 (8 waves x 4 k-steps) or of 128 (4 waves x 1).
+extern "C" int mg_gemm_skinny2_bf16(const mg_skinny_desc* a, const mg_skinny_desc* b, void* stream) {
+  SkinnyParams pa, pb;
+  if (int rc = fill_skinny(a, pa, "mg_gemm_skinny2_bf16(a)")) return rc;
+  if (int rc = fill_skinny(b, pb, "mg_gemm_skinny2_bf16(b)")) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = pa.ntiles + pb.ntiles;
+  if (pa.ksteps % 32 == 0 && pb.ksteps % 32 == 0) {
+    hipLaunchKernelGGL((skinny2_kernel<8, 4, 1>), dim3(grid), dim3(512), 0, s, pa, pb, pa.ntiles);
+  } else if (pa.ksteps % 4 == 0 && pb.ksteps % 4 == 0) {
+    hipLaunchKernelGGL((skinny2_kernel<4, 1, 1>), dim3(grid), dim3(256), 0, s, pa, pb, pa.ntiles);
+  } else {
+    MG_FAIL(MG_ERR_UNSUPPORTED, "mg_gemm_skinny2_bf16: K of both problems must be a multiple of 128");
+  }
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
+// Decode attention (rotary + KV append + attention, see mg_attn_decode_fused_bf16) co-launched with
+// one weight-streaming GEMV that does not depend on it (fc_out of the parallel GPT-J block).
+extern "C" int mg_decode_attn_gemv_bf16(const mg_bf16* qkv, mg_bf16* kcache, mg_bf16* vcache, mg_bf16* attn_out,
+                                        int32_t B, int32_t H, int32_t Smax, const int32_t* d_pos, int32_t rot_dim,
+                                        const float* sin_t, const float* cos_t, const mg_skinny_desc* gemv,
+                                        void* stream) {
+  if (B <= 0 || H <= 0 || Smax <= 0 || Smax > DEC_MAX_CTX) MG_FAIL(MG_ERR_SHAPE, "mg_decode_attn_gemv_bf16: need 0 < Smax <= %d", DEC_MAX_CTX);
+  if (rot_dim < 0 || rot_dim > 256 || (rot_dim & 7)) MG_FAIL(MG_ERR_SHAPE, "mg_decode_attn_gemv_bf16: rot_dim must be a multiple of 8 in [0,256]");
+  if (!qkv || !kcache || !vcache || !attn_out || !d_pos || (rot_dim && (!sin_t || !cos_t))) MG_FAIL(MG_ERR_SHAPE, "mg_decode_attn_gemv_bf16: null pointer");
+  if (!MG_ALIGNED16(qkv) || !MG_ALIGNED16(kcache) || !MG_ALIGNED16(vcache) || !MG_ALIGNED16(attn_out)) MG_FAIL(MG_ERR_ALIGN, "mg_decode_attn_gemv_bf16: pointers must be 16-byte aligned");
+  SkinnyParams sp;
+  if (int rc = fill_skinny(gemv, sp, "mg_decode_attn_gemv_bf16(gemv)")) return rc;
+  AttnDecodeParams ap{qkv, kcache, vcache, attn_out, H, Smax, d_pos, rot_dim, sin_t, cos_t};
+  hipStream_t s = (hipStream_t)stream;
+  const int n_attn = B * H, grid = n_attn + sp.ntiles;
+  if (sp.ksteps % 64 == 0) hipLaunchKernelGGL((decode_attn_gemv_kernel<16>), dim3(grid), dim3(256), 0, s, ap, n_attn, sp);
+  else if (sp.ksteps % 16 == 0) hipLaunchKernelGGL((decode_attn_gemv_kernel<4>), dim3(grid), dim3(256), 0, s, ap, n_attn, sp);
+  else if (sp.ksteps % 4 == 0) hipLaunchKernelGGL((decode_attn_gemv_kernel<1>), dim3(grid), dim3(256), 0, s, ap, n_attn, sp);
+  else MG_FAIL(MG_ERR_UNSUPPORTED, "mg_decode_attn_gemv_bf16: K of the GEMV must be a multiple of 128");
+  MG_CHECK_LAUNCH();
+  return MG_OK;
 }

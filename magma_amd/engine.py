@@ -108,6 +108,7 @@ class LMEngine:
         self._lm_head = lm.lm_head
         self._cache_pool = {}
         self._side_stream = torch.cuda.Stream(device=dev)
+        self.group_launches = os.environ.get("MAGMA_DECODE_GROUPED", "1") == "1"
         self.two_streams = os.environ.get("MAGMA_DECODE_STREAMS", "1") == "2"   # measured slower (3.07 vs 2.94 ms/step): off
 
     def _ensure_decode_packs(self):
@@ -281,6 +282,20 @@ class LMEngine:
                             split=(d3, st.h, ops.MG_ACT_GELU_NEW, ly.dec_in.bias_b))
             # attention branch (latency-bound, 128 workgroups) runs on a second HIP stream
             # underneath the MLP branch's weight streaming; both join at the adapter-up GEMV
+            grouped = (self.group_launches and ly.mlp_adapter is not None and ly.attn_adapter is None
+                       and ly.fc_out.Kp % 128 == 0 and ly.out.Kp % 128 == 0 and ly.mlp_adapter[0].Kp % 128 == 0)
+            if grouped:
+                # launch 2: attention workgroups + fc_out GEMV workgroups in one grid (they are independent
+                # branches of the parallel block; the latency-bound attention hides under the weight stream)
+                ops.decode_attn_gemv(st.qkv, cache.k[li], cache.v[li], st.ctx, B, self.H, cache.d_pos, self.rot,
+                                     self.sin_t, self.cos_t, (st.h, ly.fc_out, st.m, {}))
+                # launch 3: out_proj || adapter-down
+                t = st.t[:, : ly.mlp_adapter[0].N]
+                ops.gemm_skinny2((st.ctx, ly.out, st.a, {}), (st.m, ly.mlp_adapter[0], t, {"act": ops.MG_ACT_RELU}))
+                # launch 4: adapter-up + the block's three residuals
+                ops.gemm_skinny(t, ly.mlp_adapter[1], out=xn, residuals=(st.m, st.a, x))
+                x, xn = xn, x
+                continue
             if side is not None:
                 side.wait_stream(main)
                 torch.cuda.set_stream(side)

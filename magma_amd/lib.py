@@ -69,6 +69,9 @@ SYMBOLS = {
     "mg_last_error": (C.c_char_p, []),
     "mg_gemm_bf16": (C.c_int, [C.POINTER(GemmDesc), _vp]),
     "mg_gemm_skinny_bf16": (C.c_int, [C.POINTER(SkinnyDesc), _vp]),
+    "mg_gemm_skinny2_bf16": (C.c_int, [C.POINTER(SkinnyDesc), C.POINTER(SkinnyDesc), _vp]),
+    "mg_decode_attn_gemv_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp,
+                                          C.POINTER(SkinnyDesc), _vp]),
     "mg_layernorm_bf16": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp]),
     "mg_embedding_bf16": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _i64, _i32, _vp]),
     "mg_rotary_split_bf16": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp]),

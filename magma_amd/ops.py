@@ -170,14 +170,12 @@ class RawWeight:
         self.bias = bias
 
 
-def gemm_skinny(x: torch.Tensor, w: PackedLinear, out: Optional[torch.Tensor] = None, *, act: int = MG_ACT_NONE,
+def skinny_desc(x: torch.Tensor, w: PackedLinear, out: Optional[torch.Tensor] = None, *, act: int = MG_ACT_NONE,
                 residuals: Sequence[torch.Tensor] = (), act_after: int = MG_ACT_NONE, scale=None,
                 use_bias: bool = True, out_dtype=BF16, variant: int = 0, ln_fold: Optional[tuple] = None,
-                split: Optional[tuple] = None) -> torch.Tensor:
-    """Decode-shape (M <= 16) weight-streaming GEMM; needs the fragment-tiled layout.
-    ``ln_fold=(colsum fp32 [N], d, eps)``: LayerNorm of x folded into the GEMV (weights and
-    bias must be pre-folded, see fold_layernorm).  ``split=(split_n, out_b, act_b, bias_b)``:
-    columns >= split_n are written to ``out_b`` with their own activation / bias vector."""
+                split: Optional[tuple] = None):
+    """Build the C descriptor of one decode-shape (M <= 16) weight-streaming GEMM.  Returns
+    (desc, out, keepalive)."""
     _need_gpu(x)
     assert x.dtype == BF16 and x.ndim == 2 and x.stride(1) == 1 and w.ft is not None
     assert x.shape[1] == w.Kp, "decode activations must span the padded K"
@@ -196,8 +194,36 @@ def gemm_skinny(x: torch.Tensor, w: PackedLinear, out: Optional[torch.Tensor] = 
         split_n, out_b, act_b, bias_b = split
         d.split_n = split_n
         d.ep_b = _epilogue(out_b, w.N - split_n, bias_b, None, act_b, (), MG_ACT_NONE)
+    return d, out
+
+
+def gemm_skinny(x: torch.Tensor, w: PackedLinear, out: Optional[torch.Tensor] = None, **kw) -> torch.Tensor:
+    """Decode-shape (M <= 16) weight-streaming GEMM; needs the fragment-tiled layout.
+    ``ln_fold=(colsum fp32 [N], d, eps)``: LayerNorm of x folded into the GEMV (weights and
+    bias must be pre-folded, see fold_layernorm).  ``split=(split_n, out_b, act_b, bias_b)``:
+    columns >= split_n are written to ``out_b`` with their own activation / bias vector."""
+    d, out = skinny_desc(x, w, out, **kw)
     check(L.load().mg_gemm_skinny_bf16(C.byref(d), _stream()), "mg_gemm_skinny_bf16")
     return out
+
+
+def gemm_skinny2(a: tuple, b: tuple):
+    """Two independent decode GEMVs in one launch; a, b = (x, w, out, kwargs)."""
+    da, oa = skinny_desc(a[0], a[1], a[2], **a[3])
+    db, ob = skinny_desc(b[0], b[1], b[2], **b[3])
+    check(L.load().mg_gemm_skinny2_bf16(C.byref(da), C.byref(db), _stream()), "mg_gemm_skinny2_bf16")
+    return oa, ob
+
+
+def decode_attn_gemv(qkv, kcache, vcache, attn_out, B, H, d_pos, rot_dim, sin_t, cos_t, gemv: tuple):
+    """Decode attention (rotary + append + attend) co-launched with one independent GEMV
+    gemv = (x, w, out, kwargs)."""
+    _need_gpu(qkv)
+    d, og = skinny_desc(gemv[0], gemv[1], gemv[2], **gemv[3])
+    check(L.load().mg_decode_attn_gemv_bf16(qkv.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), attn_out.data_ptr(),
+                                            B, H, kcache.shape[2], d_pos.data_ptr(), rot_dim, sin_t.data_ptr(),
+                                            cos_t.data_ptr(), C.byref(d), _stream()), "mg_decode_attn_gemv_bf16")
+    return attn_out, og
 
 
 def fold_layernorm(weight: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor):
