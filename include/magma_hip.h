@@ -107,7 +107,16 @@ typedef struct mg_gemm_desc {
   const mg_bf16* zero_page; /* >= 16 zero bytes, 16-B aligned (K/halo padding) */
   mg_epilogue ep;
   int32_t tile_hint; /* 0 = auto; 128 / 256 force the workgroup-tile kernel        */
-  int32_t _pad;
+  int32_t split_k;   /* 0 = auto (only when a workspace is given); 1 = never; n = n-way */
+  /* Split-K scratch (optional): small-M GEMMs with a long K (prefill at a few hundred rows,
+   * the late CLIP stages) launch fewer tiles than the chip has CUs; with a workspace the
+   * library cuts K across several workgroups per tile, each writing an fp32 slab
+   * [M][ceil(N/128)*128] here, and a second launch adds the slabs in a fixed order and runs
+   * the epilogue (deterministic).  Needs split_k * M * ceil(N/128)*128 * 4 bytes; the
+   * library uses fewer splits if it is smaller.  Contents are scratch: do not share one
+   * workspace between streams.                                                          */
+  float* workspace;
+  int64_t workspace_bytes;
 } mg_gemm_desc;
 
 int mg_gemm_bf16(const mg_gemm_desc* d, void* stream);

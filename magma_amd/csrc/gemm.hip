@@ -25,6 +25,7 @@
 // lets bias / residual loads be vectors too.
 #include "common.h"
 
+#include <algorithm>
 #include "gemm_device.h"
 #include "attn_decode_device.h"
 
@@ -71,6 +72,11 @@ struct GemmParams {
   int H, Wd, Cin;
   const mg_bf16* zero;
   int tiles_m, tiles_n;
+  // split-K (gemm128 only): `splits` workgroups per output tile, each reducing kt_per K-tiles into
+  // its own fp32 slab ws[split][M][ldws]; splitk_fixup_kernel adds the slabs in a fixed order and
+  // applies the epilogue (deterministic, no atomics).  splits == 1: the epilogue runs in place.
+  int splits, kt_per;
+  float* ws; int64_t ldws;
   mg_epilogue ep;
 };
 
@@ -80,10 +86,12 @@ __global__ __launch_bounds__(256) void gemm128_kernel(const GemmParams p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int tm, tn;
-  tile_coords(blockIdx.x, p.tiles_m, p.tiles_n, tm, tn);
+  int tm, tn, sp = 0;
+  tile_coords(blockIdx.x, p.tiles_m, p.tiles_n * p.splits, tm, tn);
+  if (p.splits > 1) { const int t = tn / p.splits; sp = tn - t * p.splits; tn = t; }  // the splits of a tile are neighbours
   const int m0 = tm * BM, n0 = tn * BN;
   const int nkt = (p.K + BK - 1) / BK;
+  const int kt0 = sp * p.kt_per, kt1 = min(nkt, kt0 + p.kt_per);
 
   // ---- per-lane staging state: 4 DMA pieces of A and 4 of B per K-tile ----
   // piece j of wave w fills LDS rows [32w+8j, 32w+8j+8) x 128 B; lane -> (row
@@ -112,8 +120,9 @@ __global__ __launch_bounds__(256) void gemm128_kernel(const GemmParams p) {
       cv_y[j] = y; cv_x[j] = x;
       cv_ok[j] = (m < p.M);
       a_src[j] = p.A + (int64_t)mc * p.Cin;   // centre pixel, channel 0
-      cv_tap[j] = g / cpt;
-      cv_cc[j] = g - cv_tap[j] * cpt;
+      const int g_abs = g + kt0 * 8;          // first chunk this workgroup stages
+      cv_tap[j] = g_abs / cpt;
+      cv_cc[j] = g_abs - cv_tap[j] * cpt;
     }
   }
   const mg_bf16* b_src[4];
@@ -192,11 +201,11 @@ __global__ __launch_bounds__(256) void gemm128_kernel(const GemmParams p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  stage(0, 0);
+  stage(kt0, 0);
   __syncthreads();  // hipcc drains the LDS-DMA (vmcnt(0)) in front of the barrier
   int cur = 0;
-  for (int kt = 0; kt < nkt; ++kt) {
-    if (kt + 1 < nkt) stage(kt + 1, cur ^ 1);
+  for (int kt = kt0; kt < kt1; ++kt) {
+    if (kt + 1 < kt1) stage(kt + 1, cur ^ 1);
     const char* sb = smem + cur * STAGE_BYTES;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -216,6 +225,17 @@ __global__ __launch_bounds__(256) void gemm128_kernel(const GemmParams p) {
   }
 
   // ---- epilogue -------------------------------------------------------------
+  if (p.splits > 1) {   // raw partial sums -> this split's slab (ldws covers whole tiles)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + wm * 64 + i * 16 + li;
+      if (m >= p.M) continue;
+      float* row = p.ws + ((int64_t)sp * p.M + m) * p.ldws + n0 + wn * 64 + lq * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *(f32x4*)(row + j * 16) = acc[i][j];
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + wm * 64 + i * 16 + li;
@@ -226,6 +246,22 @@ __global__ __launch_bounds__(256) void gemm128_kernel(const GemmParams p) {
       epilogue_store4(p.ep, m, n, acc[i][j], p.N);
     }
   }
+}
+
+// second half of a split-K GEMM: add the slabs (fixed order) and run the fused epilogue
+__global__ __launch_bounds__(256) void splitk_fixup_kernel(const float* __restrict__ ws, int splits, int M, int N, int64_t ldws,
+                                                           const mg_epilogue ep) {
+  const int nq = (N + 3) >> 2;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)M * nq) return;
+  const int m = (int)(idx / nq), n = (int)(idx - (int64_t)m * nq) * 4;
+  const float* src = ws + (int64_t)m * ldws + n;
+  f32x4 v = *(const f32x4*)src;
+  for (int s = 1; s < splits; ++s) {
+    const f32x4 t = *(const f32x4*)(src + (int64_t)s * M * ldws);
+    v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+  }
+  epilogue_store4(ep, m, n, v, N);
 }
 
 // ---------------------------------------------------------------------------
@@ -451,8 +487,13 @@ int launch_gemm(const GemmParams& gp, hipStream_t s) {
     if (e != hipSuccess) MG_FAIL(MG_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm128_kernel<AMODE, WLAYOUT>), dim3(gp.tiles_m * gp.tiles_n), dim3(256), GEMM_LDS, s, gp);
+  hipLaunchKernelGGL((gemm128_kernel<AMODE, WLAYOUT>), dim3(gp.tiles_m * gp.tiles_n * gp.splits), dim3(256), GEMM_LDS, s, gp);
   MG_CHECK_LAUNCH();
+  if (gp.splits > 1) {
+    const int64_t quads = (int64_t)gp.M * ((gp.N + 3) >> 2);
+    hipLaunchKernelGGL(splitk_fixup_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, gp.ws, gp.splits, gp.M, gp.N, gp.ldws, gp.ep);
+    MG_CHECK_LAUNCH();
+  }
   return MG_OK;
 }
 
@@ -494,6 +535,10 @@ extern "C" int mg_gemm_bf16(const mg_gemm_desc* d, void* stream) {
   gp.zero = d->zero_page;
   gp.tiles_m = (d->M + BM - 1) / BM; gp.tiles_n = (d->N + BN - 1) / BN;
   gp.ep = d->ep;
+  gp.splits = 1; gp.kt_per = (d->K + BK - 1) / BK; gp.ws = nullptr; gp.ldws = 0;
+  if (d->split_k < 0 || d->split_k > 64) MG_FAIL(MG_ERR_SHAPE, "mg_gemm_bf16: split_k must be in [0, 64]");
+  if (d->split_k > 1 && !d->workspace) MG_FAIL(MG_ERR_SHAPE, "mg_gemm_bf16: split_k > 1 needs a workspace");
+  if (d->workspace && !MG_ALIGNED16(d->workspace)) MG_FAIL(MG_ERR_ALIGN, "mg_gemm_bf16: workspace must be 16-byte aligned");
   if (d->a_mode == MG_A_DENSE) {
     if (d->lda & 7) MG_FAIL(MG_ERR_ALIGN, "mg_gemm_bf16: lda must be a multiple of 8");
     if (d->lda < d->K) MG_FAIL(MG_ERR_SHAPE, "mg_gemm_bf16: lda < K");
@@ -517,6 +562,26 @@ extern "C" int mg_gemm_bf16(const mg_gemm_desc* d, void* stream) {
     return d->w_layout == MG_W_ROWMAJOR ? launch_gemm256<MG_W_ROWMAJOR, false>(gp, s) : launch_gemm256<MG_W_FRAGTILED, false>(gp, s);
   }
   if (d->tile_hint == 256 && !can256) MG_FAIL(MG_ERR_UNSUPPORTED, "mg_gemm_bf16: the 256x256 kernel needs dense A and K %% 128 == 0");
+  // split-K: a grid that leaves most of the 256 CUs idle and has a long K loop is cut along K
+  // until ~2 workgroups per CU exist (>= 4 K-tiles each); needs the caller's fp32 workspace.
+  if (d->workspace && d->split_k != 1) {
+    const int nkt = gp.kt_per;
+    const int tiles = gp.tiles_m * gp.tiles_n;
+    int want = d->split_k;
+    if (want == 0) want = tiles >= 192 ? 1 : std::min(std::min(16, nkt / 4), (512 + tiles - 1) / tiles);
+    want = std::max(1, std::min(want, nkt));
+    const int64_t slab = (int64_t)d->M * gp.tiles_n * BN * 4;
+    if ((int64_t)want * slab > d->workspace_bytes) {
+      if (d->split_k > 1) MG_FAIL(MG_ERR_SHAPE, "mg_gemm_bf16: workspace too small for split_k=%d (%lld bytes needed)", want, (long long)(want * slab));
+      want = (int)std::max<int64_t>(1, d->workspace_bytes / slab);
+    }
+    if (want > 1) {
+      gp.kt_per = (nkt + want - 1) / want;
+      gp.splits = (nkt + gp.kt_per - 1) / gp.kt_per;
+      gp.ws = d->workspace; gp.ldws = (int64_t)gp.tiles_n * BN;
+      if (gp.splits == 1) { gp.ws = nullptr; gp.ldws = 0; }
+    }
+  }
   if (d->a_mode == MG_A_DENSE) {
     return d->w_layout == MG_W_ROWMAJOR ? launch_gemm<MG_A_DENSE, MG_W_ROWMAJOR>(gp, s)
                                         : launch_gemm<MG_A_DENSE, MG_W_FRAGTILED>(gp, s);

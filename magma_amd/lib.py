@@ -46,7 +46,8 @@ class GemmDesc(C.Structure):
         ("H", C.c_int32), ("Wd", C.c_int32), ("Cin", C.c_int32),
         ("zero_page", C.c_void_p),
         ("ep", Epilogue),
-        ("tile_hint", C.c_int32), ("_pad", C.c_int32),
+        ("tile_hint", C.c_int32), ("split_k", C.c_int32),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
     ]
 
 

@@ -4,6 +4,7 @@ a call into libmagma_hip.so.  No CPU path exists: tensors must be on a GPU."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Sequence
 
 import torch
@@ -119,13 +120,28 @@ def _epilogue(out: torch.Tensor, N: int, bias, scale, act, residuals, act_after,
     return ep
 
 
+_SPLITK_WS = {}
+
+
+def splitk_workspace(device) -> torch.Tensor:
+    """fp32 scratch of the split-K GEMMs, one per (device, stream) -- launches on one stream are ordered,
+    so they can share it.  MAGMA_SPLITK_WS_MB sizes it (default 64)."""
+    key = (torch.device(device).index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _SPLITK_WS.get(key)
+    if ws is None:
+        mb = int(os.environ.get("MAGMA_SPLITK_WS_MB", "64"))
+        ws = _SPLITK_WS[key] = torch.empty(mb << 18, dtype=torch.float32, device=device)
+    return ws
+
+
 def gemm(a: torch.Tensor, w: PackedLinear, out: Optional[torch.Tensor] = None, *, act: int = MG_ACT_NONE,
          residuals: Sequence[torch.Tensor] = (), act_after: int = MG_ACT_NONE, scale=None,
          use_bias: bool = True, out_dtype=BF16, layout: Optional[str] = None,
          conv: Optional[tuple] = None, aux=None, aux_mode: int = MG_AUX_NONE, aux_after: bool = False,
-         out2: Optional[torch.Tensor] = None, tile: int = 0) -> torch.Tensor:
+         out2: Optional[torch.Tensor] = None, tile: int = 0, split_k: int = 0) -> torch.Tensor:
     """out[M,N] = epilogue(a[M,K] @ w^T).  ``conv=(H, W, Cin)`` switches the A
-    loader to implicit-im2col 3x3 over an NHWC image (a = [B*H*W, Cin])."""
+    loader to implicit-im2col 3x3 over an NHWC image (a = [B*H*W, Cin]).
+    ``split_k``: 0 lets the library cut K when the grid would leave the chip idle, 1 never, n forces n."""
     _need_gpu(a)
     assert a.dtype == BF16 and a.ndim == 2 and a.stride(1) == 1
     M = a.shape[0]
@@ -150,6 +166,10 @@ def gemm(a: torch.Tensor, w: PackedLinear, out: Optional[torch.Tensor] = None, *
         assert a.shape[1] == conv[2] and a.is_contiguous() and w.K == 9 * conv[2]
     d.zero_page = zero_page(a.device).data_ptr()
     d.tile_hint = tile
+    d.split_k = split_k
+    if split_k != 1:
+        ws = splitk_workspace(a.device)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     d.ep = _epilogue(out, w.N, w.bias if use_bias else None, scale, act, residuals, act_after, aux, aux_mode,
                      aux_after, out2)
     check(L.load().mg_gemm_bf16(C.byref(d), _stream()), "mg_gemm_bf16")

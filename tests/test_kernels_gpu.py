@@ -358,3 +358,37 @@ def test_gemm256_deep_pipeline(dev, layout, M, N, K):
         assert_close(out, ref, GEMM_TOL, f"gemm256 {layout} {M}x{N}x{K} rep{rep}")
         out128 = ops.gemm(a, lin, layout=layout, residuals=(res,), tile=128)
         assert float((out.float() - out128.float()).abs().max()) <= 2e-2 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("layout", ["rm", "ft"])
+def test_gemm_split_k(dev, layout):
+    """Split-K (fp32 slabs + fixed-order fixup) equals the single-pass kernel up to fp32 summation
+    order, is run-to-run deterministic, and carries the whole epilogue."""
+    from magma_amd import ops
+    M, N, K = 456, 203, 1000      # ragged M/N, K-tiles = 16 (last one partial)
+    a = rnd(M, K, dev=dev, seed=21).to(BF16)
+    w = rnd(N, K, dev=dev, seed=22, scale=0.05).to(BF16)
+    bias = rnd(N, dev=dev, seed=23)
+    r0 = rnd(M, 208, dev=dev, seed=24).to(BF16)
+    lin = ops.PackedLinear(w, bias=bias, tiled=True, rowmajor=True)
+    ref = F.gelu(a.float() @ w.float().t() + bias, approximate="tanh") + r0[:, :N].float()
+    base = ops.gemm(a, lin, layout=layout, act=ops.MG_ACT_GELU_NEW, residuals=(r0,), out_dtype=torch.float32, split_k=1)
+    assert_close(base, ref, 1e-4, "split_k=1")
+    for sk in (0, 2, 3, 7, 16):
+        buf = torch.full((M, 208), 7.0, dtype=torch.float32, device=dev)
+        ops.gemm(a, lin, out=buf, layout=layout, act=ops.MG_ACT_GELU_NEW, residuals=(r0,), split_k=sk)
+        assert_close(buf[:, :N], ref, 1e-4, f"split_k={sk}")
+        assert bool((buf[:, N:] == 7.0).all()), "wrote past N"
+        again = ops.gemm(a, lin, layout=layout, act=ops.MG_ACT_GELU_NEW, residuals=(r0,), out_dtype=torch.float32, split_k=sk)
+        assert torch.equal(again, buf[:, :N]), f"split_k={sk} is not deterministic"
+    # implicit-im2col A operand: the split has to start mid-way through the taps
+    B, H, W, Cin, Cout = 2, 7, 9, 48, 96
+    x = rnd(B, Cin, H, W, dev=dev, seed=25).to(BF16)
+    wc = rnd(Cout, Cin, 3, 3, dev=dev, seed=26, scale=0.1).to(BF16)
+    linc = ops.PackedLinear(wc.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous(), tiled=True, rowmajor=True)
+    xn = x.permute(0, 2, 3, 1).contiguous().view(B * H * W, Cin)
+    refc = F.conv2d(x.float(), wc.float(), padding=1).permute(0, 2, 3, 1).reshape(B * H * W, Cout)
+    for sk in (1, 2, 5):
+        assert_close(ops.gemm(xn, linc, conv=(H, W, Cin), layout=layout, split_k=sk), refc, GEMM_TOL, f"conv split_k={sk}")
+    with pytest.raises(Exception, match="split_k"):
+        ops.gemm(a, lin, split_k=65)

@@ -51,6 +51,22 @@ def bench_gemm(M, N, K, layout, act=0, tag=""):
         emit(kind="gemm", tag=tag, M=M, N=N, K=K, layout=layout, tile=tile, ms=ms, tflops=2.0 * M * N * K / ms / 1e9)
 
 
+def bench_prefill(M, N, K, tag):
+    nbytes = N * K * 2
+    ncopy = max(2, int(600e6 // nbytes) + 1)
+    lins = [ops.PackedLinear((torch.randn(N, K, device=dev) * 0.05).to(BF16)) for _ in range(ncopy)]
+    a = torch.randn(M, K, device=dev).to(BF16)
+    out = torch.empty(M, N, dtype=BF16, device=dev)
+    for sk in (1, 0, 2, 3, 4, 6, 8, 16):
+        try:
+            ms = timeit(lambda i: ops.gemm(a, lins[i % ncopy], out=out, act=1, split_k=sk), 4 * ncopy, warmup=ncopy)
+        except Exception as e:  # noqa: BLE001
+            emit(kind="prefill_gemm", tag=tag, split_k=sk, error=str(e)[:120])
+            continue
+        emit(kind="prefill_gemm", tag=tag, M=M, N=N, K=K, split_k=sk, ms=ms, tflops=2.0 * M * N * K / ms / 1e9,
+             gbps=nbytes / ms / 1e6)
+
+
 def bench_skinny(M, N, K, variants, tag=""):
     nbytes = N * K * 2
     ncopy = max(2, int(600e6 // nbytes) + 1)
@@ -86,6 +102,10 @@ def main():
                                 (4096, 16384, "fc_out"), (1024, 4096, "adapter_dn"), (4096, 1024, "adapter_up")]:
                 bench_gemm(1216, N, K, layout, tag="prefill152_" + tag)
             bench_gemm(32768, 16384, 4096, layout, tag="train_fc_in")
+    if which == "prefill":   # M = 8 x 57 rows: weights rotate so they stream from HBM as in a real prefill
+        for (N, K, tag) in [(12288, 4096, "qkv"), (16384, 4096, "fc_in"), (4096, 4096, "out_proj"),
+                            (4096, 16384, "fc_out"), (1024, 4096, "adapter_dn"), (4096, 1024, "adapter_up")]:
+            bench_prefill(456, N, K, tag)
     if which in ("all", "skinny"):
         variants = [(1, 8, 16), (2, 8, 16), (1, 4, 16), (2, 4, 16), (1, 8, 8), (2, 8, 8), (4, 8, 8), (2, 4, 8),
                     (4, 4, 8), (1, 8, 4), (2, 8, 4), (4, 8, 4), (1, 16, 8), (1, 16, 4), (1, 16, 2), (2, 16, 4)]

@@ -25,3 +25,18 @@ with torch.no_grad():
     t_gen, _ = timed(lambda: model.generate(emb, max_steps=32, temperature=0.0, decode=False, stop_on_eos=False), n=3)
 print(json.dumps({"res": res, "encoder_ms": t_enc, "image_prefix_ms": t_prefix, "embed_ms": t_embed, "prefill_ms": t_prefill,
                   "generate32_ms": t_gen, "S0": emb.shape[1]}))
+
+# ---- potential of graph capture for the non-decode phases ----
+def graphed(fn):
+    fn(); torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        r = fn()
+    return g, r
+
+with torch.no_grad():
+    g_enc, _ = graphed(lambda: model.image_prefix(images))
+    t_enc_g, _ = timed(lambda: g_enc.replay())
+    g_pre, _ = graphed(lambda: model.lm(inputs_embeds=emb, use_cache=True, cache_hint=32, reuse_cache=True))
+    t_pre_g, _ = timed(lambda: g_pre.replay())
+print(json.dumps({"image_prefix_graph_ms": t_enc_g, "prefill_graph_ms": t_pre_g}))
