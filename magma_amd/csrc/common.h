@@ -21,20 +21,28 @@ MG_DEV uint16_t f2bf(float f) {
   u += 0x7fffu + ((u >> 16) & 1u);
   return (uint16_t)(u >> 16);
 }
-MG_DEV uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+// two floats -> packed bf16 pair: ONE v_cvt_pk_bf16_f32 on gfx950 (round-to-nearest-even, same values as f2bf)
+typedef __attribute__((ext_vector_type(2))) float mg_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 mg_bf16x2;
+MG_DEV uint32_t pack2bf(float lo, float hi) {
+  const mg_f32x2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, mg_bf16x2));
+}
 MG_DEV float bflo(uint32_t w) { return __uint_as_float(w << 16); }
 MG_DEV float bfhi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
 MG_DEV float gelu_new_f(float x) {
   // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))   (HF NewGELUActivation)
   const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-  float u = k0 * (x + k1 * x * x * x);
-  return 0.5f * x * (1.0f + tanhf(u));
+  // 0.5 (1 + tanh u) = 1 / (1 + e^-2u): one v_exp_f32 + one v_rcp_f32 instead of the libm tanh
+  const float u = k0 * (x + k1 * x * x * x);
+  return x * __frcp_rn(1.0f + __expf(-2.0f * u));
 }
 MG_DEV float gelu_new_grad_f(float x) {
   const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-  const float t = tanhf(k0 * (x + k1 * x * x * x));
-  return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * k0 * (1.0f + 3.0f * k1 * x * x);
+  const float sg = __frcp_rn(1.0f + __expf(-2.0f * k0 * (x + k1 * x * x * x)));   // 0.5 (1 + tanh u)
+  const float t = 2.0f * sg - 1.0f;
+  return sg + 0.5f * x * (1.0f - t * t) * k0 * (1.0f + 3.0f * k1 * x * x);
 }
 MG_DEV float apply_act(float v, int act) {
   if (act == MG_ACT_RELU) return v > 0.f ? v : 0.f;

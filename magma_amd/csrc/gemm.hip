@@ -34,7 +34,9 @@ namespace {
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;        // 16 KiB per operand tile
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;    // A + B
-constexpr int GEMM_LDS = 2 * STAGE_BYTES;      // double buffered: 64 KiB
+constexpr int EPI128_ROWB = BN * 4 + 16;        // fp32 row of the LDS-staged epilogue (+16 B: bank skew)
+constexpr int GEMM_LDS = BM * EPI128_ROWB;     // max(double-buffered stages = 64 KiB, epilogue image = 66 KiB)
+static_assert(GEMM_LDS >= 2 * STAGE_BYTES, "LDS must hold both K-tile stages");
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -236,16 +238,15 @@ __global__ __launch_bounds__(256) void gemm128_kernel(const GemmParams p) {
     }
     return;
   }
+  // park the accumulators in LDS (the K loop ended on a barrier: nobody reads the stages any more),
+  // then walk rows -- see epilogue_rows
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wm * 64 + i * 16 + li;
-    if (m >= p.M) continue;
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wn * 64 + j * 16 + lq * 4;
-      epilogue_store4(p.ep, m, n, acc[i][j], p.N);
-    }
-  }
+    for (int j = 0; j < 4; ++j)
+      *(f32x4*)(smem + (wm * 64 + i * 16 + li) * EPI128_ROWB + (wn * 64 + j * 16 + lq * 4) * 4) = acc[i][j];
+  __syncthreads();
+  epilogue_rows<BN, EPI128_ROWB>(p.ep, smem, BM, 4, wave, lane, m0, 64, n0, p.M, p.N);
 }
 
 // second half of a split-K GEMM: add the slabs (fixed order) and run the fused epilogue
@@ -296,7 +297,9 @@ __global__ __launch_bounds__(256) void splitk_fixup_kernel(const float* __restri
 // ---------------------------------------------------------------------------
 constexpr int G256_TILE = 256 * 64 * 2;          // 32 KiB per operand per K-tile
 constexpr int G256_BUF = 2 * G256_TILE;          // A + W
-constexpr int G256_LDS = 2 * G256_BUF;           // 128 KiB
+constexpr int EPI256_ROWB = 256 * 4 + 16;        // fp32 row of the LDS-staged epilogue (+16 B: bank skew)
+constexpr int G256_LDS = 128 * EPI256_ROWB;      // max(two K-tiles = 128 KiB, epilogue image = 130 KiB)
+static_assert(G256_LDS >= 2 * G256_BUF, "LDS must hold two K-tiles");
 
 #define MG_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define MG_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
@@ -434,19 +437,19 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
 #undef MG_DMA_A
 #undef MG_DMA_B
 
-  // ---- epilogue (expanded by hand: a rolled loop would index acc dynamically -> scratch) ----
-#define MG_EPI(i)                                                                                        \
-  {                                                                                                      \
-    const int m_ = m0 + wr * 128 + (i) * 16 + li;                                                        \
-    if (m_ < p.M) {                                                                                      \
-      epilogue_store4(p.ep, m_, n0 + wc * 64 + 0 * 16 + lq * 4, acc[i][0], p.N);                         \
-      epilogue_store4(p.ep, m_, n0 + wc * 64 + 1 * 16 + lq * 4, acc[i][1], p.N);                         \
-      epilogue_store4(p.ep, m_, n0 + wc * 64 + 2 * 16 + lq * 4, acc[i][2], p.N);                         \
-      epilogue_store4(p.ep, m_, n0 + wc * 64 + 3 * 16 + lq * 4, acc[i][3], p.N);                         \
-    }                                                                                                    \
+  // ---- epilogue: two passes of 128 tile rows (each wave's upper / lower 64) through LDS ----
+  __syncthreads();
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (h) __syncthreads();   // pass 0 has been read
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        *(f32x4*)(smem + (wr * 64 + i * 16 + li) * EPI256_ROWB + (wc * 64 + j * 16 + lq * 4) * 4) = acc[h * 4 + i][j];
+    __syncthreads();
+    epilogue_rows<256, EPI256_ROWB>(p.ep, smem, 128, 8, wave, lane, m0 + h * 64, 128, n0, p.M, p.N);
   }
-  MG_EPI(0) MG_EPI(1) MG_EPI(2) MG_EPI(3) MG_EPI(4) MG_EPI(5) MG_EPI(6) MG_EPI(7)
-#undef MG_EPI
 }
 
 template <int WAVES, int KC, int NT>

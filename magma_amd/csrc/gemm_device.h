@@ -4,24 +4,30 @@
 #include "common.h"
 
 // ---------------------------------------------------------------------------
-// shared epilogue: 4 consecutive n of row m
+// shared epilogue: 4 consecutive n of row m.  Split in two so that row-walking callers load the
+// per-column vectors (BatchNorm scale, bias) once.
 // ---------------------------------------------------------------------------
-MG_DEV void epilogue_store4(const mg_epilogue& ep, int m, int n, f32x4 v, int N) {
-  if (n >= N) return;
-  const bool full = (n + 3 < N);
-  float sc[4] = {1.f, 1.f, 1.f, 1.f}, bi[4] = {0.f, 0.f, 0.f, 0.f};
-  if (full) {
-    if (ep.scale) { const float4 t = *(const float4*)(ep.scale + n); sc[0] = t.x; sc[1] = t.y; sc[2] = t.z; sc[3] = t.w; }
-    if (ep.bias)  { const float4 t = *(const float4*)(ep.bias + n);  bi[0] = t.x; bi[1] = t.y; bi[2] = t.z; bi[3] = t.w; }
+struct EpiCols { float sc[4], bi[4]; };
+
+MG_DEV void epilogue_cols(const mg_epilogue& ep, int n, int N, EpiCols& c) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { c.sc[r] = 1.f; c.bi[r] = 0.f; }
+  if (n + 3 < N) {
+    if (ep.scale) { const float4 t = *(const float4*)(ep.scale + n); c.sc[0] = t.x; c.sc[1] = t.y; c.sc[2] = t.z; c.sc[3] = t.w; }
+    if (ep.bias)  { const float4 t = *(const float4*)(ep.bias + n);  c.bi[0] = t.x; c.bi[1] = t.y; c.bi[2] = t.z; c.bi[3] = t.w; }
   } else {
     for (int r = 0; r < 4; ++r) if (n + r < N) {
-      if (ep.scale) sc[r] = ep.scale[n + r];
-      if (ep.bias) bi[r] = ep.bias[n + r];
+      if (ep.scale) c.sc[r] = ep.scale[n + r];
+      if (ep.bias) c.bi[r] = ep.bias[n + r];
     }
   }
+}
+
+MG_DEV void epilogue_apply4(const mg_epilogue& ep, const EpiCols& c, int m, int n, f32x4 v, int N) {
+  const bool full = (n + 3 < N);
   float o[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) o[r] = v[r] * sc[r] + bi[r];
+  for (int r = 0; r < 4; ++r) o[r] = v[r] * c.sc[r] + c.bi[r];
   if (ep.C2) {  // pre-activation copy for the backward pass
     mg_bf16* cp = ep.C2 + (int64_t)m * ep.ldc2 + n;
     if (full) { u32x2 w; w[0] = pack2bf(o[0], o[1]); w[1] = pack2bf(o[2], o[3]); *(u32x2*)cp = w; }
@@ -73,6 +79,36 @@ MG_DEV void epilogue_store4(const mg_epilogue& ep, int m, int n, f32x4 v, int N)
     mg_bf16* cp = (mg_bf16*)ep.C + (int64_t)m * ep.ldc + n;
     if (full) { u32x2 w; w[0] = pack2bf(o[0], o[1]); w[1] = pack2bf(o[2], o[3]); *(u32x2*)cp = w; }
     else for (int r = 0; r < 4; ++r) if (n + r < N) cp[r] = f2bf(o[r]);
+  }
+}
+
+MG_DEV void epilogue_store4(const mg_epilogue& ep, int m, int n, f32x4 v, int N) {
+  if (n >= N) return;
+  EpiCols c;
+  epilogue_cols(ep, n, N, c);
+  epilogue_apply4(ep, c, m, n, v, N);
+}
+
+// Tile epilogue through LDS.  The MFMA accumulators of a workgroup tile were parked in LDS as fp32
+// rows of NCOLS columns (row stride ROWB bytes; ROWB % 128 == 16 keeps the 8-lane groups of the
+// fragment-shaped ds_write_b128 on distinct bank slots).  Here every wave walks whole rows: NCOLS/4
+// lanes cover one row with 4 consecutive columns each, so residual / aux reads and the output stores
+// are full contiguous lines, and the code is one small rolled loop instead of one inlined epilogue
+// per accumulator (which made the GEMM kernels > 20k instructions, mostly instruction-cache misses).
+// Tile row r is global row  m_base + (r >> 6) * hi_stride + (r & 63).
+template <int NCOLS, int ROWB>
+MG_DEV void epilogue_rows(const mg_epilogue& ep, const char* lds, int rows, int nwaves, int wave, int lane,
+                          int m_base, int hi_stride, int n0, int M, int N) {
+  constexpr int LPR = NCOLS / 4, RPI = 64 / LPR;
+  const int cl = lane % LPR;
+  const int n = n0 + cl * 4;
+  if (n >= N) return;
+  EpiCols c;
+  epilogue_cols(ep, n, N, c);
+#pragma unroll 2
+  for (int r = wave * RPI + lane / LPR; r < rows; r += nwaves * RPI) {
+    const int m = m_base + (r >> 6) * hi_stride + (r & 63);
+    if (m < M) epilogue_apply4(ep, c, m, n, *(const f32x4*)(lds + r * ROWB + cl * 16), N);
   }
 }
 

@@ -102,6 +102,20 @@ def main():
                                 (4096, 16384, "fc_out"), (1024, 4096, "adapter_dn"), (4096, 1024, "adapter_up")]:
                 bench_gemm(1216, N, K, layout, tag="prefill152_" + tag)
             bench_gemm(32768, 16384, 4096, layout, tag="train_fc_in")
+    if which == "ksweep":   # per-tile overhead (a) vs per-K-tile cost (b) of the 256x256 kernel; clock droop on long runs
+        for K in (256, 512, 1024, 2048, 4096, 8192, 16384):
+            a = torch.randn(8192, K, device=dev).to(BF16)
+            lin = ops.PackedLinear((torch.randn(8192, K, device=dev) * 0.05).to(BF16))
+            out = torch.empty(8192, 8192, dtype=BF16, device=dev)
+            for tile in (128, 256):
+                ms = timeit(lambda i: ops.gemm(a, lin, out=out, tile=tile, split_k=1), 10)
+                emit(kind="ksweep", M=8192, N=8192, K=K, tile=tile, ms=ms, tflops=2.0 * 8192 * 8192 * K / ms / 1e9)
+        a = torch.randn(32768, 4096, device=dev).to(BF16)
+        lin = ops.PackedLinear((torch.randn(16384, 4096, device=dev) * 0.05).to(BF16))
+        out = torch.empty(32768, 16384, dtype=BF16, device=dev)
+        for iters in (1, 3, 10, 40):
+            ms = timeit(lambda i: ops.gemm(a, lin, out=out, tile=256), iters, warmup=1)
+            emit(kind="droop", M=32768, N=16384, K=4096, iters=iters, ms=ms, tflops=2.0 * 32768 * 16384 * 4096 / ms / 1e9)
     if which == "prefill":   # M = 8 x 57 rows: weights rotate so they stream from HBM as in a real prefill
         for (N, K, tag) in [(12288, 4096, "qkv"), (16384, 4096, "fc_in"), (4096, 4096, "out_proj"),
                             (4096, 16384, "fc_out"), (1024, 4096, "adapter_dn"), (4096, 1024, "adapter_up")]:
