@@ -259,7 +259,9 @@ int mg_rotary_merge_bwd_bf16(const mg_bf16* dq, const mg_bf16* dk, const mg_bf16
                              mg_bf16* dqkv, void* stream);
 
 /* causal flash-attention backward, head dim 256 (recomputes P from q,k,lse).
- * q,k,v [B,H,S,256]; qt,kt,dOt [B,H,256,ld_t]; dO,O [B*S,H*256]; lse,D [B,H,S].      */
+ * q,k,v [B,H,S,256]; qt,kt,dOt [B,H,256,ld_t] (ld_t >= round_up(S,32), zero padded);
+ * dO,O [B*S,H*256]; lse [B,H,S]; D = fp32 workspace of 2*B*H*S floats ({lse*log2e, rowsum(dO o O)}
+ * per query, written by the first launch).                                           */
 int mg_attn_bwd_bf16(const mg_bf16* q, const mg_bf16* k, const mg_bf16* v, const mg_bf16* qt,
                      const mg_bf16* kt, const mg_bf16* dO, const mg_bf16* dOt, const mg_bf16* O,
                      const float* lse, float* D, mg_bf16* dq, mg_bf16* dk, mg_bf16* dv, int32_t B,

@@ -112,8 +112,11 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lq = lane >> 4;
-  const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
-  const int qt0 = blockIdx.x * 64;
+  // all query blocks of one (b,h) on ONE XCD: its K / V^T stream is re-read from that XCD's L2
+  const int nblk = (S + 63) >> 6;
+  const int wg = xcd_contiguous_index(blockIdx.x, gridDim.x);
+  const int bh = wg / nblk, b = bh / H, h = bh - b * H;
+  const int qt0 = (nblk - 1 - (wg - bh * nblk)) * 64;   // longest blocks first
   const int qrow = qt0 + wave * 16 + li;       // this lane's query
   const int qrow_c = min(qrow, S - 1);
   const mg_bf16* kbase = kcache + (int64_t)bh * Smax * DH;
@@ -270,7 +273,7 @@ extern "C" int mg_attn_prefill_bf16(const mg_bf16* q, const mg_bf16* kcache, con
   if ((vt_ld & 7) || vt_ld < ((S + 31) & ~31)) MG_FAIL(MG_ERR_SHAPE, "mg_attn_prefill_bf16: vt_ld must be a multiple of 8 and >= round_up(S,32)");
   if (!q || !kcache || !vt || !out) MG_FAIL(MG_ERR_SHAPE, "mg_attn_prefill_bf16: null pointer");
   if (!MG_ALIGNED16(q) || !MG_ALIGNED16(kcache) || !MG_ALIGNED16(vt) || !MG_ALIGNED16(out)) MG_FAIL(MG_ERR_ALIGN, "mg_attn_prefill_bf16: pointers must be 16-byte aligned");
-  dim3 grid((S + 63) / 64, B * H);
+  dim3 grid((unsigned)(((S + 63) / 64) * B * H));
   hipLaunchKernelGGL(attn_prefill_kernel, grid, dim3(256), 0, (hipStream_t)stream, q, kcache, vt, out, lse, B, H, S,
                      Smax, vt_ld);
   MG_CHECK_LAUNCH();

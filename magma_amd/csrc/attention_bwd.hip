@@ -1,14 +1,14 @@
 // attention_bwd.hip -- causal flash-attention backward, head dim 256 (gfx950).
 //
-// Two kernels that recompute P from (q, k, lse) -- no S x S tensor in HBM:
+// Three kernels that recompute P from (q, k, lse) -- no S x S tensor in HBM:
 //
-//   attn_bwd_dq_kernel    one workgroup per 64 queries (4 waves x 16), loops over
+//   attn_bwd_dq_kernel    one workgroup per 128 queries (8 waves x 16), loops over
 //                         KV tiles of 32.  Works in the transposed frame of the
 //                         forward kernel (lane&15 = query):
 //                           S^T  = K Q^T        dP^T = V dO^T
 //                           dS^T = P^T o (dP^T - D) / 16
 //                           dQ^T += K^T dS^T
-//   attn_bwd_dkdv_kernel  one workgroup per 64 keys (4 waves x 16, lane&15 = key),
+//   attn_bwd_dkdv_kernel  one workgroup per 128 keys (8 waves x 16, lane&15 = key),
 //                         loops over query tiles of 32 from the diagonal down:
 //                           S  = Q K^T          dP = dO V^T
 //                           dV^T += dO^T P      dK^T += Q^T dS
@@ -19,26 +19,39 @@
 // the d-contractions and K^T,Q^T,dO^T [256][s] for the s-contractions (made by
 // mg_head_transpose_bf16).  The same row permutation as in the forward kernel
 // turns accumulator registers directly into the next product's operand.
-// D[b,h,q] = sum_d dO*O comes from attn_bwd_prep_kernel.
+//
+// Pipeline.  A tile step is only 32-48 MFMAs per wave, far shorter than an HBM/L2
+// round trip, so the tiles stream through a ring of LDS stages filled by LDS-DMA
+// (global_load_lds, no register staging): the loads of tile t+2 (t+3 for dV) are
+// issued while tile t is multiplied, each wave waits for ITS pieces with a counted
+// s_waitcnt vmcnt(N) and ONE barrier per tile both publishes tile t and retires the
+// stage that tile t+2 overwrites.  Past the last tile the ring re-loads the last tile
+// (in bounds, never read) so the wait counts stay constant.
 #include "common.h"
 
 namespace {
 
 constexpr int DH = 256;
-// LDS images chosen conflict-free for the ds_read_b128 lane groups of gfx950 (searched
-// offline over the fragment access patterns below):
-//   row tiles [32][256]: unpadded 512-B rows, 16-B chunk index XORed with
-//                        f(row) = (row&3) | ((row>>3)<<2)
-//   T tiles  [256][32]:  96-B row stride (6 x 16 B)
-constexpr int ROW_STRIDE = DH * 2;       // 512 B
-constexpr int T_STRIDE = 32 * 2 + 32;    // 96 B
+// LDS images, conflict-free for the ds_read_b128 lane groups of gfx950 (MI355X_MICROARCH.md, LDS):
+//   row tiles [32][256]: 512-B rows, 16-B chunk c of row r stored at position c ^ row_swz(r)
+//   T tiles  [256][32]:  64-B rows,  16-B chunk c of row r stored at position c ^ t_swz(r)
+// LDS-DMA writes 64 lanes x 16 B linearly, so the swizzles are applied to the SOURCE addresses.
 MG_DEV int row_swz(int row) { return (row & 3) | ((row >> 3) << 2); }
-constexpr int ROW_TILE = 32 * ROW_STRIDE;  // 16896
-constexpr int T_TILE = DH * T_STRIDE;      // 20480
+MG_DEV int t_swz(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; }   // {0,2,3,1}[(row>>2)&3]
+constexpr int ROW_TILE = 32 * DH * 2;     // 16 KiB
+constexpr int T_TILE = DH * 32 * 2;       // 16 KiB
+constexpr int LD_TILE = 256;              // 32 x {lse*log2e, D}
 
-// D = rowsum(dO o O); one wave per (b, s, h) row of 256
-__global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const mg_bf16* __restrict__ dO,
-                                                            const mg_bf16* __restrict__ O, float* __restrict__ D,
+constexpr int DQ_STAGE = 2 * ROW_TILE + T_TILE;             // K rows | V rows | K^T
+constexpr int DQ_STAGES = 3;
+constexpr int DK_STAGE = 2 * ROW_TILE + T_TILE + LD_TILE;   // Q rows | dO rows | Q^T | lse,D
+constexpr int DK_STAGES = 3;
+constexpr int DV_STAGE = ROW_TILE + T_TILE + LD_TILE;       // Q rows | dO^T | lse,D
+constexpr int DV_STAGES = 4;
+
+// ld2[b,h,s] = {lse * log2(e), D = rowsum(dO o O)}; one wave per (b, s, h) row of 256
+__global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const mg_bf16* __restrict__ dO, const mg_bf16* __restrict__ O,
+                                                            const float* __restrict__ lse, float* __restrict__ ld2,
                                                             int B, int H, int S) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t row = (int64_t)blockIdx.x * 4 + wave;   // over B*S*H, (b,s,h) order = memory order of [M, H*256]
@@ -51,63 +64,83 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const mg_bf16* __res
     const int h = (int)(row % H);
     const int64_t bs = row / H;
     const int sidx = (int)(bs % S), b = (int)(bs / S);
-    D[((int64_t)b * H + h) * S + sidx] = s;
+    const int64_t i = ((int64_t)b * H + h) * S + sidx;
+    ld2[i * 2] = lse[i] * 1.4426950408889634f;
+    ld2[i * 2 + 1] = s;
   }
 }
 
-// Staging is split into "issue the global loads" and "write the registers to LDS" so the
-// loads of tile t+1 are in flight while tile t is being multiplied (both kernels run at one
-// or two waves per SIMD: there is no other latency hiding).
-MG_DEV void load_rows(u32x4 (&r)[4], const mg_bf16* base, int64_t row_stride_elems, int r0, int rmax, int tid) {
+// One tile = 16 blocks of 1 KiB; wave w (of 8) moves blocks 2w and 2w+1.
+// rows [r0, r0+32) of a row-major [*][256] array (row stride in elements), rows clamped to rmax-1
+MG_DEV void dma_rows(char* tile, const mg_bf16* base, int64_t row_stride, int r0, int rmax, int wave, int lane) {
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int ci = tid + it * 256;
-    const int rr = min(r0 + (ci >> 5), rmax - 1);            // 32 rows x 32 chunks, rows clamped
-    r[it] = *(const u32x4*)(base + (int64_t)rr * row_stride_elems + (ci & 31) * 8);
+  for (int i = 0; i < 2; ++i) {
+    const int blk = wave * 2 + i;
+    const int row = blk * 2 + (lane >> 5);
+    const int c = (lane & 31) ^ row_swz(row);
+    glds16(base + (int64_t)min(r0 + row, rmax - 1) * row_stride + c * 8, tile + blk * 1024);
   }
 }
-MG_DEV void store_rows(char* lds, const u32x4 (&r)[4], int tid) {
+// columns [c0, c0+32) of a transposed [256][ld] array
+MG_DEV void dma_cols(char* tile, const mg_bf16* base_t, int ld, int c0, int wave, int lane) {
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int ci = tid + it * 256;
-    const int row = ci >> 5;
-    *(u32x4*)(lds + row * ROW_STRIDE + (((ci & 31) ^ row_swz(row)) << 4)) = r[it];
+  for (int i = 0; i < 2; ++i) {
+    const int blk = wave * 2 + i;
+    const int row = blk * 16 + (lane >> 2);
+    const int c = (lane & 3) ^ t_swz(row);
+    glds16(base_t + (int64_t)row * ld + c0 + c * 8, tile + blk * 1024);
   }
 }
-MG_DEV void load_cols(u32x4 (&r)[4], const mg_bf16* base_t, int ld, int c0, int tid) {
+
+// fragment bursts: 8 x ds_read_b128 of one operand, and the 8 MFMAs of a 16x16 tile over d = 256
+#define MG_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+MG_DEV void rd_row8(bf16x8 (&f)[8], const char* row, int lq, int sw) {
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int ci = tid + it * 256;                            // [256][32] slice at column c0
-    r[it] = *(const u32x4*)(base_t + (int64_t)(ci >> 2) * ld + c0 + (ci & 3) * 8);
-  }
+  for (int ks = 0; ks < 8; ++ks) f[ks] = *(const bf16x8*)(row + (((ks * 4 + lq) ^ sw) << 4));
 }
-MG_DEV void store_cols(char* lds, const u32x4 (&r)[4], int tid) {
+MG_DEV void rd_t8(bf16x8 (&f)[8], const char* tp) {
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int ci = tid + it * 256;
-    *(u32x4*)(lds + (ci >> 2) * T_STRIDE + (ci & 3) * 16) = r[it];
-  }
+  for (int dt = 0; dt < 8; ++dt) f[dt] = *(const bf16x8*)(tp + dt * 1024);
+}
+MG_DEV f32x4 mma8(const bf16x8 (&a)[8], const bf16x8 (&b)[8]) {
+  f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks], b[ks], c, 0, 0, 0);
+  return c;
 }
 
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
+__global__ __launch_bounds__(512) void attn_bwd_dq_kernel(
     const mg_bf16* __restrict__ q, const mg_bf16* __restrict__ k, const mg_bf16* __restrict__ v,
-    const mg_bf16* __restrict__ kt, const mg_bf16* __restrict__ dO, const float* __restrict__ lse,
-    const float* __restrict__ Dv, mg_bf16* __restrict__ dq, int B, int H, int S, int ld_t) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * ROW_TILE + T_TILE];
-  char* k_lds = smem;
-  char* v_lds = smem + ROW_TILE;
-  char* kt_lds = smem + 2 * ROW_TILE;
+    const mg_bf16* __restrict__ kt, const mg_bf16* __restrict__ dO, const float* __restrict__ ld2,
+    mg_bf16* __restrict__ dq, int B, int H, int S, int ld_t) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lq = lane >> 4;
-  const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
-  const int qt0 = blockIdx.x * 64;
+  // all query blocks of one (b,h) run on ONE XCD, so its K / V / K^T stream is fetched from HBM once and
+  // re-read from that XCD's L2 by the other blocks
+  const int nblk = (S + 127) >> 7;
+  const int wg = xcd_contiguous_index(blockIdx.x, gridDim.x);
+  const int bh = wg / nblk, b = bh / H, h = bh - b * H;
+  const int qt0 = (nblk - 1 - (wg - bh * nblk)) * 128;            // longest (latest) query blocks first
   const int qrow = qt0 + wave * 16 + li, qrow_c = min(qrow, S - 1);
   const mg_bf16* kb = k + (int64_t)bh * S * DH;
   const mg_bf16* vb = v + (int64_t)bh * S * DH;
   const mg_bf16* ktb = kt + (int64_t)bh * DH * ld_t;
   const int dmodel = H * DH;
+
+  const int kv_end = min(S, qt0 + 128);
+  const int ntiles = (kv_end + 31) >> 5;
+  auto issue = [&](int t, int buf) {
+    const int c0 = min(t, ntiles - 1) * 32;
+    char* st = smem + buf * DQ_STAGE;
+    dma_rows(st, kb, DH, c0, S, wave, lane);
+    dma_rows(st + ROW_TILE, vb, DH, c0, S, wave, lane);
+    dma_cols(st + 2 * ROW_TILE, ktb, ld_t, c0, wave, lane);
+  };
+  issue(0, 0);
+  issue(1, 1);
 
   bf16x8 qf[8], dof[8];
   {
@@ -116,64 +149,75 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) { qf[ks] = *(const bf16x8*)(qp + ks * 32); dof[ks] = *(const bf16x8*)(dp + ks * 32); }
   }
-  const float L2E = 1.4426950408889634f;
-  const float sc2 = 0.0625f * L2E;
-  const float lse2 = lse[(int64_t)bh * S + qrow_c] * L2E;
-  const float Dq = Dv[(int64_t)bh * S + qrow_c];
+  const float sc2 = 0.0625f * 1.4426950408889634f;
+  const float lse2 = ld2[((int64_t)bh * S + qrow_c) * 2];
+  const float Dq = ld2[((int64_t)bh * S + qrow_c) * 2 + 1];
   f32x4 acc[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int my_last = qt0 + wave * 16 + 15;     // key tiles past this wave's last query are fully masked
+  const int tsw = t_swz(li);
+  const int krow0 = (li >> 2) * 8 + (li & 3);   // row permutation: accumulator registers -> 8 consecutive keys
+  const int sw0 = row_swz(krow0);
 
-  const int kv_end = min(S, qt0 + 64);
-  const int ntiles = (kv_end + 31) >> 5;
-  u32x4 rk[4], rv[4], rkt[4];
-  load_rows(rk, kb, DH, 0, S, tid);
-  load_rows(rv, vb, DH, 0, S, tid);
-  load_cols(rkt, ktb, ld_t, 0, tid);
+  int sc = 0;
   for (int t = 0; t < ntiles; ++t) {
+    MG_WAIT_VMCNT(6);                 // this wave's pieces of tile t have landed (tile t+1 may be in flight)
+    MG_BARRIER_KEEP_DMA();            // tile t complete; everyone is done with tile t-1
+    issue(t + 2, sc == 0 ? 2 : sc - 1);
     const int kv0 = t * 32;
-    __syncthreads();
-    store_rows(k_lds, rk, tid);
-    store_rows(v_lds, rv, tid);
-    store_cols(kt_lds, rkt, tid);
-    __syncthreads();
-    if (t + 1 < ntiles) {
-      load_rows(rk, kb, DH, kv0 + 32, S, tid);
-      load_rows(rv, vb, DH, kv0 + 32, S, tid);
-      load_cols(rkt, ktb, ld_t, kv0 + 32, tid);
-    }
-    f32x4 st[2], dp[2];
+    if (kv0 <= my_last) {
+      const char* k_lds = smem + sc * DQ_STAGE;
+      const char* v_lds = k_lds + ROW_TILE;
+      const char* kt_lds = k_lds + 2 * ROW_TILE;
+      // Fragment reads are issued in batches of 8 (one ds_read burst, counted lgkmcnt at first use) one
+      // batch AHEAD of the MFMAs that consume them; sched_barrier pins that order.
+      const char* kp = k_lds + krow0 * 512;
+      const char* vp = v_lds + krow0 * 512;
+      const char* tp = kt_lds + li * 64 + ((lq ^ tsw) << 4);
+      bf16x8 fa[8], fb[8];
+      f32x4 st[2], dp[2];
+      rd_row8(fa, kp, lq, sw0);                    // K  keys tt=0
+      rd_row8(fb, vp, lq, sw0);                    // V  keys tt=0
+      MG_SCHED_FENCE();
+      st[0] = mma8(fa, qf);
+      MG_SCHED_FENCE();
+      rd_row8(fa, kp + 4 * 512, lq, sw0);          // K  keys tt=1 (row + 4: same swizzle)
+      MG_SCHED_FENCE();
+      dp[0] = mma8(fb, dof);
+      MG_SCHED_FENCE();
+      rd_row8(fb, vp + 4 * 512, lq, sw0);          // V  keys tt=1
+      MG_SCHED_FENCE();
+      st[1] = mma8(fa, qf);
+      MG_SCHED_FENCE();
+      rd_t8(fa, tp);                               // K^T d-tiles 0..7
+      MG_SCHED_FENCE();
+      dp[1] = mma8(fb, dof);
+      MG_SCHED_FENCE();
+      float ds[8];
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
-      st[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      dp[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      const int krow = (li >> 2) * 8 + tt * 4 + (li & 3);
-      const int sw = row_swz(krow);
-      const char* kp = k_lds + krow * ROW_STRIDE;
-      const char* vp = v_lds + krow * ROW_STRIDE;
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        const int off = ((ks * 4 + lq) ^ sw) << 4;
-        st[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(kp + off), qf[ks], st[tt], 0, 0, 0);
-        dp[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(vp + off), dof[ks], dp[tt], 0, 0, 0);
+      for (int j = 0; j < 8; ++j) {
+        const int key = kv0 + lq * 8 + j;
+        float p = __builtin_amdgcn_exp2f(st[j >> 2][j & 3] * sc2 - lse2);   // raw v_exp_f32; masked entries are dropped by the select
+        p = (key > qrow || key >= S) ? 0.f : p;
+        ds[j] = p * (dp[j >> 2][j & 3] - Dq) * 0.0625f;
       }
+      u32x4 dw;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dw[j] = pack2bf(ds[2 * j], ds[2 * j + 1]);
+      const bf16x8 dsf = __builtin_bit_cast(bf16x8, dw);
+      MG_SCHED_FENCE();
+      rd_t8(fb, tp + 8 * 1024);                    // K^T d-tiles 8..15 land under the first 8 MFMAs
+      MG_SCHED_FENCE();
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt) acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[dt], dsf, acc[dt], 0, 0, 0);
+      MG_SCHED_FENCE();
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt) acc[8 + dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[dt], dsf, acc[8 + dt], 0, 0, 0);
     }
-    float ds[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int key = kv0 + lq * 8 + j;
-      const float p = (key > qrow || key >= S) ? 0.f : exp2f(st[j >> 2][j & 3] * sc2 - lse2);
-      ds[j] = p * (dp[j >> 2][j & 3] - Dq) * 0.0625f;
-    }
-    u32x4 dw;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) dw[j] = pack2bf(ds[2 * j], ds[2 * j + 1]);
-    const bf16x8 dsf = __builtin_bit_cast(bf16x8, dw);
-    const char* tp = kt_lds + li * T_STRIDE + lq * 16;
-#pragma unroll
-    for (int dt = 0; dt < 16; ++dt)
-      acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(tp + dt * 16 * T_STRIDE), dsf, acc[dt], 0, 0, 0);
+    sc = sc == DQ_STAGES - 1 ? 0 : sc + 1;
   }
+  MG_WAIT_VMCNT(0);                   // drain the ring's trailing loads before the wave retires
   if (qrow < S) {
     mg_bf16* op = dq + ((int64_t)bh * S + qrow) * DH + lq * 4;
 #pragma unroll
@@ -188,31 +232,44 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
 
 // ---------------------------------------------------------------------------
 // DK = false: dV only (needs S -> P and dO^T);  DK = true: dK only (needs S, dP, dS and Q^T).
-// One accumulator set (64 VGPRs) per instantiation instead of two keeps the kernel at two
-// waves per SIMD / two workgroups per CU, which is what hides the LDS and HBM latency here;
-// the price is recomputing S once more (80 instead of 64 MFMAs per key-tile x query-tile).
+// One accumulator set (64 VGPRs) per instantiation instead of two keeps both at two waves per SIMD
+// with room for a 3- / 4-deep LDS ring; the price is recomputing S once more.
 template <bool DK>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(
+__global__ __launch_bounds__(512) void attn_bwd_dkdv_kernel(
     const mg_bf16* __restrict__ q, const mg_bf16* __restrict__ k, const mg_bf16* __restrict__ v,
     const mg_bf16* __restrict__ qt, const mg_bf16* __restrict__ dO, const mg_bf16* __restrict__ dOt,
-    const float* __restrict__ lse, const float* __restrict__ Dv, mg_bf16* __restrict__ dout,
-    int B, int H, int S, int ld_t) {
-  // LDS: Q rows (+ dO rows for dK) + one transposed tile (Q^T for dK, dO^T for dV) + lse/D
-  __shared__ __attribute__((aligned(16))) char smem[(DK ? 2 : 1) * ROW_TILE + T_TILE + 256];
-  char* q_lds = smem;
-  char* do_lds = smem + ROW_TILE;                         // DK only
-  char* t_lds = smem + (DK ? 2 : 1) * ROW_TILE;
-  float* ls_lds = (float*)(t_lds + T_TILE);               // 32 lse2 + 32 D
+    const float* __restrict__ ld2, mg_bf16* __restrict__ dout, int B, int H, int S, int ld_t) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int STAGE = DK ? DK_STAGE : DV_STAGE;
+  constexpr int NST = DK ? DK_STAGES : DV_STAGES;
+  constexpr int T_OFF = (DK ? 2 : 1) * ROW_TILE;
+  constexpr int LD_OFF = T_OFF + T_TILE;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lq = lane >> 4;
-  const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
-  const int k0 = blockIdx.x * 64;
+  const int nblk = (S + 127) >> 7;              // one (b,h) per XCD at a time, see attn_bwd_dq_kernel
+  const int wg = xcd_contiguous_index(blockIdx.x, gridDim.x);
+  const int bh = wg / nblk, b = bh / H, h = bh - b * H;
+  const int k0 = (wg - bh * nblk) * 128;       // earliest key blocks (most query tiles) first
   const int key = k0 + wave * 16 + li, key_c = min(key, S - 1);
   const int dmodel = H * DH;
   const mg_bf16* qb = q + (int64_t)bh * S * DH;
   const mg_bf16* tb = (DK ? qt : dOt) + (int64_t)bh * DH * ld_t;
   const mg_bf16* dob = dO + (int64_t)b * S * dmodel + h * DH;   // row stride dmodel
+  const float* ldb = ld2 + (int64_t)bh * S * 2;
+
+  const int t_begin = k0 >> 5;                 // first query tile that can see key k0
+  const int t_end = (S + 31) >> 5;
+  auto issue = [&](int t, int buf) {
+    const int q0 = min(t, t_end - 1) * 32;
+    char* st = smem + buf * STAGE;
+    dma_rows(st, qb, DH, q0, S, wave, lane);
+    if constexpr (DK) dma_rows(st + ROW_TILE, dob, dmodel, q0, S, wave, lane);
+    dma_cols(st + T_OFF, tb, ld_t, q0, wave, lane);
+    glds4(ldb + (int64_t)min(q0 + (lane >> 1), S - 1) * 2 + (lane & 1), st + LD_OFF);   // every wave writes the same 256 B
+  };
+#pragma unroll
+  for (int i = 0; i < NST - 1; ++i) issue(t_begin + i, i);
 
   bf16x8 kf[8], vf[DK ? 8 : 1];
   {
@@ -228,66 +285,93 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(
   f32x4 acc[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const float L2E = 1.4426950408889634f;
-  const float sc2 = 0.0625f * L2E;
+  const float sc2 = 0.0625f * 1.4426950408889634f;
+  const int my_first = k0 + wave * 16;         // query tiles that end before this wave's first key are fully masked
+  const int tsw = t_swz(li);
+  const int qr0 = (li >> 2) * 8 + (li & 3);    // row permutation: accumulator registers -> 8 consecutive queries
+  const int sw0 = row_swz(qr0);
+  const uint32_t ls_addr = (uint32_t)(uintptr_t)(mg_lptr_t)(smem + LD_OFF + lq * 64);   // LDS byte address, stage 0
 
-  const int q_begin = k0 & ~31;               // first query tile that can see key k0
-  const int q_tiles_end = (S + 31) >> 5;
-  u32x4 rq[4], rdo[DK ? 4 : 1], rt[4];
-  float r_ls = 0.f;
-  auto load_all = [&](int q0) {
-    load_rows(rq, qb, DH, q0, S, tid);
-    if constexpr (DK) load_rows(rdo, dob, dmodel, q0, S, tid);
-    load_cols(rt, tb, ld_t, q0, tid);
-    if (tid < 64) {
-      const int qq = min(q0 + (tid & 31), S - 1);
-      r_ls = tid < 32 ? lse[(int64_t)bh * S + qq] * L2E : Dv[(int64_t)bh * S + qq];
-    }
-  };
-  load_all(q_begin);
-  for (int t = q_begin >> 5; t < q_tiles_end; ++t) {
+  int sc = 0;
+  for (int t = t_begin; t < t_end; ++t) {
+    if constexpr (DK) { MG_WAIT_VMCNT(7); } else { MG_WAIT_VMCNT(10); }   // (NST-2) later tiles may be in flight
+    MG_BARRIER_KEEP_DMA();
+    issue(t + NST - 1, sc == 0 ? NST - 1 : sc - 1);
     const int q0 = t * 32;
-    __syncthreads();
-    store_rows(q_lds, rq, tid);
-    if constexpr (DK) store_rows(do_lds, rdo, tid);
-    store_cols(t_lds, rt, tid);
-    if (tid < 64) ls_lds[tid] = r_ls;
-    __syncthreads();
-    if (t + 1 < q_tiles_end) load_all(q0 + 32);
-    f32x4 s[2], dp[2];
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
-      s[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      dp[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      const int qr = (li >> 2) * 8 + tt * 4 + (li & 3);   // row permutation: acc regs -> 8 consecutive queries
-      const int sw = row_swz(qr);
-      const char* qp = q_lds + qr * ROW_STRIDE;
-      const char* dop = do_lds + qr * ROW_STRIDE;
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        const int off = ((ks * 4 + lq) ^ sw) << 4;
-        s[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(qp + off), kf[ks], s[tt], 0, 0, 0);
-        if constexpr (DK)
-          dp[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(dop + off), vf[ks], dp[tt], 0, 0, 0);
+    if (q0 + 31 >= my_first) {
+      const char* q_lds = smem + sc * STAGE;
+      const char* do_lds = q_lds + ROW_TILE;      // DK only
+      const char* t_lds = q_lds + T_OFF;
+      const char* qp = q_lds + qr0 * 512;
+      const char* dop = do_lds + qr0 * 512;
+      const char* tp = t_lds + li * 64 + ((lq ^ tsw) << 4);
+      bf16x8 fa[8], fb[8];
+      f32x4 s[2], dp[2];
+      dp[0] = dp[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if constexpr (DK) {
+        rd_row8(fa, qp, lq, sw0);                  // Q  queries tt=0
+        rd_row8(fb, dop, lq, sw0);                 // dO queries tt=0
+        MG_SCHED_FENCE();
+        s[0] = mma8(fa, kf);
+        MG_SCHED_FENCE();
+        rd_row8(fa, qp + 4 * 512, lq, sw0);        // Q  tt=1
+        MG_SCHED_FENCE();
+        dp[0] = mma8(fb, vf);
+        MG_SCHED_FENCE();
+        rd_row8(fb, dop + 4 * 512, lq, sw0);       // dO tt=1
+        MG_SCHED_FENCE();
+        s[1] = mma8(fa, kf);
+        MG_SCHED_FENCE();
+        rd_t8(fa, tp);                             // Q^T d-tiles 0..7
+        MG_SCHED_FENCE();
+        dp[1] = mma8(fb, vf);
+        MG_SCHED_FENCE();
+      } else {
+        rd_row8(fa, qp, lq, sw0);
+        rd_row8(fb, qp + 4 * 512, lq, sw0);
+        MG_SCHED_FENCE();
+        s[0] = mma8(fa, kf);
+        MG_SCHED_FENCE();
+        rd_t8(fa, tp);                             // dO^T d-tiles 0..7
+        MG_SCHED_FENCE();
+        s[1] = mma8(fb, kf);
+        MG_SCHED_FENCE();
       }
+      // {lse2, D} of this lane's 8 queries: 64 contiguous bytes.  Read by hand: for a compiler-visible
+      // ds_read of the DMA-filled statistics hipcc inserts s_waitcnt vmcnt(0) and drains the ring.
+      f32x4 l[4];
+      asm volatile(
+          "ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\t"
+          "ds_read_b128 %3, %4 offset:48\n\ts_waitcnt lgkmcnt(0)"
+          : "=&v"(l[0]), "=&v"(l[1]), "=&v"(l[2]), "=&v"(l[3])
+          : "v"(ls_addr + (uint32_t)(sc * STAGE))
+          : "memory");
+      // lane holds queries q0 + lq*8 + j (j = tt*4 + r) for its key
+      float val[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int qg = q0 + lq * 8 + j;
+        const float lse2 = l[j >> 1][(j & 1) * 2], Dq = l[j >> 1][(j & 1) * 2 + 1];
+        float p = __builtin_amdgcn_exp2f(s[j >> 2][j & 3] * sc2 - lse2);   // raw v_exp_f32: masked entries may overflow, the select drops them
+        p = (key > qg || qg >= S || key >= S) ? 0.f : p;
+        val[j] = DK ? p * (dp[j >> 2][j & 3] - Dq) * 0.0625f : p;
+      }
+      u32x4 pw;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) pw[j] = pack2bf(val[2 * j], val[2 * j + 1]);
+      const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
+      MG_SCHED_FENCE();
+      rd_t8(fb, tp + 8 * 1024);                    // d-tiles 8..15 land under the first 8 MFMAs
+      MG_SCHED_FENCE();
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt) acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[dt], pf, acc[dt], 0, 0, 0);
+      MG_SCHED_FENCE();
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt) acc[8 + dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[dt], pf, acc[8 + dt], 0, 0, 0);
     }
-    // lane holds queries q0 + lq*8 + j (j = tt*4 + r) for its key
-    float val[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int ql = lq * 8 + j, qg = q0 + ql;
-      const float p = (key > qg || qg >= S || key >= S) ? 0.f : exp2f(s[j >> 2][j & 3] * sc2 - ls_lds[ql]);
-      val[j] = DK ? p * (dp[j >> 2][j & 3] - ls_lds[32 + ql]) * 0.0625f : p;
-    }
-    u32x4 pw;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) pw[j] = pack2bf(val[2 * j], val[2 * j + 1]);
-    const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
-    const char* tp = t_lds + li * T_STRIDE + lq * 16;
-#pragma unroll
-    for (int dt = 0; dt < 16; ++dt)
-      acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(tp + dt * 16 * T_STRIDE), pf, acc[dt], 0, 0, 0);
+    sc = sc == NST - 1 ? 0 : sc + 1;
   }
+  MG_WAIT_VMCNT(0);
   if (key < S) {
     mg_bf16* op = dout + ((int64_t)bh * S + key) * DH + lq * 4;
 #pragma unroll
@@ -299,10 +383,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(
   }
 }
 
+int set_lds(const void* fn, int bytes) {
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) MG_FAIL(MG_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+  return MG_OK;
+}
+
 }  // namespace
 
 // q,k,v [B,H,S,256]; kt,qt,dOt [B,H,256,ld_t] (ld_t >= round_up(S,32), zero padded);
-// dO, O [B*S, H*256]; lse [B,H,S]; D [B,H,S] workspace; dq,dk,dv [B,H,S,256]
+// dO, O [B*S, H*256]; lse [B,H,S]; D [B,H,S,2] workspace; dq,dk,dv [B,H,S,256]
 extern "C" int mg_attn_bwd_bf16(const mg_bf16* q, const mg_bf16* k, const mg_bf16* v, const mg_bf16* qt,
                                 const mg_bf16* kt, const mg_bf16* dO, const mg_bf16* dOt, const mg_bf16* O,
                                 const float* lse, float* D, mg_bf16* dq, mg_bf16* dk, mg_bf16* dv, int32_t B,
@@ -313,12 +403,20 @@ extern "C" int mg_attn_bwd_bf16(const mg_bf16* q, const mg_bf16* k, const mg_bf1
     if (!p) MG_FAIL(MG_ERR_SHAPE, "mg_attn_bwd_bf16: null pointer");
     if (!MG_ALIGNED16(p)) MG_FAIL(MG_ERR_ALIGN, "mg_attn_bwd_bf16: pointers must be 16-byte aligned");
   }
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (int rc = set_lds((const void*)attn_bwd_dq_kernel, DQ_STAGES * DQ_STAGE)) return rc;
+    if (int rc = set_lds((const void*)attn_bwd_dkdv_kernel<true>, DK_STAGES * DK_STAGE)) return rc;
+    if (int rc = set_lds((const void*)attn_bwd_dkdv_kernel<false>, DV_STAGES * DV_STAGE)) return rc;
+    attr_set = true;
+  }
   hipStream_t s = (hipStream_t)stream;
   const int64_t rows = (int64_t)B * S * H;
-  hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, dO, O, D, B, H, S);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((S + 63) / 64, B * H), dim3(256), 0, s, q, k, v, kt, dO, lse, D, dq, B, H, S, ld_t);
-  hipLaunchKernelGGL(attn_bwd_dkdv_kernel<false>, dim3((S + 63) / 64, B * H), dim3(256), 0, s, q, k, v, qt, dO, dOt, lse, D, dv, B, H, S, ld_t);
-  hipLaunchKernelGGL(attn_bwd_dkdv_kernel<true>, dim3((S + 63) / 64, B * H), dim3(256), 0, s, q, k, v, qt, dO, dOt, lse, D, dk, B, H, S, ld_t);
+  const dim3 grid((unsigned)(((S + 127) / 128) * B * H));
+  hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, dO, O, lse, D, B, H, S);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(512), DQ_STAGES * DQ_STAGE, s, q, k, v, kt, dO, D, dq, B, H, S, ld_t);
+  hipLaunchKernelGGL(attn_bwd_dkdv_kernel<false>, grid, dim3(512), DV_STAGES * DV_STAGE, s, q, k, v, qt, dO, dOt, D, dv, B, H, S, ld_t);
+  hipLaunchKernelGGL(attn_bwd_dkdv_kernel<true>, grid, dim3(512), DK_STAGES * DK_STAGE, s, q, k, v, qt, dO, dOt, D, dk, B, H, S, ld_t);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }

@@ -50,6 +50,36 @@ MG_DEV float apply_act(float v, int act) {
   return v;
 }
 
+// ---- LDS-DMA: global -> LDS without a register round trip -----------------------
+typedef const __attribute__((address_space(1))) void* mg_gptr_t;
+typedef __attribute__((address_space(3))) void* mg_lptr_t;
+MG_DEV void glds16(const void* g, char* lds_wave_base) {
+  // 64 lanes x 16 B -> 1 KiB at lds_wave_base (wave-uniform) + lane*16; any swizzle goes into the SOURCE address
+  __builtin_amdgcn_global_load_lds((mg_gptr_t)g, (mg_lptr_t)lds_wave_base, 16, 0, 0);
+}
+MG_DEV void glds4(const void* g, char* lds_wave_base) {   // 64 lanes x 4 B -> 256 B
+  __builtin_amdgcn_global_load_lds((mg_gptr_t)g, (mg_lptr_t)lds_wave_base, 4, 0, 0);
+}
+#define MG_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+// workgroup barrier that does NOT drain in-flight LDS-DMA (a __syncthreads() would emit vmcnt(0)):
+// retire this wave's LDS reads, barrier, and keep the compiler from moving LDS accesses across it
+#define MG_BARRIER_KEEP_DMA()                          \
+  do {                                                 \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+    __builtin_amdgcn_s_barrier();                      \
+    asm volatile("" ::: "memory");                     \
+  } while (0)
+
+// ---- XCD-aware workgroup order ---------------------------------------------------
+// The dispatcher deals consecutive workgroup ids round-robin over the 8 XCDs (each with a private
+// 4 MiB L2).  This bijection turns the hardware id into a logical index such that every XCD owns
+// ONE contiguous run of logical indices: neighbours in logical order share an L2.
+MG_DEV int xcd_contiguous_index(int bid, int total) {
+  const int q = total >> 3, r = total & 7;
+  const int xcd = bid & 7, j = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+}
+
 // ---- wave / block reductions (wave = 64 lanes) -------------------------------
 MG_DEV float wave_sum(float v) {
 #pragma unroll

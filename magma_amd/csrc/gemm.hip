@@ -38,13 +38,6 @@ constexpr int EPI128_ROWB = BN * 4 + 16;        // fp32 row of the LDS-staged ep
 constexpr int GEMM_LDS = BM * EPI128_ROWB;     // max(double-buffered stages = 64 KiB, epilogue image = 66 KiB)
 static_assert(GEMM_LDS >= 2 * STAGE_BYTES, "LDS must hold both K-tile stages");
 
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-MG_DEV void glds16(const void* g, char* lds_wave_base) {
-  // 64 lanes x 16 B -> 1 KiB at lds_wave_base (wave-uniform) + lane*16
-  __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 0);
-}
 
 // ---------------------------------------------------------------------------
 // workgroup id -> output tile.  (1) undo the dispatcher's round-robin over the

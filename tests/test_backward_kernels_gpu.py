@@ -101,7 +101,7 @@ def test_epilogue_aux_modes(dev):
     assert rel(pre, acc) < 4e-3 and rel(out, F.gelu(acc, approximate="tanh")) < 4e-3
 
 
-@pytest.mark.parametrize("B,H,S", [(1, 1, 64), (2, 2, 57), (1, 2, 152)])
+@pytest.mark.parametrize("B,H,S", [(1, 1, 64), (2, 2, 57), (1, 2, 152), (1, 1, 1), (1, 2, 300), (2, 1, 385), (1, 1, 1024)])
 def test_attention_backward(dev, B, H, S):
     from magma_amd import ops
     d = H * 256
@@ -122,9 +122,11 @@ def test_attention_backward(dev, B, H, S):
     sc = sc.masked_fill(~torch.ones(S, S, dtype=torch.bool, device=dev).tril(), float("-inf"))
     o = (torch.softmax(sc, -1) @ vf).permute(0, 2, 1, 3).reshape(B * S, d)
     o.backward(dO.float())
-    assert rel(dq, qf.grad) < 1.5e-2, rel(dq, qf.grad)
-    assert rel(dk, kf.grad) < 1.5e-2, rel(dk, kf.grad)
-    assert rel(dv, vf.grad) < 1.5e-2, rel(dv, vf.grad)
+    for got, ref, name in ((dq, qf.grad, "dq"), (dk, kf.grad, "dk"), (dv, vf.grad, "dv")):
+        if float(ref.abs().max()) < 1e-6:      # S = 1: softmax over one key has zero gradient
+            assert float(got.float().abs().max()) < 1e-6, name
+        else:
+            assert rel(got, ref) < 1.5e-2, (name, rel(got, ref))
 
 
 def test_rotary_merge_bwd(dev):
