@@ -71,6 +71,7 @@ struct GemmParams {
   // its own fp32 slab ws[split][M][ldws]; splitk_fixup_kernel adds the slabs in a fixed order and
   // applies the epilogue (deterministic, no atomics).  splits == 1: the epilogue runs in place.
   int splits, kt_per;
+  int nt;            // non-temporal output stores (large outputs)
   float* ws; int64_t ldws;
   mg_epilogue ep;
 };
@@ -239,7 +240,8 @@ __global__ __launch_bounds__(256) void gemm128_kernel(const GemmParams p) {
     for (int j = 0; j < 4; ++j)
       *(f32x4*)(smem + (wm * 64 + i * 16 + li) * EPI128_ROWB + (wn * 64 + j * 16 + lq * 4) * 4) = acc[i][j];
   __syncthreads();
-  epilogue_rows<BN, EPI128_ROWB>(p.ep, smem, BM, 4, wave, lane, m0, 64, n0, p.M, p.N);
+  if (epilogue_wide_ok(p.ep)) epilogue_rows<BN, EPI128_ROWB, 8, false>(p.ep, smem, BM, 4, wave, lane, m0, 64, n0, p.M, p.N);
+  else epilogue_rows<BN, EPI128_ROWB, 4, false>(p.ep, smem, BM, 4, wave, lane, m0, 64, n0, p.M, p.N);
 }
 
 // second half of a split-K GEMM: add the slabs (fixed order) and run the fused epilogue
@@ -431,6 +433,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
 #undef MG_DMA_B
 
   // ---- epilogue: two passes of 128 tile rows (each wave's upper / lower 64) through LDS ----
+  const bool wide = epilogue_wide_ok(p.ep);   // 16-byte accesses when every row start allows it
   __syncthreads();
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
@@ -441,7 +444,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
       for (int j = 0; j < 4; ++j)
         *(f32x4*)(smem + (wr * 64 + i * 16 + li) * EPI256_ROWB + (wc * 64 + j * 16 + lq * 4) * 4) = acc[h * 4 + i][j];
     __syncthreads();
-    epilogue_rows<256, EPI256_ROWB>(p.ep, smem, 128, 8, wave, lane, m0 + h * 64, 128, n0, p.M, p.N);
+    const int mb = m0 + h * 64;
+    if (!wide) epilogue_rows<256, EPI256_ROWB, 4, false>(p.ep, smem, 128, 8, wave, lane, mb, 128, n0, p.M, p.N);
+    else if (p.nt) epilogue_rows<256, EPI256_ROWB, 8, true>(p.ep, smem, 128, 8, wave, lane, mb, 128, n0, p.M, p.N);
+    else epilogue_rows<256, EPI256_ROWB, 8, false>(p.ep, smem, 128, 8, wave, lane, mb, 128, n0, p.M, p.N);
   }
 }
 
@@ -531,6 +537,9 @@ extern "C" int mg_gemm_bf16(const mg_gemm_desc* d, void* stream) {
   gp.zero = d->zero_page;
   gp.tiles_m = (d->M + BM - 1) / BM; gp.tiles_n = (d->N + BN - 1) / BN;
   gp.ep = d->ep;
+  // outputs far larger than the caches are streamed out with non-temporal stores (measured -9 % on the
+  // 256x256 kernel at K = 4096: the tile no longer evicts the operand panels from L2)
+  gp.nt = (int64_t)d->M * d->N * (d->ep.out_f32 ? 4 : 2) >= (int64_t)64 << 20;
   gp.splits = 1; gp.kt_per = (d->K + BK - 1) / BK; gp.ws = nullptr; gp.ldws = 0;
   if (d->split_k < 0 || d->split_k > 64) MG_FAIL(MG_ERR_SHAPE, "mg_gemm_bf16: split_k must be in [0, 64]");
   if (d->split_k > 1 && !d->workspace) MG_FAIL(MG_ERR_SHAPE, "mg_gemm_bf16: split_k > 1 needs a workspace");

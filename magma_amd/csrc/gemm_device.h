@@ -7,47 +7,84 @@
 // shared epilogue: 4 consecutive n of row m.  Split in two so that row-walking callers load the
 // per-column vectors (BatchNorm scale, bias) once.
 // ---------------------------------------------------------------------------
-struct EpiCols { float sc[4], bi[4]; };
+template <int W> struct EpiColsW { float sc[W], bi[W]; };
+typedef EpiColsW<4> EpiCols;
 
-MG_DEV void epilogue_cols(const mg_epilogue& ep, int n, int N, EpiCols& c) {
+template <int W>
+MG_DEV void epilogue_cols(const mg_epilogue& ep, int n, int N, EpiColsW<W>& c) {
 #pragma unroll
-  for (int r = 0; r < 4; ++r) { c.sc[r] = 1.f; c.bi[r] = 0.f; }
-  if (n + 3 < N) {
-    if (ep.scale) { const float4 t = *(const float4*)(ep.scale + n); c.sc[0] = t.x; c.sc[1] = t.y; c.sc[2] = t.z; c.sc[3] = t.w; }
-    if (ep.bias)  { const float4 t = *(const float4*)(ep.bias + n);  c.bi[0] = t.x; c.bi[1] = t.y; c.bi[2] = t.z; c.bi[3] = t.w; }
+  for (int r = 0; r < W; ++r) { c.sc[r] = 1.f; c.bi[r] = 0.f; }
+  if (n + W - 1 < N) {
+#pragma unroll
+    for (int g = 0; g < W; g += 4) {
+      if (ep.scale) { const float4 t = *(const float4*)(ep.scale + n + g); c.sc[g] = t.x; c.sc[g + 1] = t.y; c.sc[g + 2] = t.z; c.sc[g + 3] = t.w; }
+      if (ep.bias)  { const float4 t = *(const float4*)(ep.bias + n + g);  c.bi[g] = t.x; c.bi[g + 1] = t.y; c.bi[g + 2] = t.z; c.bi[g + 3] = t.w; }
+    }
   } else {
-    for (int r = 0; r < 4; ++r) if (n + r < N) {
+    for (int r = 0; r < W; ++r) if (n + r < N) {
       if (ep.scale) c.sc[r] = ep.scale[n + r];
       if (ep.bias) c.bi[r] = ep.bias[n + r];
     }
   }
 }
 
-MG_DEV void epilogue_apply4(const mg_epilogue& ep, const EpiCols& c, int m, int n, f32x4 v, int N) {
-  const bool full = (n + 3 < N);
-  float o[4];
+// W consecutive bf16 of a row <-> floats (W = 4: one 8-B access, W = 8: one 16-B access; p must be W*2-byte aligned)
+template <int W>
+MG_DEV void load_bf16_row(const mg_bf16* p, float* a) {
+  if constexpr (W == 8) {
+    const u32x4 w = *(const u32x4*)p;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) o[r] = v[r] * c.sc[r] + c.bi[r];
+    for (int i = 0; i < 4; ++i) { a[2 * i] = bflo(w[i]); a[2 * i + 1] = bfhi(w[i]); }
+  } else {
+    const u32x2 w = *(const u32x2*)p;
+    a[0] = bflo(w[0]); a[1] = bfhi(w[0]); a[2] = bflo(w[1]); a[3] = bfhi(w[1]);
+  }
+}
+template <int W, bool NT>
+MG_DEV void store_bf16_row(mg_bf16* p, const float* o) {
+  if constexpr (W == 8) {
+    u32x4 w;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = pack2bf(o[2 * i], o[2 * i + 1]);
+    if (NT) __builtin_nontemporal_store(w, (u32x4*)p); else *(u32x4*)p = w;
+  } else {
+    u32x2 w; w[0] = pack2bf(o[0], o[1]); w[1] = pack2bf(o[2], o[3]);
+    if (NT) __builtin_nontemporal_store(w, (u32x2*)p); else *(u32x2*)p = w;
+  }
+}
+
+// v[W] = accumulators of columns n .. n+W-1 of row m.  NT: non-temporal output stores (large outputs
+// that nobody re-reads soon: keeps the L2 for the operand panels and streams the tile out).
+template <int W, bool NT>
+MG_DEV void epilogue_apply(const mg_epilogue& ep, const EpiColsW<W>& c, int m, int n, const float* v, int N) {
+  const bool full = (n + W - 1 < N);
+  float o[W];
+#pragma unroll
+  for (int r = 0; r < W; ++r) o[r] = v[r] * c.sc[r] + c.bi[r];
   if (ep.C2) {  // pre-activation copy for the backward pass
     mg_bf16* cp = ep.C2 + (int64_t)m * ep.ldc2 + n;
-    if (full) { u32x2 w; w[0] = pack2bf(o[0], o[1]); w[1] = pack2bf(o[2], o[3]); *(u32x2*)cp = w; }
-    else for (int r = 0; r < 4; ++r) if (n + r < N) cp[r] = f2bf(o[r]);
+    if (full) store_bf16_row<W, NT>(cp, o);
+    else for (int r = 0; r < W; ++r) if (n + r < N) cp[r] = f2bf(o[r]);
   }
 #pragma unroll
-  for (int r = 0; r < 4; ++r) o[r] = apply_act(o[r], ep.act);
-  float ax[4] = {1.f, 1.f, 1.f, 1.f};
+  for (int r = 0; r < W; ++r) o[r] = apply_act(o[r], ep.act);
+  float ax[W];
+#pragma unroll
+  for (int r = 0; r < W; ++r) ax[r] = 1.f;
   if (ep.aux_mode != MG_AUX_NONE) {
     const mg_bf16* ap = ep.aux + (int64_t)m * ep.ldaux + n;
-    float a[4] = {0.f, 0.f, 0.f, 0.f};
-    if (full) { const u32x2 w = *(const u32x2*)ap; a[0] = bflo(w[0]); a[1] = bfhi(w[0]); a[2] = bflo(w[1]); a[3] = bfhi(w[1]); }
-    else for (int r = 0; r < 4; ++r) if (n + r < N) a[r] = bf2f(ap[r]);
+    float a[W];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < W; ++r) a[r] = 0.f;
+    if (full) load_bf16_row<W>(ap, a);
+    else for (int r = 0; r < W; ++r) if (n + r < N) a[r] = bf2f(ap[r]);
+#pragma unroll
+    for (int r = 0; r < W; ++r)
       ax[r] = ep.aux_mode == MG_AUX_RELU_GATE ? (a[r] > 0.f ? 1.f : 0.f)
             : ep.aux_mode == MG_AUX_GELU_GRAD ? gelu_new_grad_f(a[r]) : a[r];
     if (!ep.aux_after) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) o[r] *= ax[r];
+      for (int r = 0; r < W; ++r) o[r] *= ax[r];
     }
   }
   const mg_bf16* rs[3] = {ep.res0, ep.res1, ep.res2};
@@ -56,59 +93,81 @@ MG_DEV void epilogue_apply4(const mg_epilogue& ep, const EpiCols& c, int m, int 
     if (rs[t]) {
       const mg_bf16* rp = rs[t] + (int64_t)m * ep.ldr + n;
       if (full) {
-        const u32x2 w = *(const u32x2*)rp;
-        o[0] += bflo(w[0]); o[1] += bfhi(w[0]); o[2] += bflo(w[1]); o[3] += bfhi(w[1]);
+        float a[W];
+        load_bf16_row<W>(rp, a);
+#pragma unroll
+        for (int r = 0; r < W; ++r) o[r] += a[r];
       } else {
-        for (int r = 0; r < 4; ++r) if (n + r < N) o[r] += bf2f(rp[r]);
+        for (int r = 0; r < W; ++r) if (n + r < N) o[r] += bf2f(rp[r]);
       }
     }
   }
   if (ep.aux_mode != MG_AUX_NONE && ep.aux_after) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) o[r] *= ax[r];
+    for (int r = 0; r < W; ++r) o[r] *= ax[r];
   }
   if (ep.act_after == MG_ACT_RELU) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) o[r] = o[r] > 0.f ? o[r] : 0.f;
+    for (int r = 0; r < W; ++r) o[r] = o[r] > 0.f ? o[r] : 0.f;
   }
   if (ep.out_f32) {
     float* cp = (float*)ep.C + (int64_t)m * ep.ldc + n;
-    if (full) *(float4*)cp = make_float4(o[0], o[1], o[2], o[3]);
-    else for (int r = 0; r < 4; ++r) if (n + r < N) cp[r] = o[r];
+    if (full) {
+#pragma unroll
+      for (int g = 0; g < W; g += 4) {
+        const f32x4 w = {o[g], o[g + 1], o[g + 2], o[g + 3]};
+        if (NT) __builtin_nontemporal_store(w, (f32x4*)(cp + g)); else *(f32x4*)(cp + g) = w;
+      }
+    } else for (int r = 0; r < W; ++r) if (n + r < N) cp[r] = o[r];
   } else {
     mg_bf16* cp = (mg_bf16*)ep.C + (int64_t)m * ep.ldc + n;
-    if (full) { u32x2 w; w[0] = pack2bf(o[0], o[1]); w[1] = pack2bf(o[2], o[3]); *(u32x2*)cp = w; }
-    else for (int r = 0; r < 4; ++r) if (n + r < N) cp[r] = f2bf(o[r]);
+    if (full) store_bf16_row<W, NT>(cp, o);
+    else for (int r = 0; r < W; ++r) if (n + r < N) cp[r] = f2bf(o[r]);
   }
 }
 
 MG_DEV void epilogue_store4(const mg_epilogue& ep, int m, int n, f32x4 v, int N) {
   if (n >= N) return;
   EpiCols c;
-  epilogue_cols(ep, n, N, c);
-  epilogue_apply4(ep, c, m, n, v, N);
+  epilogue_cols<4>(ep, n, N, c);
+  const float vv[4] = {v[0], v[1], v[2], v[3]};
+  epilogue_apply<4, false>(ep, c, m, n, vv, N);
+}
+
+// 16-byte accesses need every row start 16-byte aligned
+MG_DEV bool epilogue_wide_ok(const mg_epilogue& ep) {
+  return !((ep.ldc & 7) | (ep.C2 ? (ep.ldc2 & 7) : 0) | (ep.aux_mode != MG_AUX_NONE ? (ep.ldaux & 7) : 0) |
+           ((ep.res0 || ep.res1 || ep.res2) ? (ep.ldr & 7) : 0));
 }
 
 // Tile epilogue through LDS.  The MFMA accumulators of a workgroup tile were parked in LDS as fp32
 // rows of NCOLS columns (row stride ROWB bytes; ROWB % 128 == 16 keeps the 8-lane groups of the
 // fragment-shaped ds_write_b128 on distinct bank slots).  Here every wave walks whole rows: NCOLS/4
-// lanes cover one row with 4 consecutive columns each, so residual / aux reads and the output stores
-// are full contiguous lines, and the code is one small rolled loop instead of one inlined epilogue
+// lanes cover one row with W = 4 or 8 consecutive columns each, so residual / aux reads and the output
+// stores are full contiguous lines (8 or 16 bytes per lane), and the code is one small rolled loop instead of one inlined epilogue
 // per accumulator (which made the GEMM kernels > 20k instructions, mostly instruction-cache misses).
 // Tile row r is global row  m_base + (r >> 6) * hi_stride + (r & 63).
-template <int NCOLS, int ROWB>
+template <int NCOLS, int ROWB, int W, bool NT>
 MG_DEV void epilogue_rows(const mg_epilogue& ep, const char* lds, int rows, int nwaves, int wave, int lane,
                           int m_base, int hi_stride, int n0, int M, int N) {
-  constexpr int LPR = NCOLS / 4, RPI = 64 / LPR;
+  constexpr int LPR = NCOLS / W, RPI = 64 / LPR;     // lanes per row, rows per wave-iteration
   const int cl = lane % LPR;
-  const int n = n0 + cl * 4;
+  const int n = n0 + cl * W;
   if (n >= N) return;
-  EpiCols c;
-  epilogue_cols(ep, n, N, c);
+  EpiColsW<W> c;
+  epilogue_cols<W>(ep, n, N, c);
 #pragma unroll 2
   for (int r = wave * RPI + lane / LPR; r < rows; r += nwaves * RPI) {
     const int m = m_base + (r >> 6) * hi_stride + (r & 63);
-    if (m < M) epilogue_apply4(ep, c, m, n, *(const f32x4*)(lds + r * ROWB + cl * 16), N);
+    if (m < M) {
+      float v[W];
+#pragma unroll
+      for (int g = 0; g < W; g += 4) {
+        const f32x4 t = *(const f32x4*)(lds + r * ROWB + (cl * W + g) * 4);
+        v[g] = t[0]; v[g + 1] = t[1]; v[g + 2] = t[2]; v[g + 3] = t[3];
+      }
+      epilogue_apply<W, NT>(ep, c, m, n, v, N);
+    }
   }
 }
 

@@ -88,6 +88,14 @@ def test_gemm_epilogue(dev):
     ops.gemm(a, lin2, out=buf)
     assert_close(buf[:, :N2], acc[:, :N2] + bias[:N2], 1e-4, "odd N")
     assert bool((buf[:, N2:] == 7.0).all()), "wrote past N"
+    # row stride that is a multiple of 4 but not of 8: the epilogue must fall back from 16-byte to 8-byte accesses
+    for Mx, tile in ((M, 128), (1100, 256)):
+        ax = rnd(Mx, K, dev=dev, seed=31).to(BF16)
+        rx = rnd(Mx, 332, dev=dev, seed=32).to(BF16)
+        bufx = torch.zeros(Mx, 332, dtype=BF16, device=dev)
+        ops.gemm(ax, lin, out=bufx[:, :N], residuals=(rx,), tile=tile)
+        assert_close(bufx[:, :N], ax.float() @ w.float().t() + bias + rx[:, :N].float(), GEMM_TOL, f"ldc%8!=0 tile{tile}")
+        assert bool((bufx[:, N:] == 0).all())
 
 
 @pytest.mark.parametrize("layout", ["rm", "ft"])
