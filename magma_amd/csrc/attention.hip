@@ -11,11 +11,10 @@
 //                                    operand: MFMA contracts over 8 consecutive
 //                                    keys per lane, so V must be key-contiguous)
 #include "common.h"
+#include "attn_tile_device.h"
 #include "attn_decode_device.h"
 
 namespace {
-
-constexpr int DH = 256;
 
 // ---------------------------------------------------------------------------
 // rotary + split.  grid (ceil(S/32), B*H), 256 threads.
@@ -85,8 +84,7 @@ __global__ __launch_bounds__(256) void rotary_split_kernel(
 
 // ---------------------------------------------------------------------------
 // flash attention forward, causal, dh = 256.
-// grid (ceil(S/64), B*H), 256 threads = 4 waves x 16 query rows.
-// Per KV tile of 32 keys and per wave:
+// One workgroup = 128 queries = 8 waves x 16 query rows.  Per KV tile of 32 keys and per wave:
 //   S^T[key][q] = K . Q^T   (2 key-subtiles x 8 k-steps  = 16 MFMA)
 //   O^T[d][q]  += V^T . P^T (16 d-subtiles x 1 k-step    = 16 MFMA)
 // Both products are computed transposed so that every per-query quantity
@@ -94,33 +92,40 @@ __global__ __launch_bounds__(256) void rotary_split_kernel(
 // The key permutation keymap(i,t) = (i>>2)*8 + t*4 + (i&3) makes the S^T
 // accumulator registers of a lane exactly the 8 consecutive keys it must
 // supply as the P^T operand of the PV product -- no cross-lane movement.
+// K rows and V^T tiles stream through a 4-stage LDS ring filled by LDS-DMA (three tiles in
+// flight, counted vmcnt + one barrier per tile) -- same pipeline as attention_bwd.hip.
 // ---------------------------------------------------------------------------
-// conflict-free LDS images for the ds_read_b128 lane groups (searched offline): K rows
-// unpadded with the 16-B chunk index XORed by f(row) = (row&3)|((row>>3)<<2); V^T rows 96 B.
-constexpr int K_STRIDE = DH * 2;        // bytes per K row in LDS (512)
-constexpr int VT_STRIDE = 32 * 2 + 32;  // bytes per V^T row in LDS (96)
-MG_DEV int krow_swz(int row) { return (row & 3) | ((row >> 3) << 2); }
-constexpr int FA_LDS = 32 * K_STRIDE + DH * VT_STRIDE;  // 16896 + 20480
+constexpr int FA_STAGE = ROW_TILE + T_TILE;   // K rows | V^T
+constexpr int FA_STAGES = 4;
 
-__global__ __launch_bounds__(256, 2) void attn_prefill_kernel(
+__global__ __launch_bounds__(512) void attn_prefill_kernel(
     const mg_bf16* __restrict__ q, const mg_bf16* __restrict__ kcache,
     const mg_bf16* __restrict__ vt, mg_bf16* __restrict__ out, float* __restrict__ lse,
     int B, int H, int S, int Smax, int vt_ld) {
-  __shared__ __attribute__((aligned(16))) char smem[FA_LDS];
-  char* k_lds = smem;
-  char* v_lds = smem + 32 * K_STRIDE;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lq = lane >> 4;
   // all query blocks of one (b,h) on ONE XCD: its K / V^T stream is re-read from that XCD's L2
-  const int nblk = (S + 63) >> 6;
+  const int nblk = (S + 127) >> 7;
   const int wg = xcd_contiguous_index(blockIdx.x, gridDim.x);
   const int bh = wg / nblk, b = bh / H, h = bh - b * H;
-  const int qt0 = (nblk - 1 - (wg - bh * nblk)) * 64;   // longest blocks first
+  const int qt0 = (nblk - 1 - (wg - bh * nblk)) * 128;   // longest blocks first
   const int qrow = qt0 + wave * 16 + li;       // this lane's query
   const int qrow_c = min(qrow, S - 1);
   const mg_bf16* kbase = kcache + (int64_t)bh * Smax * DH;
   const mg_bf16* vbase = vt + (int64_t)bh * DH * vt_ld;
+
+  const int kv_end = min(S, qt0 + 128);          // causal: keys <= last query of the block
+  const int ntiles = (kv_end + 31) >> 5;
+  auto issue = [&](int t, int buf) {
+    const int c0 = min(t, ntiles - 1) * 32;
+    char* st = smem + buf * FA_STAGE;
+    dma_rows(st, kbase, DH, c0, S, wave, lane);
+    dma_cols(st + ROW_TILE, vbase, vt_ld, c0, wave, lane);
+  };
+#pragma unroll
+  for (int i = 0; i < FA_STAGES - 1; ++i) issue(i, i);
 
   // Q fragments (B operand of S^T): Q[q][ks*32 + lq*8 .. +7]
   bf16x8 qf[8];
@@ -135,90 +140,75 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(
   float m2 = -1e30f;   // running max in log2 domain
   float lsum = 0.f;    // this lane's partial row sum (its 8 keys per tile)
   const float sc2 = 0.0625f * 1.4426950408889634f;  // 1/sqrt(256) * log2(e)
+  const int my_last = qt0 + wave * 16 + 15;     // key tiles past this wave's last query are fully masked
+  const int tsw = t_swz(li);
+  const int krow0 = (li >> 2) * 8 + (li & 3);
+  const int sw0 = row_swz(krow0);
 
-  const int kv_end = min(S, qt0 + 64);          // causal: keys <= last query of the tile
-  const int ntiles = (kv_end + 31) >> 5;
-
-  // staging registers: 4 K chunks + 4 V^T chunks per thread
-  u32x4 kreg[4], vreg[4];
-  auto load_tile = [&](int kv0) {
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int ci = tid + it * 256;
-      const int row = ci >> 5, c = ci & 31;                 // K: 32 rows x 32 chunks
-      const int key = min(kv0 + row, S - 1);
-      kreg[it] = *(const u32x4*)(kbase + (int64_t)key * DH + c * 8);
-      const int dr = ci >> 2, vc = ci & 3;                  // V^T: 256 rows x 4 chunks
-      vreg[it] = *(const u32x4*)(vbase + (int64_t)dr * vt_ld + kv0 + vc * 8);
-    }
-  };
-  auto store_tile = [&]() {
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int ci = tid + it * 256;
-      *(u32x4*)(k_lds + (ci >> 5) * K_STRIDE + (((ci & 31) ^ krow_swz(ci >> 5)) << 4)) = kreg[it];
-      *(u32x4*)(v_lds + (ci >> 2) * VT_STRIDE + (ci & 3) * 16) = vreg[it];
-    }
-  };
-
-  load_tile(0);
+  int sc = 0;
   for (int t = 0; t < ntiles; ++t) {
+    MG_WAIT_VMCNT(8);                 // this wave's pieces of tile t landed (tiles t+1, t+2 may be in flight)
+    MG_BARRIER_KEEP_DMA();            // tile t complete; everyone is done with tile t-1
+    issue(t + FA_STAGES - 1, sc == 0 ? FA_STAGES - 1 : sc - 1);
     const int kv0 = t * 32;
-    __syncthreads();          // all waves finished reading the previous tile
-    store_tile();
-    __syncthreads();
-    if (t + 1 < ntiles) load_tile(kv0 + 32);   // in flight during the MFMAs
-
-    // ---- S^T = K Q^T ----
-    f32x4 st[2];
+    if (kv0 <= my_last) {
+      const char* kp = smem + sc * FA_STAGE + krow0 * 512;
+      const char* tp = smem + sc * FA_STAGE + ROW_TILE + li * 64 + ((lq ^ tsw) << 4);
+      bf16x8 fa[8], fb[8];
+      f32x4 st[2];
+      rd_row8(fa, kp, lq, sw0);                    // K keys tt=0
+      rd_row8(fb, kp + 4 * 512, lq, sw0);          // K keys tt=1
+      MG_SCHED_FENCE();
+      st[0] = mma8(fa, qf);
+      MG_SCHED_FENCE();
+      rd_t8(fa, tp);                               // V^T d-tiles 0..7
+      MG_SCHED_FENCE();
+      st[1] = mma8(fb, qf);
+      MG_SCHED_FENCE();
+      // lane holds keys kv0 + lq*8 + j, j = tt*4 + r, for query li
+      float p[8];
+      float tmax = -1e30f;
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
-      st[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      const int krow = (li >> 2) * 8 + tt * 4 + (li & 3);
-      const int sw = krow_swz(krow);
-      const char* kp = k_lds + krow * K_STRIDE;
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        const bf16x8 kf = *(const bf16x8*)(kp + (((ks * 4 + lq) ^ sw) << 4));
-        st[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], st[tt], 0, 0, 0);
+      for (int j = 0; j < 8; ++j) {
+        const int key = kv0 + lq * 8 + j;
+        float v = st[j >> 2][j & 3] * sc2;
+        v = (key > qrow || key >= S) ? -1e30f : v;
+        p[j] = v;
+        tmax = fmaxf(tmax, v);
       }
-    }
-    // lane holds keys kv0 + lq*8 + j, j = tt*4 + r, for query li
-    float p[8];
-    float tmax = -1e30f;
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      const float mnew = fmaxf(m2, tmax);
+      const float alpha = __builtin_amdgcn_exp2f(m2 - mnew);
+      m2 = mnew;
+      float psum = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int key = kv0 + lq * 8 + j;
-      float v = st[j >> 2][j & 3] * sc2;
-      if (key > qrow || key >= S) v = -1e30f;
-      p[j] = v;
-      tmax = fmaxf(tmax, v);
-    }
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-    const float mnew = fmaxf(m2, tmax);
-    const float alpha = exp2f(m2 - mnew);
-    m2 = mnew;
-    float psum = 0.f;
+      for (int j = 0; j < 8; ++j) {
+        p[j] = __builtin_amdgcn_exp2f(p[j] - mnew);   // masked: exp2(-1e30 - m) = 0 (key 0 is visible to every query, so m is finite)
+        psum += p[j];
+      }
+      lsum = lsum * alpha + psum;
+      u32x4 pw;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      p[j] = (p[j] <= -1e29f) ? 0.f : exp2f(p[j] - mnew);
-      psum += p[j];
-    }
-    lsum = lsum * alpha + psum;
-    u32x4 pw;
+      for (int j = 0; j < 4; ++j) pw[j] = pack2bf(p[2 * j], p[2 * j + 1]);
+      const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
+      MG_SCHED_FENCE();
+      rd_t8(fb, tp + 8 * 1024);                    // V^T d-tiles 8..15 land under the first 8 MFMAs
+      MG_SCHED_FENCE();
+      // ---- O^T = O^T * alpha + V^T P^T  (the rescale is skipped while no running max moved) ----
+      if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) pw[j] = pack2bf(p[2 * j], p[2 * j + 1]);
-    const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
-    // ---- O^T = O^T * alpha + V^T P^T ----
-    const char* vp = v_lds + li * VT_STRIDE + lq * 16;
+        for (int dt = 0; dt < 16; ++dt) o[dt] *= alpha;
+      }
 #pragma unroll
-    for (int dt = 0; dt < 16; ++dt) {
-      const bf16x8 vf = *(const bf16x8*)(vp + dt * 16 * VT_STRIDE);
-      o[dt] *= alpha;
-      o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);
+      for (int dt = 0; dt < 8; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[dt], pf, o[dt], 0, 0, 0);
+      MG_SCHED_FENCE();
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt) o[8 + dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[dt], pf, o[8 + dt], 0, 0, 0);
     }
+    sc = sc == FA_STAGES - 1 ? 0 : sc + 1;
   }
+  MG_WAIT_VMCNT(0);                   // drain the ring's trailing loads before the wave retires
   // row sum across the 4 key-slot lanes of this query
   lsum += __shfl_xor(lsum, 16, 64);
   lsum += __shfl_xor(lsum, 32, 64);
@@ -273,9 +263,15 @@ extern "C" int mg_attn_prefill_bf16(const mg_bf16* q, const mg_bf16* kcache, con
   if ((vt_ld & 7) || vt_ld < ((S + 31) & ~31)) MG_FAIL(MG_ERR_SHAPE, "mg_attn_prefill_bf16: vt_ld must be a multiple of 8 and >= round_up(S,32)");
   if (!q || !kcache || !vt || !out) MG_FAIL(MG_ERR_SHAPE, "mg_attn_prefill_bf16: null pointer");
   if (!MG_ALIGNED16(q) || !MG_ALIGNED16(kcache) || !MG_ALIGNED16(vt) || !MG_ALIGNED16(out)) MG_FAIL(MG_ERR_ALIGN, "mg_attn_prefill_bf16: pointers must be 16-byte aligned");
-  dim3 grid((unsigned)(((S + 63) / 64) * B * H));
-  hipLaunchKernelGGL(attn_prefill_kernel, grid, dim3(256), 0, (hipStream_t)stream, q, kcache, vt, out, lse, B, H, S,
-                     Smax, vt_ld);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)attn_prefill_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FA_STAGES * FA_STAGE);
+    if (e != hipSuccess) MG_FAIL(MG_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  dim3 grid((unsigned)(((S + 127) / 128) * B * H));
+  hipLaunchKernelGGL(attn_prefill_kernel, grid, dim3(512), FA_STAGES * FA_STAGE, (hipStream_t)stream, q, kcache, vt, out, lse,
+                     B, H, S, Smax, vt_ld);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }
