@@ -61,6 +61,10 @@ MG_DEV void glds4(const void* g, char* lds_wave_base) {   // 64 lanes x 4 B -> 2
   __builtin_amdgcn_global_load_lds((mg_gptr_t)g, (mg_lptr_t)lds_wave_base, 4, 0, 0);
 }
 #define MG_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+// vmcnt(0) through the BUILTIN (gfx9 encoding: vmcnt = 0, expcnt / lgkmcnt untouched): unlike the inline-asm
+// form this one updates hipcc's own scoreboard, so it does not re-wait (vmcnt(0), draining the DMA ring)
+// at the first use of an ordinary load's result inside the pipelined loop.  Use it once, before the loop.
+#define MG_WAIT_VMCNT0_TRACKED() __builtin_amdgcn_s_waitcnt(0x0F70)
 // workgroup barrier that does NOT drain in-flight LDS-DMA (a __syncthreads() would emit vmcnt(0)):
 // retire this wave's LDS reads, barrier, and keep the compiler from moving LDS accesses across it
 #define MG_BARRIER_KEEP_DMA()                          \
