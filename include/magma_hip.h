@@ -284,6 +284,19 @@ int mg_adamw_f32(float* p, float* m, float* v, const float* g, mg_bf16* p_bf16, 
                  float beta1, float beta2, float eps, float weight_decay, int32_t step, float max_norm,
                  const float* norm_sq, float grad_scale, void* stream);
 
+/* ---- image preprocessing (reference magma/transforms.py:121-134) ----------------
+ * One pass of Pillow's 8-bit antialiased resampling (ImagingResample, the arithmetic behind torchvision's
+ * Resize(n, BICUBIC) on a PIL image): src is HWC uint8 RGB [H][W][3]; axis 1 resamples every row to
+ * out_size pixels (dst [H][out_size][3]), axis 0 every column (dst [out_size][W][3]).  coeffs is
+ * [out_size][ksize] int32 (22 fractional bits), bounds [out_size][2] = {first source index, count}; both
+ * are built on the host exactly as Pillow's precompute_coeffs / normalize_coeffs_8bpc do.  Bit-exact.   */
+int mg_resample_u8(const uint8_t* src, int32_t H, int32_t W, uint8_t* dst, int32_t out_size, int32_t axis,
+                   const int32_t* coeffs, const int32_t* bounds, int32_t ksize, void* stream);
+/* CenterCrop + ToTensor + Normalize: out[c][y][x] = (src[top+y][left+x][c] / 255 - mean[c]) / std[c] in
+ * IEEE fp32 (CHW, n x n); mean3 / std3 are HOST pointers to 3 floats.                                   */
+int mg_crop_normalize_f32(const uint8_t* src, int32_t H, int32_t W, int32_t top, int32_t left, int32_t n,
+                          const float* mean3, const float* std3, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,6 +14,7 @@ from __future__ import annotations
 from copy import deepcopy
 from os.path import exists
 from pathlib import Path
+import os
 from typing import List, Optional
 
 import torch
@@ -64,8 +65,11 @@ class Magma(nn.Module):
         self.image_prefix = ImagePrefix(config=config, out_dim=self.lm.config.hidden_size, device=self.device,
                                         dtype=dtype, enc=enc)
         self.image_prefix_seq_len = self.image_prefix.out_seq_len
+        # RGB images are resized / cropped / normalised on the GPU (bit-identical to the PIL host path of
+        # reference transforms.py:121-134; MAGMA_HOST_PREPROCESS=1 keeps everything on the host)
         self.transforms = get_transforms(config.image_size, config.encoder_name,
-                                         input_resolution=self.image_prefix.enc.input_resolution)
+                                         input_resolution=self.image_prefix.enc.input_resolution,
+                                         device=None if os.environ.get("MAGMA_HOST_PREPROCESS") == "1" else self.device)
         if config.adapter_config:
             mlp_config = deepcopy(config.adapter_config.get("mlp", None))
             if mlp_config:

@@ -519,3 +519,27 @@ def sumsq(g: torch.Tensor, out: torch.Tensor):
 def adamw(p, m, v, g, p_bf16, lr, beta1, beta2, eps, wd, step, max_norm=0.0, norm_sq=None, grad_scale=1.0):
     check(L.load().mg_adamw_f32(p.data_ptr(), m.data_ptr(), v.data_ptr(), g.data_ptr(), _p(p_bf16), p.numel(), lr,
                                 beta1, beta2, eps, wd, step, max_norm, _p(norm_sq), grad_scale, _stream()), "mg_adamw_f32")
+
+
+# ---- image preprocessing (reference magma/transforms.py:121-134) ------------------------------------------------
+def resample_u8(img: torch.Tensor, out_size: int, axis: int, coeffs: torch.Tensor, bounds: torch.Tensor) -> torch.Tensor:
+    """One pass of Pillow's 8-bit antialiased resampling on an HWC uint8 RGB image (axis 1: width, axis 0: height)."""
+    _need_gpu(img)
+    assert img.dtype == torch.uint8 and img.ndim == 3 and img.shape[2] == 3 and img.is_contiguous()
+    assert coeffs.dtype == torch.int32 and bounds.dtype == torch.int32 and coeffs.is_contiguous() and bounds.is_contiguous()
+    H, W, _ = img.shape
+    out = torch.empty((H, out_size, 3) if axis == 1 else (out_size, W, 3), dtype=torch.uint8, device=img.device)
+    check(L.load().mg_resample_u8(img.data_ptr(), H, W, out.data_ptr(), out_size, axis, coeffs.data_ptr(), bounds.data_ptr(),
+                                  coeffs.shape[1], _stream()), "mg_resample_u8")
+    return out
+
+
+def crop_normalize(img: torch.Tensor, top: int, left: int, n: int, mean, std) -> torch.Tensor:
+    """HWC uint8 -> [3, n, n] fp32, (v / 255 - mean) / std  (CenterCrop + ToTensor + Normalize)."""
+    _need_gpu(img)
+    assert img.dtype == torch.uint8 and img.ndim == 3 and img.shape[2] == 3 and img.is_contiguous()
+    out = torch.empty(3, n, n, dtype=torch.float32, device=img.device)
+    m3, s3 = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
+    check(L.load().mg_crop_normalize_f32(img.data_ptr(), img.shape[0], img.shape[1], top, left, n, m3, s3, out.data_ptr(), _stream()),
+          "mg_crop_normalize_f32")
+    return out

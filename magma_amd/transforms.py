@@ -4,6 +4,9 @@ bicubic resize of the short side -> center crop -> RGB -> [0,1] tensor ->
 batch dim -> CLIP mean/std.  torchvision is not available in this image, so the
 same steps are written with PIL + torch (T.Resize(n, BICUBIC) on a PIL image is
 PIL's own bicubic resampling, which is what is called here)."""
+import functools
+import math
+
 import numpy as np
 import PIL.Image as PilImage
 import torch
@@ -32,13 +35,77 @@ def _center_crop(img, n_px):
     return img.crop((left, top, left + n_px, top + n_px))
 
 
-def clip_preprocess(n_px, use_pad=False):
+# ---- Pillow's resampling coefficients (host side of the device path) --------------------------------------------
+_PRECISION_BITS = 32 - 8 - 2
+
+
+def _bicubic_kernel(x, a=-0.5):
+    x = -x if x < 0.0 else x
+    if x < 1.0:
+        return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    if x < 2.0:
+        return (((x - 5) * x + 8) * x - 4) * a
+    return 0.0
+
+
+@functools.lru_cache(maxsize=64)
+def pil_bicubic_tables(in_size: int, out_size: int):
+    """(coeffs int32 [out, ksize], bounds int32 [out, 2]) of Pillow's ImagingResample for BICUBIC, 8 bits per
+    channel: precompute_coeffs + normalize_coeffs_8bpc (Pillow src/libImaging/Resample.c), doubles, same
+    expression order -- the integer tables are identical to Pillow's, so the device passes are bit-exact."""
+    scale = filterscale = float(in_size) / out_size
+    if filterscale < 1.0:
+        filterscale = 1.0
+    support = 2.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    kk = np.zeros((out_size, ksize), dtype=np.int32)
+    bounds = np.zeros((out_size, 2), dtype=np.int32)
+    inv = 1.0 / filterscale
+    one = float(1 << _PRECISION_BITS)
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        lo = max(int(center - support + 0.5), 0)
+        n = min(int(center + support + 0.5), in_size) - lo
+        w = [_bicubic_kernel((i + lo - center + 0.5) * inv) for i in range(n)]
+        total = 0.0
+        for v in w:
+            total += v
+        for i, v in enumerate(w):
+            if total != 0.0:
+                v = v / total
+            kk[xx, i] = int(-0.5 + v * one) if v < 0 else int(0.5 + v * one)
+        bounds[xx] = (lo, n)
+    return kk, bounds
+
+
+def _device_pipeline(image, n_px, device):
+    """RGB PIL image -> [1, 3, n, n] fp32 on `device`: upload the raw pixels once, resize / crop / normalise
+    with the HIP kernels (bit-identical to the host path below)."""
+    from . import ops
+    w, h = image.size
+    nw, nh = (n_px, int(n_px * h / w)) if w <= h else (int(n_px * w / h), n_px)
+    img = torch.from_numpy(np.asarray(image, dtype=np.uint8).copy()).to(device)
+    if nw != w:      # Pillow: horizontal pass first, uint8 intermediate
+        kx, bx = pil_bicubic_tables(w, nw)
+        img = ops.resample_u8(img, nw, 1, torch.from_numpy(kx).to(device), torch.from_numpy(bx).to(device))
+    if nh != h:
+        ky, by = pil_bicubic_tables(h, nh)
+        img = ops.resample_u8(img, nh, 0, torch.from_numpy(ky).to(device), torch.from_numpy(by).to(device))
+    left, top = int(round((nw - n_px) / 2.0)), int(round((nh - n_px) / 2.0))
+    return ops.crop_normalize(img, top, left, n_px, CLIP_MEAN, CLIP_STD).unsqueeze(0)
+
+
+def clip_preprocess(n_px, use_pad=False, device=None):
+    """``device``: a GPU -> RGB images are resized / cropped / normalised on it (same bits as the host path);
+    other modes (palette, alpha, grey) and ``device=None`` use PIL on the host like the reference."""
     if use_pad:
         raise NotImplementedError("pad mode is not used by any shipped config")
     mean = torch.tensor(CLIP_MEAN).view(3, 1, 1)
     std = torch.tensor(CLIP_STD).view(3, 1, 1)
 
     def fn(image):
+        if device is not None and torch.device(device).type == "cuda" and image.mode == "RGB" and min(image.size) >= 2:
+            return _device_pipeline(image, n_px, device)
         image = _center_crop(_resize_short_side(image, n_px), n_px).convert("RGB")
         t = torch.from_numpy(np.asarray(image, dtype=np.uint8).copy()).permute(2, 0, 1).float() / 255.0
         return maybe_add_batch_dim((t - mean) / std)
@@ -46,10 +113,10 @@ def clip_preprocess(n_px, use_pad=False):
     return fn
 
 
-def get_transforms(image_size, encoder_name, input_resolution=None, use_extra_transforms=False):
+def get_transforms(image_size, encoder_name, input_resolution=None, use_extra_transforms=False, device=None):
     """reference magma/transforms.py:87-111.  Only the clip branch is in scope
     (both shipped YAMLs use clip_resnet_large)."""
     if "clip" in encoder_name:
         assert input_resolution is not None
-        return clip_preprocess(input_resolution)
+        return clip_preprocess(input_resolution, device=device)
     raise NotImplementedError(f"transforms for encoder {encoder_name!r} are out of scope (SURVEY 8f row 4)")

@@ -4,6 +4,8 @@ reference's own code, captured by tests/golden/make_golden.py (which ran
 import os
 import types
 
+import pytest
+
 import torch
 
 from oracle import model as O
@@ -89,3 +91,36 @@ def test_generate_loop_matches_reference():
     assert torch.equal(toks, pin["tokens"])
     assert tm.lm.calls == pin["calls"]
     assert S.generate(ToyModel(), pin["emb"], max_steps=6, temperature=0.0, decode=True) == pin["strings"]
+
+
+# ---- preprocessing: the third-party arithmetic behind reference transforms.py:121-134 is Pillow's resampler ----
+PRE_GEOMS = [(480, 640, 384), (300, 200, 224), (224, 224, 384), (1000, 750, 384), (97, 131, 384), (384, 384, 384),
+             (500, 333, 224), (64, 64, 224)]
+
+
+@pytest.mark.parametrize("H,W,n_px", PRE_GEOMS)
+def test_preprocess_matches_pil(H, W, n_px):
+    """oracle/preprocess.py (numpy integer restatement of Pillow's ImagingResample) against PIL itself, bit for bit,
+    then the whole clip transform against the host pipeline that mirrors the reference (PIL + torch)."""
+    import numpy as np
+    import PIL.Image as PilImage
+    from oracle.preprocess import clip_preprocess_u8, resize_bicubic_u8
+    from magma_amd.transforms import clip_preprocess
+    rng = np.random.default_rng(H * 1000 + W)
+    img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    nw, nh = (n_px, int(n_px * H / W)) if W <= H else (int(n_px * W / H), n_px)
+    ref = np.asarray(PilImage.fromarray(img).resize((nw, nh), PilImage.BICUBIC))
+    assert np.array_equal(resize_bicubic_u8(img, nw, nh), ref)
+    host = clip_preprocess(n_px)(PilImage.fromarray(img))[0].numpy()
+    assert np.array_equal(clip_preprocess_u8(img, n_px), host)
+
+
+def test_product_coefficient_tables_equal_oracle():
+    """the host half of the device path (magma_amd.transforms.pil_bicubic_tables) builds the same integer tables"""
+    import numpy as np
+    from oracle.preprocess import precompute_coeffs
+    from magma_amd.transforms import pil_bicubic_tables
+    for a, b in [(640, 512), (200, 224), (750, 288), (131, 384), (1000, 384), (333, 224), (64, 224), (4000, 384)]:
+        kk, bounds = pil_bicubic_tables(a, b)
+        rk, rb = precompute_coeffs(a, b)
+        assert np.array_equal(kk.astype(np.int64), rk) and np.array_equal(bounds.astype(np.int64), rb)
