@@ -165,26 +165,29 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(
       MG_SCHED_FENCE();
       st[1] = mma8(fb, qf);
       MG_SCHED_FENCE();
-      // lane holds keys kv0 + lq*8 + j, j = tt*4 + r, for query li
-      float p[8];
-      float tmax = -1e30f;
+      // lane holds keys kv0 + lq*8 + j, j = tt*4 + r, for query li.  Only the diagonal tiles of this wave (and the
+      // ragged last tile) need the mask: a masked score of -1e30 turns into exp2(-huge) = 0 further down.
+      float sv[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int key = kv0 + lq * 8 + j;
-        float v = st[j >> 2][j & 3] * sc2;
-        v = (key > qrow || key >= S) ? -1e30f : v;
-        p[j] = v;
-        tmax = fmaxf(tmax, v);
+      for (int j = 0; j < 8; ++j) sv[j] = st[j >> 2][j & 3];
+      if (kv0 + 31 > qt0 + wave * 16 || kv0 + 32 > S) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int key = kv0 + lq * 8 + j;
+          sv[j] = (key > qrow || key >= S) ? -1e30f : sv[j];
+        }
       }
+      float tmax = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
       tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
       tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-      const float mnew = fmaxf(m2, tmax);
+      const float mnew = fmaxf(m2, tmax * sc2);      // key 0 is visible to every query: finite from the first tile on
       const float alpha = __builtin_amdgcn_exp2f(m2 - mnew);
       m2 = mnew;
+      float p[8];
       float psum = 0.f;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        p[j] = __builtin_amdgcn_exp2f(p[j] - mnew);   // masked: exp2(-1e30 - m) = 0 (key 0 is visible to every query, so m is finite)
+        p[j] = __builtin_amdgcn_exp2f(fmaf(sv[j], sc2, -mnew));
         psum += p[j];
       }
       lsum = lsum * alpha + psum;

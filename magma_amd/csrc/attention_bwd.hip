@@ -147,12 +147,18 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(
       MG_SCHED_FENCE();
       dp[1] = mma8(fb, dof);
       MG_SCHED_FENCE();
+      // only this wave's diagonal tiles (and the ragged last tile) need the mask: -1e30 -> exp2(-huge) = 0
+      if (kv0 + 31 > qt0 + wave * 16 || kv0 + 32 > S) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int key = kv0 + lq * 8 + j;
+          st[j >> 2][j & 3] = (key > qrow || key >= S) ? -1e30f : st[j >> 2][j & 3];
+        }
+      }
       float ds[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const int key = kv0 + lq * 8 + j;
-        float p = __builtin_amdgcn_exp2f(st[j >> 2][j & 3] * sc2 - lse2);   // raw v_exp_f32; masked entries are dropped by the select
-        p = (key > qrow || key >= S) ? 0.f : p;
+        const float p = __builtin_amdgcn_exp2f(fmaf(st[j >> 2][j & 3], sc2, -lse2));   // raw v_exp_f32
         ds[j] = p * (dp[j >> 2][j & 3] - Dq) * 0.0625f;
       }
       u32x4 dw;
@@ -300,13 +306,19 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_kernel(
           : "v"(ls_addr + (uint32_t)(sc * STAGE))
           : "memory");
       // lane holds queries q0 + lq*8 + j (j = tt*4 + r) for its key
+      // only the tiles that straddle this wave's keys (and the ragged last tile) need the mask
+      if (q0 < my_first + 15 || q0 + 32 > S) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int qg = q0 + lq * 8 + j;
+          s[j >> 2][j & 3] = (key > qg || qg >= S) ? -1e30f : s[j >> 2][j & 3];
+        }
+      }
       float val[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const int qg = q0 + lq * 8 + j;
         const float lse2 = l[j >> 1][(j & 1) * 2], Dq = l[j >> 1][(j & 1) * 2 + 1];
-        float p = __builtin_amdgcn_exp2f(s[j >> 2][j & 3] * sc2 - lse2);   // raw v_exp_f32: masked entries may overflow, the select drops them
-        p = (key > qg || qg >= S || key >= S) ? 0.f : p;
+        const float p = __builtin_amdgcn_exp2f(fmaf(s[j >> 2][j & 3], sc2, -lse2));   // raw v_exp_f32; masked -> 0
         val[j] = DK ? p * (dp[j >> 2][j & 3] - Dq) * 0.0625f : p;
       }
       u32x4 pw;

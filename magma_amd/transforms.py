@@ -84,7 +84,7 @@ def _device_pipeline(image, n_px, device):
     from . import ops
     w, h = image.size
     nw, nh = (n_px, int(n_px * h / w)) if w <= h else (int(n_px * w / h), n_px)
-    img = torch.from_numpy(np.asarray(image, dtype=np.uint8).copy()).to(device)
+    img = torch.from_numpy(np.array(image, dtype=np.uint8)).to(device)
     if nw != w:      # Pillow: horizontal pass first, uint8 intermediate
         kx, bx = pil_bicubic_tables(w, nw)
         img = ops.resample_u8(img, nw, 1, torch.from_numpy(kx).to(device), torch.from_numpy(bx).to(device))
