@@ -37,6 +37,9 @@ MG_DEV void dma_cols(char* tile, const mg_bf16* base_t, int ld, int c0, int wave
 
 // fragment bursts: 8 x ds_read_b128 of one operand, and the 8 MFMAs of a 16x16 tile over d = 256
 #define MG_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#ifndef MG_ATTN_MFMA_PRIO
+#define MG_ATTN_MFMA_PRIO 0   // wave priority inside MFMA bursts: raising it measured no gain (fwd 1.03 vs 1.04 ms, bwd 3.30 vs 3.25 ms)
+#endif
 MG_DEV void rd_row8(bf16x8 (&f)[8], const char* row, int lq, int sw) {
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks) f[ks] = *(const bf16x8*)(row + (((ks * 4 + lq) ^ sw) << 4));
@@ -47,7 +50,9 @@ MG_DEV void rd_t8(bf16x8 (&f)[8], const char* tp) {
 }
 MG_DEV f32x4 mma8(const bf16x8 (&a)[8], const bf16x8 (&b)[8]) {
   f32x4 c = {0.f, 0.f, 0.f, 0.f};
+  __builtin_amdgcn_s_setprio(MG_ATTN_MFMA_PRIO);
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks], b[ks], c, 0, 0, 0);
+  __builtin_amdgcn_s_setprio(0);
   return c;
 }
