@@ -2,7 +2,7 @@
 //
 //   C[M,N] = A[M,K] * W[N,K]^T  (+ fused epilogue), fp32 accumulate.
 //
-// Two kernels:
+// Kernels:
 //   gemm128_kernel   128x128x64 workgroup tile, 4 waves (2x2), each wave a 64x64
 //                    sub-tile as 4x4 v_mfma_f32_16x16x32_bf16 accumulators.
 //                    Operand tiles go HBM -> LDS with global_load_lds_dwordx4
@@ -12,17 +12,21 @@
 //                    lane-linearly) and again on the ds_read_b128; fragment-tiled
 //                    weights need no swizzle at all (LDS image == fragment order).
 //                    A-operand loaders: dense rows, or implicit-im2col 3x3 conv
-//                    over an NHWC image (CLIP trunk).
+//                    over an NHWC image (CLIP trunk).  Split-K for grids that
+//                    would leave most CUs idle (+ splitk_fixup_kernel).
+//   gemm256_kernel   256x256x64 tile, 8 waves, deep LDS-DMA pipeline with counted
+//                    waits and two staggered wave groups (see its own header).
 //   skinny_kernel    M <= 16 (decode): pure weight streaming from fragment-tiled
 //                    weights straight into VGPRs (1 KiB contiguous per wave
 //                    instruction), K split across the waves of a workgroup,
 //                    fp32 cross-wave reduction through LDS.  HBM-bound.
+//                    skinny2 / decode_attn_gemv co-launch two workgroup kinds.
 //
 // MFMA operand roles are swapped (weights as the "A" operand, activations as
 // "B") so that each lane ends up with 4 *consecutive n* of one output row:
 //   acc[r] = C[m0 + (lane&15)][n0 + (lane>>4)*4 + r]
-// which makes the epilogue an 8-byte (bf16) / 16-byte (fp32) vector store and
-// lets bias / residual loads be vectors too.
+// so consecutive lanes own consecutive columns.  The tile kernels park the accumulators in LDS
+// and run the epilogue row-wise with 16-byte accesses (gemm_device.h: epilogue_rows).
 #include "common.h"
 
 #include <algorithm>

@@ -53,12 +53,14 @@ class ImagePrefix(nn.Module):
         assert feats.ndim == 3, "clip resnet encoders return (b, hw, d)"
         B, P, E = feats.shape
         pk = self._ensure_packed()
-        y = ops.gemm(feats.reshape(B * P, E), pk["proj"])
-        if self.training and self.dropout.p > 0:
+        mask = None
+        if self.training and self.dropout.p > 0:      # inverted dropout, applied in the projection's epilogue
             if dropout_mask is None:
                 keep = 1.0 - self.dropout.p
-                dropout_mask = (torch.rand(B * P, self.out_dim, device=y.device) < keep).to(y.dtype) / keep
-            y = y * dropout_mask.reshape(B * P, self.out_dim).to(y.dtype)   # TODO(train path): fuse into the proj epilogue
+                dropout_mask = (torch.rand(B * P, self.out_dim, device=feats.device) < keep).to(feats.dtype) / keep
+            mask = dropout_mask.reshape(B * P, self.out_dim).to(feats.dtype).contiguous()
+        y = ops.gemm(feats.reshape(B * P, E), pk["proj"], aux=mask,
+                     aux_mode=ops.MG_AUX_MUL if mask is not None else ops.MG_AUX_NONE)
         if self.use_layernorm:
             y = ops.layernorm(y, pk["ln_g"], pk["ln_b"], self.ln.eps)
         return y.view(B, P, self.out_dim)
