@@ -121,6 +121,19 @@ typedef struct mg_gemm_desc {
 
 int mg_gemm_bf16(const mg_gemm_desc* d, void* stream);
 
+/* fp8 operands (BASELINE config 5): A and W hold OCP e4m3 bytes (mg_quantize_rows_fp8), the product
+ * runs on v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales) at twice the bf16 MFMA rate with fp32
+ * accumulation, and the epilogue applies  acc * row_scale[m] * ep.scale[n]  (per-row activation scale, per-column
+ * weight scale) before bias / activation / residuals.  Same descriptor with every K / lda / ldw counting fp8
+ * ELEMENTS: K and lda multiples of 16; row-major W: ldw multiple of 16; fragment-tiled W: the bf16 tiling applied
+ * to byte pairs, Kp (ldw) multiple of 128; dense A only; 128x128 tile kernel (split-K as for bf16).  Output
+ * bf16 / fp32.                                                                                               */
+int mg_gemm_fp8(const mg_gemm_desc* d, const float* row_scale, void* stream);
+/* bf16 rows -> e4m3 rows + one fp32 scale per row (x ~= q * scale[m], scale = rowmax|x| / 448, round to
+ * nearest even, saturating); q columns [K, ldq) are zero-filled.  K, ldx, ldq multiples of 8.                */
+int mg_quantize_rows_fp8(const mg_bf16* x, int64_t ldx, int32_t M, int32_t K, uint8_t* q, int64_t ldq,
+                         float* scale, void* stream);
+
 /* Decode-shape (M <= 16) weight-streaming GEMM: HBM-bound, W must be
  * MG_W_FRAGTILED.  Same epilogue.  Used for every projection of a decode
  * step (reference magma/sampling.py:86-90 -> model.lm(input_ids=...)).       */

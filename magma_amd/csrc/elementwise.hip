@@ -340,3 +340,60 @@ extern "C" int mg_ce_reduce_f32(const float* loss_row, const int64_t* tgt, int32
   MG_CHECK_LAUNCH();
   return MG_OK;
 }
+
+
+// ---------------------------------------------------------------------------
+// bf16 rows -> OCP e4m3 with one fp32 scale per row (x ~= q * scale, scale = amax / 448).  One workgroup
+// per row; the row is read twice (the second pass hits L2).  Columns [K, ldq) are zero-filled so the byte
+// matrix can be fed to the GEMM with K rounded up.
+// ---------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const mg_bf16* __restrict__ x, int64_t ldx, int K,
+                                                                uint8_t* __restrict__ q, int64_t ldq, float* __restrict__ scale) {
+  __shared__ float red[4];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const mg_bf16* xr = x + (int64_t)row * ldx;
+  float amax = 0.f;
+  for (int c = tid * 8; c < K; c += 256 * 8) {          // K % 8 == 0
+    const u32x4 w = *(const u32x4*)(xr + c);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) amax = fmaxf(amax, fmaxf(fabsf(bflo(w[i])), fabsf(bfhi(w[i]))));
+  }
+  amax = wave_max(amax);
+  if ((tid & 63) == 0) red[tid >> 6] = amax;
+  __syncthreads();
+  amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+  const float inv = 1.0f / sc;
+  if (tid == 0) scale[row] = sc;
+  uint8_t* qr = q + (int64_t)row * ldq;
+  for (int c = tid * 8; c < (int)ldq; c += 256 * 8) {   // ldq % 8 == 0
+    u32x2 o = {0u, 0u};
+    if (c < K) {
+      const u32x4 w = *(const u32x4*)(xr + c);
+      float f[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { f[2 * i] = bflo(w[i]) * inv; f[2 * i + 1] = bfhi(w[i]) * inv; }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) f[i] = fminf(fmaxf(f[i], -448.f), 448.f);
+      int lo = 0, hi = 0;
+      lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
+      lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+      hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
+      hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+      o[0] = (uint32_t)lo; o[1] = (uint32_t)hi;
+    }
+    *(u32x2*)(qr + c) = o;
+  }
+}
+}  // namespace
+
+extern "C" int mg_quantize_rows_fp8(const mg_bf16* x, int64_t ldx, int32_t M, int32_t K, uint8_t* q, int64_t ldq,
+                                    float* scale, void* stream) {
+  if (!x || !q || !scale) MG_FAIL(MG_ERR_SHAPE, "mg_quantize_rows_fp8: null pointer");
+  if (M <= 0 || K <= 0 || (K & 7) || (ldx & 7) || (ldq & 7) || ldq < K || ldx < K) MG_FAIL(MG_ERR_SHAPE, "mg_quantize_rows_fp8: need K, ldx, ldq multiples of 8, ldq >= K");
+  if (!MG_ALIGNED16(x) || ((uintptr_t)q & 7)) MG_FAIL(MG_ERR_ALIGN, "mg_quantize_rows_fp8: x must be 16-byte and q 8-byte aligned");
+  hipLaunchKernelGGL(quantize_rows_fp8_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, x, ldx, K, q, ldq, scale);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}

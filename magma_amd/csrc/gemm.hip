@@ -76,11 +76,14 @@ struct GemmParams {
   // applies the epilogue (deterministic, no atomics).  splits == 1: the epilogue runs in place.
   int splits, kt_per;
   int nt;            // non-temporal output stores (large outputs)
+  const float* row_scale;   // fp8 path: per-row scale of the A operand (nullptr otherwise)
   float* ws; int64_t ldws;
   mg_epilogue ep;
 };
 
-template <int AMODE, int WLAYOUT>
+// FP8: A and W hold OCP e4m3 bytes and every quantity below counts PAIRS of them (the host passes K/2, lda/2, ldw/2:
+// a 64-"element" K-tile is 128 fp8 values, the byte images in LDS are the same); only the MFMA differs.
+template <int AMODE, int WLAYOUT, bool FP8 = false>
 __global__ __launch_bounds__(256) void gemm128_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -207,18 +210,32 @@ __global__ __launch_bounds__(256) void gemm128_kernel(const GemmParams p) {
   for (int kt = kt0; kt < kt1; ++kt) {
     if (kt + 1 < kt1) stage(kt + 1, cur ^ 1);
     const char* sb = smem + cur * STAGE_BYTES;
+    if constexpr (FP8) {
+      i32x8 af[4], bfr[4];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      bf16x8 af[4], bfr[4];
+      for (int t = 0; t < 4; ++t)
+        af[t] = __builtin_shufflevector(*(const i32x4*)(sb + a_rd[0] + t * A_MT_STRIDE), *(const i32x4*)(sb + a_rd[1] + t * A_MT_STRIDE), 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) af[t] = *(const bf16x8*)(sb + a_rd[s] + t * A_MT_STRIDE);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) bfr[t] = *(const bf16x8*)(sb + b_rd[s] + t * B_NT_STRIDE);
+      for (int t = 0; t < 4; ++t)
+        bfr[t] = __builtin_shufflevector(*(const i32x4*)(sb + b_rd[0] + t * B_NT_STRIDE), *(const i32x4*)(sb + b_rd[1] + t * B_NT_STRIDE), 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma_fp8_k128(bfr[j], af[i], acc[i][j]);
+    } else {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bf16x8 af[4], bfr[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) af[t] = *(const bf16x8*)(sb + a_rd[s] + t * A_MT_STRIDE);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bfr[t] = *(const bf16x8*)(sb + b_rd[s] + t * B_NT_STRIDE);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+      }
     }
     __syncthreads();  // next tile landed (vmcnt(0)) + everyone done reading `cur`
     cur ^= 1;
@@ -244,13 +261,13 @@ __global__ __launch_bounds__(256) void gemm128_kernel(const GemmParams p) {
     for (int j = 0; j < 4; ++j)
       *(f32x4*)(smem + (wm * 64 + i * 16 + li) * EPI128_ROWB + (wn * 64 + j * 16 + lq * 4) * 4) = acc[i][j];
   __syncthreads();
-  if (epilogue_wide_ok(p.ep)) epilogue_rows<BN, EPI128_ROWB, 8, false>(p.ep, smem, BM, 4, wave, lane, m0, 64, n0, p.M, p.N);
-  else epilogue_rows<BN, EPI128_ROWB, 4, false>(p.ep, smem, BM, 4, wave, lane, m0, 64, n0, p.M, p.N);
+  if (epilogue_wide_ok(p.ep)) epilogue_rows<BN, EPI128_ROWB, 8, false>(p.ep, smem, BM, 4, wave, lane, m0, 64, n0, p.M, p.N, p.row_scale);
+  else epilogue_rows<BN, EPI128_ROWB, 4, false>(p.ep, smem, BM, 4, wave, lane, m0, 64, n0, p.M, p.N, p.row_scale);
 }
 
 // second half of a split-K GEMM: add the slabs (fixed order) and run the fused epilogue
 __global__ __launch_bounds__(256) void splitk_fixup_kernel(const float* __restrict__ ws, int splits, int M, int N, int64_t ldws,
-                                                           const mg_epilogue ep) {
+                                                           const mg_epilogue ep, const float* __restrict__ row_scale) {
   const int nq = (N + 3) >> 2;
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (int64_t)M * nq) return;
@@ -261,6 +278,7 @@ __global__ __launch_bounds__(256) void splitk_fixup_kernel(const float* __restri
     const f32x4 t = *(const f32x4*)(src + (int64_t)s * M * ldws);
     v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
   }
+  if (row_scale) { const float rs = row_scale[m]; v[0] *= rs; v[1] *= rs; v[2] *= rs; v[3] *= rs; }
   epilogue_store4(ep, m, n, v, N);
 }
 
@@ -449,9 +467,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
         *(f32x4*)(smem + (wr * 64 + i * 16 + li) * EPI256_ROWB + (wc * 64 + j * 16 + lq * 4) * 4) = acc[h * 4 + i][j];
     __syncthreads();
     const int mb = m0 + h * 64;
-    if (!wide) epilogue_rows<256, EPI256_ROWB, 4, false>(p.ep, smem, 128, 8, wave, lane, mb, 128, n0, p.M, p.N);
-    else if (p.nt) epilogue_rows<256, EPI256_ROWB, 8, true>(p.ep, smem, 128, 8, wave, lane, mb, 128, n0, p.M, p.N);
-    else epilogue_rows<256, EPI256_ROWB, 8, false>(p.ep, smem, 128, 8, wave, lane, mb, 128, n0, p.M, p.N);
+    if (!wide) epilogue_rows<256, EPI256_ROWB, 4, false>(p.ep, smem, 128, 8, wave, lane, mb, 128, n0, p.M, p.N, p.row_scale);
+    else if (p.nt) epilogue_rows<256, EPI256_ROWB, 8, true>(p.ep, smem, 128, 8, wave, lane, mb, 128, n0, p.M, p.N, p.row_scale);
+    else epilogue_rows<256, EPI256_ROWB, 8, false>(p.ep, smem, 128, 8, wave, lane, mb, 128, n0, p.M, p.N, p.row_scale);
   }
 }
 
@@ -484,20 +502,20 @@ int check_epilogue(const mg_epilogue& ep, const char* who) {
   return MG_OK;
 }
 
-template <int AMODE, int WLAYOUT>
+template <int AMODE, int WLAYOUT, bool FP8 = false>
 int launch_gemm(const GemmParams& gp, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm128_kernel<AMODE, WLAYOUT>,
+    hipError_t e = hipFuncSetAttribute((const void*)gemm128_kernel<AMODE, WLAYOUT, FP8>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
     if (e != hipSuccess) MG_FAIL(MG_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm128_kernel<AMODE, WLAYOUT>), dim3(gp.tiles_m * gp.tiles_n * gp.splits), dim3(256), GEMM_LDS, s, gp);
+  hipLaunchKernelGGL((gemm128_kernel<AMODE, WLAYOUT, FP8>), dim3(gp.tiles_m * gp.tiles_n * gp.splits), dim3(256), GEMM_LDS, s, gp);
   MG_CHECK_LAUNCH();
   if (gp.splits > 1) {
     const int64_t quads = (int64_t)gp.M * ((gp.N + 3) >> 2);
-    hipLaunchKernelGGL(splitk_fixup_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, gp.ws, gp.splits, gp.M, gp.N, gp.ldws, gp.ep);
+    hipLaunchKernelGGL(splitk_fixup_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, gp.ws, gp.splits, gp.M, gp.N, gp.ldws, gp.ep, gp.row_scale);
     MG_CHECK_LAUNCH();
   }
   return MG_OK;
@@ -527,50 +545,57 @@ int launch_skinny(const SkinnyParams& sp, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int mg_gemm_bf16(const mg_gemm_desc* d, void* stream) {
-  if (!d) MG_FAIL(MG_ERR_SHAPE, "mg_gemm_bf16: null descriptor");
-  if (d->M <= 0 || d->N <= 0 || d->K <= 0) MG_FAIL(MG_ERR_SHAPE, "mg_gemm_bf16: M,N,K must be positive (%d,%d,%d)", d->M, d->N, d->K);
-  if (d->K & 7) MG_FAIL(MG_ERR_SHAPE, "mg_gemm_bf16: K=%d must be a multiple of 8", d->K);
-  if (!d->A || !d->W || !d->zero_page) MG_FAIL(MG_ERR_SHAPE, "mg_gemm_bf16: null A/W/zero_page");
-  if (!MG_ALIGNED16(d->A) || !MG_ALIGNED16(d->W) || !MG_ALIGNED16(d->zero_page)) MG_FAIL(MG_ERR_ALIGN, "mg_gemm_bf16: A/W/zero_page must be 16-byte aligned");
-  if (int rc = check_epilogue(d->ep, "mg_gemm_bf16")) return rc;
+namespace {
+// Shared by mg_gemm_bf16 and mg_gemm_fp8: validation, tile / split-K policy, launch.  For fp8 the descriptor counts
+// e4m3 elements; the kernels see pairs of them (K/2, lda/2, ldw/2) -- same byte images, see gemm128_kernel.
+int gemm_dispatch(const mg_gemm_desc* d, bool fp8, const float* row_scale, hipStream_t s, const char* who) {
+  if (!d) MG_FAIL(MG_ERR_SHAPE, "%s: null descriptor", who);
+  if (d->M <= 0 || d->N <= 0 || d->K <= 0) MG_FAIL(MG_ERR_SHAPE, "%s: M,N,K must be positive (%d,%d,%d)", who, d->M, d->N, d->K);
+  const int epb = fp8 ? 2 : 1;               // descriptor elements per kernel element
+  if (d->K & (8 * epb - 1)) MG_FAIL(MG_ERR_SHAPE, "%s: K=%d must be a multiple of %d", who, d->K, 8 * epb);
+  if (!d->A || !d->W || !d->zero_page) MG_FAIL(MG_ERR_SHAPE, "%s: null A/W/zero_page", who);
+  if (!MG_ALIGNED16(d->A) || !MG_ALIGNED16(d->W) || !MG_ALIGNED16(d->zero_page)) MG_FAIL(MG_ERR_ALIGN, "%s: A/W/zero_page must be 16-byte aligned", who);
+  if (int rc = check_epilogue(d->ep, who)) return rc;
+  if (fp8 && d->a_mode != MG_A_DENSE) MG_FAIL(MG_ERR_UNSUPPORTED, "%s: fp8 operands need a dense A", who);
   GemmParams gp;
-  gp.A = d->A; gp.lda = d->lda; gp.W = d->W; gp.ldw = d->ldw;
-  gp.M = d->M; gp.N = d->N; gp.K = d->K;
+  gp.A = d->A; gp.lda = d->lda / epb; gp.W = d->W; gp.ldw = d->ldw / epb;
+  gp.M = d->M; gp.N = d->N; gp.K = d->K / epb;
   gp.H = d->H; gp.Wd = d->Wd; gp.Cin = d->Cin;
   gp.zero = d->zero_page;
   gp.tiles_m = (d->M + BM - 1) / BM; gp.tiles_n = (d->N + BN - 1) / BN;
   gp.ep = d->ep;
+  gp.row_scale = row_scale;
   // outputs far larger than the caches are streamed out with non-temporal stores (measured -9 % on the
   // 256x256 kernel at K = 4096: the tile no longer evicts the operand panels from L2)
   gp.nt = (int64_t)d->M * d->N * (d->ep.out_f32 ? 4 : 2) >= (int64_t)64 << 20;
-  gp.splits = 1; gp.kt_per = (d->K + BK - 1) / BK; gp.ws = nullptr; gp.ldws = 0;
-  if (d->split_k < 0 || d->split_k > 64) MG_FAIL(MG_ERR_SHAPE, "mg_gemm_bf16: split_k must be in [0, 64]");
-  if (d->split_k > 1 && !d->workspace) MG_FAIL(MG_ERR_SHAPE, "mg_gemm_bf16: split_k > 1 needs a workspace");
-  if (d->workspace && !MG_ALIGNED16(d->workspace)) MG_FAIL(MG_ERR_ALIGN, "mg_gemm_bf16: workspace must be 16-byte aligned");
+  gp.splits = 1; gp.kt_per = (gp.K + BK - 1) / BK; gp.ws = nullptr; gp.ldws = 0;
+  if (d->split_k < 0 || d->split_k > 64) MG_FAIL(MG_ERR_SHAPE, "%s: split_k must be in [0, 64]", who);
+  if (d->split_k > 1 && !d->workspace) MG_FAIL(MG_ERR_SHAPE, "%s: split_k > 1 needs a workspace", who);
+  if (d->workspace && !MG_ALIGNED16(d->workspace)) MG_FAIL(MG_ERR_ALIGN, "%s: workspace must be 16-byte aligned", who);
   if (d->a_mode == MG_A_DENSE) {
-    if (d->lda & 7) MG_FAIL(MG_ERR_ALIGN, "mg_gemm_bf16: lda must be a multiple of 8");
-    if (d->lda < d->K) MG_FAIL(MG_ERR_SHAPE, "mg_gemm_bf16: lda < K");
+    if (d->lda & (8 * epb - 1)) MG_FAIL(MG_ERR_ALIGN, "%s: lda must be a multiple of %d", who, 8 * epb);
+    if (d->lda < d->K) MG_FAIL(MG_ERR_SHAPE, "%s: lda < K", who);
   } else if (d->a_mode == MG_A_CONV3X3) {
-    if (d->Cin <= 0 || (d->Cin & 7) || d->K != 9 * d->Cin) MG_FAIL(MG_ERR_SHAPE, "mg_gemm_bf16: conv3x3 needs Cin%%8==0 and K==9*Cin");
-    if (d->H <= 0 || d->Wd <= 0 || d->M % (d->H * d->Wd)) MG_FAIL(MG_ERR_SHAPE, "mg_gemm_bf16: conv3x3 needs M == B*H*W");
-  } else MG_FAIL(MG_ERR_SHAPE, "mg_gemm_bf16: bad a_mode %d", d->a_mode);
+    if (d->Cin <= 0 || (d->Cin & 7) || d->K != 9 * d->Cin) MG_FAIL(MG_ERR_SHAPE, "%s: conv3x3 needs Cin%%8==0 and K==9*Cin", who);
+    if (d->H <= 0 || d->Wd <= 0 || d->M % (d->H * d->Wd)) MG_FAIL(MG_ERR_SHAPE, "%s: conv3x3 needs M == B*H*W", who);
+  } else MG_FAIL(MG_ERR_SHAPE, "%s: bad a_mode %d", who, d->a_mode);
   if (d->w_layout == MG_W_ROWMAJOR) {
-    if ((d->ldw & 7) || d->ldw < d->K) MG_FAIL(MG_ERR_ALIGN, "mg_gemm_bf16: ldw must be >= K and a multiple of 8");
+    if ((d->ldw & (8 * epb - 1)) || d->ldw < d->K) MG_FAIL(MG_ERR_ALIGN, "%s: ldw must be >= K and a multiple of %d", who, 8 * epb);
   } else if (d->w_layout == MG_W_FRAGTILED) {
-    if ((d->ldw & 63) || d->ldw < d->K) MG_FAIL(MG_ERR_ALIGN, "mg_gemm_bf16: tiled weights need Kp (ldw) %%64==0 and >= K");
-  } else MG_FAIL(MG_ERR_SHAPE, "mg_gemm_bf16: bad w_layout %d", d->w_layout);
-  hipStream_t s = (hipStream_t)stream;
+    if ((d->ldw & (64 * epb - 1)) || d->ldw < d->K) MG_FAIL(MG_ERR_ALIGN, "%s: tiled weights need Kp (ldw) %%%d==0 and >= K", who, 64 * epb);
+  } else MG_FAIL(MG_ERR_SHAPE, "%s: bad w_layout %d", who, d->w_layout);
+  const bool rm = d->w_layout == MG_W_ROWMAJOR;
   // large dense shapes go to the deep-pipelined 256x256 kernel (tile_hint: 0 auto, 128 / 256 force)
   const int64_t wgs256 = (int64_t)((d->M + 255) / 256) * ((d->N + 255) / 256);
-  const bool can256 = d->a_mode == MG_A_DENSE && (d->K % 128) == 0;
+  const bool can256 = !fp8 && d->a_mode == MG_A_DENSE && (gp.K % 128) == 0;   // fp8: 128x128 kernel only (the 8-register
+                                                                              // operands do not fit the 256x256 kernel's budget)
   const bool want256 = d->tile_hint == 256 || d->tile_hint == 257 || (d->tile_hint == 0 && wgs256 >= 192 && d->M >= 1024 && d->N >= 512);
   if (can256 && want256) {
     if (d->tile_hint == 257)   // experiment: LDS-read wait after the barrier
-      return d->w_layout == MG_W_ROWMAJOR ? launch_gemm256<MG_W_ROWMAJOR, true>(gp, s) : launch_gemm256<MG_W_FRAGTILED, true>(gp, s);
-    return d->w_layout == MG_W_ROWMAJOR ? launch_gemm256<MG_W_ROWMAJOR, false>(gp, s) : launch_gemm256<MG_W_FRAGTILED, false>(gp, s);
+      return rm ? launch_gemm256<MG_W_ROWMAJOR, true>(gp, s) : launch_gemm256<MG_W_FRAGTILED, true>(gp, s);
+    return rm ? launch_gemm256<MG_W_ROWMAJOR, false>(gp, s) : launch_gemm256<MG_W_FRAGTILED, false>(gp, s);
   }
-  if (d->tile_hint == 256 && !can256) MG_FAIL(MG_ERR_UNSUPPORTED, "mg_gemm_bf16: the 256x256 kernel needs dense A and K %% 128 == 0");
+  if (d->tile_hint == 256 && !can256) MG_FAIL(MG_ERR_UNSUPPORTED, "%s: the 256x256 kernel needs dense A and K %% %d == 0", who, 128 * epb);
   // split-K: a grid that leaves most of the 256 CUs idle and has a long K loop is cut along K
   // until ~2 workgroups per CU exist (>= 4 K-tiles each); needs the caller's fp32 workspace.
   if (d->workspace && d->split_k != 1) {
@@ -581,7 +606,7 @@ extern "C" int mg_gemm_bf16(const mg_gemm_desc* d, void* stream) {
     want = std::max(1, std::min(want, nkt));
     const int64_t slab = (int64_t)d->M * gp.tiles_n * BN * 4;
     if ((int64_t)want * slab > d->workspace_bytes) {
-      if (d->split_k > 1) MG_FAIL(MG_ERR_SHAPE, "mg_gemm_bf16: workspace too small for split_k=%d (%lld bytes needed)", want, (long long)(want * slab));
+      if (d->split_k > 1) MG_FAIL(MG_ERR_SHAPE, "%s: workspace too small for split_k=%d (%lld bytes needed)", who, want, (long long)(want * slab));
       want = (int)std::max<int64_t>(1, d->workspace_bytes / slab);
     }
     if (want > 1) {
@@ -591,12 +616,19 @@ extern "C" int mg_gemm_bf16(const mg_gemm_desc* d, void* stream) {
       if (gp.splits == 1) { gp.ws = nullptr; gp.ldws = 0; }
     }
   }
-  if (d->a_mode == MG_A_DENSE) {
-    return d->w_layout == MG_W_ROWMAJOR ? launch_gemm<MG_A_DENSE, MG_W_ROWMAJOR>(gp, s)
-                                        : launch_gemm<MG_A_DENSE, MG_W_FRAGTILED>(gp, s);
-  }
-  return d->w_layout == MG_W_ROWMAJOR ? launch_gemm<MG_A_CONV3X3, MG_W_ROWMAJOR>(gp, s)
-                                      : launch_gemm<MG_A_CONV3X3, MG_W_FRAGTILED>(gp, s);
+  if (fp8) return rm ? launch_gemm<MG_A_DENSE, MG_W_ROWMAJOR, true>(gp, s) : launch_gemm<MG_A_DENSE, MG_W_FRAGTILED, true>(gp, s);
+  if (d->a_mode == MG_A_DENSE) return rm ? launch_gemm<MG_A_DENSE, MG_W_ROWMAJOR>(gp, s) : launch_gemm<MG_A_DENSE, MG_W_FRAGTILED>(gp, s);
+  return rm ? launch_gemm<MG_A_CONV3X3, MG_W_ROWMAJOR>(gp, s) : launch_gemm<MG_A_CONV3X3, MG_W_FRAGTILED>(gp, s);
+}
+}  // namespace
+
+extern "C" int mg_gemm_bf16(const mg_gemm_desc* d, void* stream) {
+  return gemm_dispatch(d, false, nullptr, (hipStream_t)stream, "mg_gemm_bf16");
+}
+
+extern "C" int mg_gemm_fp8(const mg_gemm_desc* d, const float* row_scale, void* stream) {
+  if (!row_scale) MG_FAIL(MG_ERR_SHAPE, "mg_gemm_fp8: null row_scale");
+  return gemm_dispatch(d, true, row_scale, (hipStream_t)stream, "mg_gemm_fp8");
 }
 
 namespace {

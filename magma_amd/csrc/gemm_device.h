@@ -4,6 +4,18 @@
 #include "common.h"
 
 // ---------------------------------------------------------------------------
+// fp8 (OCP e4m3) MFMA: v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales -- the only fp8 form that runs
+// at twice the bf16 rate on gfx950 (the non-scaled 16x16x32 fp8 MFMA runs at the bf16 rate).  A lane supplies 32
+// consecutive-in-its-own-order k bytes: here the two 16-byte fragments a bf16 kernel would feed to two 16x16x32
+// steps.  Both operands use the same k order, so the dot product is unaffected.
+// ---------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+MG_DEV f32x4 mfma_fp8_k128(i32x8 a, i32x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0 /*A: e4m3*/, 0 /*B: e4m3*/, 0, 0x7F7F7F7F /*2^0*/, 0, 0x7F7F7F7F);
+}
+
+// ---------------------------------------------------------------------------
 // shared epilogue: 4 consecutive n of row m.  Split in two so that row-walking callers load the
 // per-column vectors (BatchNorm scale, bias) once.
 // ---------------------------------------------------------------------------
@@ -149,7 +161,7 @@ MG_DEV bool epilogue_wide_ok(const mg_epilogue& ep) {
 // Tile row r is global row  m_base + (r >> 6) * hi_stride + (r & 63).
 template <int NCOLS, int ROWB, int W, bool NT>
 MG_DEV void epilogue_rows(const mg_epilogue& ep, const char* lds, int rows, int nwaves, int wave, int lane,
-                          int m_base, int hi_stride, int n0, int M, int N) {
+                          int m_base, int hi_stride, int n0, int M, int N, const float* row_scale = nullptr) {
   constexpr int LPR = NCOLS / W, RPI = 64 / LPR;     // lanes per row, rows per wave-iteration
   const int cl = lane % LPR;
   const int n = n0 + cl * W;
@@ -165,6 +177,11 @@ MG_DEV void epilogue_rows(const mg_epilogue& ep, const char* lds, int rows, int 
       for (int g = 0; g < W; g += 4) {
         const f32x4 t = *(const f32x4*)(lds + r * ROWB + (cl * W + g) * 4);
         v[g] = t[0]; v[g + 1] = t[1]; v[g + 2] = t[2]; v[g + 3] = t[3];
+      }
+      if (row_scale) {   // fp8 operands: per-row activation scale (the per-column weight scale is ep.scale)
+        const float rs = row_scale[m];
+#pragma unroll
+        for (int g = 0; g < W; ++g) v[g] *= rs;
       }
       epilogue_apply<W, NT>(ep, c, m, n, v, N);
     }

@@ -543,3 +543,69 @@ def crop_normalize(img: torch.Tensor, top: int, left: int, n: int, mean, std) ->
     check(L.load().mg_crop_normalize_f32(img.data_ptr(), img.shape[0], img.shape[1], top, left, n, m3, s3, out.data_ptr(), _stream()),
           "mg_crop_normalize_f32")
     return out
+
+
+# ---- fp8 (OCP e4m3) GEMM operands: BASELINE config 5 ---------------------------------------------------------------
+def quantize_rows_fp8(x: torch.Tensor, ldq: Optional[int] = None):
+    """bf16 [M, K] -> (uint8 e4m3 [M, ldq] zero padded, fp32 row scales [M]);  x ~= q * scale[:, None]."""
+    _need_gpu(x)
+    assert x.dtype == BF16 and x.ndim == 2 and x.stride(1) == 1
+    M, K = x.shape
+    ldq = ceil_to(K, 128) if ldq is None else ldq
+    q = torch.empty(M, ldq, dtype=torch.uint8, device=x.device)
+    scale = torch.empty(M, dtype=torch.float32, device=x.device)
+    check(L.load().mg_quantize_rows_fp8(x.data_ptr(), x.stride(0), M, K, q.data_ptr(), ldq, scale.data_ptr(), _stream()),
+          "mg_quantize_rows_fp8")
+    return q, scale
+
+
+class PackedLinearFP8:
+    """A [N, K] weight as e4m3 bytes with one fp32 scale per output channel (W ~= q * scale[:, None]), in the same two
+    layouts as PackedLinear: row-major [N, Kp] and fragment-tiled (the bf16 tiling applied to byte PAIRS, Kp % 128 == 0)."""
+
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, tiled: bool = True, rowmajor: bool = False):
+        _need_gpu(weight)
+        self.N, self.K = weight.shape
+        assert self.K % 16 == 0, "fp8 GEMM needs K % 16 == 0"
+        self.Kp = ceil_to(self.K, 128)
+        n16 = ceil_to(self.N, 16)
+        w = torch.zeros(n16, self.K, dtype=BF16, device=weight.device)
+        w[: self.N] = weight.detach().to(BF16)
+        q, sc = quantize_rows_fp8(w, self.Kp)
+        self.scale = sc[: self.N].contiguous()
+        self.bias = None if bias is None else bias.detach().to(torch.float32).contiguous()
+        self.rm = q[: self.N].contiguous() if rowmajor else None
+        self.ft = PackedLinear.tile(q.view(torch.int16)).view(torch.uint8) if tiled else None   # pairs of bytes tile like bf16
+
+    def dequant(self) -> torch.Tensor:
+        q = self.rm if self.rm is not None else PackedLinear.untile(self.ft.view(torch.int16)).view(torch.uint8)[: self.N]
+        return q[:, : self.K].view(torch.float8_e4m3fn).float() * self.scale[:, None]
+
+
+def gemm_fp8(aq: torch.Tensor, a_scale: torch.Tensor, w: PackedLinearFP8, out: Optional[torch.Tensor] = None, *,
+             act: int = MG_ACT_NONE, residuals: Sequence[torch.Tensor] = (), act_after: int = MG_ACT_NONE,
+             use_bias: bool = True, out_dtype=BF16, layout: Optional[str] = None, split_k: int = 0) -> torch.Tensor:
+    """out[M,N] = epilogue((aq @ wq^T) * a_scale[m] * w.scale[n]) on the fp8 MFMA (fp32 accumulate)."""
+    _need_gpu(aq)
+    assert aq.dtype == torch.uint8 and aq.ndim == 2 and aq.stride(1) == 1 and aq.shape[1] >= w.K
+    M = aq.shape[0]
+    if out is None:
+        out = torch.empty(M, ceil_to(w.N, 8), dtype=out_dtype, device=aq.device)[:, : w.N]
+    d = GemmDesc()
+    d.A, d.lda = aq.data_ptr(), aq.stride(0)
+    if layout is None:
+        layout = "ft" if w.ft is not None else "rm"
+    if layout == "ft":
+        d.W, d.ldw, d.w_layout = w.ft.data_ptr(), w.Kp, MG_W_FRAGTILED
+    else:
+        d.W, d.ldw, d.w_layout = w.rm.data_ptr(), w.rm.stride(0), MG_W_ROWMAJOR
+    d.M, d.N, d.K = M, w.N, w.K
+    d.a_mode = MG_A_DENSE
+    d.zero_page = zero_page(aq.device).data_ptr()
+    d.split_k = split_k
+    if split_k != 1:
+        ws = splitk_workspace(aq.device)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    d.ep = _epilogue(out, w.N, w.bias if use_bias else None, w.scale, act, residuals, act_after)
+    check(L.load().mg_gemm_fp8(C.byref(d), a_scale.data_ptr(), _stream()), "mg_gemm_fp8")
+    return out
