@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--train-batch", type=int, default=16, help="per-GPU micro-batch of the training step (BASELINE config[2])")
     ap.add_argument("--train-truncate", action="store_true", help="also time the exact-truncation variant (SURVEY Q3)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--fp8", choices=["attn", "all"], default=None,
+                    help="also time BASELINE config[4]: fp8 (e4m3) MFMA for QKV/out_proj/adapter GEMMs ('attn') or every "
+                         "block GEMM ('all') in the forward pass; reported in an extra 'fp8' object, never in 'value'")
     return ap.parse_args()
 
 
@@ -167,6 +170,26 @@ def bench_train(model, args, rank, world, dev):
     f_fwd = B * (S * L * (8 * d * d + 4 * d * ff + 4 * d * r) + 4 * L * d * S * S + 47.72e9 * (args.res / 224.0) ** 2)
     out["forward_only"] = {"ms": dtf * 1e3, "algorithmic_tflops": f_fwd / dtf / 1e12, "mfma_frac_of_2.5PF": f_fwd / dtf / 2.5e15,
                            "note": "image prefix + 28 blocks at S=2048 (full-S^2 attention flops, as the reference computes) + loss on target rows"}
+    if args.fp8:
+        # BASELINE config[4]: same forward with the fp8 projections (inference engine only; the backward stays bf16)
+        lm_eng = model.lm.engine
+        with torch.no_grad():
+            ref_loss = float(model(images, caps).loss)
+            lm_eng.fp8_mode = args.fp8
+            try:
+                l8 = float(model(images, caps).loss)      # packs the e4m3 weights
+                sync()
+                t0 = time.perf_counter()
+                for _ in range(2):
+                    model(images, caps)
+                sync()
+                dt8 = (time.perf_counter() - t0) / 2
+            finally:
+                lm_eng.fp8_mode = None
+        out["forward_only_fp8"] = {"mode": args.fp8, "ms": dt8 * 1e3, "speedup_vs_bf16": dtf / dt8, "loss_bf16": ref_loss, "loss_fp8": l8,
+                                   "algorithmic_tflops": f_fwd / dt8 / 1e12,
+                                   "note": "e4m3 operands with per-row / per-channel fp32 scales on v_mfma_scale_f32_16x16x128_f8f6f4 "
+                                           "(unit block scales), fp32 accumulate, bf16 I/O; attention itself stays bf16"}
     eng.train()
     for trunc in ([False, True] if args.train_truncate else [False]):
         eng.truncate = trunc

@@ -107,6 +107,9 @@ class LMEngine:
         self.head_dec = None
         self._lm_head = lm.lm_head
         self._cache_pool = {}
+        # fp8 operands for the prefill / forward GEMMs (BASELINE config 5): None | "attn" (QKV, out_proj, adapters)
+        # | "all" (+ fc_in, fc_out).  bf16 stays the default: it is what the parity tests and the headline use.
+        self.fp8_mode = os.environ.get("MAGMA_FP8") or None
         self._side_stream = torch.cuda.Stream(device=dev)
         self.group_launches = os.environ.get("MAGMA_DECODE_GROUPED", "1") == "1"
         self.two_streams = os.environ.get("MAGMA_DECODE_STREAMS", "1") == "2"   # measured slower (3.07 vs 2.94 ms/step): off
@@ -142,6 +145,26 @@ class LMEngine:
             if ly.mlp_adapter is not None:
                 ad = blk.mlp[1].adapter
                 ly.mlp_adapter = (ops.PackedLinear(ad[0].weight, ad[0].bias), ops.PackedLinear(ad[2].weight, ad[2].bias))
+            ly.fp8 = {}
+
+    # ---- fp8 operand path (config 5) ----------------------------------------------------------------
+    def _fp8_weight(self, ly, name: str, lin):
+        """e4m3 copy (per-output-channel scales) of a packed bf16 weight, made on first use."""
+        packs = ly.__dict__.setdefault("fp8", {})
+        w8 = packs.get(name)
+        if w8 is None:
+            w = ops.PackedLinear.untile(lin.ft)[: lin.N, : lin.K] if lin.ft is not None else lin.rm[: lin.N, : lin.K]
+            w8 = packs[name] = ops.PackedLinearFP8(w, lin.bias)
+        return w8
+
+    def _linear(self, ly, name, lin, x, xq=None, **kw):
+        """x @ lin^T through the bf16 tile GEMM, or -- when this projection is in the active fp8 set -- through the
+        fp8 MFMA on a freshly quantised (per-row scale) copy of x.  ``xq`` passes an already quantised x."""
+        on = self.fp8_mode == "all" or (self.fp8_mode == "attn" and name not in ("fc_in", "fc_out"))
+        if not on or lin.K % 16:
+            return ops.gemm(x, lin, **kw)
+        q, sc = xq if xq is not None else ops.quantize_rows_fp8(x)
+        return ops.gemm_fp8(q, sc, self._fp8_weight(ly, name, lin), **kw)
 
     # ------------------------------------------------------------------ API
     def forward(self, input_ids=None, inputs_embeds=None, labels=None, use_cache=False, past_key_values=None,
@@ -190,21 +213,22 @@ class LMEngine:
         hs = [x.view(B, S, d)] if want_hidden else None
         for li, ly in enumerate(self.layers):
             ln = ops.layernorm(x, ly.ln_g, ly.ln_b, self.eps)
-            qkv = ops.gemm(ln, ly.qkv)
+            lnq = ops.quantize_rows_fp8(ln) if self.fp8_mode else None      # shared by qkv (and fc_in in "all" mode)
+            qkv = self._linear(ly, "qkv", ly.qkv, ln, lnq)
             kc, vc = (cache.k[li], cache.v[li]) if cache is not None else (kscr, vscr)
             ops.rotary_split(qkv, B, S, self.H, self.rot, self.sin_t, self.cos_t, q, kc, vc, pos0=0, vt=vt)
             ops.attn_prefill(q, kc, vt, ctx, B, self.H, S, lse=None if lse_out is None else lse_out[li])
-            a = ops.gemm(ctx, ly.out)
+            a = self._linear(ly, "out", ly.out, ctx)
             if ly.attn_adapter is not None:
-                t = ops.gemm(a, ly.attn_adapter[0], act=ops.MG_ACT_RELU)
-                a = ops.gemm(t, ly.attn_adapter[1], residuals=(a,))
-            h = ops.gemm(ln, ly.fc_in, act=ops.MG_ACT_GELU_NEW)
+                t = self._linear(ly, "attn_dn", ly.attn_adapter[0], a, act=ops.MG_ACT_RELU)
+                a = self._linear(ly, "attn_up", ly.attn_adapter[1], t, residuals=(a,))
+            h = self._linear(ly, "fc_in", ly.fc_in, ln, lnq, act=ops.MG_ACT_GELU_NEW)
             if ly.mlp_adapter is not None:
-                m = ops.gemm(h, ly.fc_out)
-                t = ops.gemm(m, ly.mlp_adapter[0], act=ops.MG_ACT_RELU)
-                x = ops.gemm(t, ly.mlp_adapter[1], residuals=(m, a, x))
+                m = self._linear(ly, "fc_out", ly.fc_out, h)
+                t = self._linear(ly, "mlp_dn", ly.mlp_adapter[0], m, act=ops.MG_ACT_RELU)
+                x = self._linear(ly, "mlp_up", ly.mlp_adapter[1], t, residuals=(m, a, x))
             else:
-                x = ops.gemm(h, ly.fc_out, residuals=(a, x))
+                x = self._linear(ly, "fc_out", ly.fc_out, h, residuals=(a, x))
             if want_hidden:
                 hs.append(x.view(B, S, d))
         return x, hs

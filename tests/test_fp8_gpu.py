@@ -59,3 +59,32 @@ def test_gemm_fp8(dev, layout, M, N, K):
     full = a.float() @ w.float().t()
     plain = ops.gemm_fp8(aq, asc, lin, layout=layout, use_bias=False, out_dtype=torch.float32)
     assert rel(plain, full) < 0.06, rel(plain, full)
+
+
+@pytest.mark.parametrize("mode", ["attn", "all"])
+def test_model_forward_in_fp8_stays_close_to_bf16(dev, mode):
+    """config 5 at model level: the fp8 projections change logits / loss only at the e4m3 quantisation level
+    (stated tolerance: rel-L2 of the logits <= 0.1, |loss difference| <= 0.05 nats on a random-init model)."""
+    from magma_amd.testing import build_reduced_magma
+    torch.manual_seed(3)
+    model = build_reduced_magma(dev, mlp_factor=4, attn_factor=8)
+    model.eval()
+    g = torch.Generator().manual_seed(5)
+    images = torch.randn(2, 3, 64, 64, generator=g).to(dev)
+    caps = torch.randint(0, 1000, (2, model.seq_len), generator=g).to(dev)
+    caps[:, 12:] = model.eos_token
+    eng = model.lm.engine
+    with torch.no_grad():
+        ref = model(images, caps)
+        emb = model.embed([images, caps[:, :6].contiguous()])
+        ref_logits = model.lm(inputs_embeds=emb).logits.float()
+        eng.fp8_mode = mode
+        try:
+            got = model(images, caps)
+            got_logits = model.lm(inputs_embeds=emb).logits.float()
+        finally:
+            eng.fp8_mode = None
+    assert torch.isfinite(got_logits).all()
+    assert rel(got_logits, ref_logits) < 0.1, rel(got_logits, ref_logits)
+    assert abs(float(got.loss) - float(ref.loss)) < 0.05, (float(got.loss), float(ref.loss))
+    assert not torch.equal(got_logits, ref_logits), "fp8 mode did not change anything: the fp8 path was not taken"

@@ -116,6 +116,22 @@ def main():
         for iters in (1, 3, 10, 40):
             ms = timeit(lambda i: ops.gemm(a, lin, out=out, tile=256), iters, warmup=1)
             emit(kind="droop", M=32768, N=16384, K=4096, iters=iters, ms=ms, tflops=2.0 * 32768 * 16384 * 4096 / ms / 1e9)
+    if which == "fp8":   # fp8 (MX-rate MFMA) vs bf16 on the config-5 GEMMs: QKV, out_proj, adapters (and fc for reference)
+        for M in (456, 32768):
+            for (N, K, tag) in [(12288, 4096, "qkv"), (4096, 4096, "out_proj"), (1024, 4096, "adapter_dn"), (4096, 1024, "adapter_up"),
+                                (16384, 4096, "fc_in")]:
+                a = torch.randn(M, K, device=dev).to(BF16)
+                w = (torch.randn(N, K, device=dev) * 0.05).to(BF16)
+                lin, lin8 = ops.PackedLinear(w), ops.PackedLinearFP8(w)
+                out = torch.empty(M, N, dtype=BF16, device=dev)
+                aq, asc = ops.quantize_rows_fp8(a)
+                it = 20 if M < 4096 else 5
+                ms16 = timeit(lambda i: ops.gemm(a, lin, out=out), it)
+                ms8 = timeit(lambda i: ops.gemm_fp8(aq, asc, lin8, out=out), it)
+                msq = timeit(lambda i: ops.quantize_rows_fp8(a), it)
+                fl = 2.0 * M * N * K
+                emit(kind="fp8", tag=tag, M=M, N=N, K=K, bf16_ms=ms16, fp8_ms=ms8, quant_ms=msq, bf16_tflops=fl / ms16 / 1e9,
+                     fp8_tflops=fl / ms8 / 1e9)
     if which == "prefill":   # M = 8 x 57 rows: weights rotate so they stream from HBM as in a real prefill
         for (N, K, tag) in [(12288, 4096, "qkv"), (16384, 4096, "fc_in"), (4096, 4096, "out_proj"),
                             (4096, 16384, "fc_out"), (1024, 4096, "adapter_dn"), (4096, 1024, "adapter_up")]:
