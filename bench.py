@@ -209,6 +209,25 @@ def bench_train(model, args, rank, world, dev):
         out[key] = {"images_per_s": world * B / dt, "ms_per_step": dt * 1e3, "loss": float(loss),
                     "algorithmic_tflops_per_gpu": None if trunc else fl / dt / 1e12,
                     "mfma_frac_of_2.5PF": None if trunc else fl / dt / 2.5e15}
+    if args.fp8:   # BASELINE config[4], training side: frozen-weight block GEMMs (forward + dgrad) on the fp8 MFMA
+        eng.fp8, eng.truncate = True, False
+        try:
+            step()
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(args.train_steps):
+                loss8 = step()
+            sync()
+            dt8 = (time.perf_counter() - t0) / args.train_steps
+        finally:
+            eng.fp8 = False
+        if world > 1:
+            t = torch.tensor([dt8], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt8 = float(t)
+        out["full_S2048_fp8"] = {"images_per_s": world * B / dt8, "ms_per_step": dt8 * 1e3, "loss": float(loss8),
+                                 "note": "qkv / out_proj / fc_in / fc_out forward and dgrad GEMMs in e4m3 (per-row / per-channel scales, "
+                                         "fp32 accumulate); adapters, attention, wgrads, trunk stay bf16"}
     out["policy"] = "no recompute; bf16; adapters+CLIP trunk+prefix trainable; clip 1.0 + AdamW in the timed region"
     out["per_gpu_batch"], out["seq_len"] = B, S
     out["max_memory_allocated_GB"] = torch.cuda.max_memory_allocated() / 2 ** 30

@@ -584,7 +584,8 @@ class PackedLinearFP8:
 
 def gemm_fp8(aq: torch.Tensor, a_scale: torch.Tensor, w: PackedLinearFP8, out: Optional[torch.Tensor] = None, *,
              act: int = MG_ACT_NONE, residuals: Sequence[torch.Tensor] = (), act_after: int = MG_ACT_NONE,
-             use_bias: bool = True, out_dtype=BF16, layout: Optional[str] = None, split_k: int = 0) -> torch.Tensor:
+             use_bias: bool = True, out_dtype=BF16, layout: Optional[str] = None, split_k: int = 0,
+             aux=None, aux_mode: int = MG_AUX_NONE, aux_after: bool = False, out2: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[M,N] = epilogue((aq @ wq^T) * a_scale[m] * w.scale[n]) on the fp8 MFMA (fp32 accumulate)."""
     _need_gpu(aq)
     assert aq.dtype == torch.uint8 and aq.ndim == 2 and aq.stride(1) == 1 and aq.shape[1] >= w.K
@@ -606,6 +607,6 @@ def gemm_fp8(aq: torch.Tensor, a_scale: torch.Tensor, w: PackedLinearFP8, out: O
     if split_k != 1:
         ws = splitk_workspace(aq.device)
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
-    d.ep = _epilogue(out, w.N, w.bias if use_bias else None, w.scale, act, residuals, act_after)
+    d.ep = _epilogue(out, w.N, w.bias if use_bias else None, w.scale, act, residuals, act_after, aux, aux_mode, aux_after, out2)
     check(L.load().mg_gemm_fp8(C.byref(d), a_scale.data_ptr(), _stream()), "mg_gemm_fp8")
     return out

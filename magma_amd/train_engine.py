@@ -113,6 +113,10 @@ class MagmaEngine:
         self.device = model.device
         self.betas, self.eps = betas, eps
         self.truncate = truncate or os.environ.get("MAGMA_TRUNCATE", "0") == "1"
+        # BASELINE config[4]: the frozen-weight block GEMMs (qkv, out_proj, fc_in, fc_out; forward and dgrad) on the fp8
+        # MFMA -- activations / gradients quantised per row to e4m3, weights per output channel.  Off by default.
+        self.fp8 = os.environ.get("MAGMA_TRAIN_FP8", "0") == "1"
+        self._fp8_packs = {}
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.gas = max(1, int(self.config.gradient_accumulation_steps))
         self.clip = float(self.config.gradient_clipping or 0.0)
@@ -256,6 +260,16 @@ class MagmaEngine:
         return (RawWeight(dn.weight.data, bias=self.master_of(dn.bias)),
                 RawWeight(up.weight.data, bias=self.master_of(up.bias)))
 
+    def _fgemm(self, key, x, lin, xq=None, **kw):
+        """GEMM against a FROZEN packed weight: bf16 tile GEMM, or (self.fp8) the fp8 MFMA on a per-row quantised x."""
+        if not self.fp8:
+            return ops.gemm(x, lin, **kw)
+        w8 = self._fp8_packs.get(key)
+        if w8 is None:
+            w8 = self._fp8_packs[key] = ops.PackedLinearFP8(ops.PackedLinear.untile(lin.ft)[: lin.N, : lin.K], lin.bias)
+        q, sc = xq if xq is not None else ops.quantize_rows_fp8(x)
+        return ops.gemm_fp8(q, sc, w8, **kw)
+
     def forward_train(self, images, captions, dropout_mask=None) -> LMOutput:
         model = self.module
         eng = model.lm.engine
@@ -292,10 +306,11 @@ class MagmaEngine:
         vt_ld = ops.ceil_to(S, 32)
         vt = torch.empty(B, H, 256, vt_ld, dtype=BF16, device=dev)
         saved = []
-        for ly, blk in zip(eng.layers, self.module.lm.transformer.h):
+        for li, (ly, blk) in enumerate(zip(eng.layers, self.module.lm.transformer.h)):
             sv = {"x": x}
             ln = ops.layernorm(x, ly.ln_g, ly.ln_b, eng.eps)
-            qkv = ops.gemm(ln, ly.qkv)
+            lnq = ops.quantize_rows_fp8(ln) if self.fp8 else None     # shared by qkv and fc_in
+            qkv = self._fgemm((li, "qkv"), ln, ly.qkv, lnq)
             q = torch.empty(B, H, S, 256, dtype=BF16, device=dev)
             k = torch.empty(B, H, S, 256, dtype=BF16, device=dev)
             v = torch.empty(B, H, S, 256, dtype=BF16, device=dev)
@@ -304,7 +319,7 @@ class MagmaEngine:
             lse = torch.empty(B, H, S, dtype=F32, device=dev)
             ops.attn_prefill(q, k, vt, ctx, B, H, S, lse=lse)
             sv.update(q=q, k=k, v=v, ctx=ctx, lse=lse)
-            a = ops.gemm(ctx, ly.out)
+            a = self._fgemm((li, "out"), ctx, ly.out)
             if ly.attn_adapter is not None:
                 dn, up = self._adapter_ops(blk.attn.adapter)
                 ta = ops.gemm(a, dn, act=ops.MG_ACT_RELU, layout="rm")
@@ -312,16 +327,16 @@ class MagmaEngine:
                 sv.update(a=a, ta=ta)
                 a = a2
             hpre = torch.empty(M, ly.fc_in.N, dtype=BF16, device=dev)
-            h = ops.gemm(ln, ly.fc_in, act=ops.MG_ACT_GELU_NEW, out2=hpre)
+            h = self._fgemm((li, "fc_in"), ln, ly.fc_in, lnq, act=ops.MG_ACT_GELU_NEW, out2=hpre)
             sv["hpre"] = hpre
             if ly.mlp_adapter is not None:
                 dn, up = self._adapter_ops(blk.mlp[1].adapter)
-                m = ops.gemm(h, ly.fc_out)
+                m = self._fgemm((li, "fc_out"), h, ly.fc_out)
                 t = ops.gemm(m, dn, act=ops.MG_ACT_RELU, layout="rm")
                 x = ops.gemm(t, up, residuals=(m, a, x), layout="rm")
                 sv.update(m=m, t=t)
             else:
-                x = ops.gemm(h, ly.fc_out, residuals=(a, x))
+                x = self._fgemm((li, "fc_out"), h, ly.fc_out, residuals=(a, x))
             del h, qkv, ln
             saved.append(sv)
         tape["layers"] = saved
@@ -389,8 +404,8 @@ class MagmaEngine:
                 dm = ops.gemm(dt, dn_t, residuals=(g,), layout="rm", use_bias=False)
             else:
                 dm = g
-            dhpre = ops.gemm(dm, pk["fc_out_t"], aux=sv["hpre"], aux_mode=ops.MG_AUX_GELU_GRAD)
-            dln_mlp = ops.gemm(dhpre, pk["fc_in_t"])
+            dhpre = self._fgemm((li, "fc_out_t"), dm, pk["fc_out_t"], aux=sv["hpre"], aux_mode=ops.MG_AUX_GELU_GRAD)
+            dln_mlp = self._fgemm((li, "fc_in_t"), dhpre, pk["fc_in_t"])
             del dhpre, dm
             # ---- attention branch ----
             if ly.attn_adapter is not None:
@@ -398,7 +413,7 @@ class MagmaEngine:
                 da = ops.gemm(dta, dn_t, residuals=(g,), layout="rm", use_bias=False)
             else:
                 da = g
-            dctx = ops.gemm(da, pk["out_t"])
+            dctx = self._fgemm((li, "out_t"), da, pk["out_t"])
             q, k, v = sv["q"], sv["k"], sv["v"]
             hs = H * S * 256
             qt = ops.head_transpose(q, B, H, S, sb=hs, ss=256, sh=S * 256)
@@ -406,7 +421,7 @@ class MagmaEngine:
             dOt = ops.head_transpose(dctx, B, H, S, sb=S * d, ss=d, sh=256)
             dq, dk, dv = ops.attn_bwd(q, k, v, qt, kt, dctx, dOt, sv["ctx"], sv["lse"], B, H, S)
             dqkv = ops.rotary_merge_bwd(dq, dk, dv, B, S, H, eng.rot, eng.sin_t, eng.cos_t)
-            dln = ops.gemm(dqkv, pk["qkv_t"], residuals=(dln_mlp,))
+            dln = self._fgemm((li, "qkv_t"), dqkv, pk["qkv_t"], residuals=(dln_mlp,))
             g = ops.layernorm_bwd(dln, sv["x"], ly.ln_g, eng.eps, res=g)
             tape["layers"][li] = None     # free this layer's activations
             self._reduce_params_async([p for p in blk.parameters() if p.requires_grad])

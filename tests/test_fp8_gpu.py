@@ -88,3 +88,37 @@ def test_model_forward_in_fp8_stays_close_to_bf16(dev, mode):
     assert rel(got_logits, ref_logits) < 0.1, rel(got_logits, ref_logits)
     assert abs(float(got.loss) - float(ref.loss)) < 0.05, (float(got.loss), float(ref.loss))
     assert not torch.equal(got_logits, ref_logits), "fp8 mode did not change anything: the fp8 path was not taken"
+
+
+def test_training_step_in_fp8_tracks_bf16(dev):
+    """MAGMA_TRAIN_FP8: frozen-weight GEMMs (forward and dgrad) on the fp8 MFMA.  Stated tolerance against the bf16
+    engine on the same batch: |loss difference| <= 0.02, overall gradient cosine >= 0.98."""
+    from magma_amd.testing import build_reduced_magma
+    from magma_amd.train_engine import MagmaEngine
+    grads = {}
+    losses = {}
+    for mode in (False, True):
+        torch.manual_seed(11)
+        model = build_reduced_magma(dev, mlp_factor=4, attn_factor=None, n_positions=128)
+        model.config.gradient_accumulation_steps = 1
+        eng = MagmaEngine(model)
+        eng.fp8 = mode
+        eng.train()
+        g = torch.Generator().manual_seed(3)
+        B, S = 2, model.seq_len
+        images = torch.randn(B, 3, 64, 64, generator=g).to(dev)
+        caps = torch.full((B, S), model.eos_token, dtype=torch.int64)
+        caps[0, :23] = torch.randint(0, 1000, (23,), generator=g)
+        caps[1, :11] = torch.randint(0, 1000, (11,), generator=g)
+        mask = ((torch.rand(B, 4, model.lm.config.hidden_size, generator=g) < 0.9).float() / 0.9).to(dev)
+        out = eng(images, caps.to(dev), dropout_mask=mask)
+        eng.backward(out.loss)
+        losses[mode] = float(out.loss)
+        grads[mode] = torch.cat([grp.grad.float().flatten() for grp in eng.groups]).clone()
+        if mode:
+            assert eng._fp8_packs, "fp8 mode did not pack any weight: the fp8 path was not taken"
+    assert abs(losses[True] - losses[False]) < 0.02, losses
+    a, b = grads[True], grads[False]
+    cos = float((a * b).sum() / (a.norm() * b.norm()))
+    assert cos > 0.98, cos
+    assert not torch.equal(a, b)
