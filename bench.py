@@ -354,6 +354,26 @@ def main():
                 "token_step": {"ms": ms_tok, "decode_tokens_per_s": B / (ms_tok * 1e-3),
                                "hbm_frac_whole_step": wbytes / (ms_tok * 1e-3) / 8e12}}
 
+    gen8 = None
+    if args.fp8:
+        # BASELINE config[4] on the inference side: e4m3 weights in every decode GEMV (W8A16: bf16 activations, weights
+        # widened in registers -> half the bytes per token step) + fp8 MFMA projections in the prefill.  Different
+        # numerics (weight quantisation), so this is a separate object and never the headline `value`.
+        eng.decode_w8, eng.fp8_mode = True, args.fp8
+        eng._cache_pool.clear()
+        try:
+            one_step()
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                one_step()
+            sync()
+            dt8 = (time.perf_counter() - t0) / args.steps
+        finally:
+            eng.decode_w8, eng.fp8_mode = False, None
+            eng._cache_pool.clear()
+        gen8 = {"mode": f"decode W8A16 + prefill fp8 '{args.fp8}'", "tokens_per_s": world * B * gen / dt8, "ms_per_call": dt8 * 1e3,
+                "speedup_vs_bf16": (dt / args.steps) / dt8}
     if rank == 0:
         line = {"metric": "generate tokens/sec (MAGMA_v1, batch-8 images, 32 new tokens, greedy)",
                 "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -364,6 +384,8 @@ def main():
                            "parallelism": f"replicas x{world}", "layers": model.lm.config.num_layers,
                            "prefill_len": int(toks.shape[1] - gen)},
                 "roofline": roof}
+        if gen8 is not None:
+            line["generate_fp8"] = gen8
         line["train"] = None
     train = None
     if args.train_steps > 0:

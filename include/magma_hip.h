@@ -156,6 +156,12 @@ typedef struct mg_skinny_desc {
   int32_t split_n;
   int32_t _pad;
   mg_epilogue ep_b;
+  /* fp8 weights, bf16 activations (W8A16; halves the weight stream of a decode step).  NULL = bf16 weights.
+   * Otherwise W holds e4m3 bytes tiled as [ceil(N/16)][Kp/64][64 lanes][16 B] (lane = kq*16 + n; bytes 0-7 =
+   * W[n][64j + 8kq ..+7], bytes 8-15 = W[n][64j + 32 + 8kq ..+7]), w_scale[n] is the per-output-channel scale
+   * (W ~= q * w_scale[n]); the kernel widens the bytes to bf16 in registers (exact) and multiplies the
+   * accumulators by w_scale before the LayerNorm fold / epilogue.  Needs Kp % 1024 == 0.                     */
+  const float* w_scale;
 } mg_skinny_desc;
 
 int mg_gemm_skinny_bf16(const mg_skinny_desc* d, void* stream);

@@ -473,19 +473,19 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   }
 }
 
-template <int WAVES, int KC, int NT>
+template <int WAVES, int KC, int NT, bool W8 = false>
 __global__ __launch_bounds__(WAVES * 64) void skinny_kernel(const SkinnyParams p) {
   __shared__ __attribute__((aligned(16))) char lds[skinny_lds_bytes<WAVES, NT>()];
-  skinny_body<WAVES, KC, NT>(p, blockIdx.x, lds);
+  skinny_body<WAVES, KC, NT, W8>(p, blockIdx.x, lds);
 }
 
 // two independent GEMVs (same variant) in ONE launch: blocks [0, g0) work on p0, the rest on p1.
 // Decode uses it for out_proj || adapter-down: the 64-workgroup adapter GEMV hides under the other.
-template <int WAVES, int KC, int NT>
+template <int WAVES, int KC, int NT, bool W8 = false>
 __global__ __launch_bounds__(WAVES * 64) void skinny2_kernel(const SkinnyParams p0, const SkinnyParams p1, int g0) {
   __shared__ __attribute__((aligned(16))) char lds[skinny_lds_bytes<WAVES, NT>()];
-  if ((int)blockIdx.x < g0) skinny_body<WAVES, KC, NT>(p0, blockIdx.x, lds);
-  else skinny_body<WAVES, KC, NT>(p1, blockIdx.x - g0, lds);
+  if ((int)blockIdx.x < g0) skinny_body<WAVES, KC, NT, W8>(p0, blockIdx.x, lds);
+  else skinny_body<WAVES, KC, NT, W8>(p1, blockIdx.x - g0, lds);
 }
 
 int check_epilogue(const mg_epilogue& ep, const char* who) {
@@ -535,10 +535,10 @@ int launch_gemm256(GemmParams gp, hipStream_t s) {
   return MG_OK;
 }
 
-template <int WAVES, int KC, int NT>
+template <int WAVES, int KC, int NT, bool W8 = false>
 int launch_skinny(const SkinnyParams& sp, hipStream_t s) {
   const int grid = (sp.ntiles + NT - 1) / NT;
-  hipLaunchKernelGGL((skinny_kernel<WAVES, KC, NT>), dim3(grid), dim3(WAVES * 64), 0, s, sp);
+  hipLaunchKernelGGL((skinny_kernel<WAVES, KC, NT, W8>), dim3(grid), dim3(WAVES * 64), 0, s, sp);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }
@@ -644,6 +644,8 @@ int fill_skinny(const mg_skinny_desc* d, SkinnyParams& sp, const char* who) {
   sp.ntiles = (d->N + 15) / 16; sp.ksteps = d->Kp / 32; sp.ep = d->ep;
   sp.ln_colsum = d->ln_colsum; sp.ln_inv_d = d->ln_inv_d; sp.ln_eps = d->ln_eps;
   sp.split_n = d->split_n; sp.ep_b = d->ep_b;
+  sp.w_scale = d->w_scale;
+  if (d->w_scale && (!MG_ALIGNED16(d->w_scale) || (d->Kp & 1023))) MG_FAIL(MG_ERR_SHAPE, "%s: fp8 weights need a 16-byte aligned w_scale and Kp %% 1024 == 0", who);
   if (d->split_n != 0) {
     if (d->split_n < 0 || d->split_n >= d->N || (d->split_n & 15)) MG_FAIL(MG_ERR_SHAPE, "%s: split_n must be a multiple of 16 inside (0, N)", who);
     if (int rc = check_epilogue(d->ep_b, who)) return rc;
@@ -655,12 +657,12 @@ int fill_skinny(const mg_skinny_desc* d, SkinnyParams& sp, const char* who) {
 // decode attention workgroups and the workgroups of one weight-streaming GEMV in ONE launch: the
 // attention part (B*H workgroups, latency-bound, a few hundred KB of KV) runs underneath the GEMV's
 // HBM stream instead of leaving most of the chip idle for ~10 us per layer.
-template <int KC>
+template <int KC, bool W8 = false>
 __global__ __launch_bounds__(256) void decode_attn_gemv_kernel(const AttnDecodeParams ap, int n_attn, const SkinnyParams sp) {
   constexpr int LDS = ATTN_DEC_LDS > skinny_lds_bytes<4, 1>() ? ATTN_DEC_LDS : skinny_lds_bytes<4, 1>();
   __shared__ __attribute__((aligned(16))) char lds[LDS];
   if ((int)blockIdx.x < n_attn) attn_decode_body<true>(ap, blockIdx.x, lds);
-  else skinny_body<4, KC, 1>(sp, blockIdx.x - n_attn, lds);
+  else skinny_body<4, KC, 1, W8>(sp, blockIdx.x - n_attn, lds);
 }
 }  // namespace
 
@@ -682,6 +684,10 @@ extern "C" int mg_gemm_skinny_bf16(const mg_skinny_desc* d, void* stream) {
   }
   if (waves <= 0 || kc <= 0 || nt <= 0 || sp.ksteps % (waves * kc) != 0)
     MG_FAIL(MG_ERR_SHAPE, "mg_gemm_skinny_bf16: variant (waves=%d,kc=%d,nt=%d) does not divide ksteps=%d", waves, kc, nt, sp.ksteps);
+  if (sp.w_scale) {   // fp8 weights: the two tuned default variants (Kp % 1024 == 0 guarantees both divide)
+    if (d->nt_hint == 0 ? (sp.ksteps >= 512) : (waves == 4 && kc == 16)) return launch_skinny<4, 16, 1, true>(sp, s);
+    return launch_skinny<8, 4, 1, true>(sp, s);
+  }
 #define MG_SK(W_, K_, N_) if (waves == W_ && kc == K_ && nt == N_) return launch_skinny<W_, K_, N_>(sp, s)
   MG_SK(8, 16, 1); MG_SK(8, 16, 2); MG_SK(4, 16, 1); MG_SK(4, 16, 2);
   MG_SK(8, 8, 1);  MG_SK(8, 8, 2);  MG_SK(8, 8, 4);  MG_SK(4, 8, 2); MG_SK(4, 8, 4);
@@ -700,7 +706,10 @@ extern "C" int mg_gemm_skinny2_bf16(const mg_skinny_desc* a, const mg_skinny_des
   if (int rc = fill_skinny(b, pb, "mg_gemm_skinny2_bf16(b)")) return rc;
   hipStream_t s = (hipStream_t)stream;
   const int grid = pa.ntiles + pb.ntiles;
-  if (pa.ksteps % 32 == 0 && pb.ksteps % 32 == 0) {
+  if ((pa.w_scale != nullptr) != (pb.w_scale != nullptr)) MG_FAIL(MG_ERR_UNSUPPORTED, "mg_gemm_skinny2_bf16: both problems must use the same weight type");
+  if (pa.w_scale) {
+    hipLaunchKernelGGL((skinny2_kernel<8, 4, 1, true>), dim3(grid), dim3(512), 0, s, pa, pb, pa.ntiles);
+  } else if (pa.ksteps % 32 == 0 && pb.ksteps % 32 == 0) {
     hipLaunchKernelGGL((skinny2_kernel<8, 4, 1>), dim3(grid), dim3(512), 0, s, pa, pb, pa.ntiles);
   } else if (pa.ksteps % 4 == 0 && pb.ksteps % 4 == 0) {
     hipLaunchKernelGGL((skinny2_kernel<4, 1, 1>), dim3(grid), dim3(256), 0, s, pa, pb, pa.ntiles);
@@ -726,7 +735,9 @@ extern "C" int mg_decode_attn_gemv_bf16(const mg_bf16* qkv, mg_bf16* kcache, mg_
   AttnDecodeParams ap{qkv, kcache, vcache, attn_out, H, Smax, d_pos, rot_dim, sin_t, cos_t};
   hipStream_t s = (hipStream_t)stream;
   const int n_attn = B * H, grid = n_attn + sp.ntiles;
-  if (sp.ksteps % 64 == 0) hipLaunchKernelGGL((decode_attn_gemv_kernel<16>), dim3(grid), dim3(256), 0, s, ap, n_attn, sp);
+  if (sp.w_scale && sp.ksteps % 64 != 0) MG_FAIL(MG_ERR_UNSUPPORTED, "mg_decode_attn_gemv_bf16: fp8 weights need K %% 2048 == 0 here");
+  if (sp.w_scale) hipLaunchKernelGGL((decode_attn_gemv_kernel<16, true>), dim3(grid), dim3(256), 0, s, ap, n_attn, sp);
+  else if (sp.ksteps % 64 == 0) hipLaunchKernelGGL((decode_attn_gemv_kernel<16>), dim3(grid), dim3(256), 0, s, ap, n_attn, sp);
   else if (sp.ksteps % 16 == 0) hipLaunchKernelGGL((decode_attn_gemv_kernel<4>), dim3(grid), dim3(256), 0, s, ap, n_attn, sp);
   else if (sp.ksteps % 4 == 0) hipLaunchKernelGGL((decode_attn_gemv_kernel<1>), dim3(grid), dim3(256), 0, s, ap, n_attn, sp);
   else MG_FAIL(MG_ERR_UNSUPPORTED, "mg_decode_attn_gemv_bf16: K of the GEMV must be a multiple of 128");

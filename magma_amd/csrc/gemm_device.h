@@ -204,6 +204,10 @@ struct SkinnyParams {
   int split_n;
   mg_epilogue ep;
   mg_epilogue ep_b;
+  // fp8 weights, bf16 activations (W8A16): W holds e4m3 bytes in the layout [n-tile][k-step pair][64 lanes][16 B]
+  // (lane = kq*16 + n: bytes 0-7 = W[n][32*(2j) + 8kq ..], bytes 8-15 = the same columns of k-step 2j+1) and
+  // w_scale[n] the per-output-channel scale; the weights are widened to bf16 in registers, so the stream is half as long.
+  const float* w_scale;
 };
 
 // Device body: `block` is the workgroup's index inside THIS problem's grid, `lds` a caller-provided
@@ -212,8 +216,18 @@ struct SkinnyParams {
 template <int WAVES, int NT>
 constexpr int skinny_lds_bytes() { return WAVES * NT * 256 * 4 + WAVES * 16 * 2 * 4; }
 
-template <int WAVES, int KC, int NT>
+// 8 e4m3 bytes -> 8 bf16 (exact: every e4m3 value is a bf16 value)
+MG_DEV bf16x8 fp8x8_to_bf16(uint32_t w0, uint32_t w1) {
+  typedef __attribute__((ext_vector_type(2))) float f2;
+  const f2 a = __builtin_amdgcn_cvt_pk_f32_fp8((int)w0, false), b = __builtin_amdgcn_cvt_pk_f32_fp8((int)w0, true);
+  const f2 c = __builtin_amdgcn_cvt_pk_f32_fp8((int)w1, false), d = __builtin_amdgcn_cvt_pk_f32_fp8((int)w1, true);
+  const u32x4 o = {pack2bf(a[0], a[1]), pack2bf(b[0], b[1]), pack2bf(c[0], c[1]), pack2bf(d[0], d[1])};
+  return __builtin_bit_cast(bf16x8, o);
+}
+
+template <int WAVES, int KC, int NT, bool W8 = false>
 MG_DEV void skinny_body(const SkinnyParams& p, int block, char* lds) {
+  static_assert(!W8 || KC % 2 == 0, "fp8 weights are stored in k-step pairs");
   float* red = (float*)lds;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -233,13 +247,15 @@ MG_DEV void skinny_body(const SkinnyParams& p, int block, char* lds) {
     // Issue the whole chunk's loads before the first MFMA (GEMV recipe: loads
     // straight to VGPRs, deep queue, late wait): weights first (HBM, non-temporal
     // -- each byte is read exactly once per step), then the x fragments (L2 hits).
-    u32x4 wf[NT][KC];
+    constexpr int WL = W8 ? KC / 2 : KC;      // 16-byte loads per n-tile and chunk
+    u32x4 wf[NT][WL];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int nt = min(nt0 + t, p.ntiles - 1);
-      const u32x4* wp = (const u32x4*)p.W + ((int64_t)nt * p.ksteps + ks0 + kc) * 64 + lane;
+      const u32x4* wp = W8 ? (const u32x4*)p.W + ((int64_t)nt * (p.ksteps >> 1) + ((ks0 + kc) >> 1)) * 64 + lane
+                           : (const u32x4*)p.W + ((int64_t)nt * p.ksteps + ks0 + kc) * 64 + lane;
 #pragma unroll
-      for (int i = 0; i < KC; ++i) wf[t][i] = __builtin_nontemporal_load(wp + i * 64);
+      for (int i = 0; i < WL; ++i) wf[t][i] = __builtin_nontemporal_load(wp + i * 64);
     }
     bf16x8 xf[KC];
 #pragma unroll
@@ -264,8 +280,12 @@ MG_DEV void skinny_body(const SkinnyParams& p, int block, char* lds) {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int i = 0; i < KC; ++i)
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[t][i]), xf[i], acc[t], 0, 0, 0);
+      for (int i = 0; i < KC; ++i) {
+        bf16x8 w;
+        if constexpr (W8) w = fp8x8_to_bf16(wf[t][i >> 1][(i & 1) * 2], wf[t][i >> 1][(i & 1) * 2 + 1]);
+        else w = __builtin_bit_cast(bf16x8, wf[t][i]);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, xf[i], acc[t], 0, 0, 0);
+      }
     __builtin_amdgcn_sched_barrier(0);
   }
 
@@ -294,6 +314,10 @@ MG_DEV void skinny_body(const SkinnyParams& p, int block, char* lds) {
     for (int w = 0; w < WAVES; ++w) s += *(const f32x4*)(red + ((w * NT + t) * 64 + lane) * 4);
     if (!xok) continue;
     const int n = (nt0 + t) * 16 + lq * 4;
+    if (W8 && n < p.N) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[r] *= (n + r < p.N ? p.w_scale[n + r] : 0.f);
+    }
     if (p.ln_colsum && n < p.N) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) s[r] = rstd * (s[r] - mean * (n + r < p.N ? p.ln_colsum[n + r] : 0.f));

@@ -110,6 +110,9 @@ class LMEngine:
         # fp8 operands for the prefill / forward GEMMs (BASELINE config 5): None | "attn" (QKV, out_proj, adapters)
         # | "all" (+ fc_in, fc_out).  bf16 stays the default: it is what the parity tests and the headline use.
         self.fp8_mode = os.environ.get("MAGMA_FP8") or None
+        # W8A16 decode: e4m3 weights (per-output-channel scales) widened to bf16 in registers by the weight-streaming
+        # GEMVs -> half the bytes per token step.  Changes the numerics (weight quantisation), so it is opt-in.
+        self.decode_w8 = os.environ.get("MAGMA_DECODE_W8", "0") == "1"
         self._side_stream = torch.cuda.Stream(device=dev)
         self.group_launches = os.environ.get("MAGMA_DECODE_GROUPED", "1") == "1"
         self.two_streams = os.environ.get("MAGMA_DECODE_STREAMS", "1") == "2"   # measured slower (3.07 vs 2.94 ms/step): off
@@ -134,6 +137,32 @@ class LMEngine:
         w2, b2, cs = ops.fold_layernorm(self._lm_head.weight, self._lm_head.bias, self.lnf_g, self.lnf_b)
         self.head_dec = ops.PackedLinear(w2, bias=b2)
         self.head_dec.colsum = cs
+
+    def _ensure_decode_packs_w8(self):
+        """e4m3 copies of every decode operand (same LayerNorm folds; the fold's column sums are taken from the
+        DEQUANTISED weights so that  rstd*(acc*scale - mean*colsum)  stays exact for what the kernel multiplies)."""
+        if getattr(self, "head_w8", None) is not None:
+            return
+        d3 = 3 * self.d
+        for ly in self.layers:
+            a, mlp = ly._src
+            w = torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight, mlp.c_fc.weight], dim=0)
+            b = torch.cat([torch.zeros(d3, device=self.device), mlp.c_fc.bias.detach().float()])
+            w2, b2, _ = ops.fold_layernorm(w, b, ly.ln_g, ly.ln_b)
+            lin = ops.PackedLinearW8(w2, bias=b2[:d3])
+            lin.bias_b, lin.colsum = b2[d3:].contiguous(), lin.dequant().sum(1).contiguous()
+            w8 = _Layer()
+            w8.dec_in = lin
+            w8.out = ops.PackedLinearW8(a.out_proj.weight)
+            w8.fc_out = ops.PackedLinearW8(mlp.c_proj.weight, mlp.c_proj.bias)
+            w8.mlp_adapter = None
+            if ly.mlp_adapter is not None:
+                w8.mlp_adapter = tuple(ops.PackedLinearW8(ops.PackedLinear.untile(p.ft)[: p.N, : p.K], p.bias) for p in ly.mlp_adapter)
+            ly.w8 = w8
+            del w, w2
+        w2, b2, _ = ops.fold_layernorm(self._lm_head.weight, self._lm_head.bias, self.lnf_g, self.lnf_b)
+        self.head_w8 = ops.PackedLinearW8(w2, bias=b2)
+        self.head_w8.colsum = self.head_w8.dequant().sum(1).contiguous()
 
     def repack_adapters(self, lm):
         """Refresh only the (trainable) adapter operands after optimizer steps; the
@@ -300,10 +329,12 @@ class LMEngine:
         d3 = 3 * self.d
         main = torch.cuda.current_stream()
         side = self._side_stream if self.two_streams else None
+        w8_on = self.decode_w8
         for li, ly in enumerate(self.layers):
+            src = ly.w8 if w8_on else ly                 # e4m3 or bf16 operands (same launches)
             # ln_1 + qkv + fc_in(+gelu) in ONE weight-streaming launch
-            ops.gemm_skinny(x, ly.dec_in, out=st.qkv, ln_fold=(ly.dec_in.colsum, self.d, self.eps),
-                            split=(d3, st.h, ops.MG_ACT_GELU_NEW, ly.dec_in.bias_b))
+            ops.gemm_skinny(x, src.dec_in, out=st.qkv, ln_fold=(src.dec_in.colsum, self.d, self.eps),
+                            split=(d3, st.h, ops.MG_ACT_GELU_NEW, src.dec_in.bias_b))
             # attention branch (latency-bound, 128 workgroups) runs on a second HIP stream
             # underneath the MLP branch's weight streaming; both join at the adapter-up GEMV
             grouped = (self.group_launches and ly.mlp_adapter is not None and ly.attn_adapter is None
@@ -312,14 +343,16 @@ class LMEngine:
                 # launch 2: attention workgroups + fc_out GEMV workgroups in one grid (they are independent
                 # branches of the parallel block; the latency-bound attention hides under the weight stream)
                 ops.decode_attn_gemv(st.qkv, cache.k[li], cache.v[li], st.ctx, B, self.H, cache.d_pos, self.rot,
-                                     self.sin_t, self.cos_t, (st.h, ly.fc_out, st.m, {}))
+                                     self.sin_t, self.cos_t, (st.h, src.fc_out, st.m, {}))
                 # launch 3: out_proj || adapter-down
                 t = st.t[:, : ly.mlp_adapter[0].N]
-                ops.gemm_skinny2((st.ctx, ly.out, st.a, {}), (st.m, ly.mlp_adapter[0], t, {"act": ops.MG_ACT_RELU}))
+                ops.gemm_skinny2((st.ctx, src.out, st.a, {}), (st.m, src.mlp_adapter[0], t, {"act": ops.MG_ACT_RELU}))
                 # launch 4: adapter-up + the block's three residuals
-                ops.gemm_skinny(t, ly.mlp_adapter[1], out=xn, residuals=(st.m, st.a, x))
+                ops.gemm_skinny(t, src.mlp_adapter[1], out=xn, residuals=(st.m, st.a, x))
                 x, xn = xn, x
                 continue
+            if w8_on:
+                raise NotImplementedError("W8A16 decode covers the grouped MAGMA_v1 step (mlp adapters, K % 128 == 0) only")
             if side is not None:
                 side.wait_stream(main)
                 torch.cuda.set_stream(side)
@@ -344,7 +377,8 @@ class LMEngine:
                     main.wait_stream(side)
                 ops.gemm_skinny(st.h, ly.fc_out, out=xn, residuals=(a, x))
             x, xn = xn, x
-        ops.gemm_skinny(x, self.head_dec, out=st.logits, ln_fold=(self.head_dec.colsum, self.d, self.eps))
+        head = self.head_w8 if w8_on else self.head_dec
+        ops.gemm_skinny(x, head, out=st.logits, ln_fold=(head.colsum, self.d, self.eps))
         ops.argmax(st.logits[:, : self.V], out=st.token)
         ops.advance_pos(cache.d_pos, 1)
 
@@ -358,6 +392,8 @@ class LMEngine:
         st = cache.decode_state
         if st is None:
             self._ensure_decode_packs()
+            if self.decode_w8:
+                self._ensure_decode_packs_w8()
             st = cache.decode_state = self._alloc_decode_state(cache)
         st.ids.copy_(input_ids.reshape(cache.B, 1))
         if not use_graph:

@@ -60,6 +60,7 @@ class SkinnyDesc(C.Structure):
         ("ln_colsum", C.c_void_p), ("ln_inv_d", C.c_float), ("ln_eps", C.c_float),
         ("split_n", C.c_int32), ("_pad", C.c_int32),
         ("ep_b", Epilogue),
+        ("w_scale", C.c_void_p),
     ]
 
 

@@ -199,12 +199,15 @@ def skinny_desc(x: torch.Tensor, w: PackedLinear, out: Optional[torch.Tensor] = 
     _need_gpu(x)
     assert x.dtype == BF16 and x.ndim == 2 and x.stride(1) == 1 and w.ft is not None
     assert x.shape[1] == w.Kp, "decode activations must span the padded K"
+    w8 = isinstance(w, PackedLinearW8)
     M = x.shape[0]
     if out is None:
         out = torch.empty(M, ceil_to(w.N, 8), dtype=out_dtype, device=x.device)[:, : w.N]
     d = SkinnyDesc()
     d.X, d.ldx, d.W = x.data_ptr(), x.stride(0), w.ft.data_ptr()
     d.M, d.N, d.Kp, d.nt_hint = M, w.N, w.Kp, variant
+    if w8:
+        d.w_scale = w.scale.data_ptr()
     n_a = w.N if split is None else split[0]
     d.ep = _epilogue(out, n_a, w.bias if use_bias else None, scale, act, residuals, act_after)
     if ln_fold is not None:
@@ -215,6 +218,31 @@ def skinny_desc(x: torch.Tensor, w: PackedLinear, out: Optional[torch.Tensor] = 
         d.split_n = split_n
         d.ep_b = _epilogue(out_b, w.N - split_n, bias_b, None, act_b, (), MG_ACT_NONE)
     return d, out
+
+
+class PackedLinearW8:
+    """Decode weight as e4m3 bytes + one fp32 scale per output channel, for the W8A16 weight-streaming GEMV (bf16
+    activations; the kernel widens the bytes in registers).  ``ft`` = [ceil(N/16)][Kp/64][64 lanes][16 B]: lane
+    kq*16+n holds W[n][64j + 8kq .. +7] then W[n][64j + 32 + 8kq .. +7].  K must be a multiple of 1024."""
+
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor] = None):
+        _need_gpu(weight)
+        self.N, self.K = weight.shape
+        assert self.K % 1024 == 0, "W8A16 decode weights need K % 1024 == 0"
+        self.Kp = self.K
+        n16 = ceil_to(self.N, 16)
+        w = torch.zeros(n16, self.K, dtype=BF16, device=weight.device)
+        w[: self.N] = weight.detach().to(BF16)
+        q, sc = quantize_rows_fp8(w, self.K)
+        self.scale = sc.contiguous()                               # padded to n16 (rows beyond N are zero)
+        self.bias = None if bias is None else bias.detach().to(torch.float32).contiguous()
+        # [n16, K] -> [nt, n(16), pair j, step(2), kq(4), 8] -> [nt, j, kq, n, step, 8]
+        self.ft = q.view(n16 // 16, 16, self.K // 64, 2, 4, 8).permute(0, 2, 4, 1, 3, 5).contiguous()
+
+    def dequant(self) -> torch.Tensor:
+        n16 = self.ft.shape[0] * 16
+        q = self.ft.permute(0, 3, 1, 4, 2, 5).reshape(n16, self.K)
+        return (q.view(torch.float8_e4m3fn).float() * self.scale[:, None])[: self.N]
 
 
 def gemm_skinny(x: torch.Tensor, w: PackedLinear, out: Optional[torch.Tensor] = None, **kw) -> torch.Tensor:

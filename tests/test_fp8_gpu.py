@@ -122,3 +122,74 @@ def test_training_step_in_fp8_tracks_bf16(dev):
     cos = float((a * b).sum() / (a.norm() * b.norm()))
     assert cos > 0.98, cos
     assert not torch.equal(a, b)
+
+
+@pytest.mark.parametrize("N,K", [(4096, 4096), (1024, 4096), (4096, 1024), (50258, 4096), (4096, 16384)])
+def test_w8a16_decode_gemv(dev, N, K):
+    """fp8-weight decode GEMV == bf16 activations x exactly-dequantised weights (e4m3 -> bf16 is exact)."""
+    from magma_amd import ops
+    g = torch.Generator(device=dev).manual_seed(N + K)
+    x = torch.randn(8, K, device=dev, generator=g).to(BF16)
+    w = (torch.randn(N, K, device=dev, generator=g) * 0.05).to(BF16)
+    bias = torch.randn(N, device=dev, generator=g)
+    lin = ops.PackedLinearW8(w, bias=bias)
+    ref = x.float() @ lin.dequant().t() + bias
+    out = ops.gemm_skinny(x, lin, out_dtype=torch.float32)
+    assert rel(out, ref) < 1e-4, rel(out, ref)
+    assert rel(out, x.float() @ w.float().t() + bias) < 0.05          # weight-only quantisation error
+
+
+def test_w8a16_layernorm_fold_and_pairs(dev):
+    from magma_amd import ops
+    g = torch.Generator(device=dev).manual_seed(5)
+    d, N = 4096, 512
+    x = (torch.randn(8, d, device=dev, generator=g) * 2 + 0.3).to(BF16)
+    w = (torch.randn(N, d, device=dev, generator=g) * 0.05).to(BF16)
+    gamma, beta = torch.rand(d, device=dev, generator=g) + 0.5, torch.randn(d, device=dev, generator=g) * 0.1
+    w2, b2, _ = ops.fold_layernorm(w, None, gamma, beta)
+    lin = ops.PackedLinearW8(w2, bias=b2)
+    deq = lin.dequant()
+    lin.colsum = deq.sum(1).contiguous()
+    out = ops.gemm_skinny(x, lin, ln_fold=(lin.colsum, d, 1e-5), out_dtype=torch.float32)
+    xf = x.float()
+    mean, var = xf.mean(1, keepdim=True), xf.var(1, unbiased=False, keepdim=True)
+    ref = ((xf - mean) * torch.rsqrt(var + 1e-5)) @ deq.t() + b2
+    assert rel(out, ref) < 2e-3, rel(out, ref)
+    # two problems in one launch
+    o1 = torch.empty(8, 512, dtype=BF16, device=dev)
+    o2 = torch.empty(8, 512, dtype=BF16, device=dev)
+    linb = ops.PackedLinearW8((torch.randn(512, d, device=dev, generator=g) * 0.05).to(BF16))
+    ops.gemm_skinny2((x, lin, o1, {}), (x, linb, o2, {"act": ops.MG_ACT_RELU}))
+    assert rel(o1, xf @ deq.t() + b2) < 4e-3
+    assert rel(o2, torch.relu(xf @ linb.dequant().t())) < 4e-3
+
+
+def test_w8a16_generate_tracks_bf16(dev):
+    """Full-width 2-block model: greedy decode with e4m3 weights stays close to the bf16 decode (stated tolerance:
+    rel-L2 of the step logits <= 0.08; identical tokens where the bf16 top-1 margin is clear)."""
+    from magma_amd import Magma
+    from magma_amd.language_model import GPTJConfig
+    torch.manual_seed(7)
+    model = Magma("MAGMA_v1", device=dev, lm_config=GPTJConfig(num_layers=2, vocab_size=50258))
+    model.eval()
+    eng = model.lm.engine
+    g = torch.Generator(device=dev).manual_seed(3)
+    images = torch.randn(8, 3, 224, 224, device=dev, generator=g).to(BF16)
+    prompt = torch.randint(0, 50256, (8, 8), device=dev, generator=g)
+    with torch.no_grad():
+        emb = model.embed([images, prompt])
+        logits = {}
+        for mode in (False, True):
+            eng.decode_w8 = mode
+            eng._cache_pool.clear()
+            pre = model.lm(inputs_embeds=emb, use_cache=True, cache_hint=8)
+            tok = pre.logits[:, -1].argmax(-1, keepdim=True)
+            step = model.lm(input_ids=tok, use_cache=True, past_key_values=pre.past_key_values)
+            logits[mode] = step.logits[:, -1].float().clone()
+        eng.decode_w8 = False
+        eng._cache_pool.clear()
+    assert rel(logits[True], logits[False]) < 0.08, rel(logits[True], logits[False])
+    top2 = logits[False].topk(2, dim=-1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 0.2 * logits[False].std(dim=-1)
+    assert bool((logits[True].argmax(-1)[clear] == logits[False].argmax(-1)[clear]).all())
+    assert not torch.equal(logits[True], logits[False])
