@@ -684,9 +684,18 @@ extern "C" int mg_gemm_skinny_bf16(const mg_skinny_desc* d, void* stream) {
   }
   if (waves <= 0 || kc <= 0 || nt <= 0 || sp.ksteps % (waves * kc) != 0)
     MG_FAIL(MG_ERR_SHAPE, "mg_gemm_skinny_bf16: variant (waves=%d,kc=%d,nt=%d) does not divide ksteps=%d", waves, kc, nt, sp.ksteps);
-  if (sp.w_scale) {   // fp8 weights: the two tuned default variants (Kp % 1024 == 0 guarantees both divide)
-    if (d->nt_hint == 0 ? (sp.ksteps >= 512) : (waves == 4 && kc == 16)) return launch_skinny<4, 16, 1, true>(sp, s);
-    return launch_skinny<8, 4, 1, true>(sp, s);
+  if (sp.w_scale) {   // fp8 weights: a 16-byte load covers TWO k-steps, so the bursts are twice as deep as for bf16 to keep
+                      // the same bytes in flight (Kp % 1024 == 0 guarantees that every variant below divides)
+    if (d->nt_hint != 0) {
+      if (waves == 8 && kc == 4) return launch_skinny<8, 4, 1, true>(sp, s);
+      if (waves == 8 && kc == 8 && sp.ksteps % 64 == 0) return launch_skinny<8, 8, 1, true>(sp, s);
+      if (waves == 4 && kc == 16 && sp.ksteps % 64 == 0) return launch_skinny<4, 16, 1, true>(sp, s);
+      if (waves == 4 && kc == 8) return launch_skinny<4, 8, 1, true>(sp, s);
+      MG_FAIL(MG_ERR_UNSUPPORTED, "mg_gemm_skinny_bf16: fp8-weight variant (waves=%d,kc=%d) not instantiated", waves, kc);
+    }
+    if (sp.ksteps >= 512) return launch_skinny<4, 16, 1, true>(sp, s);
+    if (sp.ksteps % 64 == 0) return launch_skinny<8, 8, 1, true>(sp, s);
+    return launch_skinny<4, 8, 1, true>(sp, s);
   }
 #define MG_SK(W_, K_, N_) if (waves == W_ && kc == K_ && nt == N_) return launch_skinny<W_, K_, N_>(sp, s)
   MG_SK(8, 16, 1); MG_SK(8, 16, 2); MG_SK(4, 16, 1); MG_SK(4, 16, 2);
@@ -707,7 +716,9 @@ extern "C" int mg_gemm_skinny2_bf16(const mg_skinny_desc* a, const mg_skinny_des
   hipStream_t s = (hipStream_t)stream;
   const int grid = pa.ntiles + pb.ntiles;
   if ((pa.w_scale != nullptr) != (pb.w_scale != nullptr)) MG_FAIL(MG_ERR_UNSUPPORTED, "mg_gemm_skinny2_bf16: both problems must use the same weight type");
-  if (pa.w_scale) {
+  if (pa.w_scale && pa.ksteps % 64 == 0 && pb.ksteps % 64 == 0) {
+    hipLaunchKernelGGL((skinny2_kernel<8, 8, 1, true>), dim3(grid), dim3(512), 0, s, pa, pb, pa.ntiles);
+  } else if (pa.w_scale) {
     hipLaunchKernelGGL((skinny2_kernel<8, 4, 1, true>), dim3(grid), dim3(512), 0, s, pa, pb, pa.ntiles);
   } else if (pa.ksteps % 32 == 0 && pb.ksteps % 32 == 0) {
     hipLaunchKernelGGL((skinny2_kernel<8, 4, 1>), dim3(grid), dim3(512), 0, s, pa, pb, pa.ntiles);
