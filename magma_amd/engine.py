@@ -175,6 +175,23 @@ class LMEngine:
                 ad = blk.mlp[1].adapter
                 ly.mlp_adapter = (ops.PackedLinear(ad[0].weight, ad[0].bias), ops.PackedLinear(ad[2].weight, ad[2].bias))
             ly.fp8 = {}
+            ly.__dict__.pop("up_cat", None)
+
+    def _adapter_up_cat(self, ly):
+        """[W_up_mlp | W_up_attn] along K (bias = sum) for blocks that carry both adapters, or None."""
+        if ly.mlp_adapter is None or ly.attn_adapter is None:
+            return None
+        cat = ly.__dict__.get("up_cat")
+        if cat is None:
+            (dn_m, up_m), (dn_a, up_a) = ly.mlp_adapter, ly.attn_adapter
+            ok = (dn_m.N == up_m.K == up_m.Kp and dn_a.N == up_a.K == up_a.Kp and (up_m.K + up_a.K) % 128 == 0
+                  and ly.fc_out.Kp % 128 == 0 and ly.out.Kp % 128 == 0 and dn_m.Kp % 128 == 0 and dn_a.Kp % 128 == 0)
+            if not ok:
+                ly.up_cat = False
+                return None
+            w = torch.cat([ops.PackedLinear.untile(up_m.ft)[: up_m.N, : up_m.K], ops.PackedLinear.untile(up_a.ft)[: up_a.N, : up_a.K]], dim=1)
+            cat = ly.up_cat = ops.PackedLinear(w, bias=up_m.bias + up_a.bias)
+        return cat or None
 
     # ---- fp8 operand path (config 5) ----------------------------------------------------------------
     def _fp8_weight(self, ly, name: str, lin):
@@ -313,6 +330,7 @@ class LMEngine:
         r_mlp = max([ly.mlp_adapter[0].N for ly in self.layers if ly.mlp_adapter] + [8])
         r_att = max([ly.attn_adapter[0].N for ly in self.layers if ly.attn_adapter] + [8])
         st.t, st.ta = e(B, r_mlp), e(B, r_att)
+        st.tcat = e(B, r_mlp + r_att)      # [mlp bottleneck | attention bottleneck] side by side (fused up-projection)
         st.lnf = e(B, d)
         st.logits = e(B, self.Vp, dt=torch.float32)
         st.token = torch.zeros(B, dtype=torch.int64, device=dev)
@@ -353,6 +371,19 @@ class LMEngine:
                 continue
             if w8_on:
                 raise NotImplementedError("W8A16 decode covers the grouped MAGMA_v1 step (mlp adapters, K % 128 == 0) only")
+            up_cat = self._adapter_up_cat(ly) if self.group_launches else None
+            if up_cat is not None:
+                # MAGMA_v2 (attention AND mlp adapters): 5 launches.  x' = up_m(t) + up_a(ta) + m + a + x is ONE GEMV over
+                # the concatenated bottlenecks [t | ta] against [W_up_m | W_up_a] (the adapter outputs only ever appear summed).
+                r1 = ly.mlp_adapter[0].N
+                t, ta = st.tcat[:, :r1], st.tcat[:, r1: r1 + ly.attn_adapter[0].N]
+                ops.decode_attn_gemv(st.qkv, cache.k[li], cache.v[li], st.ctx, B, self.H, cache.d_pos, self.rot,
+                                     self.sin_t, self.cos_t, (st.h, ly.fc_out, st.m, {}))
+                ops.gemm_skinny2((st.ctx, ly.out, st.a, {}), (st.m, ly.mlp_adapter[0], t, {"act": ops.MG_ACT_RELU}))
+                ops.gemm_skinny(st.a, ly.attn_adapter[0], out=ta, act=ops.MG_ACT_RELU)
+                ops.gemm_skinny(st.tcat[:, : up_cat.Kp], up_cat, out=xn, residuals=(st.m, st.a, x))
+                x, xn = xn, x
+                continue
             if side is not None:
                 side.wait_stream(main)
                 torch.cuda.set_stream(side)
