@@ -190,7 +190,7 @@ int mg_embedding_bf16(const int64_t* ids, int32_t B, int32_t T, const mg_bf16* w
 /* K9 epilogue: split fused qkv rows, GPT-J interleaved rotary on the first
  * rot_dim dims of q,k, scatter K,V into the cache, optional V^T for prefill.
  *   qkv [B*S, 3*H*256];  q_out [B,H,S,256];  kcache/vcache [B,H,Smax,256];
- *   vt (nullable) [B,H,256,vt_ld];  position of row s = pos0 + s where
+ *   vt (nullable) [B,H,vt_ld/32,256,32] (values transposed in 32-key tiles, vt_ld % 32 == 0);  position of row s = pos0 + s where
  *   pos0 = d_pos ? *d_pos : pos0_host.  sin/cos tables [n_pos, rot_dim/2] f32 */
 int mg_rotary_split_bf16(const mg_bf16* qkv, int32_t B, int32_t S, int32_t H, int32_t rot_dim,
                          const float* sin_t, const float* cos_t, int32_t pos0_host,
@@ -199,7 +199,7 @@ int mg_rotary_split_bf16(const mg_bf16* qkv, int32_t B, int32_t S, int32_t H, in
 
 /* K10 prefill/training forward: causal flash attention, head dim 256, fp32
  * online softmax, scale 1/16.  q [B,H,S,256]; k rows from kcache [B,H,Smax,256];
- * vt [B,H,256,vt_ld]; out [B*S, H*256].  lse (nullable) [B,H,S] fp32.         */
+ * vt [B,H,vt_ld/32,256,32]; out [B*S, H*256].  lse (nullable) [B,H,S] fp32.         */
 int mg_attn_prefill_bf16(const mg_bf16* q, const mg_bf16* kcache, const mg_bf16* vt, mg_bf16* out,
                          float* lse, int32_t B, int32_t H, int32_t S, int32_t Smax, int32_t vt_ld,
                          void* stream);
@@ -278,7 +278,8 @@ int mg_rotary_merge_bwd_bf16(const mg_bf16* dq, const mg_bf16* dk, const mg_bf16
                              mg_bf16* dqkv, void* stream);
 
 /* causal flash-attention backward, head dim 256 (recomputes P from q,k,lse).
- * q,k,v [B,H,S,256]; qt,kt,dOt [B,H,256,ld_t] (ld_t >= round_up(S,32), zero padded);
+ * q,k,v [B,H,S,256]; qt,kt,dOt [B,H,ld_t/32,256,32] (column-tiled transposes from mg_head_transpose_bf16,
+ * ld_t = round_up(S,32), zero padded);
  * dO,O [B*S,H*256]; lse [B,H,S]; D = fp32 workspace of 2*B*H*S floats ({lse*log2e, rowsum(dO o O)}
  * per query, written by the first launch).                                           */
 int mg_attn_bwd_bf16(const mg_bf16* q, const mg_bf16* k, const mg_bf16* v, const mg_bf16* qt,

@@ -7,7 +7,7 @@
 //   q      [B, H, S, 256]            rotated
 //   kcache [B, H, Smax, 256]         rotated keys, row-major (decode + prefill)
 //   vcache [B, H, Smax, 256]         values, row-major (decode: coalesced rows)
-//   vt     [B, H, 256, vt_ld]        values transposed (prefill/training PV
+//   vt     [B, H, vt_ld/32, 256, 32] values transposed, in 32-key tiles (prefill/training PV
 //                                    operand: MFMA contracts over 8 consecutive
 //                                    keys per lane, so V must be key-contiguous)
 #include "common.h"
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void rotary_split_kernel(
   __syncthreads();
   // thread = one d; gather its 32 keys and write 64 contiguous bytes of V^T
   const int dd = tid;
-  mg_bf16* dst = vt + ((int64_t)bh * DH + dd) * vt_ld + s0;
+  mg_bf16* dst = vt + (((int64_t)bh * (vt_ld >> 5) + blockIdx.x) * DH + dd) * 32;   // column-tiled: [b,h][tile][256][32]
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     u32x4 o;
@@ -249,7 +249,7 @@ extern "C" int mg_rotary_split_bf16(const mg_bf16* qkv, int32_t B, int32_t S, in
     MG_FAIL(MG_ERR_ALIGN, "mg_rotary_split_bf16: pointers must be 16-byte aligned");
   if (vt) {
     if (d_pos || pos0_host != 0) MG_FAIL(MG_ERR_SHAPE, "mg_rotary_split_bf16: V^T output requires pos0 == 0 (prefill)");
-    if ((vt_ld & 7) || vt_ld < ((S + 31) & ~31)) MG_FAIL(MG_ERR_SHAPE, "mg_rotary_split_bf16: vt_ld must be a multiple of 8 and >= round_up(S,32)");
+    if ((vt_ld & 31) || vt_ld < ((S + 31) & ~31)) MG_FAIL(MG_ERR_SHAPE, "mg_rotary_split_bf16: vt_ld must be a multiple of 32 and >= S");
   }
   if (!d_pos && pos0_host + S > Smax) MG_FAIL(MG_ERR_SHAPE, "mg_rotary_split_bf16: pos0+S exceeds Smax");
   dim3 grid((S + 31) / 32, B * H);
@@ -263,7 +263,7 @@ extern "C" int mg_attn_prefill_bf16(const mg_bf16* q, const mg_bf16* kcache, con
                                     float* lse, int32_t B, int32_t H, int32_t S, int32_t Smax, int32_t vt_ld,
                                     void* stream) {
   if (B <= 0 || H <= 0 || S <= 0 || S > Smax) MG_FAIL(MG_ERR_SHAPE, "mg_attn_prefill_bf16: bad B/H/S/Smax");
-  if ((vt_ld & 7) || vt_ld < ((S + 31) & ~31)) MG_FAIL(MG_ERR_SHAPE, "mg_attn_prefill_bf16: vt_ld must be a multiple of 8 and >= round_up(S,32)");
+  if ((vt_ld & 31) || vt_ld < ((S + 31) & ~31)) MG_FAIL(MG_ERR_SHAPE, "mg_attn_prefill_bf16: vt_ld must be a multiple of 32 and >= S");
   if (!q || !kcache || !vt || !out) MG_FAIL(MG_ERR_SHAPE, "mg_attn_prefill_bf16: null pointer");
   if (!MG_ALIGNED16(q) || !MG_ALIGNED16(kcache) || !MG_ALIGNED16(vt) || !MG_ALIGNED16(out)) MG_FAIL(MG_ERR_ALIGN, "mg_attn_prefill_bf16: pointers must be 16-byte aligned");
   static bool attr_set = false;

@@ -356,13 +356,13 @@ int set_lds(const void* fn, int bytes) {
 
 }  // namespace
 
-// q,k,v [B,H,S,256]; kt,qt,dOt [B,H,256,ld_t] (ld_t >= round_up(S,32), zero padded);
+// q,k,v [B,H,S,256]; kt,qt,dOt column-tiled transposed [B,H,ld_t/32,256,32] (mg_head_transpose_bf16; zero padded);
 // dO, O [B*S, H*256]; lse [B,H,S]; D [B,H,S,2] workspace; dq,dk,dv [B,H,S,256]
 extern "C" int mg_attn_bwd_bf16(const mg_bf16* q, const mg_bf16* k, const mg_bf16* v, const mg_bf16* qt,
                                 const mg_bf16* kt, const mg_bf16* dO, const mg_bf16* dOt, const mg_bf16* O,
                                 const float* lse, float* D, mg_bf16* dq, mg_bf16* dk, mg_bf16* dv, int32_t B,
                                 int32_t H, int32_t S, int32_t ld_t, void* stream) {
-  if (B <= 0 || H <= 0 || S <= 0 || (ld_t & 7) || ld_t < ((S + 31) & ~31)) MG_FAIL(MG_ERR_SHAPE, "mg_attn_bwd_bf16: ld_t must be a multiple of 8 and >= round_up(S,32)");
+  if (B <= 0 || H <= 0 || S <= 0 || (ld_t & 31) || ld_t < ((S + 31) & ~31)) MG_FAIL(MG_ERR_SHAPE, "mg_attn_bwd_bf16: ld_t must be a multiple of 32 and >= S");
   const void* ptrs[] = {q, k, v, qt, kt, dO, dOt, O, lse, D, dq, dk, dv};
   for (const void* p : ptrs) {
     if (!p) MG_FAIL(MG_ERR_SHAPE, "mg_attn_bwd_bf16: null pointer");

@@ -24,14 +24,18 @@ MG_DEV void dma_rows(char* tile, const mg_bf16* base, int64_t row_stride, int r0
     glds16(base + (int64_t)min(r0 + row, rmax - 1) * row_stride + c * 8, tile + blk * 1024);
   }
 }
-// columns [c0, c0+32) of a transposed [256][ld] array
+// positions [c0, c0+32) (c0 % 32 == 0) of a transposed operand in the column-tiled layout [tile][256][32]: the
+// 16-KiB tile is contiguous, a wave instruction reads 1 KiB of it (16 rows x 64 B), the swizzle permutes 16-byte
+// chunks inside each 64-byte row only
 MG_DEV void dma_cols(char* tile, const mg_bf16* base_t, int ld, int c0, int wave, int lane) {
+  (void)ld;
+  const mg_bf16* src = base_t + (int64_t)(c0 >> 5) * (DH * 32);
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int blk = wave * 2 + i;
     const int row = blk * 16 + (lane >> 2);
     const int c = (lane & 3) ^ t_swz(row);
-    glds16(base_t + (int64_t)row * ld + c0 + c * 8, tile + blk * 1024);
+    glds16(src + row * 32 + c * 8, tile + blk * 1024);
   }
 }
 

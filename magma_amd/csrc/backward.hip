@@ -47,7 +47,8 @@ __global__ __launch_bounds__(256) void transpose_kernel(const mg_bf16* __restric
 
 // ---------------------------------------------------------------------------
 // head transpose: element (b, s, h, d) at src + b*sb + s*ss + h*sh + d  ->
-// dst[((b*H + h)*256 + d)*ld + s]; columns s in [S, round_up(S,32)) zero filled.
+// dst[(((b*H + h)*(ld/32) + s/32)*256 + d)*32 + s%32]  (column-tiled transposed layout); positions in
+// [S, round_up(S,32)) zero filled.
 // grid (ceil(S/32), B*H), 256 threads.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void head_transpose_kernel(const mg_bf16* __restrict__ src, int64_t sb,
@@ -66,7 +67,9 @@ __global__ __launch_bounds__(256) void head_transpose_kernel(const mg_bf16* __re
     *(u32x4*)(tile + row * 256 + c * 8) = v;
   }
   __syncthreads();
-  mg_bf16* d = dst + ((int64_t)bh * 256 + tid) * ld + s0;
+  // column-tiled transposed layout [b,h][ld/32 tiles][256][32]: every 32-position tile is 16 KiB contiguous, so
+  // the attention kernels' LDS-DMA reads whole cache lines (64-byte row pieces cost 30 % of the fill rate)
+  mg_bf16* d = dst + (((int64_t)bh * (ld >> 5) + blockIdx.x) * 256 + tid) * 32;
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     u32x4 o;
@@ -497,7 +500,7 @@ extern "C" int mg_transpose_bf16(const mg_bf16* in, int64_t ld_in, int64_t bs_in
 
 extern "C" int mg_head_transpose_bf16(const mg_bf16* src, int64_t sb, int64_t ss, int64_t sh, mg_bf16* dst, int32_t ld,
                                       int32_t B, int32_t H, int32_t S, void* stream) {
-  if (B <= 0 || H <= 0 || S <= 0 || (ld & 7) || ld < ((S + 31) & ~31)) MG_FAIL(MG_ERR_SHAPE, "mg_head_transpose_bf16: ld must be a multiple of 8 and >= round_up(S,32)");
+  if (B <= 0 || H <= 0 || S <= 0 || (ld & 31) || ld < ((S + 31) & ~31)) MG_FAIL(MG_ERR_SHAPE, "mg_head_transpose_bf16: ld must be a multiple of 32 and >= S");
   if (!src || !dst || !MG_ALIGNED16(src) || !MG_ALIGNED16(dst) || (sb & 7) || (ss & 7) || (sh & 7)) MG_FAIL(MG_ERR_ALIGN, "mg_head_transpose_bf16: 16-byte alignment required");
   hipLaunchKernelGGL(head_transpose_kernel, dim3((S + 31) / 32, B * H), dim3(256), 0, (hipStream_t)stream, src, sb, ss, sh, dst, ld, H, S);
   MG_CHECK_LAUNCH();

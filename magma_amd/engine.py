@@ -251,7 +251,7 @@ class LMEngine:
         M = B * S
         vt_ld = ops.ceil_to(S, 32)
         q = torch.empty(B, self.H, S, 256, dtype=BF16, device=dev)
-        vt = torch.empty(B, self.H, 256, vt_ld, dtype=BF16, device=dev)
+        vt = torch.empty(B, self.H, vt_ld // 32, 256, 32, dtype=BF16, device=dev)   # V^T in 32-key tiles
         if cache is None:   # no cache requested: one scratch K/V shared by all layers
             kscr = torch.empty(B, self.H, S, 256, dtype=BF16, device=dev)
             vscr = torch.empty(B, self.H, S, 256, dtype=BF16, device=dev)

@@ -317,14 +317,14 @@ def rotary_split(qkv, B, S, H, rot_dim, sin_t, cos_t, q_out, kcache, vcache, *, 
     Smax = kcache.shape[2]
     check(L.load().mg_rotary_split_bf16(qkv.data_ptr(), B, S, H, rot_dim, sin_t.data_ptr(), cos_t.data_ptr(), pos0,
                                         _p(d_pos), q_out.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), Smax,
-                                        _p(vt), 0 if vt is None else vt.shape[3], _stream()),
+                                        _p(vt), 0 if vt is None else vt.shape[2] * 32, _stream()),
           "mg_rotary_split_bf16")
 
 
 def attn_prefill(q, kcache, vt, out, B, H, S, lse: Optional[torch.Tensor] = None):
     _need_gpu(q)
     check(L.load().mg_attn_prefill_bf16(q.data_ptr(), kcache.data_ptr(), vt.data_ptr(), out.data_ptr(), _p(lse),
-                                        B, H, S, kcache.shape[2], vt.shape[3], _stream()), "mg_attn_prefill_bf16")
+                                        B, H, S, kcache.shape[2], vt.shape[2] * 32, _stream()), "mg_attn_prefill_bf16")
     return out
 
 
@@ -422,11 +422,11 @@ def transpose(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tens
 
 def head_transpose(src: torch.Tensor, B: int, H: int, S: int, sb: int, ss: int, sh: int,
                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """-> [B, H, 256, round_up(S,32)] with zero padding."""
+    """-> column-tiled transposed layout [B, H, ceil(S/32), 256, 32]: out[b,h,t,d,i] = src[b, 32t+i, h, d], zero padded."""
     _need_gpu(src)
     ld = ceil_to(S, 32)
     if out is None:
-        out = torch.empty(B, H, 256, ld, dtype=BF16, device=src.device)
+        out = torch.empty(B, H, ld // 32, 256, 32, dtype=BF16, device=src.device)
     check(L.load().mg_head_transpose_bf16(src.data_ptr(), sb, ss, sh, out.data_ptr(), ld, B, H, S, _stream()),
           "mg_head_transpose_bf16")
     return out
@@ -485,7 +485,7 @@ def attn_bwd(q, k, v, qt, kt, dO, dOt, O, lse, B, H, S):
     dq, dk, dv = (torch.empty(B, H, S, 256, dtype=BF16, device=dev) for _ in range(3))
     check(L.load().mg_attn_bwd_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), qt.data_ptr(), kt.data_ptr(),
                                     dO.data_ptr(), dOt.data_ptr(), O.data_ptr(), lse.data_ptr(), D.data_ptr(),
-                                    dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, H, S, qt.shape[3], _stream()),
+                                    dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, H, S, qt.shape[2] * 32, _stream()),
           "mg_attn_bwd_bf16")
     return dq, dk, dv
 

@@ -304,7 +304,7 @@ class MagmaEngine:
         M, H = B * S, eng.H
         x = emb.view(M, d)
         vt_ld = ops.ceil_to(S, 32)
-        vt = torch.empty(B, H, 256, vt_ld, dtype=BF16, device=dev)
+        vt = torch.empty(B, H, vt_ld // 32, 256, 32, dtype=BF16, device=dev)   # V^T in 32-key tiles
         saved = []
         for li, (ly, blk) in enumerate(zip(eng.layers, self.module.lm.transformer.h)):
             sv = {"x": x}

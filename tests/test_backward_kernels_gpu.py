@@ -29,11 +29,14 @@ def test_transposes(dev):
     B, H, S = 2, 3, 57
     src = rnd(B * S, H * 256, dev=dev, seed=2).to(BF16)          # [M, d] activation -> per-head transposed
     out = ops.head_transpose(src, B, H, S, sb=S * H * 256, ss=H * 256, sh=256)
+    def untile(t):     # [B,H,T,256,32] column-tiled -> [B,H,256,T*32]
+        return t.permute(0, 1, 3, 2, 4).reshape(t.shape[0], t.shape[1], 256, -1)
     ref = src.view(B, S, H, 256).permute(0, 2, 3, 1)
-    assert torch.equal(out[..., :S], ref) and bool((out[..., S:] == 0).all())
+    assert out.shape == (B, H, 2, 256, 32)
+    assert torch.equal(untile(out)[..., :S], ref) and bool((untile(out)[..., S:] == 0).all())
     q = rnd(B, H, S, 256, dev=dev, seed=3).to(BF16)               # [B,H,S,256] -> [B,H,256,S]
     out = ops.head_transpose(q, B, H, S, sb=H * S * 256, ss=256, sh=S * 256)
-    assert torch.equal(out[..., :S], q.transpose(2, 3))
+    assert torch.equal(untile(out)[..., :S], q.transpose(2, 3))
 
 
 def test_colsum(dev):

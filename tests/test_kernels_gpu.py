@@ -179,7 +179,7 @@ def test_rotary_split_and_prefill_attention(dev, B, S, H):
     kc = torch.zeros(B, H, Smax, 256, dtype=BF16, device=dev)
     vc = torch.zeros(B, H, Smax, 256, dtype=BF16, device=dev)
     vt_ld = (S + 31) // 32 * 32
-    vt = torch.full((B, H, 256, vt_ld), float("nan"), dtype=BF16, device=dev)
+    vt = torch.full((B, H, vt_ld // 32, 256, 32), float("nan"), dtype=BF16, device=dev)   # V^T in 32-key tiles
     ops.rotary_split(qkv, B, S, H, 64, sin_t, cos_t, q, kc, vc, pos0=0, vt=vt)
     x = qkv.view(B, S, 3, H, 256).float().cpu()
     pos = torch.arange(S)
@@ -189,8 +189,9 @@ def test_rotary_split_and_prefill_attention(dev, B, S, H):
     assert_close(q.cpu(), q_ref, 3e-3, "q rotary")
     assert_close(kc[:, :, :S].cpu(), k_ref, 3e-3, "k rotary")
     assert torch.equal(vc[:, :, :S].float().cpu(), v_ref)
-    assert torch.equal(vt[:, :, :, :S].float().cpu(), v_ref.transpose(2, 3))
-    assert bool((vt[:, :, :, S:] == 0).all()), "V^T padding must be zero"
+    vt_flat = vt.permute(0, 1, 3, 2, 4).reshape(B, H, 256, vt_ld)       # [b,h,tile,d,i] -> [b,h,d,32*tile+i]
+    assert torch.equal(vt_flat[:, :, :, :S].float().cpu(), v_ref.transpose(2, 3))
+    assert bool((vt_flat[:, :, :, S:] == 0).all()), "V^T padding must be zero"
     # flash attention on the kernel's own (bf16-rounded) q,k,v
     out = torch.empty(B * S, d, dtype=BF16, device=dev)
     lse = torch.empty(B, H, S, dtype=torch.float32, device=dev)
@@ -212,7 +213,7 @@ def test_attention_online_softmax_rescale(dev):
     k = rnd(B, H, Smax, 256, dev=dev, seed=72, scale=0.5).to(BF16)
     v = rnd(B, H, Smax, 256, dev=dev, seed=73).to(BF16)
     k[0, 0, 100] = (q[0, 0, 120].float() * 4).to(BF16)   # spike for late queries at key 100
-    vt = v.transpose(2, 3).contiguous()
+    vt = v.transpose(2, 3).reshape(B, H, 256, Smax // 32, 32).permute(0, 1, 3, 2, 4).contiguous()   # 32-key tiles
     out = torch.empty(B * S, 256, dtype=BF16, device=dev)
     ops.attn_prefill(q, k, vt, out, B, H, S)
     sc = q.float() @ k.float().transpose(-1, -2) / 16.0
