@@ -178,8 +178,7 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(
         }
       }
       float tmax = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      tmax = quad_rows_max(tmax);                    // over the 4 key-slot lanes of this query (VALU lane swaps)
       const float mnew = fmaxf(m2, tmax * sc2);      // key 0 is visible to every query: finite from the first tile on
       const float alpha = __builtin_amdgcn_exp2f(m2 - mnew);
       m2 = mnew;
@@ -213,8 +212,7 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(
   }
   MG_WAIT_VMCNT(0);                   // drain the ring's trailing loads before the wave retires
   // row sum across the 4 key-slot lanes of this query
-  lsum += __shfl_xor(lsum, 16, 64);
-  lsum += __shfl_xor(lsum, 32, 64);
+  lsum = quad_rows_sum(lsum);
   if (qrow < S) {
     const float inv = 1.0f / lsum;
     mg_bf16* op = out + (int64_t)(b * S + qrow) * (H * DH) + h * DH + lq * 4;

@@ -84,6 +84,26 @@ MG_DEV int xcd_contiguous_index(int bid, int total) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
 }
 
+// ---- reductions over the four lanes {l, l^16, l^32, l^48} that share an MFMA row / column -----------------
+// v_permlane32_swap / v_permlane16_swap (new on gfx950) exchange half-waves / odd-even rows between two VGPRs in
+// one VALU op each: no LDS round trip (ds_bpermute costs two in the attention kernel's serial softmax chain).
+MG_DEV float quad_rows_max(float x) {
+  const uint32_t u = __float_as_uint(x);
+  const auto a = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  const float m = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  const uint32_t v = __float_as_uint(m);
+  const auto b = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+MG_DEV float quad_rows_sum(float x) {
+  const uint32_t u = __float_as_uint(x);
+  const auto a = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  const float m = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const uint32_t v = __float_as_uint(m);
+  const auto b = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 // ---- wave / block reductions (wave = 64 lanes) -------------------------------
 MG_DEV float wave_sum(float v) {
 #pragma unroll
