@@ -260,7 +260,7 @@ def main():
     from magma_amd import Magma
     from magma_amd.language_model import GPTJConfig
 
-    torch.manual_seed(1234 + rank)
+    torch.manual_seed(1234)            # same random-init weights on every rank (the data below is rank-dependent)
     lm_cfg = None
     if args.layers is not None:
         lm_cfg = GPTJConfig(num_layers=args.layers, vocab_size=50258)

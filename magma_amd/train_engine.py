@@ -142,6 +142,15 @@ class MagmaEngine:
         self._comm_stream = torch.cuda.Stream(device=self.device) if self._dist else None
         self._reduced = [[] for _ in self.groups]     # per group: (lo, hi) ranges already handed to RCCL this step
         self._works = []
+        if self._dist and self.world > 1:
+            # every replica starts from rank 0's trainable parameters and BatchNorm statistics (what
+            # deepspeed.initialize does for the reference, train.py:103-111)
+            for g in self.groups:
+                dist.broadcast(g.master, src=0)
+                g.model.copy_(g.master)
+            for buf in model.buffers():
+                if buf.is_floating_point() and buf.device.type == "cuda":
+                    dist.broadcast(buf, src=0)
         model.invalidate_packed()
         self._lm_train_packs = None
         self._adapters_dirty = False
