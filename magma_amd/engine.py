@@ -113,6 +113,7 @@ class LMEngine:
         # W8A16 decode: e4m3 weights (per-output-channel scales) widened to bf16 in registers by the weight-streaming
         # GEMVs -> half the bytes per token step.  Changes the numerics (weight quantisation), so it is opt-in.
         self.decode_w8 = os.environ.get("MAGMA_DECODE_W8", "0") == "1"
+        self._dec_in_variant = int(os.environ.get("MAGMA_DEC_IN_VARIANT", "0"))   # tuning knob: nt | waves<<4 | kc<<8
         self._side_stream = torch.cuda.Stream(device=dev)
         self.group_launches = os.environ.get("MAGMA_DECODE_GROUPED", "1") == "1"
         self.two_streams = os.environ.get("MAGMA_DECODE_STREAMS", "1") == "2"   # measured slower (3.07 vs 2.94 ms/step): off
@@ -352,7 +353,7 @@ class LMEngine:
             src = ly.w8 if w8_on else ly                 # e4m3 or bf16 operands (same launches)
             # ln_1 + qkv + fc_in(+gelu) in ONE weight-streaming launch
             ops.gemm_skinny(x, src.dec_in, out=st.qkv, ln_fold=(src.dec_in.colsum, self.d, self.eps),
-                            split=(d3, st.h, ops.MG_ACT_GELU_NEW, src.dec_in.bias_b))
+                            split=(d3, st.h, ops.MG_ACT_GELU_NEW, src.dec_in.bias_b), variant=self._dec_in_variant)
             # attention branch (latency-bound, 128 workgroups) runs on a second HIP stream
             # underneath the MLP branch's weight streaming; both join at the adapter-up GEMV
             grouped = (self.group_launches and ly.mlp_adapter is not None and ly.attn_adapter is None
