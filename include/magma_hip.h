@@ -177,7 +177,9 @@ int mg_decode_attn_gemv_bf16(const mg_bf16* qkv, mg_bf16* kcache, mg_bf16* vcach
                              const float* sin_t, const float* cos_t, const mg_skinny_desc* gemv,
                              void* stream);
 
-/* K8/K17 + ImagePrefix LN: y = (x-mean)/sqrt(var+eps)*gamma+beta, fp32 stats */
+/* K8/K17 + ImagePrefix LN: y = (x-mean)/sqrt(var+eps)*gamma+beta, fp32 stats.  Replaces nn.LayerNorm at reference
+ * magma/image_prefix.py:58-60,106-107 and ln_1 / ln_f of the GPT-J blocks built at magma/language_model.py:12-45
+ * (arithmetic in the un-vendored transformers fork).                                                        */
 int mg_layernorm_bf16(const mg_bf16* x, int64_t ldx, const float* gamma, const float* beta,
                       mg_bf16* y, int64_t ldy, int32_t rows, int32_t d, float eps, void* stream);
 
@@ -187,7 +189,8 @@ int mg_layernorm_bf16(const mg_bf16* x, int64_t ldx, const float* gamma, const f
 int mg_embedding_bf16(const int64_t* ids, int32_t B, int32_t T, const mg_bf16* wte, int32_t vocab,
                       int32_t d, mg_bf16* out, int64_t out_bstride, int32_t row_off, void* stream);
 
-/* K9 epilogue: split fused qkv rows, GPT-J interleaved rotary on the first
+/* K9 epilogue (the fork's GPT-Neo attention with rotary=True, jax=True, configured at reference
+ * magma/language_model.py:17-24; called through magma/magma.py:270-274): split fused qkv rows, GPT-J interleaved rotary on the first
  * rot_dim dims of q,k, scatter K,V into the cache, optional V^T for prefill.
  *   qkv [B*S, 3*H*256];  q_out [B,H,S,256];  kcache/vcache [B,H,Smax,256];
  *   vt (nullable) [B,H,vt_ld/32,256,32] (values transposed in 32-key tiles, vt_ld % 32 == 0);  position of row s = pos0 + s where
@@ -197,14 +200,16 @@ int mg_rotary_split_bf16(const mg_bf16* qkv, int32_t B, int32_t S, int32_t H, in
                          const int32_t* d_pos, mg_bf16* q_out, mg_bf16* kcache, mg_bf16* vcache,
                          int32_t Smax, mg_bf16* vt, int32_t vt_ld, void* stream);
 
-/* K10 prefill/training forward: causal flash attention, head dim 256, fp32
+/* K10 prefill/training forward (same attention module; reference call sites magma/magma.py:270-274 and the
+ * prefill step magma/sampling.py:81-85): causal flash attention, head dim 256, fp32
  * online softmax, scale 1/16.  q [B,H,S,256]; k rows from kcache [B,H,Smax,256];
  * vt [B,H,vt_ld/32,256,32]; out [B*S, H*256].  lse (nullable) [B,H,S] fp32.         */
 int mg_attn_prefill_bf16(const mg_bf16* q, const mg_bf16* kcache, const mg_bf16* vt, mg_bf16* out,
                          float* lse, int32_t B, int32_t H, int32_t S, int32_t Smax, int32_t vt_ld,
                          void* stream);
 
-/* K10 decode: one query row per (b,h) against ctx = *d_pos + 1 cached keys.   */
+/* K10 decode (reference magma/sampling.py:86-90, past_key_values path): one query row per (b,h) against
+ * ctx = *d_pos + 1 cached keys.                                                                            */
 int mg_attn_decode_bf16(const mg_bf16* q, const mg_bf16* kcache, const mg_bf16* vcache,
                         mg_bf16* out, int32_t B, int32_t H, int32_t Smax, const int32_t* d_pos,
                         void* stream);
@@ -215,17 +220,18 @@ int mg_attn_decode_fused_bf16(const mg_bf16* qkv, mg_bf16* kcache, mg_bf16* vcac
                               int32_t H, int32_t Smax, const int32_t* d_pos, int32_t rot_dim,
                               const float* sin_t, const float* cos_t, void* stream);
 
-/* K24 greedy: token[b] = argmax_v logits[b, v] (first maximum), int64 out;
+/* K24 greedy (reference magma/sampling.py:96-97, temperature == 0.0): token[b] = argmax_v logits[b, v] (first maximum), int64 out;
  * optionally appends to out_tokens[b*out_ld + *d_pos_out] and bumps *d_pos.  */
 int mg_argmax_f32(const float* logits, int64_t ld, int32_t B, int32_t V, int64_t* token,
                   void* stream);
 int mg_advance_pos(int32_t* d_pos, int32_t delta, void* stream);
 
-/* K4: 2x2 average pool, NHWC bf16.  x [B,H,W,C] -> y [B,H/2,W/2,C]           */
+/* K4: 2x2 average pool, NHWC bf16.  x [B,H,W,C] -> y [B,H/2,W/2,C]  (stem pool and the anti-aliased stride of
+ * CLIP's ModifiedResNet bottlenecks; trunk selected at reference magma/image_encoders.py:65-74).              */
 int mg_avgpool2_nhwc_bf16(const mg_bf16* x, mg_bf16* y, int32_t B, int32_t H, int32_t W, int32_t C,
                           void* stream);
 
-/* K1 stem conv1 (3->C, 3x3, stride 2, pad 1): explicit im2col of the NCHW
+/* K1 stem conv1 of the same trunk (3->C, 3x3, stride 2, pad 1): explicit im2col of the NCHW
  * bf16 image into [B*(H/2)*(W/2), 32] (27 taps*channels + 5 zero columns,
  * column = c*9 + ky*3 + kx, i.e. the conv weight's own
  * [cout, 3, 3, 3] flattening) for mg_gemm_bf16.                                */
@@ -238,7 +244,8 @@ int mg_stem_im2col_bf16(const mg_bf16* img_nchw, mg_bf16* out, int32_t B, int32_
 int mg_build_labels_i64(const int64_t* captions, int64_t* labels, int32_t B, int32_t S, int32_t P,
                         int64_t eos, void* stream);
 
-/* K19: shifted CE pieces.  For each row r of `logits` [R, V] fp32 with target
+/* K19: shifted cross-entropy of the LM call with labels (reference magma/magma.py:270-274; loss computed inside
+ * the fork's GPTNeoForCausalLM.forward in fp32).  For each row r of `logits` [R, V] fp32 with target
  * tgt[r] (int64, -100 = ignore): loss_row[r] = logsumexp - logit[tgt] (0 if
  * ignored).  The caller passes already-shifted rows.  mg_ce_reduce produces
  * mean over valid rows into out[0] and the valid count into out[1].          */
@@ -247,14 +254,17 @@ int mg_ce_rows_f32(const float* logits, int64_t ld, const int64_t* tgt, float* l
 int mg_ce_reduce_f32(const float* loss_row, const int64_t* tgt, int32_t R, float* out,
                      void* stream);
 
-/* ===================== training path (backward + optimizer) ===================== */
+/* ===================== training path (backward + optimizer) =====================
+ * Replaces model_engine.backward(loss) / model_engine.step() of reference magma/train_loop.py:15-19 (torch.autograd +
+ * the DeepSpeed engine configured at magma/config.py:113-134).                                                  */
 
 /* out[C,R] = in[R,C]^T (batched).  Feeds the wgrad GEMMs, which contract over the
  * row index M of activations: dW[N,K] = dY^T[N,M] * (X^T[K,M])^T.                 */
 int mg_transpose_bf16(const mg_bf16* in, int64_t ld_in, int64_t bs_in, mg_bf16* out, int64_t ld_out,
                       int64_t bs_out, int32_t R, int32_t C, int32_t batch, void* stream);
 
-/* dst[((b*H+h)*256+d)*ld + s] = src[b*sb + s*ss + h*sh + d]; zero fill to round_up(S,32). */
+/* per-head transposes for the attention kernels, column-tiled: dst[(((b*H+h)*(ld/32) + s/32)*256 + d)*32 + s%32]
+ * = src[b*sb + s*ss + h*sh + d]; ld = round_up(S,32), zero filled.                                              */
 int mg_head_transpose_bf16(const mg_bf16* src, int64_t sb, int64_t ss, int64_t sh, mg_bf16* dst, int32_t ld,
                            int32_t B, int32_t H, int32_t S, void* stream);
 
