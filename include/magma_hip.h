@@ -305,6 +305,16 @@ int mg_scale_rows_acc_f32(float* dst, const float* src, int64_t ld_src, const fl
 int mg_add_gate_bf16(const mg_bf16* a, const mg_bf16* b, const mg_bf16* gate, mg_bf16* out, int64_t n, void* stream);
 int mg_bn_param_grad_f32(const mg_bf16* g, const mg_bf16* y, const mg_bf16* sub, const float* gamma,
                          const float* beta, float* dgamma, float* dbeta, int32_t M, int32_t C, void* stream);
+/* trainable conv weight [Cout][Cin][k][k] (k = 1, 3) -> row-major GEMM operand, rows zero padded to ldo:
+ *   mode 0: out[co][tap*Cin + ci] = w[co][ci][ky][kx]                       (forward, implicit-im2col order)
+ *   mode 1: out[ci][tap*Cout + co] = bf16(w[co][ci][k-1-ky][k-1-kx] * scale[co])   (dgrad: flipped taps, BN scale folded)
+ * (one launch instead of PyTorch's permute / flip / multiply / cast / pad copies, every step, for each of the 127 convs). */
+int mg_conv_weight_relayout_bf16(const mg_bf16* w, const float* scale, mg_bf16* out, int64_t ldo, int32_t Cout, int32_t Cin,
+                                 int32_t k, int32_t mode, void* stream);
+/* frozen-statistics BatchNorm as a per-channel affine for the conv epilogues (one launch per BN and step):
+ * scale = gamma / sqrt(var + eps), shift = beta - mean * scale; all fp32 [C].                                   */
+int mg_bn_fold_f32(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                   float* scale, float* shift, int32_t C, void* stream);
 int mg_im2col_t_bf16(const mg_bf16* x, mg_bf16* out, int64_t ldo, int32_t B, int32_t H, int32_t W, int32_t Cin, void* stream);
 
 /* optimizer (replaces DeepSpeed's fp16 ZeRO-2 step: global-norm clip + AdamW on fp32

@@ -615,3 +615,64 @@ extern "C" int mg_scale_rows_acc_f32(float* dst, const float* src, int64_t ld_sr
   MG_CHECK_LAUNCH();
   return MG_OK;
 }
+
+// ---------------------------------------------------------------------------
+// Conv weight [Cout][Cin][k][k] (k = 1 or 3, bf16, trainable: re-laid out every step) -> row-major GEMM operand.
+//   mode 0 (forward / implicit-im2col order):  out[co][tap*Cin + ci]      = w[co][ci][ky][kx]
+//   mode 1 (dgrad: dX = conv(dY, W') with the taps flipped, folded BN scale applied in fp32):
+//                                              out[ci][tap*Cout + co]     = bf16( w[co][ci][k-1-ky][k-1-kx] * scale[co] )
+// tap = ky*k + kx; rows zero padded to ldo.  One launch replaces the permute / flip / multiply / cast / pad chain of
+// PyTorch copies (about 10 launches per conv and step on the 127 convs of the trunk).
+// ---------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void conv_weight_relayout_kernel(const mg_bf16* __restrict__ w, const float* __restrict__ scale,
+                                                                   mg_bf16* __restrict__ out, int64_t ldo, int Cout, int Cin, int k, int mode) {
+  const int taps = k * k;
+  const int rows = mode == 0 ? Cout : Cin, inner = mode == 0 ? Cin : Cout;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)rows * ldo) return;
+  const int r = (int)(idx / ldo), c = (int)(idx - (int64_t)r * ldo);
+  mg_bf16 v = 0;
+  if (c < taps * inner) {
+    const int tap = c / inner, i = c - tap * inner;
+    const int ky = tap / k, kx = tap - ky * k;
+    if (mode == 0) v = w[(((int64_t)r * Cin + i) * k + ky) * k + kx];
+    else v = f2bf(bf2f(w[(((int64_t)i * Cin + r) * k + (k - 1 - ky)) * k + (k - 1 - kx)]) * (scale ? scale[i] : 1.0f));
+  }
+  out[idx] = v;
+}
+}  // namespace
+
+extern "C" int mg_conv_weight_relayout_bf16(const mg_bf16* w, const float* scale, mg_bf16* out, int64_t ldo, int32_t Cout,
+                                            int32_t Cin, int32_t k, int32_t mode, void* stream) {
+  if (!w || !out) MG_FAIL(MG_ERR_SHAPE, "mg_conv_weight_relayout_bf16: null pointer");
+  if (Cout <= 0 || Cin <= 0 || (k != 1 && k != 3) || (mode != 0 && mode != 1)) MG_FAIL(MG_ERR_SHAPE, "mg_conv_weight_relayout_bf16: bad geometry");
+  const int64_t need = (int64_t)k * k * (mode == 0 ? Cin : Cout);
+  if (ldo < need) MG_FAIL(MG_ERR_SHAPE, "mg_conv_weight_relayout_bf16: ldo too small");
+  const int64_t n = (int64_t)(mode == 0 ? Cout : Cin) * ldo;
+  hipLaunchKernelGGL(conv_weight_relayout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, scale, out, ldo,
+                     Cout, Cin, k, mode);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
+// frozen-statistics BatchNorm folded to a per-channel affine: scale = gamma / sqrt(var + eps), shift = beta - mean * scale
+namespace {
+__global__ __launch_bounds__(256) void bn_fold_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const float* __restrict__ mean, const float* __restrict__ var, float eps,
+                                                      float* __restrict__ scale, float* __restrict__ shift, int C) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float s = gamma[c] / sqrtf(var[c] + eps);
+  scale[c] = s;
+  shift[c] = beta[c] - mean[c] * s;
+}
+}  // namespace
+
+extern "C" int mg_bn_fold_f32(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                              float* scale, float* shift, int32_t C, void* stream) {
+  if (!gamma || !beta || !mean || !var || !scale || !shift || C <= 0) MG_FAIL(MG_ERR_SHAPE, "mg_bn_fold_f32: bad arguments");
+  hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta, mean, var, eps, scale, shift, C);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}

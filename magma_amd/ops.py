@@ -549,6 +549,31 @@ def adamw(p, m, v, g, p_bf16, lr, beta1, beta2, eps, wd, step, max_norm=0.0, nor
                                 beta1, beta2, eps, wd, step, max_norm, _p(norm_sq), grad_scale, _stream()), "mg_adamw_f32")
 
 
+def bn_fold(gamma, beta, mean, var, eps: float):
+    """(scale, shift) fp32 [C] of a frozen-statistics BatchNorm: scale = gamma / sqrt(var + eps), shift = beta - mean*scale."""
+    _need_gpu(gamma)
+    for t in (gamma, beta, mean, var):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+    scale, shift = torch.empty_like(gamma), torch.empty_like(gamma)
+    check(L.load().mg_bn_fold_f32(gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), var.data_ptr(), eps, scale.data_ptr(),
+                                  shift.data_ptr(), gamma.numel(), _stream()), "mg_bn_fold_f32")
+    return scale, shift
+
+
+def conv_weight_relayout(w: torch.Tensor, mode: int, scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[Cout, Cin, k, k] bf16 conv weight -> row-major GEMM operand with K zero padded to a multiple of 64.
+    mode 0: [Cout, k*k*Cin] in (ky, kx, ci) order; mode 1: [Cin, k*k*Cout] with flipped taps times scale[co] (dgrad)."""
+    _need_gpu(w)
+    assert w.dtype == BF16 and w.ndim == 4 and w.is_contiguous() and w.shape[2] == w.shape[3]
+    cout, cin, k, _ = w.shape
+    rows, inner = (cout, cin) if mode == 0 else (cin, cout)
+    ldo = ceil_to(k * k * inner, 64)
+    out = torch.empty(rows, ldo, dtype=BF16, device=w.device)
+    check(L.load().mg_conv_weight_relayout_bf16(w.data_ptr(), _p(scale), out.data_ptr(), ldo, cout, cin, k, mode, _stream()),
+          "mg_conv_weight_relayout_bf16")
+    return out
+
+
 # ---- image preprocessing (reference magma/transforms.py:121-134) ------------------------------------------------
 def resample_u8(img: torch.Tensor, out_size: int, axis: int, coeffs: torch.Tensor, bounds: torch.Tensor) -> torch.Tensor:
     """One pass of Pillow's 8-bit antialiased resampling on an HWC uint8 RGB image (axis 1: width, axis 0: height)."""

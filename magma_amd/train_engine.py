@@ -117,6 +117,7 @@ class MagmaEngine:
         # MFMA -- activations / gradients quantised per row to e4m3, weights per output channel.  Off by default.
         self.fp8 = os.environ.get("MAGMA_TRAIN_FP8", "0") == "1"
         self._fp8_packs = {}
+        self._bn_stats = {}
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.gas = max(1, int(self.config.gradient_accumulation_steps))
         self.clip = float(self.config.gradient_clipping or 0.0)
@@ -482,8 +483,10 @@ class MagmaEngine:
     # The trunk is executed unit by unit; a unit = conv (+ frozen-statistics BN) (+ ReLU).
     def _bn_vectors(self, bn):
         gamma, beta = self.master_of(bn.weight), self.master_of(bn.bias)
-        scale = (gamma / torch.sqrt(bn.running_var.float() + bn.eps)).contiguous()
-        shift = (beta - bn.running_mean.float() * scale).contiguous()
+        st = self._bn_stats.get(id(bn))
+        if st is None:      # frozen statistics: fp32 copies made once (dropped when a checkpoint is loaded)
+            st = self._bn_stats[id(bn)] = (bn.running_mean.float().contiguous(), bn.running_var.float().contiguous())
+        scale, shift = ops.bn_fold(gamma, beta, st[0], st[1], bn.eps)
         return gamma, beta, scale, shift
 
     def _unit_fwd(self, conv, bn, a, geom, relu, residual=None, kind=None):
@@ -495,9 +498,9 @@ class MagmaEngine:
             w2[:, :27] = w.reshape(cout, 27)
             wop, convarg = RawWeight(w2, bias=shift, K=32), None
         elif kh == 1:
-            wop, convarg = RawWeight(self._pad_k(w.reshape(cout, cin)), bias=shift, K=cin), None
+            wop, convarg = RawWeight(ops.conv_weight_relayout(w, 0), bias=shift, K=cin), None
         else:
-            wop = RawWeight(self._pad_k(w.permute(0, 2, 3, 1).reshape(cout, 9 * cin)), bias=shift, K=9 * cin)
+            wop = RawWeight(ops.conv_weight_relayout(w, 0), bias=shift, K=9 * cin)
             convarg = (geom[1], geom[2], cin)
         if residual is None:
             y = ops.gemm(a, wop, scale=scale, act=ops.MG_ACT_RELU if relu else ops.MG_ACT_NONE, conv=convarg, layout="rm")
@@ -576,11 +579,9 @@ class MagmaEngine:
             aux_kw = dict(aux=gate, aux_mode=ops.MG_AUX_RELU_GATE, aux_after=gate_after)
         if rec["kind"] == "3x3":
             # dX = conv3x3(g, W') with W'[ci][(ky,kx),co] = W[co][ci][2-ky][2-kx] * scale[co]
-            wf = (w.float() * scale.view(cout, 1, 1, 1)).flip(2, 3).permute(1, 2, 3, 0).reshape(cin, 9 * cout).to(BF16)
-            wop = RawWeight(self._pad_k(wf), K=9 * cout)
+            wop = RawWeight(ops.conv_weight_relayout(w, 1, scale), K=9 * cout)
             return ops.gemm(g, wop, conv=(hh, ww, cout), layout="rm", use_bias=False, residuals=residuals, **aux_kw)
-        wf = (w.reshape(cout, cin).float() * scale.view(cout, 1)).t().contiguous().to(BF16)    # [cin, cout]
-        wop = RawWeight(self._pad_k(wf), K=cout)
+        wop = RawWeight(ops.conv_weight_relayout(w, 1, scale), K=cout)     # [cin, cout] * scale[co]
         return ops.gemm(g, wop, layout="rm", use_bias=False, residuals=residuals, **aux_kw)
 
     def _encoder_backward(self, et, g_out):
@@ -681,6 +682,7 @@ class MagmaEngine:
             return None, None
         sd = torch.load(path, map_location="cpu", weights_only=False)
         self.module.load_checkpoint_state(sd["module"])
+        self._bn_stats = {}         # BatchNorm statistics may have changed
         for g in self.groups:       # parameters were re-pointed at the flat buffers; refresh masters from the loaded values
             for p, o in zip(g.params, g.offsets):
                 g.master[o:o + p.numel()].copy_(p.data.reshape(-1).float())

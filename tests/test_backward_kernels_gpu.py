@@ -194,3 +194,17 @@ def test_adamw_and_clip(dev):
         ops.adamw(p, m, v, g, pb, 1e-2, 0.9, 0.95, 1e-8, 0.1, step, max_norm=1.0, norm_sq=nsq)
     assert rel(p, ref_p.detach()) < 1e-5
     assert torch.equal(pb, p.to(BF16))
+
+
+@pytest.mark.parametrize("cout,cin,k", [(24, 16, 3), (96, 48, 3), (40, 72, 1), (768, 768, 3)])
+def test_conv_weight_relayout(dev, cout, cin, k):
+    """bit-exact against the PyTorch expressions it replaces in the training engine"""
+    from magma_amd import ops
+    w = rnd(cout, cin, k, k, dev=dev, seed=50, scale=0.1).to(BF16)
+    scale = rnd(cout, dev=dev, seed=51).abs() + 0.5
+    f = ops.conv_weight_relayout(w, 0)
+    ref_f = w.permute(0, 2, 3, 1).reshape(cout, k * k * cin)
+    assert f.shape[1] % 64 == 0 and torch.equal(f[:, : k * k * cin], ref_f) and bool((f[:, k * k * cin:] == 0).all())
+    d = ops.conv_weight_relayout(w, 1, scale)
+    ref_d = (w.float() * scale.view(cout, 1, 1, 1)).flip(2, 3).permute(1, 2, 3, 0).reshape(cin, k * k * cout).to(BF16)
+    assert d.shape[1] % 64 == 0 and torch.equal(d[:, : k * k * cout], ref_d) and bool((d[:, k * k * cout:] == 0).all())
