@@ -62,9 +62,9 @@ def parse():
 
 
 def cpu_baseline(args, budget_s):
-    """Oracle on the host cores: one full-size GPT-J block (+adapter) at the
-    prefill shape and at the decode shape, x28 layers, plus lm_head; encoder
-    measured on 1 image.  Bounded to ~budget_s seconds."""
+    """Oracle on the host cores ("port"): the CLIP trunk + prefix on one image (x batch), one full-size GPT-J
+    block (+adapter) at the prefill shape and at the decode shape (x28 layers), plus lm_head -- timed in fp32 and
+    in bf16, the faster one is `value`, both are reported.  Bounded to ~budget_s seconds."""
     from oracle import model as O
     cores = os.cpu_count()
     cfg = O.OracleConfig.magma_v1()
@@ -75,6 +75,8 @@ def cpu_baseline(args, budget_s):
     h = "lm.transformer.h.0."
     a = h + "mlp.1.adapter."
     t_used = time.time()
+    nthr = min(cores, 32)
+    torch.set_num_threads(nthr)
 
     def build(dtype):
         g = torch.Generator().manual_seed(0)
@@ -89,48 +91,52 @@ def cpu_baseline(args, budget_s):
         p[a + "2.weight"], p[a + "2.bias"] = mk(d, 1024), mk(d)
         return p, mk
 
-    best = None
+    L = 28
+    legs = {}
     with torch.no_grad():
-        # report the fastest host configuration found inside the budget (thread count x dtype)
-        for nthr, dtype in ((min(cores, 32), torch.float32), (cores, torch.float32), (min(cores, 32), torch.bfloat16)):
-            if best is not None and nthr == best[5] and dtype == best[1]:
-                continue
-            torch.set_num_threads(nthr)
+        # image encoder + prefix projection: the full RN50x16 trunk on ONE image in fp32, scaled by the batch
+        enc_p = {k: v for k, v in O.init_params(O.OracleConfig(n_layer=0, vocab_in=8, vocab_out=8), seed=0).items()
+                 if k.startswith("image_prefix.")}
+        img = torch.randn(1, 3, args.res, args.res)
+        ecfg = O.OracleConfig.magma_v1()
+        O.image_prefix_fwd(enc_p, ecfg, img)
+        t0 = time.time(); O.image_prefix_fwd(enc_p, ecfg, img); t_enc = (time.time() - t0) * B
+        del enc_p
+        for dtype in (torch.float32, torch.bfloat16):
+            if legs and time.time() - t_used > budget_s * 0.6:
+                break
             p, mk = build(dtype)
             x = mk(B, S0, d) * 50
             O.block_fwd(p, cfg, 0, x, None, 0)
             t0 = time.time(); _, past = O.block_fwd(p, cfg, 0, x, None, 0); tp = time.time() - t0
-            if best is None or tp < best[0]:
-                best = (tp, dtype, p, mk, past, nthr)
-            if time.time() - t_used > budget_s * 0.5:
-                break
-        cores = best[5]
-        torch.set_num_threads(cores)
-        best = best[:5]
-        t_prefill_layer, dtype, p, mk, past = best
-        x1 = mk(B, 1, d) * 50
-        t0 = time.time()
-        n_dec = 0
-        while n_dec < 2 or (time.time() - t0 < budget_s * 0.3 and n_dec < 8):
-            O.block_fwd(p, cfg, 0, x1, past, S0); n_dec += 1
-        t_decode_layer = (time.time() - t0) / n_dec
-        head_w, head_b = mk(cfg.vocab_out, d), mk(cfg.vocab_out)
-        t0 = time.time(); torch.nn.functional.linear(x1[:, 0], head_w, head_b); t_head = time.time() - t0
-    L = 28
-    total = L * t_prefill_layer + args.gen * (L * t_decode_layer + t_head)
-    toks = B * args.gen
-    return {"value": toks / total, "unit": "tokens/s", "cores": cores, "kind": "port",
-            "sample": f"oracle (PyTorch CPU {str(dtype).split('.')[-1]}, {cores} threads) one full-size GPT-J block+adapter timed at "
-                      f"prefill B={B},S={S0} ({t_prefill_layer*1e3:.0f} ms) and decode ({t_decode_layer*1e3:.0f} ms), x{L} layers + "
-                      f"lm_head ({t_head*1e3:.0f} ms) x {args.gen} steps; image encoder excluded; measured in {time.time()-t_used:.0f} s"}
+            x1 = mk(B, 1, d) * 50
+            t0 = time.time()
+            n_dec = 0
+            while n_dec < 2 or (time.time() - t0 < budget_s * 0.12 and n_dec < 6):
+                O.block_fwd(p, cfg, 0, x1, past, S0); n_dec += 1
+            td = (time.time() - t0) / n_dec
+            head_w, head_b = mk(cfg.vocab_out, d), mk(cfg.vocab_out)
+            t0 = time.time(); torch.nn.functional.linear(x1[:, 0], head_w, head_b); th = time.time() - t0
+            total = t_enc + L * tp + args.gen * (L * td + th)
+            legs[str(dtype).split(".")[-1]] = {"tokens_per_s": B * args.gen / total, "prefill_layer_ms": tp * 1e3,
+                                               "decode_layer_ms": td * 1e3, "lm_head_ms": th * 1e3}
+            del p, head_w, head_b, past
+    best = max(legs, key=lambda k: legs[k]["tokens_per_s"])
+    return {"value": legs[best]["tokens_per_s"], "unit": "tokens/s", "cores": nthr, "kind": "port", "dtype": best,
+            "legs": legs, "encoder_ms_per_batch": t_enc * 1e3,
+            "sample": f"oracle (PyTorch CPU, {nthr} threads of {cores}): CLIP RN50x16 trunk + prefix on 1 image x{B} "
+                      f"({t_enc*1e3:.0f} ms, fp32) + one full-size GPT-J block+adapter timed at prefill B={B},S={S0} and at the "
+                      f"cached decode shape, x{L} layers + lm_head x {args.gen} steps, in fp32 and bf16 (faster leg = value: {best}); "
+                      f"measured in {time.time()-t_used:.0f} s"}
 
 
-def train_flops_per_image(model, res, S):
-    """SURVEY 8d, 'no recompute' policy: T = 2G + 3A + W + 3E per image."""
+def train_flops_per_image(model, res, S, c=1.0):
+    """SURVEY 8d, 'no recompute' policy: T = 2G + 3A + W + 3E per image.  c = 1: full-S^2 attention FLOPs, as the
+    reference computes them; c = 0.5: the causal tiles the flash kernels actually execute."""
     L, d, ff, V = model.lm.config.num_layers, model.lm.config.hidden_size, model.lm.config.intermediate_size, model.lm.config.vocab_size
     r = sum(ad.N for ad in (model.lm.engine.layers[0].mlp_adapter or ())[:1]) + sum(ad.N for ad in (model.lm.engine.layers[0].attn_adapter or ())[:1])
     G = S * (L * (8 * d * d + 4 * d * ff + 4 * d * r))            # block GEMMs fwd (head runs on target rows only)
-    A = 4 * L * d * S * S                                          # attention fwd, full S^2 as the reference computes
+    A = 4 * L * d * S * S * c                                      # attention fwd
     Wg = 4 * S * L * d * r                                         # adapter wgrad
     E = 47.72e9 * (res / 224.0) ** 2                               # CLIP trunk fwd per image
     return 2 * G + 3 * A + Wg + 3 * E
@@ -172,9 +178,10 @@ def bench_train(model, args, rank, world, dev):
     eng.train()
     B, S = args.train_batch, model.seq_len
     images, caps = synthetic_batch(B, args.res, S, model.eos_token, 50256, 1234 + rank, device=dev, dtype=torch.bfloat16)
+    caps_host = caps.cpu()      # what a data loader hands over: the label index plumbing is done on the host (no sync)
 
     def step():
-        o = eng(images, caps)
+        o = eng(images, caps, captions_host=caps_host)
         eng.backward(o.loss)
         eng.step()
         return o.loss
@@ -198,8 +205,11 @@ def bench_train(model, args, rank, world, dev):
     L, d, ff = model.lm.config.num_layers, model.lm.config.hidden_size, model.lm.config.intermediate_size
     r = sum(ad.N for ad in (model.lm.engine.layers[0].mlp_adapter or ())[:1]) + sum(ad.N for ad in (model.lm.engine.layers[0].attn_adapter or ())[:1])
     f_fwd = B * (S * L * (8 * d * d + 4 * d * ff + 4 * d * r) + 4 * L * d * S * S + 47.72e9 * (args.res / 224.0) ** 2)
+    f_fwd_exec = f_fwd - B * 2 * L * d * S * S          # causal tiles only (c = 1/2): what the kernels execute
     out["forward_only"] = {"ms": dtf * 1e3, "algorithmic_tflops": f_fwd / dtf / 1e12, "mfma_frac_of_2.5PF": f_fwd / dtf / 2.5e15,
-                           "note": "image prefix + 28 blocks at S=2048 (full-S^2 attention flops, as the reference computes) + loss on target rows"}
+                           "executed_tflops": f_fwd_exec / dtf / 1e12, "mfma_frac_executed": f_fwd_exec / dtf / 2.5e15,
+                           "note": "image prefix + 28 blocks at S=2048 + loss on target rows; 'algorithmic' counts full-S^2 attention "
+                                   "FLOPs as the reference computes them (c = 1), 'executed' the causal tiles the kernel runs (c = 1/2)"}
     if args.fp8:
         out["forward_only_fp8"] = _forward_fp8(model, images, caps, args.fp8, sync, dtf, f_fwd)
     eng.train()
@@ -218,13 +228,16 @@ def bench_train(model, args, rank, world, dev):
             dt = float(t)
         key = "truncated" if trunc else "full_S2048"
         fl = train_flops_per_image(model, args.res, S) * B
+        fl_exec = train_flops_per_image(model, args.res, S, c=0.5) * B
         out[key] = {"images_per_s": world * B / dt, "ms_per_step": dt * 1e3, "loss": float(loss),
                     "algorithmic_tflops_per_gpu": None if trunc else fl / dt / 1e12,
-                    "mfma_frac_of_2.5PF": None if trunc else fl / dt / 2.5e15}
+                    "mfma_frac_of_2.5PF": None if trunc else fl / dt / 2.5e15,
+                    "mfma_frac_executed": None if trunc else fl_exec / dt / 2.5e15}
         if trunc:
             out[key]["note"] = ("NOT the BASELINE config: the sequence is cut after the longest caption (+ prefix); with causal "
-                                "attention and the masked loss this leaves loss and gradients bit-for-bit unchanged "
-                                "(tests/test_train_gpu.py::test_truncation_is_exact) but skips the padded positions the reference computes")
+                                "attention and the masked loss this leaves loss and gradients mathematically unchanged (same values up "
+                                "to bf16 summation order: tests/test_train_gpu.py::test_truncation_is_exact, loss within 2e-3, gradients "
+                                "within 2e-2 rel-L2) but skips the padded positions the reference computes")
     eng.truncate = False
     if args.fp8:   # BASELINE config[4], training side: frozen-weight block GEMMs (forward + dgrad) on the fp8 MFMA
         eng.fp8, eng.truncate = True, False
@@ -249,6 +262,9 @@ def bench_train(model, args, rank, world, dev):
             eng.fp8 = False
     out["policy"] = "no recompute; bf16; adapters+CLIP trunk+prefix trainable; clip 1.0 + AdamW in the timed region"
     out["per_gpu_batch"], out["seq_len"] = B, S
+    out["data_parallel"] = {"ranks": world, "backend": "RCCL (torch.distributed nccl)" if world > 1 else None,
+                            "gradient_exchange": ("bf16 buckets" if eng.exchange_bf16 else "fp32") if world > 1 else None,
+                            "global_batch": world * B}
     out["max_memory_allocated_GB"] = torch.cuda.max_memory_allocated() / 2 ** 30
     return out
 
@@ -416,6 +432,10 @@ def main():
             train = {"error": repr(e)[:300]}
     if rank == 0:
         line["train"] = train
+        # data-parallel training throughput of the whole job (BASELINE metric, first half), next to the headline
+        full = (train or {}).get("full_S2048") or {}
+        line["train_images_per_s"] = full.get("images_per_s")
+        line["train_ranks"] = world
         if not args.no_cpu_baseline and world == 1:   # reported on rank 0 at N=1 only
             try:
                 line["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)

@@ -323,6 +323,15 @@ int mg_sumsq_f32(const float* g, int64_t n, float* out, void* stream);
 int mg_adamw_f32(float* p, float* m, float* v, const float* g, mg_bf16* p_bf16, int64_t n, float lr,
                  float beta1, float beta2, float eps, float weight_decay, int32_t step, float max_norm,
                  const float* norm_sq, float grad_scale, void* stream);
+/* data-parallel exchange (reference train_loop.py:18-19 -> DeepSpeed ZeRO-2 reduces fp16 gradients; here bf16, 0.77 GB
+ * per step for MAGMA_v1): the fp32 flat gradients are cast into bf16 buckets, summed over the ranks by RCCL
+ * (torch.distributed, host side) and consumed as bf16 by the same fused clip + AdamW (g holds the SUM; grad_scale the
+ * 1 / (gas * world) of the mean).  n % 4 == 0 for the cast.                                                          */
+int mg_cast_f32_bf16(const float* src, mg_bf16* dst, int64_t n, void* stream);
+int mg_sumsq_bf16(const mg_bf16* g, int64_t n, float* out, void* stream);
+int mg_adamw_gbf16_f32(float* p, float* m, float* v, const mg_bf16* g, mg_bf16* p_bf16, int64_t n, float lr,
+                       float beta1, float beta2, float eps, float weight_decay, int32_t step, float max_norm,
+                       const float* norm_sq, float grad_scale, void* stream);
 
 /* ---- image preprocessing (reference magma/transforms.py:121-134) ----------------
  * One pass of Pillow's 8-bit antialiased resampling (ImagingResample, the arithmetic behind torchvision's

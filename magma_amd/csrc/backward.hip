@@ -422,20 +422,26 @@ __global__ __launch_bounds__(256) void im2col_t_kernel(const mg_bf16* __restrict
 // ---------------------------------------------------------------------------
 // optimizer: sum of squares (global grad norm) and fused clip + AdamW
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ out) {
+// gradient element as fp32: fp32 flat gradients (single GPU) or the bf16 buckets that went through RCCL (DP)
+MG_DEV float grad_ld(const float* g, int64_t i) { return g[i]; }
+MG_DEV float grad_ld(const mg_bf16* g, int64_t i) { return bf2f(g[i]); }
+
+template <typename G>
+__global__ __launch_bounds__(256) void sumsq_kernel(const G* __restrict__ g, int64_t n, float* __restrict__ out) {
   __shared__ float red[4];
   float s = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) { const float v = g[i]; s += v * v; }
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) { const float v = grad_ld(g, i); s += v * v; }
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
   if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
 }
 
-// p (fp32 master), m, v, g (fp32 grads, already averaged over ranks); writes the
-// bf16 model copy.  clip = min(1, max_norm / (sqrt(*norm_sq) + 1e-6)).
+// p (fp32 master), m, v, g (gradient SUM over micro-steps and ranks; grad_scale = 1 / (gas * world) turns it into the
+// mean); writes the bf16 model copy.  clip = min(1, max_norm / (sqrt(*norm_sq) + 1e-6)).
+template <typename G>
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
-                                                    const float* __restrict__ g, mg_bf16* __restrict__ p_bf16,
+                                                    const G* __restrict__ g, mg_bf16* __restrict__ p_bf16,
                                                     int64_t n, float lr, float beta1, float beta2, float eps,
                                                     float wd, float bc1, float bc2, float max_norm,
                                                     const float* __restrict__ norm_sq, float grad_scale) {
@@ -445,7 +451,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
     clip = grad_scale * fminf(1.0f, max_norm / (nrm + 1e-6f));
   }
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const float gi = g[i] * clip;
+    const float gi = grad_ld(g, i) * clip;
     float pi = p[i];
     pi -= lr * wd * pi;                                  // decoupled weight decay (torch.optim.AdamW)
     const float mi = beta1 * m[i] + (1.f - beta1) * gi;
@@ -454,6 +460,15 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
     pi -= lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
     p[i] = pi;
     if (p_bf16) p_bf16[i] = f2bf(pi);
+  }
+}
+
+// fp32 flat gradients -> bf16 exchange bucket (n % 4 == 0: one 16-byte load, one 8-byte store per thread)
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ src, mg_bf16* __restrict__ dst, int64_t nq) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nq; i += (int64_t)gridDim.x * 256) {
+    const f32x4 v = ((const f32x4*)src)[i];
+    u32x2 o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
+    ((u32x2*)dst)[i] = o;
   }
 }
 
@@ -585,19 +600,49 @@ extern "C" int mg_im2col_t_bf16(const mg_bf16* x, mg_bf16* out, int64_t ldo, int
 
 extern "C" int mg_sumsq_f32(const float* g, int64_t n, float* out, void* stream) {
   if (n <= 0 || !g || !out) MG_FAIL(MG_ERR_SHAPE, "mg_sumsq_f32: bad arguments");
-  hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n) > 1024 ? 1024 : grid_for(n)), dim3(256), 0, (hipStream_t)stream, g, n, out);
+  hipLaunchKernelGGL(sumsq_kernel<float>, dim3(grid_for(n) > 1024 ? 1024 : grid_for(n)), dim3(256), 0, (hipStream_t)stream, g, n, out);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }
 
+extern "C" int mg_sumsq_bf16(const mg_bf16* g, int64_t n, float* out, void* stream) {
+  if (n <= 0 || !g || !out) MG_FAIL(MG_ERR_SHAPE, "mg_sumsq_bf16: bad arguments");
+  hipLaunchKernelGGL(sumsq_kernel<mg_bf16>, dim3(grid_for(n) > 1024 ? 1024 : grid_for(n)), dim3(256), 0, (hipStream_t)stream, g, n, out);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
+extern "C" int mg_cast_f32_bf16(const float* src, mg_bf16* dst, int64_t n, void* stream) {
+  if (n <= 0 || (n & 3) || !src || !dst) MG_FAIL(MG_ERR_SHAPE, "mg_cast_f32_bf16: n must be a positive multiple of 4");
+  if (!MG_ALIGNED16(src) || (((uintptr_t)dst) & 7u)) MG_FAIL(MG_ERR_ALIGN, "mg_cast_f32_bf16: src 16-byte, dst 8-byte alignment required");
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, src, dst, n / 4);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
+namespace {
+template <typename G>
+int adamw_launch(float* p, float* m, float* v, const G* g, mg_bf16* p_bf16, int64_t n, float lr, float beta1, float beta2,
+                 float eps, float weight_decay, int32_t step, float max_norm, const float* norm_sq, float grad_scale,
+                 void* stream, const char* who) {
+  if (n <= 0 || step <= 0 || !p || !m || !v || !g) MG_FAIL(MG_ERR_SHAPE, "%s: bad arguments", who);
+  const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adamw_kernel<G>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, m, v, g, p_bf16, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, max_norm, norm_sq, grad_scale);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+}  // namespace
+
 extern "C" int mg_adamw_f32(float* p, float* m, float* v, const float* g, mg_bf16* p_bf16, int64_t n, float lr,
                             float beta1, float beta2, float eps, float weight_decay, int32_t step, float max_norm,
                             const float* norm_sq, float grad_scale, void* stream) {
-  if (n <= 0 || step <= 0 || !p || !m || !v || !g) MG_FAIL(MG_ERR_SHAPE, "mg_adamw_f32: bad arguments");
-  const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
-  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, m, v, g, p_bf16, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, max_norm, norm_sq, grad_scale);
-  MG_CHECK_LAUNCH();
-  return MG_OK;
+  return adamw_launch<float>(p, m, v, g, p_bf16, n, lr, beta1, beta2, eps, weight_decay, step, max_norm, norm_sq, grad_scale, stream, "mg_adamw_f32");
+}
+
+extern "C" int mg_adamw_gbf16_f32(float* p, float* m, float* v, const mg_bf16* g, mg_bf16* p_bf16, int64_t n, float lr,
+                                  float beta1, float beta2, float eps, float weight_decay, int32_t step, float max_norm,
+                                  const float* norm_sq, float grad_scale, void* stream) {
+  return adamw_launch<mg_bf16>(p, m, v, g, p_bf16, n, lr, beta1, beta2, eps, weight_decay, step, max_norm, norm_sq, grad_scale, stream, "mg_adamw_gbf16_f32");
 }
 
 extern "C" int mg_mul_bf16(const mg_bf16* a, const mg_bf16* b, mg_bf16* out, int64_t n, void* stream) {

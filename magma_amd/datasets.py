@@ -1,9 +1,67 @@
-"""Synthetic image-caption data with the output contract of the reference's
-ImgCptDataset + collate_fn (reference magma/datasets/dataset.py:133-143,155-160):
-images (B,3,H,W) float, captions (B,seq_len) int64 = T_i ~ U{8..64} random tokens
-followed by EOS padding to seq_len.  Real dataset readers are out
-of scope."""
+"""Image-caption data with the output contract of the reference's ImgCptDataset +
+collate_fn (reference magma/datasets/dataset.py:92-160): every item is
+(image (1,3,H,W) float, caption (1,seq_len) int64 right-padded with EOS); a batch is
+((B,3,H,W), (B,seq_len)).
+
+``ImgCptDataset`` reads the reference's on-disk layout (``<dir>/image_data/*/*.json`` records
+{"image_path": ..., "captions": [...]}, images relative to ``<dir>``); ``SyntheticImgCptDataset``
+draws T_i ~ U{8..64} random tokens + EOS padding for the benchmarks.  The dataset
+converters (reference convert_datasets.py) are out of scope."""
+import json
+import random
+from pathlib import Path
+
 import torch
+
+
+class ImgCptDataset(torch.utils.data.Dataset):
+    """On-disk image-caption records in the reference's standard format (dataset.py:92-153).
+
+    ``transforms`` maps a PIL image to (1,3,H,W) (Magma.transforms: on the GPU path the resize / crop /
+    normalise arithmetic runs as HIP kernels); ``tokenizer.encode(..., max_length=seq_len,
+    padding="max_length", truncation=True)`` yields the (1,seq_len) caption.  One caption of the record is drawn
+    at random per access; an unreadable image is replaced by another random item, as in the reference."""
+
+    def __init__(self, data_dir, tokenizer, transforms, seq_len: int = 2048, load_data_in_memory: bool = False):
+        self.data_dir = Path(data_dir)
+        self.tokenizer, self.transforms, self.seq_len = tokenizer, transforms, seq_len
+        self.paths = sorted((self.data_dir / "image_data").glob("*/*.json"))
+        if not self.paths:
+            raise FileNotFoundError(f"no records under {self.data_dir / 'image_data'}/*/*.json")
+        self.records = [self._read(p) for p in self.paths] if load_data_in_memory else None
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return json.load(f)
+        except (OSError, ValueError):
+            return None
+
+    def __len__(self):
+        return len(self.paths)
+
+    def _image_path(self, idx, rec):
+        if "image_path" in rec:
+            return self.data_dir / rec["image_path"]
+        p = self.paths[idx]            # no path in the record: images/<shard>/<name>.jpg next to image_data/<shard>/<name>.json
+        return self.data_dir / "images" / p.parent.name / (p.stem + ".jpg")
+
+    def __getitem__(self, idx):
+        import PIL.Image
+        for _ in range(64):
+            rec = self.records[idx] if self.records is not None else self._read(self.paths[idx])
+            if rec is not None and rec.get("captions"):
+                try:
+                    img = PIL.Image.open(self._image_path(idx, rec))
+                    image = self.transforms(img)
+                    caption = self.tokenizer.encode(random.choice(rec["captions"]), return_tensors="pt",
+                                                    max_length=self.seq_len, padding="max_length", truncation=True)
+                    return image, caption
+                except (PIL.UnidentifiedImageError, OSError, PIL.Image.DecompressionBombError, IndexError):
+                    print(f"Warning: Could not load image of record {self.paths[idx]}")
+            idx = random.randint(0, len(self) - 1)
+        raise RuntimeError(f"no readable image-caption record found under {self.data_dir}")
 
 
 class SyntheticImgCptDataset(torch.utils.data.Dataset):

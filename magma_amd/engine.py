@@ -76,11 +76,20 @@ class LMEngine:
         self.V = lm.lm_head.weight.shape[0]
         self.layers: List[_Layer] = []
         f32 = lambda t: t.detach().float().contiguous()  # noqa: E731
+        from .adapters import ParallelAdapter
         for blk in lm.transformer.h:
             ly = _Layer()
             attn = blk.attn
             ly.attn_adapter = None
-            if hasattr(attn, "attn_block"):          # AdapterWrapper (v2)
+            # parallel adapters (reference adapters.py:42-92) read the block INPUT (ln_1 output) instead of the wrapped
+            # module's output and are scaled by adapter_scale: *_par = fp32 [d] vector holding the scale, else None
+            ly.attn_par = ly.mlp_par = None
+            if isinstance(attn, ParallelAdapter):    # ParallelAdapterWrapper
+                ad = attn.adapter
+                ly.attn_adapter = (ops.PackedLinear(ad[0].weight, ad[0].bias), ops.PackedLinear(ad[2].weight, ad[2].bias))
+                ly.attn_par = torch.full((self.d,), attn.scale_value(), dtype=torch.float32, device=dev)
+                attn = attn.module
+            elif hasattr(attn, "attn_block"):        # AdapterWrapper (v2)
                 ad = attn.adapter
                 ly.attn_adapter = (ops.PackedLinear(ad[0].weight, ad[0].bias), ops.PackedLinear(ad[2].weight, ad[2].bias))
                 attn = attn.attn_block
@@ -89,7 +98,12 @@ class LMEngine:
             ly.out = ops.PackedLinear(a.out_proj.weight)
             mlp = blk.mlp
             ly.mlp_adapter = None
-            if isinstance(mlp, torch.nn.Sequential):  # Sequential(mlp, Adapter)  (reference magma.py:143-149)
+            if isinstance(mlp, ParallelAdapter):
+                ad = mlp.adapter
+                ly.mlp_adapter = (ops.PackedLinear(ad[0].weight, ad[0].bias), ops.PackedLinear(ad[2].weight, ad[2].bias))
+                ly.mlp_par = torch.full((self.d,), mlp.scale_value(), dtype=torch.float32, device=dev)
+                mlp = mlp.module
+            elif isinstance(mlp, torch.nn.Sequential):  # Sequential(mlp, Adapter)  (reference magma.py:143-149)
                 ad = mlp[1].adapter
                 ly.mlp_adapter = (ops.PackedLinear(ad[0].weight, ad[0].bias), ops.PackedLinear(ad[2].weight, ad[2].bias))
                 mlp = mlp[0]
@@ -106,7 +120,8 @@ class LMEngine:
         self.rot = cfg.rotary_dim
         self.head_dec = None
         self._lm_head = lm.lm_head
-        self._cache_pool = {}
+        self._cache_pool = {}                        # (B, Smax) -> KVCache + captured decode graph, LRU-bounded
+        self._cache_pool_max = int(os.environ.get("MAGMA_CACHE_POOL", "4"))
         # fp8 operands for the prefill / forward GEMMs (BASELINE config 5): None | "attn" (QKV, out_proj, adapters)
         # | "all" (+ fc_in, fc_out).  bf16 stays the default: it is what the parity tests and the headline use.
         self.fp8_mode = os.environ.get("MAGMA_FP8") or None
@@ -178,6 +193,18 @@ class LMEngine:
             ly.fp8 = {}
             ly.__dict__.pop("up_cat", None)
 
+    @staticmethod
+    def _par_up(up, par):
+        """(scale vector, packed up-projection whose bias is pre-multiplied by the scale) of a parallel adapter:
+        the epilogue computes acc*scale[n] + bias[n], the reference (acc + b_up) * adapter_scale."""
+        key = "_par_scaled"
+        sc = up.__dict__.get(key)
+        if sc is None:
+            sc = up.__dict__[key] = ops.PackedLinear.__new__(ops.PackedLinear)
+            sc.__dict__.update(up.__dict__)
+            sc.bias = None if up.bias is None else (up.bias * par[: up.N]).contiguous()
+        return par, sc
+
     def _adapter_up_cat(self, ly):
         """[W_up_mlp | W_up_attn] along K (bias = sum) for blocks that carry both adapters, or None."""
         if ly.mlp_adapter is None or ly.attn_adapter is None:
@@ -215,11 +242,12 @@ class LMEngine:
 
     # ------------------------------------------------------------------ API
     def forward(self, input_ids=None, inputs_embeds=None, labels=None, use_cache=False, past_key_values=None,
-                output_hidden_states=False, cache_hint: Optional[int] = None, reuse_cache: bool = False) -> LMOutput:
+                output_hidden_states=False, cache_hint: Optional[int] = None, reuse_cache: bool = False,
+                return_logits: bool = False) -> LMOutput:
         if labels is not None:
             if inputs_embeds is None:
                 inputs_embeds = self.embed_ids(input_ids)
-            return self.forward_loss(inputs_embeds, labels, output_hidden_states)
+            return self.forward_loss(inputs_embeds, labels, output_hidden_states, return_logits)
         if past_key_values is not None:
             if input_ids is None or input_ids.shape[1] != 1:
                 raise NotImplementedError("cached decoding takes one new token id per sequence (reference sampling.py:88-90)")
@@ -266,11 +294,20 @@ class LMEngine:
             ops.rotary_split(qkv, B, S, self.H, self.rot, self.sin_t, self.cos_t, q, kc, vc, pos0=0, vt=vt)
             ops.attn_prefill(q, kc, vt, ctx, B, self.H, S, lse=None if lse_out is None else lse_out[li])
             a = self._linear(ly, "out", ly.out, ctx)
-            if ly.attn_adapter is not None:
+            if ly.attn_adapter is not None and ly.attn_par is not None:      # parallel: adapter reads the attention INPUT
+                sc, up = self._par_up(ly.attn_adapter[1], ly.attn_par)
+                t = self._linear(ly, "attn_dn", ly.attn_adapter[0], ln, act=ops.MG_ACT_RELU)
+                a = ops.gemm(t, up, scale=sc, residuals=(a,))
+            elif ly.attn_adapter is not None:
                 t = self._linear(ly, "attn_dn", ly.attn_adapter[0], a, act=ops.MG_ACT_RELU)
                 a = self._linear(ly, "attn_up", ly.attn_adapter[1], t, residuals=(a,))
             h = self._linear(ly, "fc_in", ly.fc_in, ln, lnq, act=ops.MG_ACT_GELU_NEW)
-            if ly.mlp_adapter is not None:
+            if ly.mlp_adapter is not None and ly.mlp_par is not None:        # parallel: adapter reads the MLP INPUT
+                sc, up = self._par_up(ly.mlp_adapter[1], ly.mlp_par)
+                m = self._linear(ly, "fc_out", ly.fc_out, h)
+                t = self._linear(ly, "mlp_dn", ly.mlp_adapter[0], ln, act=ops.MG_ACT_RELU)
+                x = ops.gemm(t, up, scale=sc, residuals=(m, a, x))
+            elif ly.mlp_adapter is not None:
                 m = self._linear(ly, "fc_out", ly.fc_out, h)
                 t = self._linear(ly, "mlp_dn", ly.mlp_adapter[0], m, act=ops.MG_ACT_RELU)
                 x = self._linear(ly, "mlp_up", ly.mlp_adapter[1], t, residuals=(m, a, x))
@@ -289,9 +326,12 @@ class LMEngine:
             # generate() owns the cache for the duration of one call: keep one KV cache (and the
             # hipGraph of the token step captured on it) per shape instead of re-allocating and
             # re-capturing for every call
-            cache = self._cache_pool.get((B, Smax))
+            cache = self._cache_pool.pop((B, Smax), None)
             if cache is None:
-                cache = self._cache_pool[(B, Smax)] = KVCache(self.L, B, self.H, Smax, self.device)
+                while len(self._cache_pool) >= self._cache_pool_max:      # least recently used shape goes first
+                    self._cache_pool.pop(next(iter(self._cache_pool)))
+                cache = KVCache(self.L, B, self.H, Smax, self.device)
+            self._cache_pool[(B, Smax)] = cache                          # (re-)insert as most recently used
         else:
             cache = KVCache(self.L, B, self.H, Smax, self.device)
         x, hs = self._blocks_prefill(embeds, cache, want_hidden)
@@ -356,7 +396,8 @@ class LMEngine:
                             split=(d3, st.h, ops.MG_ACT_GELU_NEW, src.dec_in.bias_b), variant=self._dec_in_variant)
             # attention branch (latency-bound, 128 workgroups) runs on a second HIP stream
             # underneath the MLP branch's weight streaming; both join at the adapter-up GEMV
-            grouped = (self.group_launches and ly.mlp_adapter is not None and ly.attn_adapter is None
+            par = ly.mlp_par is not None or ly.attn_par is not None
+            grouped = (self.group_launches and not par and ly.mlp_adapter is not None and ly.attn_adapter is None
                        and ly.fc_out.Kp % 128 == 0 and ly.out.Kp % 128 == 0 and ly.mlp_adapter[0].Kp % 128 == 0)
             if grouped:
                 # launch 2: attention workgroups + fc_out GEMV workgroups in one grid (they are independent
@@ -372,7 +413,7 @@ class LMEngine:
                 continue
             if w8_on:
                 raise NotImplementedError("W8A16 decode covers the grouped MAGMA_v1 step (mlp adapters, K % 128 == 0) only")
-            up_cat = self._adapter_up_cat(ly) if self.group_launches else None
+            up_cat = self._adapter_up_cat(ly) if self.group_launches and not par else None
             if up_cat is not None:
                 # MAGMA_v2 (attention AND mlp adapters): 5 launches.  x' = up_m(t) + up_a(ta) + m + a + x is ONE GEMV over
                 # the concatenated bottlenecks [t | ta] against [W_up_m | W_up_a] (the adapter outputs only ever appear summed).
@@ -391,19 +432,31 @@ class LMEngine:
             ops.attn_decode_fused(st.qkv, cache.k[li], cache.v[li], st.ctx, B, self.H, cache.d_pos, self.rot,
                                   self.sin_t, self.cos_t)
             a = ops.gemm_skinny(st.ctx, ly.out, out=st.a)
+            if par:      # parallel adapters read ln_1(x): the one decode configuration that needs the LayerNorm as a tensor
+                ops.layernorm(x, ly.ln_g, ly.ln_b, self.eps, out=st.ln)
             if ly.attn_adapter is not None:
                 ta = st.ta[:, : ly.attn_adapter[0].N]
-                ops.gemm_skinny(a, ly.attn_adapter[0], out=ta, act=ops.MG_ACT_RELU)
-                a = ops.gemm_skinny(ta, ly.attn_adapter[1], out=st.a2, residuals=(a,))
+                if ly.attn_par is not None:
+                    sc, up = self._par_up(ly.attn_adapter[1], ly.attn_par)
+                    ops.gemm_skinny(st.ln, ly.attn_adapter[0], out=ta, act=ops.MG_ACT_RELU)
+                    a = ops.gemm_skinny(ta, up, out=st.a2, scale=sc, residuals=(a,))
+                else:
+                    ops.gemm_skinny(a, ly.attn_adapter[0], out=ta, act=ops.MG_ACT_RELU)
+                    a = ops.gemm_skinny(ta, ly.attn_adapter[1], out=st.a2, residuals=(a,))
             if side is not None:
                 torch.cuda.set_stream(main)
             if ly.mlp_adapter is not None:
                 ops.gemm_skinny(st.h, ly.fc_out, out=st.m)
                 t = st.t[:, : ly.mlp_adapter[0].N]
-                ops.gemm_skinny(st.m, ly.mlp_adapter[0], out=t, act=ops.MG_ACT_RELU)
                 if side is not None:
                     main.wait_stream(side)
-                ops.gemm_skinny(t, ly.mlp_adapter[1], out=xn, residuals=(st.m, a, x))
+                if ly.mlp_par is not None:
+                    sc, up = self._par_up(ly.mlp_adapter[1], ly.mlp_par)
+                    ops.gemm_skinny(st.ln, ly.mlp_adapter[0], out=t, act=ops.MG_ACT_RELU)
+                    ops.gemm_skinny(t, up, out=xn, scale=sc, residuals=(st.m, a, x))
+                else:
+                    ops.gemm_skinny(st.m, ly.mlp_adapter[0], out=t, act=ops.MG_ACT_RELU)
+                    ops.gemm_skinny(t, ly.mlp_adapter[1], out=xn, residuals=(st.m, a, x))
             else:
                 if side is not None:
                     main.wait_stream(side)
@@ -445,7 +498,7 @@ class LMEngine:
         return st.logits[:, : self.V], st.token
 
     # ------------------------------------------------- loss (eval) forward
-    def forward_loss(self, embeds: torch.Tensor, labels: torch.Tensor, want_hidden=False) -> LMOutput:
+    def forward_loss(self, embeds: torch.Tensor, labels: torch.Tensor, want_hidden=False, want_logits=False) -> LMOutput:
         """Shifted cross-entropy of the full sequence (reference magma.py:270-274).
         lm_head + CE are evaluated only on rows that carry a target (the others
         contribute nothing to the loss); inference-mode forward, see train engine
@@ -464,5 +517,6 @@ class LMEngine:
         logits = torch.empty(xl.shape[0], self.Vp, dtype=torch.float32, device=self.device)
         ops.gemm(xl, self.head, out=logits)
         loss, _ = ops.cross_entropy(logits[:, : self.V], tgt[keep].contiguous())
-        return LMOutput(loss=loss, logits=None, hidden_states=hs, past_key_values=None,
+        full = self._full_logits(x, B * S).view(B, S, self.V) if want_logits else None   # reference magma.py:270-276 .logits
+        return LMOutput(loss=loss, logits=full, hidden_states=hs, past_key_values=None,
                         target_rows=rows[keep], target_logits=logits[:, : self.V])

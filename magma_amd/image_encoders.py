@@ -1,8 +1,9 @@
 """Image encoders for the MAGMA path (reference magma/image_encoders.py:48-91).
 
-Only ``clip_resnet_large`` (CLIP RN50x16 trunk with the attention pool replaced
-by ``b d h w -> b (h w) d``) is selected by the shipped YAMLs and is in scope;
-the others raise.  The module tree carries openai/CLIP's
+``clip_resnet_large`` (CLIP RN50x16 trunk with the attention pool replaced by
+``b d h w -> b (h w) d``) is what the shipped YAMLs select; ``clip_resnet``
+(RN50x4) is the same trunk at another width/depth.  ViT-B/32 and nfresnet50
+raise.  The module tree carries openai/CLIP's
 parameter names (conv1..3, bn1..3, layer{1..4}.{j}.{conv,bn}{1..3},
 downsample.{0,1}) so reference checkpoints load by name, but the arithmetic is
 NOT torch: forward() drives the HIP kernels -- NHWC activations, every conv an
@@ -20,8 +21,10 @@ from . import ops
 
 CLIP_RESNETS = {
     # name: (layers, width, input_resolution)
-    "clip_resnet_large": ((6, 8, 18, 8), 96, 384),  # RN50x16
+    "clip_resnet_large": ((6, 8, 18, 8), 96, 384),  # RN50x16 (MAGMA_v1 / v2)
+    "clip_resnet": ((4, 6, 10, 6), 80, 288),         # RN50x4 (reference image_encoders.py:58-59): same trunk, 2560 channels
 }
+_ALIASES = {"RN50x16": "clip_resnet_large", "RN50x4": "clip_resnet"}
 
 
 class Bottleneck(nn.Module):
@@ -152,11 +155,13 @@ class ModifiedResNetTrunk(nn.Module):
 
 
 def clip_encoder(device=None, name: str = "clip_resnet_large", dtype=None) -> nn.Module:
-    if name in ("clip_resnet_large", "RN50x16"):
-        layers, width, res = CLIP_RESNETS["clip_resnet_large"]
+    name = _ALIASES.get(name, name)
+    if name in CLIP_RESNETS:
+        layers, width, res = CLIP_RESNETS[name]
         return ModifiedResNetTrunk(layers, width, res, device=device, dtype=dtype)
-    raise NotImplementedError(f"encoder {name!r} is out of scope for the MI355X path (SURVEY 8f row 4); "
-                              "only clip_resnet_large (RN50x16) is implemented")
+    raise NotImplementedError(f"encoder {name!r} is not implemented on the MI355X path (SURVEY 8f row 4): the CLIP ResNet "
+                              "trunks (clip_resnet_large = RN50x16, clip_resnet = RN50x4) are; ViT-B/32 needs a dh=64 "
+                              "attention kernel this build does not have")
 
 
 def get_image_encoder(name: str, device=None, pretrained: bool = False, dtype=None) -> nn.Module:

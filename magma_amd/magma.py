@@ -20,7 +20,7 @@ from typing import List, Optional
 import torch
 import torch.nn as nn
 
-from .adapters import Adapter, AdapterWrapper
+from .adapters import Adapter, AdapterWrapper, ParallelAdapter, ParallelAdapterWrapper
 from .config import MultimodalConfig
 from .image_input import ImageInput
 from .image_prefix import ImagePrefix
@@ -44,6 +44,10 @@ class Magma(nn.Module):
             from .lib import MagmaHipError
             raise MagmaHipError("magma_amd.Magma runs on MI355X only (device=%s requested); there is no CPU "
                                 "execution path -- the CPU restatement lives in oracle/ and is test-only" % self.device)
+        # every kernel launches on the CURRENT HIP device / stream (ops._need_gpu refuses operands that live elsewhere):
+        # the model's device becomes current here and again in the entry points below
+        torch.cuda.set_device(self.device)
+        self.device = torch.device("cuda", torch.cuda.current_device())
         self.config = config
         self.dtype = dtype
         self.lm = get_gptj(device=self.device, dtype=dtype, config=lm_config, init=True)
@@ -94,16 +98,22 @@ class Magma(nn.Module):
         assert adapter_type in ["normal", "parallel", "scaled_parallel"], \
             "adapter_type must be one of 'normal', 'parallel', or 'scaled_parallel'"
         assert location in ["mlp", "attention"], "location must be one of 'mlp' or 'attention'"
-        if adapter_type != "normal":
-            raise NotImplementedError("parallel adapters are not used by MAGMA_v1/v2 and are out of scope (SURVEY 8f row 4)")
+        parallel = adapter_type in ("parallel", "scaled_parallel")
         if (location == "mlp" and self.mlp_adapter_added) or (location == "attention" and self.attn_adapter_added):
             raise ValueError("Adapter layer already added")
         dim = self.lm.config.hidden_size
         kw = dict(device=self.device, dtype=self.dtype)
         for blk in self.transformer:
-            if location == "mlp":
+            if location == "mlp" and parallel:        # reference magma.py:129-136
+                setattr(blk, ff_attr, ParallelAdapter(module=getattr(blk, ff_attr), dim=dim, downsample_factor=downsample_factor,
+                                                      scaled=adapter_type == "scaled_parallel", **adapter_kwargs, **kw))
+            elif location == "mlp":
                 adpt = Adapter(dim=dim, downsample_factor=downsample_factor, **adapter_kwargs, **kw)
                 setattr(blk, ff_attr, nn.Sequential(getattr(blk, ff_attr), adpt))
+            elif parallel:                            # reference magma.py:154-161
+                setattr(blk, attn_attr, ParallelAdapterWrapper(module=getattr(blk, attn_attr), dim=dim,
+                                                               downsample_factor=downsample_factor,
+                                                               scaled="scaled" in adapter_type, **adapter_kwargs, **kw))
             else:
                 setattr(blk, attn_attr, AdapterWrapper(attn_block=getattr(blk, attn_attr), dim=dim,
                                                        downsample_factor=downsample_factor, **adapter_kwargs, **kw))
@@ -141,6 +151,7 @@ class Magma(nn.Module):
         """2-D -> word embeddings, 4-D -> image prefix; written straight into one
         (b, s, d) buffer (replaces the torch.cat at reference magma.py:212)."""
         from . import ops
+        torch.cuda.set_device(self.device)
         parts, total, B = [], 0, None
         for x in inputs:
             if x.ndim == 2:
@@ -175,12 +186,17 @@ class Magma(nn.Module):
     @torch.no_grad()
     def generate(self, embeddings, max_steps: int = 100, temperature: float = 0.7, top_k: int = 0,
                  top_p: float = 0.9, decode: bool = True, stop_on_eos: bool = True):
+        torch.cuda.set_device(self.device)
         return generate(self, embeddings=embeddings, max_steps=max_steps, temperature=temperature, top_k=top_k,
                         top_p=top_p, decode=decode, stop_on_eos=stop_on_eos)
 
     # ------------------------------------------------------------- forward
     def forward(self, images=None, captions=None, output_hidden_states: bool = False, input_embeddings=None,
-                dropout_mask=None) -> LMOutput:
+                dropout_mask=None, return_logits: bool = False) -> LMOutput:
+        """reference magma.py:238-276.  ``.loss`` always; ``.logits`` (B, seq_len, V) bf16 only with
+        ``return_logits=True`` -- the reference materialises them on every call (2048 x 50258 per sample), this
+        path evaluates lm_head on the rows that carry a target unless the caller asks for the full tensor."""
+        torch.cuda.set_device(self.device)
         assert captions is not None, "Must provide captions in training"
         assert (images is None) != (input_embeddings is None), "Pass in either images, or input embeddings, not both."
         assert captions.shape[1] == self.seq_len, \
@@ -195,7 +211,8 @@ class Magma(nn.Module):
         emb = torch.empty(B, S, self.lm.config.hidden_size, dtype=self.dtype, device=self.device)
         emb[:, :P] = input_embeddings
         ops.embedding(captions[:, : S - P].contiguous(), self.lm.engine.wte, emb, row_off=P)
-        out = self.lm(inputs_embeds=emb, labels=labels, output_hidden_states=output_hidden_states)
+        out = self.lm(inputs_embeds=emb, labels=labels, output_hidden_states=output_hidden_states,
+                      return_logits=return_logits)
         out["labels"] = labels
         return out
 
@@ -208,11 +225,20 @@ class Magma(nn.Module):
         if not exists(checkpoint_path):
             raise FileNotFoundError(f"checkpoint {checkpoint_path} does not exist (no network download in this build)")
         model = cls(config=config_path, device=device)
+        from .tokenizer import ByteTokenizer
+        if isinstance(model.tokenizer, ByteTokenizer) and os.environ.get("MAGMA_ALLOW_BYTE_TOKENIZER") != "1":
+            raise RuntimeError("from_checkpoint needs the real GPT-2 tokenizer (set MAGMA_TOKENIZER_DIR to its files): the "
+                               "byte-level stand-in would feed the wrong token ids to trained weights.  "
+                               "MAGMA_ALLOW_BYTE_TOKENIZER=1 overrides (synthetic checkpoints / tests).")
         sd = torch.load(checkpoint_path, map_location=torch.device("cpu"))
         if "module" in sd.keys():
             sd = sd["module"]
         print_main(f"loading magma checkpoint from: {checkpoint_path}")
-        model.load_checkpoint_state(sd)
+        missing, unexpected = model.load_checkpoint_state(sd)
+        if missing:
+            print_main(f"checkpoint has no value for {len(missing)} tensors (kept at their initial values): {missing[:8]}...")
+        if unexpected:
+            print_main(f"checkpoint keys without a destination: {unexpected[:8]}...")
         print_main("magma successfully loaded")
         model.eval()
         return model
@@ -238,12 +264,18 @@ class Magma(nn.Module):
                 self.word_embedding = self.lm.transformer.wte
                 own = self.state_dict()
         missing, unexpected = [], []
+        bad = [f"{k}: checkpoint {tuple(v.shape)} vs model {tuple(own[k].shape)}" for k, v in fixed.items()
+               if k in own and own[k].shape != v.shape]
+        if bad:     # load_state_dict(strict=False) raises on a size mismatch too (reference magma.py:298)
+            raise RuntimeError("size mismatch while loading the checkpoint: " + "; ".join(bad[:6]))
         with torch.no_grad():
             for k, v in fixed.items():
-                if k in own and own[k].shape == v.shape:
+                if k in own:
                     own[k].copy_(v.to(own[k].dtype))
                 else:
                     unexpected.append(k)
-        missing = [k for k in own if k not in fixed]
+        # the aliases of Q8 and BatchNorm's step counters are not "missing"
+        missing = [k for k in own if k not in fixed and not k.endswith("num_batches_tracked")
+                   and not k.startswith(("transformer.", "word_embedding."))]
         self.invalidate_packed()
         return missing, unexpected

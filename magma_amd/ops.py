@@ -23,10 +23,18 @@ def _stream() -> int:
 
 
 def _need_gpu(*ts):
+    """Every op launches on the CURRENT device and its current stream (_stream): operands on a CPU, or on a GPU
+    that is not the current one, are refused instead of faulting / silently peer-accessing (Magma.__init__ and the
+    entry points of Magma / MagmaEngine make the model's device current)."""
     for t in ts:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise L.MagmaHipError(
                 "magma_amd ops run on MI355X only (tensor on %s); there is no CPU fallback" % t.device)
+        if t.device.index != torch.cuda.current_device():
+            raise L.MagmaHipError("tensor on %s but the current HIP device is cuda:%d: wrap the call in "
+                                  "torch.cuda.device(tensor.device)" % (t.device, torch.cuda.current_device()))
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -126,7 +134,7 @@ _SPLITK_WS = {}
 def splitk_workspace(device) -> torch.Tensor:
     """fp32 scratch of the split-K GEMMs, one per (device, stream) -- launches on one stream are ordered,
     so they can share it.  MAGMA_SPLITK_WS_MB sizes it (default 64)."""
-    key = (torch.device(device).index, torch.cuda.current_stream(device).cuda_stream)
+    key = (torch.cuda.current_device(), _stream())        # same device / stream the kernels launch on
     ws = _SPLITK_WS.get(key)
     if ws is None:
         mb = int(os.environ.get("MAGMA_SPLITK_WS_MB", "64"))
@@ -188,6 +196,16 @@ class RawWeight:
         self.Kp = w.stride(0)
         self.rm, self.ft = w, None
         self.bias = bias
+
+
+def pad_k_rowmajor(w: torch.Tensor) -> torch.Tensor:
+    """[N, K] bf16 -> contiguous row-major GEMM operand whose row stride is a multiple of 8 elements."""
+    n, k = w.shape
+    if k % 8 == 0:
+        return w.contiguous()
+    out = torch.zeros(n, ceil_to(k, 8), dtype=w.dtype, device=w.device)
+    out[:, :k] = w
+    return out
 
 
 def skinny_desc(x: torch.Tensor, w: PackedLinear, out: Optional[torch.Tensor] = None, *, act: int = MG_ACT_NONE,
@@ -541,12 +559,25 @@ def im2col_t(x_nhwc: torch.Tensor, B, H, W, Cin) -> torch.Tensor:
 
 
 def sumsq(g: torch.Tensor, out: torch.Tensor):
-    check(L.load().mg_sumsq_f32(g.data_ptr(), g.numel(), out.data_ptr(), _stream()), "mg_sumsq_f32")
+    """out[0] += sum(g^2); g fp32 or bf16 (the exchanged buckets of the data-parallel step)."""
+    _need_gpu(g, out)
+    fn = L.load().mg_sumsq_bf16 if g.dtype == BF16 else L.load().mg_sumsq_f32
+    check(fn(g.data_ptr(), g.numel(), out.data_ptr(), _stream()), "mg_sumsq")
+
+
+def cast_f32_bf16(src: torch.Tensor, dst: torch.Tensor):
+    _need_gpu(src, dst)
+    assert src.dtype == torch.float32 and dst.dtype == BF16 and src.numel() == dst.numel() and src.is_contiguous()
+    check(L.load().mg_cast_f32_bf16(src.data_ptr(), dst.data_ptr(), src.numel(), _stream()), "mg_cast_f32_bf16")
+    return dst
 
 
 def adamw(p, m, v, g, p_bf16, lr, beta1, beta2, eps, wd, step, max_norm=0.0, norm_sq=None, grad_scale=1.0):
-    check(L.load().mg_adamw_f32(p.data_ptr(), m.data_ptr(), v.data_ptr(), g.data_ptr(), _p(p_bf16), p.numel(), lr,
-                                beta1, beta2, eps, wd, step, max_norm, _p(norm_sq), grad_scale, _stream()), "mg_adamw_f32")
+    """Fused clip + AdamW on fp32 master / m / v; g = gradient sum in fp32 or bf16."""
+    _need_gpu(p, g)
+    fn = L.load().mg_adamw_gbf16_f32 if g.dtype == BF16 else L.load().mg_adamw_f32
+    check(fn(p.data_ptr(), m.data_ptr(), v.data_ptr(), g.data_ptr(), _p(p_bf16), p.numel(), lr,
+             beta1, beta2, eps, wd, step, max_norm, _p(norm_sq), grad_scale, _stream()), "mg_adamw")
 
 
 def bn_fold(gamma, beta, mean, var, eps: float):

@@ -4,12 +4,15 @@ The reference calls ``GPT2TokenizerFast.from_pretrained("gpt2")`` (network) and
 adds ``<|image|>`` as cls token (reference magma/utils.py:43-58): ids eos = pad
 = 50256, image = 50257, len = 50258.  With no network we (1) use the real GPT-2
 tokenizer when its files are available locally (``MAGMA_TOKENIZER_DIR`` or the
-HF cache), else (2) fall back to a byte-level tokenizer with the same special
-ids and vocabulary size, which is enough for synthetic-data runs and for every
-shape/plumbing contract on the hot path (token ids are just integers to it)."""
+HF cache), else (2) fall back -- with a warning -- to a byte-level tokenizer
+with the same special ids and vocabulary size, which is enough for synthetic-data
+runs and for every shape/plumbing contract on the hot path (token ids are just
+integers to it).  The stand-in produces the WRONG ids for real MAGMA weights, so
+``Magma.from_checkpoint`` refuses it unless ``MAGMA_ALLOW_BYTE_TOKENIZER=1``."""
 from __future__ import annotations
 
 import os
+import warnings
 from typing import List
 
 import torch
@@ -63,5 +66,10 @@ def get_tokenizer(name: str = "gpt2", sequence_length: int = 2048):
         if tok.eos_token_id != EOS_ID or tok.cls_token_id != IMAGE_ID or len(tok) != VOCAB:
             raise RuntimeError("local gpt2 tokenizer files are missing or incomplete")
         return tok
-    except Exception:  # noqa: BLE001 -- no local GPT-2 files: byte-level stand-in
+    except Exception as e:  # noqa: BLE001 -- no local GPT-2 files: byte-level stand-in, loudly
+        if os.environ.get("MAGMA_REQUIRE_GPT2_TOKENIZER") == "1":
+            raise RuntimeError("the GPT-2 tokenizer files are not available locally (set MAGMA_TOKENIZER_DIR)") from e
+        warnings.warn("GPT-2 tokenizer files not found locally (%s: %s): using the byte-level stand-in (ids 0..255 + "
+                      "specials).  Fine for synthetic data; WRONG for real MAGMA checkpoints -- set MAGMA_TOKENIZER_DIR."
+                      % (type(e).__name__, str(e)[:120]), RuntimeWarning, stacklevel=2)
         return ByteTokenizer(sequence_length)

@@ -48,6 +48,7 @@ class FlatGroup:
         self.v = torch.zeros(n, dtype=F32, device=device)
         self.grad = torch.zeros(n, dtype=F32, device=device)
         self.model = torch.zeros(n, dtype=BF16, device=device)     # bf16 copy the kernels read
+        self.comm = None                                           # bf16 exchange buckets (data-parallel runs only)
         for p, o in zip(params, self.offsets):
             self.master[o:o + p.numel()].copy_(p.data.reshape(-1).float())
         self.model.copy_(self.master)
@@ -111,6 +112,14 @@ class MagmaEngine:
         self.module = model
         self.config = config or model.config
         self.device = model.device
+        torch.cuda.set_device(self.device)      # kernels launch on the current device (ops._need_gpu)
+        if not self.config.freeze_lm:
+            raise NotImplementedError("freeze_lm: false (training the 6B GPT-J weights, ~100 GB of fp32 optimizer state) is not "
+                                      "implemented: no LM weight gradients are computed on this path (SURVEY Q2: adapters, image "
+                                      "encoder and prefix train)")
+        from .adapters import ParallelAdapter
+        if any(isinstance(m, ParallelAdapter) for m in model.modules()):
+            raise NotImplementedError("training with parallel / scaled_parallel adapters is not implemented (inference only)")
         self.betas, self.eps = betas, eps
         self.truncate = truncate or os.environ.get("MAGMA_TRUNCATE", "0") == "1"
         # BASELINE config[4]: the frozen-weight block GEMMs (qkv, out_proj, fc_in, fc_out; forward and dgrad) on the fp8
@@ -141,14 +150,24 @@ class MagmaEngine:
         self._norm_sq = torch.zeros(1, dtype=F32, device=self.device)
         self._dist = dist.is_initialized()            # a 1-rank process group still exercises the overlap path
         self._comm_stream = torch.cuda.Stream(device=self.device) if self._dist else None
+        # gradient exchange dtype: bf16 buckets (0.77 GB per step for MAGMA_v1; the reference's ZeRO-2 reduces its fp16
+        # gradients the same way) or the fp32 flat buffers themselves (MAGMA_DP_GRAD_DTYPE=fp32, 1.54 GB)
+        self.exchange_bf16 = self._dist and os.environ.get("MAGMA_DP_GRAD_DTYPE", "bf16") != "fp32"
+        if self.exchange_bf16:
+            for g in self.groups:
+                g.comm = torch.zeros(g.n, dtype=BF16, device=self.device)
         self._reduced = [[] for _ in self.groups]     # per group: (lo, hi) ranges already handed to RCCL this step
         self._works = []
         if self._dist and self.world > 1:
-            # every replica starts from rank 0's trainable parameters and BatchNorm statistics (what
-            # deepspeed.initialize does for the reference, train.py:103-111)
+            # every replica starts from rank 0's model: trainable masters, FROZEN parameters (a random-init GPT-J differs
+            # per process unless seeded) and BatchNorm statistics -- what deepspeed.initialize does for the reference
+            # (train.py:103-111 broadcasts every module parameter).  One-off 12.9 GB over xGMI.
             for g in self.groups:
                 dist.broadcast(g.master, src=0)
                 g.model.copy_(g.master)
+            for p in model.parameters():
+                if id(p) not in self._where and p.device.type == "cuda":
+                    dist.broadcast(p.data, src=0)
             for buf in model.buffers():
                 if buf.is_floating_point() and buf.device.type == "cuda":
                     dist.broadcast(buf, src=0)
@@ -180,15 +199,24 @@ class MagmaEngine:
             spans[gi] = (min(a, lo), max(b, hi))
             sizes[gi] = sizes.get(gi, 0) + (hi - lo)
         spans = {gi: s for gi, s in spans.items() if s[1] - s[0] == sizes[gi]}   # contiguous buckets only
+        todo = [(gi, lo, hi) for gi, (lo, hi) in spans.items()
+                if not any(not (hi <= a or lo >= b) for a, b in self._reduced[gi])]   # overlapping an in-flight range: step()
+        bufs = [self._exchange_view(gi, lo, hi) for gi, lo, hi in todo]           # bf16 casts run on the compute stream
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
-        for gi, (lo, hi) in spans.items():
-            if any(not (hi <= a or lo >= b) for a, b in self._reduced[gi]):
-                continue                                  # overlaps a range already in flight: leave it to step()
+        for (gi, lo, hi), buf in zip(todo, bufs):
             with torch.cuda.stream(self._comm_stream):
                 self._comm_stream.wait_event(ev)
-                self._works.append(dist.all_reduce(self.groups[gi].grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+                self._works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True))
             self._reduced[gi].append((lo, hi))
+
+    def _exchange_view(self, gi, lo, hi):
+        """The tensor RCCL sums for flat-gradient range [lo, hi) of group gi: the bf16 bucket (filled here from the fp32
+        accumulator) or the fp32 range itself."""
+        g = self.groups[gi]
+        if not self.exchange_bf16:
+            return g.grad[lo:hi]
+        return ops.cast_f32_bf16(g.grad[lo:hi], g.comm[lo:hi])
 
     def _finish_reduce(self):
         """Reduce whatever backward did not hand over, then join the comm stream."""
@@ -200,14 +228,14 @@ class MagmaEngine:
             pos, rest = 0, []
             for a, b in done:
                 if a > pos:
-                    rest.append(g.grad[pos:a])
+                    rest.append(self._exchange_view(gi, pos, a))
                 pos = max(pos, b)
             if pos < g.n:
-                rest.append(g.grad[pos:g.n])
+                rest.append(self._exchange_view(gi, pos, g.n))
             allreduce_grads(rest)
             self._reduced[gi] = []
         for w in self._works:
-            w.wait()
+            w.wait()                      # stream-side join (no host block for the RCCL backend)
         self._works = []
         torch.cuda.current_stream().wait_stream(self._comm_stream)
 
@@ -236,11 +264,31 @@ class MagmaEngine:
         return self.train(False)
 
     # ---- forward ---------------------------------------------------------------
-    def __call__(self, images, captions, dropout_mask=None) -> LMOutput:
+    def __call__(self, images, captions, dropout_mask=None, captions_host=None) -> LMOutput:
+        torch.cuda.set_device(self.device)
         if not self.training:
             with torch.no_grad():
                 return self.module(images, captions)
-        return self.forward_train(images, captions, dropout_mask)
+        return self.forward_train(images, captions, dropout_mask, captions_host)
+
+    @staticmethod
+    def target_index(captions_host: torch.Tensor, P: int, eos: int, S: int):
+        """Index plumbing of the loss head, computed on the HOST from the captions the data loader produced there (no
+        device sync in the step): flat rows b*S + j of the hidden states whose NEXT position carries a
+        label, and those labels.  Mirrors build_labels (reference utils.py:334-364): position P + k holds captions[b, k]
+        for k <= first EOS of the row (the EOS itself is kept), everything else is -100; shifted by one for the loss."""
+        cap = captions_host[:, : S - P].to(torch.int64)
+        B, T = cap.shape
+        is_eos = cap == eos
+        first = torch.where(is_eos.any(1), is_eos.int().argmax(1), torch.full((B,), T - 1, dtype=torch.int64))
+        k = torch.arange(T)[None, :]
+        valid = k <= first[:, None]                          # label positions P + k
+        if P == 0:
+            valid[:, 0] = False                              # position 0 has no predecessor
+        b_idx, k_idx = valid.nonzero(as_tuple=True)
+        rows = b_idx * S + (P + k_idx - 1)
+        return rows, cap[b_idx, k_idx], first
+
 
     def _lm_packs(self):
         """Transposed copies of the frozen LM weights for the dgrad GEMMs (one-off, 12 GB)."""
@@ -280,11 +328,13 @@ class MagmaEngine:
         q, sc = xq if xq is not None else ops.quantize_rows_fp8(x)
         return ops.gemm_fp8(q, sc, w8, **kw)
 
-    def forward_train(self, images, captions, dropout_mask=None) -> LMOutput:
+    def forward_train(self, images, captions, dropout_mask=None, captions_host=None) -> LMOutput:
         model = self.module
         eng = model.lm.engine
         dev = self.device
-        captions = captions.to(dev).contiguous()
+        if captions_host is None:      # captions straight from the loader are host tensors; a device tensor costs one D2H sync
+            captions_host = captions if not captions.is_cuda else captions.cpu()
+        captions = captions.to(dev, non_blocking=True).contiguous()
         B, S_full = captions.shape
         assert S_full == model.seq_len, "captions must be padded to the sequence length (reference magma.py:249-251)"
         tape = {"B": B}
@@ -294,12 +344,12 @@ class MagmaEngine:
         P = prefix.shape[1]
         labels = ops.build_labels(captions, P, model.eos_token)
         S = S_full
+        rows, tgt, first = self.target_index(captions_host, P, model.eos_token, S_full)
         if self.truncate:     # causal attention + masked loss => identical loss/grads
-            first_eos = (captions[:, : S_full - P] == model.eos_token).int().argmax(1)
-            has = (captions[:, : S_full - P] == model.eos_token).any(1)
-            last = torch.where(has, first_eos, torch.full_like(first_eos, S_full - P - 1))
-            S = min(S_full, ops.ceil_to(int(last.max()) + 1 + P + 1, 64))
-        tape["S"], tape["P"] = S, P
+            S = min(S_full, ops.ceil_to(int(first.max()) + 1 + P + 1, 64))
+            rows = (rows // S_full) * S + rows % S_full
+        idx = torch.stack([rows, tgt]).pin_memory().to(dev, non_blocking=True)      # one small H2D copy, no sync
+        tape["S"], tape["P"], tape["rows"], tape["tgt"] = S, P, idx[0], idx[1]
         emb = torch.empty(B, S, eng.d, dtype=BF16, device=dev)
         emb[:, :P] = prefix
         ops.embedding(captions[:, : S - P].contiguous(), eng.wte, emb, row_off=P)
@@ -351,17 +401,16 @@ class MagmaEngine:
             saved.append(sv)
         tape["layers"] = saved
         # ---- head + loss on rows that carry a target ----
-        tgt = labels[:, 1:].reshape(-1)
-        rows = (torch.arange(B, device=dev)[:, None] * S + torch.arange(S - 1, device=dev)[None, :]).reshape(-1)
-        keep = (tgt != -100).nonzero().squeeze(1)       # index plumbing (one host sync per micro-step)
-        rows, tgt = rows[keep], tgt[keep].contiguous()
+        rows, tgt = tape["rows"], tape["tgt"]             # built on the host (target_index): no device sync here
+        if rows.numel() == 0:
+            raise ValueError("no caption token carries a label in this batch")
         xr = x.index_select(0, rows)
         xl = ops.layernorm(xr, eng.lnf_g, eng.lnf_b, eng.eps)
         logits = torch.empty(xl.shape[0], eng.Vp, dtype=F32, device=dev)
         ops.gemm(xl, eng.head, out=logits)
         _, head_t = self._lm_packs()
         loss, dlogits = ops.cross_entropy_fwd_bwd(logits[:, : eng.V], tgt, head_t.K)
-        tape.update(rows=rows, xr=xr, dlogits=dlogits, M=M)
+        tape.update(xr=xr, dlogits=dlogits, M=M)
         return loss
 
     # ---- backward ----------------------------------------------------------------
@@ -631,10 +680,11 @@ class MagmaEngine:
             self._finish_reduce()
             grad_scale /= self.world
         self._norm_sq.zero_()
-        for g in self.groups:
-            ops.sumsq(g.grad, self._norm_sq)
-        for g, lr in zip(self.groups, lrs):
-            ops.adamw(g.master, g.m, g.v, g.grad, g.model, lr, self.betas[0], self.betas[1], self.eps, g.wd,
+        grads = [g.comm if self.exchange_bf16 else g.grad for g in self.groups]    # what came back from the exchange
+        for gr in grads:
+            ops.sumsq(gr, self._norm_sq)
+        for g, gr, lr in zip(self.groups, grads, lrs):
+            ops.adamw(g.master, g.m, g.v, gr, g.model, lr, self.betas[0], self.betas[1], self.eps, g.wd,
                       self.global_steps, max_norm=self.clip, norm_sq=self._norm_sq, grad_scale=grad_scale)
             g.grad.zero_()
         self.lr_scheduler.step()
@@ -695,7 +745,8 @@ class MagmaEngine:
         if load_lr_scheduler_states and "lr_scheduler" in sd:
             self.lr_scheduler.load_state_dict(sd["lr_scheduler"])
         self.module.invalidate_packed()
-        self._lm_train_packs = None if False else self._lm_train_packs
+        self._lm_train_packs = None        # transposed dgrad copies / e4m3 copies of the old frozen weights are stale now
+        self._fp8_packs = {}
         return str(path), sd
 
 

@@ -11,19 +11,48 @@ def _to_device(images, captions, device):
     return images.to(device=device, dtype=torch.bfloat16, non_blocking=True), captions.to(device, non_blocking=True)
 
 
+class LazyLoss:
+    """The step's mean loss, still on the device.  The reference returns ``.item()`` (train_loop.py:21), a host sync
+    per step that is only ever read every ``log_every`` steps (train.py:146-152); this object syncs when -- and only
+    when -- it is formatted, compared or converted."""
+
+    def __init__(self, t: torch.Tensor):
+        self.tensor = t
+
+    def item(self) -> float:
+        return float(self.tensor)
+
+    __float__ = item
+
+    def __format__(self, spec):
+        return format(self.item(), spec)
+
+    def __repr__(self):
+        return repr(self.item())
+
+    __str__ = __repr__
+
+    def __lt__(self, o):
+        return self.item() < float(o)
+
+    def __gt__(self, o):
+        return self.item() > float(o)
+
+
 def train_step(config, train_loader, model_engine):
     losses = []
     for _ in range(config.gradient_accumulation_steps):
         images, captions = next(train_loader)
+        host_caps = captions if not captions.is_cuda else None        # loader output: label index plumbing without a sync
         images, captions = _to_device(images, captions, model_engine.device)
         if config.run_blind:
             images = torch.zeros_like(images)
-        outputs = model_engine(images, captions)
+        outputs = model_engine(images, captions, captions_host=host_caps)
         loss = outputs.loss
         losses.append(loss)
         model_engine.backward(loss)
         model_engine.step()
-    return reduce_losses(torch.mean(torch.stack(losses))).item()
+    return LazyLoss(reduce_losses(torch.mean(torch.stack(losses))))
 
 
 def eval_step(config, eval_loader, model_engine):

@@ -1,13 +1,13 @@
 """smoke(): one small invocation of the hot path on cuda:0 (image -> prefix ->
 prefill -> 4 greedy decode steps, reduced-size MAGMA_v1 structure) checked
-against the CPU oracle.  Importing oracle here is allowed: it is the checker."""
+against the CPU oracle.  Lives OUTSIDE the product package (next to __graft_entry__.py): it imports the oracle, which is the checker."""
 import torch
 
 
 def run_smoke():
     from oracle.model import OracleConfig, embed, generate_greedy, init_params
-    from .lib import load
-    from .testing import build_reduced_magma
+    from magma_amd.lib import load
+    from magma_amd.testing import build_reduced_magma
 
     load()
     assert torch.cuda.is_available(), "smoke() needs an MI355X"

@@ -2,7 +2,8 @@
 """train.py -- entry point with the reference's CLI (reference train.py:72-193):
     python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 train.py --config configs/MAGMA_v1.yml
 (the reference used the `deepspeed` launcher; here one process per GPU, RCCL over xGMI).
-Datasets named "synthetic" use magma_amd.datasets.SyntheticImgCptDataset."""
+Dataset directories in the reference's image_data/*.json layout are read by magma_amd.datasets.ImgCptDataset;
+"synthetic" (or a missing directory) selects SyntheticImgCptDataset."""
 import os
 import sys
 
@@ -10,7 +11,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from magma_amd import Magma  # noqa: E402
-from magma_amd.datasets import SyntheticImgCptDataset  # noqa: E402
+from magma_amd.datasets import ImgCptDataset, SyntheticImgCptDataset  # noqa: E402
 from magma_amd.train_engine import initialize  # noqa: E402
 from magma_amd.train_loop import eval_step, inference_step, train_step  # noqa: E402
 from magma_amd.utils import (configure_param_groups, cycle, init_distributed, load_model, parse_args, print_main,  # noqa: E402
@@ -32,7 +33,7 @@ if __name__ == "__main__":
         if directory in (None, "synthetic") or not os.path.isdir(str(directory)):
             return SyntheticImgCptDataset(n, image_size=config.image_size, seq_len=model.seq_len, eos=model.eos_token,
                                           vocab=model.eos_token, seed=seed + 1000 * rank)
-        raise NotImplementedError("on-disk ImgCptDataset readers are out of scope (SURVEY 2.1 row 12)")
+        return ImgCptDataset(directory, tokenizer, transforms, seq_len=model.seq_len)   # reference train.py:43-60
 
     train_dataset = make_dataset(config.train_dataset_dir, 1 << 16, 1234)
     eval_dataset = make_dataset(config.eval_dataset_dir, 1 << 10, 4321)
