@@ -218,13 +218,13 @@ class Magma(nn.Module):
 
     # ---------------------------------------------------------- checkpoints
     @classmethod
-    def from_checkpoint(cls, config_path, checkpoint_path, device="cuda"):
+    def from_checkpoint(cls, config_path, checkpoint_path, device="cuda", **model_kwargs):
         """Load a (DeepSpeed-layout) MAGMA checkpoint: a torch-saved dict, optionally
         wrapped in "module" (reference magma.py:292-297).  The download fallback of
         the reference needs the network and is not reproduced."""
         if not exists(checkpoint_path):
             raise FileNotFoundError(f"checkpoint {checkpoint_path} does not exist (no network download in this build)")
-        model = cls(config=config_path, device=device)
+        model = cls(config=config_path, device=device, **model_kwargs)     # model_kwargs: reduced lm_config / enc (tests)
         from .tokenizer import ByteTokenizer
         if isinstance(model.tokenizer, ByteTokenizer) and os.environ.get("MAGMA_ALLOW_BYTE_TOKENIZER") != "1":
             raise RuntimeError("from_checkpoint needs the real GPT-2 tokenizer (set MAGMA_TOKENIZER_DIR to its files): the "

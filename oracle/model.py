@@ -46,6 +46,11 @@ class OracleConfig:
     ln_eps: float = 1e-5
     mlp_adapter_hidden: int = 1024  # 4096 // downsample_factor 4 ; 0 = none
     attn_adapter_hidden: int = 0  # v2: 512 ; 0 = none
+    # adapter placement (reference magma/magma.py:102-174): "normal" = after the block's output with its own residual
+    # (adapters.py:38-39, 109-116); "parallel" / "scaled_parallel" = beside the block, reading its INPUT
+    # (adapters.py:42-92), the latter with the trainable scalar ``adapter_scale``
+    mlp_adapter_type: str = "normal"
+    attn_adapter_type: str = "normal"
     # image side
     enc_width: int = 96  # RN50x16
     enc_layers: Tuple[int, int, int, int] = (6, 8, 18, 8)
@@ -93,14 +98,21 @@ class OracleConfig:
 
 def attn_prefix(cfg: OracleConfig, i: int) -> str:
     if cfg.attn_adapter_hidden:
-        return f"lm.transformer.h.{i}.attn.attn_block.attention."
+        # AdapterWrapper keeps the block as ``attn_block`` (adapters.py:107), ParallelAdapterWrapper as ``module`` (:56)
+        holder = "attn_block" if cfg.attn_adapter_type == "normal" else "module"
+        return f"lm.transformer.h.{i}.attn.{holder}.attention."
     return f"lm.transformer.h.{i}.attn.attention."
 
 
 def mlp_prefix(cfg: OracleConfig, i: int) -> str:
     if cfg.mlp_adapter_hidden:
-        return f"lm.transformer.h.{i}.mlp.0."
+        # Sequential(mlp, Adapter) (magma.py:143-148) vs ParallelAdapter(module=mlp) (magma.py:129-136)
+        return f"lm.transformer.h.{i}.mlp." + ("0." if cfg.mlp_adapter_type == "normal" else "module.")
     return f"lm.transformer.h.{i}.mlp."
+
+
+def mlp_adapter_prefix(cfg: OracleConfig, i: int) -> str:
+    return f"lm.transformer.h.{i}.mlp." + ("1.adapter." if cfg.mlp_adapter_type == "normal" else "adapter.")
 
 
 def enc_conv_specs(cfg: OracleConfig) -> List[Tuple[str, int, int, int]]:
@@ -161,9 +173,13 @@ def init_params(cfg: OracleConfig, seed: int = 0, dtype=torch.float32,
         p[mp + "c_proj.weight"] = normal(d, cfg.d_ff, std=lm_std)
         p[mp + "c_proj.bias"] = normal(d, std=lm_std)
         if cfg.mlp_adapter_hidden:
-            adapter(h + "mlp.1.adapter.", cfg.mlp_adapter_hidden)
+            adapter(mlp_adapter_prefix(cfg, i), cfg.mlp_adapter_hidden)
+            if cfg.mlp_adapter_type == "scaled_parallel":
+                p[h + "mlp.adapter_scale"] = 1.0 + normal(1, std=0.3)
         if cfg.attn_adapter_hidden:
             adapter(h + "attn.adapter.", cfg.attn_adapter_hidden)
+            if cfg.attn_adapter_type == "scaled_parallel":
+                p[h + "attn.adapter_scale"] = 1.0 + normal(1, std=0.3)
     p["lm.transformer.ln_f.weight"] = 1.0 + normal(d, std=0.05)
     p["lm.transformer.ln_f.bias"] = normal(d, std=0.02)
     p["lm.lm_head.weight"] = normal(cfg.vocab_out, d, std=lm_std)
@@ -227,11 +243,22 @@ def apply_rotary(x: torch.Tensor, pos: torch.Tensor, rotary_dim: int) -> torch.T
     return torch.cat((xr * cos + rot * sin, xp), dim=-1)
 
 
-def adapter_fwd(p: Params, prefix: str, x: torch.Tensor) -> torch.Tensor:
-    """reference magma/adapters.py:38-39: adapter(x) + x, adapter =
-    Linear -> ReLU -> Linear (adapters.py:18-25, defaults: ReLU, no LayerNorm)."""
+def adapter_branch(p: Params, prefix: str, x: torch.Tensor) -> torch.Tensor:
+    """The adapter Sequential itself: Linear -> ReLU -> Linear (adapters.py:18-25, defaults: ReLU, no LayerNorm)."""
     h = F.relu(F.linear(x, p[prefix + "0.weight"], p[prefix + "0.bias"]))
-    return F.linear(h, p[prefix + "2.weight"], p[prefix + "2.bias"]) + x
+    return F.linear(h, p[prefix + "2.weight"], p[prefix + "2.bias"])
+
+
+def adapter_fwd(p: Params, prefix: str, x: torch.Tensor) -> torch.Tensor:
+    """reference magma/adapters.py:38-39: adapter(x) + x."""
+    return adapter_branch(p, prefix, x) + x
+
+
+def parallel_adapter_fwd(p: Params, prefix: str, scale_key: Optional[str], x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """reference magma/adapters.py:62-65 / 88-92: y = module(x); return y + adapter(x) * adapter_scale
+    (adapter_scale = 1 for "parallel", the trainable scalar for "scaled_parallel")."""
+    z = adapter_branch(p, prefix, x)
+    return y + z * (p[scale_key] if scale_key is not None and scale_key in p else 1)
 
 
 def attention_fwd(p: Params, cfg: OracleConfig, i: int, x: torch.Tensor,
@@ -260,9 +287,12 @@ def attention_fwd(p: Params, cfg: OracleConfig, i: int, x: torch.Tensor,
     w = torch.softmax(scores, dim=-1).to(v.dtype)
     o = torch.matmul(w, v).permute(0, 2, 1, 3).reshape(B, S, d)
     o = F.linear(o, p[ap + "out_proj.weight"])
-    if cfg.attn_adapter_hidden:
+    if cfg.attn_adapter_hidden and cfg.attn_adapter_type == "normal":
         # reference magma/adapters.py:109-116 AdapterWrapper
         o = adapter_fwd(p, f"lm.transformer.h.{i}.attn.adapter.", o)
+    elif cfg.attn_adapter_hidden:
+        # reference magma/adapters.py:82-92 ParallelAdapterWrapper: the adapter reads the attention block's input x
+        o = parallel_adapter_fwd(p, f"lm.transformer.h.{i}.attn.adapter.", f"lm.transformer.h.{i}.attn.adapter_scale", x, o)
     return o, present
 
 
@@ -270,9 +300,12 @@ def mlp_fwd(p: Params, cfg: OracleConfig, i: int, x: torch.Tensor) -> torch.Tens
     mp = mlp_prefix(cfg, i)
     h = gelu_new(F.linear(x, p[mp + "c_fc.weight"], p[mp + "c_fc.bias"]))
     m = F.linear(h, p[mp + "c_proj.weight"], p[mp + "c_proj.bias"])
-    if cfg.mlp_adapter_hidden:
+    if cfg.mlp_adapter_hidden and cfg.mlp_adapter_type == "normal":
         # reference magma/magma.py:143-149: Sequential(mlp, Adapter)
-        m = adapter_fwd(p, f"lm.transformer.h.{i}.mlp.1.adapter.", m)
+        m = adapter_fwd(p, mlp_adapter_prefix(cfg, i), m)
+    elif cfg.mlp_adapter_hidden:
+        # reference magma/magma.py:129-136 + adapters.py:62-65: ParallelAdapter(module=mlp)
+        m = parallel_adapter_fwd(p, mlp_adapter_prefix(cfg, i), f"lm.transformer.h.{i}.mlp.adapter_scale", x, m)
     return m
 
 
@@ -319,8 +352,8 @@ def lm_forward(p: Params, cfg: OracleConfig, inputs_embeds: Optional[torch.Tenso
 # reference call site: magma/image_encoders.py:65-74
 # ----------------------------------------------------------------------------
 
-def _conv_bn(p: Params, cfg: OracleConfig, name: str, x: torch.Tensor, relu: bool,
-             stride: int = 1, bn_train: bool = False) -> torch.Tensor:
+def _conv_bn_impl(p: Params, cfg: OracleConfig, name: str, x: torch.Tensor, relu: bool,
+                  stride: int = 1, bn_train: bool = False) -> torch.Tensor:
     e = "image_prefix.enc."
     w = p[e + name + ".weight"]
     x = F.conv2d(x, w, None, stride=stride, padding=w.shape[-1] // 2)
@@ -330,9 +363,17 @@ def _conv_bn(p: Params, cfg: OracleConfig, name: str, x: torch.Tensor, relu: boo
     return F.relu(x) if relu else x
 
 
-def encoder_fwd(p: Params, cfg: OracleConfig, x: torch.Tensor) -> torch.Tensor:
-    """(B,3,H,W) -> (B, (H/32)*(W/32), 32*width).  BatchNorm in eval mode
-    (clip.load returns .eval() and Magma.__init__ never flips it)."""
+def encoder_fwd(p: Params, cfg: OracleConfig, x: torch.Tensor, bn_train: bool = False) -> torch.Tensor:
+    """(B,3,H,W) -> (B, (H/32)*(W/32), 32*width).  BatchNorm in eval mode by default
+    (clip.load returns .eval() and Magma.__init__ never flips it); ``bn_train=True`` = batch statistics,
+    the reference's behaviour after its first eval phase (train.py:164,182) -- the running statistics in ``p`` are
+    updated in place, as nn.BatchNorm2d does."""
+    from functools import partial
+    cb = partial(_conv_bn_impl, bn_train=bn_train)
+    return _encoder_body(p, cfg, x, cb)
+
+
+def _encoder_body(p, cfg, x, _conv_bn):
     x = _conv_bn(p, cfg, "conv1", x, True, stride=2)
     x = _conv_bn(p, cfg, "conv2", x, True)
     x = _conv_bn(p, cfg, "conv3", x, True)
@@ -362,10 +403,10 @@ def encoder_fwd(p: Params, cfg: OracleConfig, x: torch.Tensor) -> torch.Tensor:
 
 
 def image_prefix_fwd(p: Params, cfg: OracleConfig, images: torch.Tensor,
-                     dropout_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+                     dropout_mask: Optional[torch.Tensor] = None, bn_train: bool = False) -> torch.Tensor:
     """reference magma/image_prefix.py:78-109: enc -> proj -> dropout -> ln.
     ``dropout_mask`` (already scaled by 1/(1-p)) makes train-mode deterministic."""
-    feats = encoder_fwd(p, cfg, images)
+    feats = encoder_fwd(p, cfg, images, bn_train=bn_train)
     x = F.linear(feats, p["image_prefix.proj.weight"], p["image_prefix.proj.bias"])
     if dropout_mask is not None:
         x = x * dropout_mask
@@ -393,9 +434,9 @@ def build_labels(prefix_len: int, captions: torch.Tensor, eos_token: int) -> tor
 
 
 def magma_forward(p: Params, cfg: OracleConfig, images: torch.Tensor, captions: torch.Tensor,
-                  dropout_mask: Optional[torch.Tensor] = None, n_layer: Optional[int] = None):
+                  dropout_mask: Optional[torch.Tensor] = None, n_layer: Optional[int] = None, bn_train: bool = False):
     """reference magma/magma.py:238-276."""
-    prefix = image_prefix_fwd(p, cfg, images, dropout_mask)
+    prefix = image_prefix_fwd(p, cfg, images, dropout_mask, bn_train=bn_train)
     P = prefix.shape[1]
     labels = build_labels(P, captions, cfg.eos_token)
     words = F.embedding(captions, p["lm.transformer.wte.weight"]).to(prefix.dtype)

@@ -75,6 +75,25 @@ def main():
     pins["adapter_wrapper"] = {"sd": {k: v.clone() for k, v in aw.state_dict().items()}, "x": x,
                                "y": out[0].detach(), "rest": list(out[1:])}
 
+    # ---- ParallelAdapter / ParallelAdapterWrapper (reference magma/adapters.py:42-92) ----
+    class FakeMlp(torch.nn.Module):
+        def forward(self, x):
+            return torch.tanh(x) * 2.0 - 0.25
+
+    for scaled in (False, True):
+        pa = adapters.ParallelAdapter(module=FakeMlp(), dim=64, downsample_factor=4, scaled=scaled)
+        if scaled:
+            with torch.no_grad():
+                pa.adapter_scale.fill_(1.75)
+        pins["parallel_adapter_scaled" if scaled else "parallel_adapter"] = {
+            "sd": {k: v.clone() for k, v in pa.state_dict().items()}, "x": x, "y": pa(x).detach()}
+    paw = adapters.ParallelAdapterWrapper(module=FakeAttn(), dim=64, downsample_factor=8, scaled=True)
+    with torch.no_grad():
+        paw.adapter_scale.fill_(0.6)
+    out = paw(x)
+    pins["parallel_adapter_wrapper"] = {"sd": {k: v.clone() for k, v in paw.state_dict().items()}, "x": x,
+                                        "y": out[0].detach(), "rest": list(out[1:])}
+
     # ---- sampling filters (reference magma/sampling.py:7-40) ----
     g = torch.Generator().manual_seed(1)
     logits = torch.randn(4, 50, generator=g) * 3

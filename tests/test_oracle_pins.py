@@ -124,3 +124,20 @@ def test_product_coefficient_tables_equal_oracle():
         kk, bounds = pil_bicubic_tables(a, b)
         rk, rb = precompute_coeffs(a, b)
         assert np.array_equal(kk.astype(np.int64), rk) and np.array_equal(bounds.astype(np.int64), rb)
+
+
+def test_parallel_adapters_match_reference():
+    """ParallelAdapter / ParallelAdapterWrapper (reference magma/adapters.py:42-92), run in place by make_golden.py
+    around a toy wrapped module: y = module(x) + adapter(x) * adapter_scale."""
+    for key, module_out in (("parallel_adapter", lambda x: torch.tanh(x) * 2.0 - 0.25),
+                            ("parallel_adapter_scaled", lambda x: torch.tanh(x) * 2.0 - 0.25),
+                            ("parallel_adapter_wrapper", lambda x: x * 0.5 + 1.0)):
+        pin = PINS[key]
+        p = {"a." + k.replace("adapter.", ""): v for k, v in pin["sd"].items() if k.startswith("adapter.")}
+        if "adapter_scale" in pin["sd"]:
+            p["scale"] = pin["sd"]["adapter_scale"]
+        y = O.parallel_adapter_fwd(p, "a.", "scale", pin["x"], module_out(pin["x"]))
+        assert torch.allclose(y, pin["y"], atol=1e-6, rtol=1e-6), key
+    assert "adapter_scale" not in PINS["parallel_adapter"]["sd"]          # plain "parallel": the scale is the constant 1
+    assert float(PINS["parallel_adapter_scaled"]["sd"]["adapter_scale"]) == 1.75
+    assert PINS["parallel_adapter_wrapper"]["rest"] == ["present", "weights"]
