@@ -12,9 +12,9 @@ GREEDY_B = 2
 PREFILL_LEN = 57          # 49 prefix tokens (224^2 image) + 8 prompt tokens: BASELINE config[1]
 # input seed for the free-running greedy test, found by tools/find_margin_seed.py: with it EVERY one of the
 # GREEDY_B x GREEDY_STEPS top-1 decisions of the fp32 oracle has a top-1/top-2 gap above SEARCH_MARGIN x std(logits)
-# (margin-controlled inputs; the test itself demands TEST_MARGIN, half of it)
+# (margin-controlled inputs; the test itself demands TEST_MARGIN, a quarter of it)
 GREEDY_INPUT_SEED = None  # filled in below
-SEARCH_MARGIN = 0.03
+SEARCH_MARGIN = 0.06
 TEST_MARGIN = 0.015
 
 
@@ -56,4 +56,4 @@ def oracle_greedy_margins(params, cfg, emb, steps: int):
     return toks, margins, logits
 
 
-GREEDY_INPUT_SEED = 6
+GREEDY_INPUT_SEED = 1692
