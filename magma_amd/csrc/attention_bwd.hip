@@ -368,13 +368,9 @@ extern "C" int mg_attn_bwd_bf16(const mg_bf16* q, const mg_bf16* k, const mg_bf1
     if (!p) MG_FAIL(MG_ERR_SHAPE, "mg_attn_bwd_bf16: null pointer");
     if (!MG_ALIGNED16(p)) MG_FAIL(MG_ERR_ALIGN, "mg_attn_bwd_bf16: pointers must be 16-byte aligned");
   }
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (int rc = set_lds((const void*)attn_bwd_dq_kernel, DQ_STAGES * DQ_STAGE)) return rc;
-    if (int rc = set_lds((const void*)attn_bwd_dkdv_kernel<true>, DK_STAGES * DK_STAGE)) return rc;
-    if (int rc = set_lds((const void*)attn_bwd_dkdv_kernel<false>, DV_STAGES * DV_STAGE)) return rc;
-    attr_set = true;
-  }
+  if (int rc = mg_allow_dynamic_lds((const void*)attn_bwd_dq_kernel, DQ_STAGES * DQ_STAGE, "mg_attn_bwd_bf16")) return rc;
+  if (int rc = mg_allow_dynamic_lds((const void*)attn_bwd_dkdv_kernel<true>, DK_STAGES * DK_STAGE, "mg_attn_bwd_bf16")) return rc;
+  if (int rc = mg_allow_dynamic_lds((const void*)attn_bwd_dkdv_kernel<false>, DV_STAGES * DV_STAGE, "mg_attn_bwd_bf16")) return rc;
   hipStream_t s = (hipStream_t)stream;
   const int64_t rows = (int64_t)B * S * H;
   const dim3 grid((unsigned)(((S + 127) / 128) * B * H));

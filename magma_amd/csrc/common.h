@@ -129,3 +129,6 @@ void mg_set_error(const char* fmt, ...);
     if (e__ != hipSuccess) MG_FAIL(MG_ERR_HIP, "%s: %s", __func__, hipGetErrorString(e__)); \
   } while (0)
 #define MG_ALIGNED16(p) ((((uintptr_t)(p)) & 15u) == 0)
+// Raise a kernel's dynamic-LDS limit once per (kernel, device): thread-safe, and per device because
+// hipFuncSetAttribute acts on the current device's copy of the function (capi.hip).
+int mg_allow_dynamic_lds(const void* fn, int bytes, const char* who);

@@ -504,13 +504,7 @@ int check_epilogue(const mg_epilogue& ep, const char* who) {
 
 template <int AMODE, int WLAYOUT, bool FP8 = false>
 int launch_gemm(const GemmParams& gp, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm128_kernel<AMODE, WLAYOUT, FP8>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-    if (e != hipSuccess) MG_FAIL(MG_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_set = true;
-  }
+  if (int rc = mg_allow_dynamic_lds((const void*)gemm128_kernel<AMODE, WLAYOUT, FP8>, GEMM_LDS, "mg_gemm")) return rc;
   hipLaunchKernelGGL((gemm128_kernel<AMODE, WLAYOUT, FP8>), dim3(gp.tiles_m * gp.tiles_n * gp.splits), dim3(256), GEMM_LDS, s, gp);
   MG_CHECK_LAUNCH();
   if (gp.splits > 1) {
@@ -523,12 +517,7 @@ int launch_gemm(const GemmParams& gp, hipStream_t s) {
 
 template <int WLAYOUT, bool LATE_LGKM>
 int launch_gemm256(GemmParams gp, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<WLAYOUT, LATE_LGKM>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS);
-    if (e != hipSuccess) MG_FAIL(MG_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_set = true;
-  }
+  if (int rc = mg_allow_dynamic_lds((const void*)gemm256_kernel<WLAYOUT, LATE_LGKM>, G256_LDS, "mg_gemm")) return rc;
   gp.tiles_m = (gp.M + 255) / 256; gp.tiles_n = (gp.N + 255) / 256;
   hipLaunchKernelGGL((gemm256_kernel<WLAYOUT, LATE_LGKM>), dim3(gp.tiles_m * gp.tiles_n), dim3(512), G256_LDS, s, gp);
   MG_CHECK_LAUNCH();
