@@ -497,10 +497,13 @@ extern "C" int mg_attn_prefill_bf16(const mg_bf16* q, const mg_bf16* kcache, con
   if ((vt_ld & 31) || vt_ld < ((S + 31) & ~31)) MG_FAIL(MG_ERR_SHAPE, "mg_attn_prefill_bf16: vt_ld must be a multiple of 32 and >= S");
   if (!q || !kcache || !vt || !out) MG_FAIL(MG_ERR_SHAPE, "mg_attn_prefill_bf16: null pointer");
   if (!MG_ALIGNED16(q) || !MG_ALIGNED16(kcache) || !MG_ALIGNED16(vt) || !MG_ALIGNED16(out)) MG_FAIL(MG_ERR_ALIGN, "mg_attn_prefill_bf16: pointers must be 16-byte aligned");
-  // kernel structure: 2 (default) = 32-query waves on the 32x32x16 MFMA with scheduling hints (fragment reads kept ahead
-  // of the MFMA chains); 1 = the same, compiler's own schedule; 0 = the first structure (16-query waves, 8 waves).
-  // MAGMA_ATTN_FWD overrides.
-  static const int variant = [] { const char* e = getenv("MAGMA_ATTN_FWD"); return e ? atoi(e) : 2; }();
+  // kernel structure (MAGMA_ATTN_FWD overrides; measured at B=16, S=2048, profiles/r02_attention_variants.txt):
+  //   3 (default)  16-query waves x 8 (two per SIMD), deferred running max          0.95 ms
+  //   0            the same with the plain running max (round 1)                     1.00 ms
+  //   2 / 1        32-query waves x 4 (one per SIMD) on the 32x32x16 MFMA, with / without scheduling hints: half the LDS
+  //                fragment traffic per MFMA, but a single wave per SIMD exposes every LDS / barrier / VALU latency that
+  //                the second wave used to cover                                      1.10 / 1.13 ms  (kept for reference)
+  static const int variant = [] { const char* e = getenv("MAGMA_ATTN_FWD"); return e ? atoi(e) : 3; }();
   const int lds = FA_STAGES * FA_STAGE;
   const void* fn = (variant == 0 || variant == 3) ? (const void*)attn_prefill_kernel
                  : variant == 1 ? (const void*)attn_prefill32_kernel<false> : (const void*)attn_prefill32_kernel<true>;
