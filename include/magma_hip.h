@@ -226,6 +226,20 @@ int mg_argmax_f32(const float* logits, int64_t ld, int32_t B, int32_t V, int64_t
                   void* stream);
 int mg_advance_pos(int32_t* d_pos, int32_t delta, void* stream);
 
+/* K24 sampled (reference magma/sampling.py:99-107: top_k_filter :22-30, top_p_filter :7-19 -- the reference's own rule, SURVEY Q6 --
+ * softmax(logits / temperature), multinomial) as one launch per token step, graph-capturable (csrc/sampling.hip).
+ *   logits [B, V] fp32 (row stride ld); top_k == 0 / top_p == 0 disable the respective filter;
+ *   seed  device uint64 (read at run time: a new seed needs no re-capture), state device int32[2] = {step, first step at which
+ *   every row produced eos (-1 until then)}: the random stream is Philox4x32-10 keyed by the seed at counter (step, row);
+ *   token [B] int64 sampled ids (NULL: filter only); filtered [B, V] optional copy of the filtered logits (-inf where the
+ *   reference's filters put -inf).
+ * mg_sample_finish is the loop bookkeeping: records the first step with (token == eos).all() (reference sampling.py:109, read
+ * by the host every few steps instead of a sync per token) and advances the step counter.                                  */
+int mg_sample_f32(const float* logits, int64_t ld, int32_t B, int32_t V, float temperature, int32_t top_k, float top_p,
+                  const uint64_t* seed, const int32_t* state, int64_t* token, float* filtered, int64_t ld_filtered,
+                  void* stream);
+int mg_sample_finish(const int64_t* token, int32_t B, int64_t eos, int32_t* state, void* stream);
+
 /* K4: 2x2 average pool, NHWC bf16.  x [B,H,W,C] -> y [B,H/2,W/2,C]  (stem pool and the anti-aliased stride of
  * CLIP's ModifiedResNet bottlenecks; trunk selected at reference magma/image_encoders.py:65-74).              */
 int mg_avgpool2_nhwc_bf16(const mg_bf16* x, mg_bf16* y, int32_t B, int32_t H, int32_t W, int32_t C,

@@ -1,0 +1,289 @@
+// sampling.hip -- the non-greedy branch of the decode loop on the device:
+// reference magma/sampling.py:99-107
+//     if top_k > 0: logits = top_k_filter(logits, k=top_k)          (:22-30)
+//     if top_p > 0: logits = top_p_filter(logits, threshold=top_p)  (:7-19, the reference's own rule -- SURVEY Q6)
+//     probs = softmax(logits / temperature); next_token = multinomial(probs, 1)
+// and the early-stop test (next_token == eos).all() (:109), as ONE launch per token step + a one-thread bookkeeping
+// launch, both graph-capturable: no host round trip per step (the reference syncs once per token, and runs the filters
+// as ~10 PyTorch launches including a full sort of the 50 258 logits).
+//
+// One workgroup of 1024 threads per row; the row (200 KB of fp32 at V = 50 258) stays in L2 and is swept a few times:
+//   top-k        threshold = the k-th largest logit by MSB-first radix selection on order-preserving 32-bit keys
+//                (4 sweeps, integer histograms in LDS); every logit below it becomes -inf (all ties at the threshold are
+//                kept -- torch.topk keeps an unspecified subset of them).
+//   "top-p"      the reference sorts descending, accumulates softmax probabilities and DROPS every rank r >= 1 whose
+//                preceding mass cum[r-1] is still below 1 - threshold.  No sort is needed for that: an element is dropped
+//                iff it is not the first maximum and the probability mass of the strictly larger logits is < 1 - threshold,
+//                and that mass is monotone in the logit -- so the set is {x >= t*} minus the maximum, with t* the smallest
+//                logit whose strictly-larger mass is below the bound.  t* comes from the same radix descent with MASS
+//                histograms.  Masses are 2^-40 fixed point in 64-bit integers: integer atomics are associative, so the
+//                result does not depend on the order in which the lanes arrive (fp32 atomics would make a sampled token
+//                depend on scheduling).  Ties at t* are dropped one by one in index order, as a stable sort would.
+//   multinomial  inverse-CDF draw in index order over the same fixed-point weights exp((x - max) / temperature):
+//                target = floor(r * total / 2^64) with r = 64 Philox4x32-10 bits keyed by (seed, step, row); prefix sums
+//                are integer, hence exact and reproducible (tests restate the draw in Python integers / float64).
+#include "common.h"
+
+namespace {
+
+constexpr int ST = 1024;
+
+MG_DEV uint32_t fkey(float x) {            // order-preserving map float -> uint32 (larger float, larger key)
+  const uint32_t b = __float_as_uint(x);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+// ---- deterministic block reductions (fixed tree, 16 waves) ----
+MG_DEV float blk_max(float v, float* sh) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = sh[0];
+#pragma unroll
+  for (int w = 1; w < ST / 64; ++w) r = fmaxf(r, sh[w]);
+  return r;
+}
+MG_DEV float blk_sum(float v, float* sh) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = sh[0];
+#pragma unroll
+  for (int w = 1; w < ST / 64; ++w) r += sh[w];
+  return r;
+}
+MG_DEV int blk_min_i(int v, int* sh) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  int r = sh[0];
+#pragma unroll
+  for (int w = 1; w < ST / 64; ++w) r = min(r, sh[w]);
+  return r;
+}
+
+// Philox4x32-10 (Salmon et al. 2011), counter (c0..c3), key (k0, k1)
+MG_DEV void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+
+struct SampleParams {
+  const float* logits; int64_t ld; int V;
+  float temperature; int top_k; float top_p;
+  const uint64_t* seed;       // device: 64-bit seed (may change between graph replays)
+  const int32_t* state;       // device: [0] = step counter (read here, advanced by sample_finish_kernel)
+  int64_t* out;               // [B] sampled token (nullptr: filter only)
+  float* filtered; int64_t ldf;   // optional [B, V] filtered logits (tests / callers that want the reference's tensor)
+};
+
+constexpr double FIX = 1099511627776.0;   // 2^40
+
+__global__ __launch_bounds__(ST) void sample_kernel(const SampleParams p) {
+  __shared__ unsigned long long hist64[256];
+  __shared__ uint32_t hist32[256];
+  __shared__ float shf[ST / 64];
+  __shared__ int shi[ST / 64];
+  __shared__ unsigned long long shu[ST / 64 + 1];
+  __shared__ uint32_t bc[4];
+  __shared__ unsigned long long bc64[2];
+  const int tid = threadIdx.x, V = p.V;
+  const float* x = p.logits + (int64_t)blockIdx.x * p.ld;
+
+  // ---------------- top-k: key of the k-th largest logit ----------------
+  uint32_t tk = 0;                                  // alive(i) = fkey(x[i]) >= tk
+  if (p.top_k > 0 && p.top_k < V) {
+    uint32_t prefix = 0, mask = 0, remaining = (uint32_t)p.top_k;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+      if (tid < 256) hist32[tid] = 0;
+      __syncthreads();
+      for (int i = tid; i < V; i += ST) {
+        const uint32_t k = fkey(x[i]);
+        if ((k & mask) == prefix) atomicAdd(&hist32[(k >> shift) & 255], 1u);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        uint32_t rem = remaining; int d = 0;
+        for (int b = 255; b >= 0; --b) {
+          if (hist32[b] >= rem) { d = b; break; }
+          rem -= hist32[b];
+        }
+        bc[0] = (uint32_t)d; bc[1] = rem;
+      }
+      __syncthreads();
+      prefix |= bc[0] << shift; mask |= 255u << shift; remaining = bc[1];
+      __syncthreads();
+    }
+    tk = prefix;
+  }
+
+  // ---------------- first maximum (rank 0 of the reference's sort; never dropped) ----------------
+  float mx = -INFINITY;
+  for (int i = tid; i < V; i += ST) mx = fmaxf(mx, x[i]);
+  mx = blk_max(mx, shf);
+  int imax = 0x7fffffff;
+  for (int i = tid; i < V; i += ST) if (x[i] == mx) { imax = min(imax, i); }
+  imax = blk_min_i(imax, shi);
+
+  // ---------------- the reference's top-p rule ----------------
+  uint32_t tstar = 0xffffffffu;    // dropped(i) = alive && i != imax && (key > tstar || (key == tstar && i < tie_cut))
+  int tie_cut = 0;
+  const double bound = (double)(float)(1.0 - (double)p.top_p);      // tensor < python scalar compares in fp32
+  if (p.top_p > 0.f && bound > 0.0) {
+    float z = 0.f;
+    for (int i = tid; i < V; i += ST) if (fkey(x[i]) >= tk) z += __expf(x[i] - mx);
+    z = blk_sum(z, shf);
+    const float rz = 1.0f / z;
+    const unsigned long long cfix = (unsigned long long)(bound * FIX);
+    uint32_t prefix = 0, mask = 0;
+    unsigned long long above = 0;     // mass of the alive keys strictly above the current key range
+    uint32_t n_eq = 0;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+      if (tid < 256) { hist64[tid] = 0; hist32[tid] = 0; }
+      __syncthreads();
+      for (int i = tid; i < V; i += ST) {
+        const uint32_t k = fkey(x[i]);
+        if (k >= tk && (k & mask) == prefix) {
+          const unsigned long long q = (unsigned long long)((double)(__expf(x[i] - mx) * rz) * FIX + 0.5);
+          atomicAdd(&hist64[(k >> shift) & 255], q);
+          atomicAdd(&hist32[(k >> shift) & 255], 1u);
+        }
+      }
+      __syncthreads();
+      if (tid == 0) {
+        // lowest non-empty bucket whose strictly-larger mass is still below the bound (it exists: the highest one has mass
+        // `above` < bound by induction, 0 at the top level)
+        unsigned long long s = above, cand_s = above; int cand = -1;
+        for (int b = 255; b >= 0; --b) {
+          if (hist32[b] == 0) continue;
+          if (s < cfix) { cand = b; cand_s = s; } else break;
+          s += hist64[b];
+        }
+        bc[0] = (uint32_t)(cand < 0 ? 0 : cand); bc[1] = cand < 0 ? 0u : hist32[cand];
+        bc64[0] = cand_s; bc64[1] = cand < 0 ? 0ull : hist64[cand];
+      }
+      __syncthreads();
+      prefix |= bc[0] << shift; mask |= 255u << shift; above = bc64[0]; n_eq = bc[1];
+      __syncthreads();
+    }
+    tstar = prefix;
+    // ties at t*: the j-th of them (index order) has preceding mass above + j * q_eq
+    int m = (int)n_eq;
+    if (n_eq > 1) {
+      const unsigned long long q_eq = bc64[1] / n_eq;
+      unsigned long long s = above; m = 0;
+      while (m < (int)n_eq && s < cfix) { ++m; s += q_eq; }
+    }
+    tie_cut = 0x7fffffff;
+    if (m < (int)n_eq) {           // rare: only the first m ties (by index) go -- one thread finds the (m+1)-th tie's index
+      if (tid == 0) {
+        int seen = 0, cut = 0x7fffffff;
+        for (int i = 0; i < V; ++i) if (fkey(x[i]) == tstar) { if (seen == m) { cut = i; break; } ++seen; }
+        bc[2] = (uint32_t)cut;
+      }
+      __syncthreads();
+      tie_cut = (int)bc[2];
+    }
+  }
+  auto kept = [&](int i, float v) -> bool {
+    const uint32_t k = fkey(v);
+    if (k < tk) return false;
+    if (i == imax) return true;
+    return !(k > tstar || (k == tstar && i < tie_cut));
+  };
+
+  if (p.filtered) {
+    float* f = p.filtered + (int64_t)blockIdx.x * p.ldf;
+    for (int i = tid; i < V; i += ST) { const float v = x[i]; f[i] = kept(i, v) ? v : -INFINITY; }
+  }
+  if (!p.out) return;
+
+  // ---------------- multinomial draw: inverse CDF over fixed-point weights, index order ----------------
+  // thread t owns the contiguous index range [t*C, (t+1)*C)
+  const int C = (V + ST - 1) / ST;
+  const int i0 = tid * C, i1 = min(V, i0 + C);
+  const float rt = 1.0f / p.temperature;
+  unsigned long long mine = 0;
+  for (int i = i0; i < i1; ++i) {
+    const float v = x[i];
+    if (kept(i, v)) mine += (unsigned long long)((double)__expf((v - mx) * rt) * 4294967296.0 + 0.5);
+  }
+  // exclusive scan over the 1024 partial sums: wave scan + serial scan of the 16 wave totals
+  unsigned long long incl = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned long long t = __shfl_up(incl, o, 64);
+    if ((tid & 63) >= o) incl += t;
+  }
+  __syncthreads();
+  if ((tid & 63) == 63) shu[tid >> 6] = incl;
+  __syncthreads();
+  if (tid == 0) {
+    unsigned long long run = 0;
+    for (int w = 0; w < ST / 64; ++w) { const unsigned long long t = shu[w]; shu[w] = run; run += t; }
+    shu[ST / 64] = run;
+  }
+  __syncthreads();
+  const unsigned long long excl = shu[tid >> 6] + incl - mine, total = shu[ST / 64];
+  uint32_t c[4] = {(uint32_t)p.state[0], blockIdx.x, 0u, 0u};
+  const unsigned long long seed = p.seed ? *p.seed : 0ull;
+  philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  const unsigned long long r = ((unsigned long long)c[0] << 32) | c[1];
+  const unsigned long long target = __umul64hi(r, total);           // uniform in [0, total)
+  if (mine > 0 && target >= excl && target < excl + mine) {         // exactly one thread
+    unsigned long long run = excl;
+    int tok = i0;
+    for (int i = i0; i < i1; ++i) {
+      const float v = x[i];
+      if (!kept(i, v)) continue;
+      run += (unsigned long long)((double)__expf((v - mx) * rt) * 4294967296.0 + 0.5);
+      tok = i;
+      if (run > target) break;
+    }
+    p.out[blockIdx.x] = tok;
+  }
+  if (total == 0 && tid == 0) p.out[blockIdx.x] = imax == 0x7fffffff ? 0 : imax;   // nothing representable: the maximum
+}
+
+// one thread: (next_token == eos).all() of reference sampling.py:109, recorded as the FIRST step at which it held, and the
+// step counter of the random stream.  state = {step, first_all_eos_step (-1 = not yet)}
+__global__ void sample_finish_kernel(const int64_t* __restrict__ tok, int B, int64_t eos, int32_t* __restrict__ state) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  bool all = true;
+  for (int b = 0; b < B; ++b) all = all && (tok[b] == eos);
+  if (all && state[1] < 0) state[1] = state[0];
+  state[0] += 1;
+}
+
+}  // namespace
+
+extern "C" int mg_sample_f32(const float* logits, int64_t ld, int32_t B, int32_t V, float temperature, int32_t top_k,
+                             float top_p, const uint64_t* seed, const int32_t* state, int64_t* token, float* filtered,
+                             int64_t ld_filtered, void* stream) {
+  if (B <= 0 || V <= 0 || !logits || ld < V) MG_FAIL(MG_ERR_SHAPE, "mg_sample_f32: bad logits / B / V / ld");
+  if (!token && !filtered) MG_FAIL(MG_ERR_SHAPE, "mg_sample_f32: nothing to produce (token and filtered are both null)");
+  if (token && (!state || !(temperature > 0.f))) MG_FAIL(MG_ERR_SHAPE, "mg_sample_f32: sampling needs temperature > 0 and a state buffer (greedy decoding is mg_argmax_f32)");
+  if (top_k < 0 || top_p < 0.f || top_p > 1.f) MG_FAIL(MG_ERR_SHAPE, "mg_sample_f32: need top_k >= 0 and 0 <= top_p <= 1");
+  if (filtered && ld_filtered < V) MG_FAIL(MG_ERR_SHAPE, "mg_sample_f32: ld_filtered < V");
+  SampleParams p{logits, ld, V, temperature, top_k, top_p, seed, state, token, filtered, ld_filtered};
+  hipLaunchKernelGGL(sample_kernel, dim3(B), dim3(ST), 0, (hipStream_t)stream, p);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
+extern "C" int mg_sample_finish(const int64_t* token, int32_t B, int64_t eos, int32_t* state, void* stream) {
+  if (!token || !state || B <= 0) MG_FAIL(MG_ERR_SHAPE, "mg_sample_finish: bad arguments");
+  hipLaunchKernelGGL(sample_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, token, B, eos, state);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}

@@ -46,6 +46,11 @@ class KVCache:
         self.v = torch.empty(n_layer, B, H, Smax, 256, dtype=BF16, device=device)
         self.d_pos = torch.zeros(1, dtype=torch.int32, device=device)   # next write position
         self.pos = 0                                                     # host mirror
+        # token-selection state of the generate() loop (device side): {step, first step at which every row emitted eos},
+        # the seed of the sampling stream, the eos id the bookkeeping launch compares against
+        self.sample_state = torch.tensor([0, -1], dtype=torch.int32, device=device)
+        self.seed = torch.zeros(1, dtype=torch.int64, device=device)
+        self.eos = -1
         self.B, self.Smax = B, Smax
         self.decode_state = None
 
@@ -243,7 +248,8 @@ class LMEngine:
     # ------------------------------------------------------------------ API
     def forward(self, input_ids=None, inputs_embeds=None, labels=None, use_cache=False, past_key_values=None,
                 output_hidden_states=False, cache_hint: Optional[int] = None, reuse_cache: bool = False,
-                return_logits: bool = False) -> LMOutput:
+                return_logits: bool = False, sampling=None, eos_token: Optional[int] = None,
+                seed: Optional[int] = None) -> LMOutput:
         if labels is not None:
             if inputs_embeds is None:
                 inputs_embeds = self.embed_ids(input_ids)
@@ -251,14 +257,23 @@ class LMEngine:
         if past_key_values is not None:
             if input_ids is None or input_ids.shape[1] != 1:
                 raise NotImplementedError("cached decoding takes one new token id per sequence (reference sampling.py:88-90)")
-            logits, tok = self.decode(input_ids, past_key_values)
-            return LMOutput(logits=logits.unsqueeze(1), past_key_values=past_key_values, next_token=tok, loss=None)
+            logits, tok = self.decode(input_ids, past_key_values, sampling=sampling)
+            return LMOutput(logits=logits.unsqueeze(1), past_key_values=past_key_values, next_token=tok, loss=None,
+                            eos_state=past_key_values.sample_state)
         if inputs_embeds is None:
             inputs_embeds = self.embed_ids(input_ids)
         if use_cache:
             logits, cache, hs = self.prefill(inputs_embeds, cache_hint, output_hidden_states, reuse_cache)
             # generate() only reads the last position, so only that row is computed
-            return LMOutput(logits=logits.unsqueeze(1), past_key_values=cache, hidden_states=hs, loss=None)
+            out = LMOutput(logits=logits.unsqueeze(1), past_key_values=cache, hidden_states=hs, loss=None)
+            if eos_token is not None:     # generate(): first token of the loop selected here, device-side bookkeeping armed
+                cache.eos = int(eos_token)
+                cache.sample_state.copy_(torch.tensor([0, -1], dtype=torch.int32), non_blocking=True)
+                if seed is not None:
+                    cache.seed.fill_(int(seed) & 0x7fffffffffffffff)
+                out["next_token"] = self.select_token(logits, cache, sampling)
+                out["eos_state"] = cache.sample_state
+            return out
         x, hs = self._blocks_prefill(inputs_embeds, None, output_hidden_states)
         B, S, _ = inputs_embeds.shape
         logits = self._full_logits(x, B * S).view(B, S, self.V)
@@ -375,11 +390,22 @@ class LMEngine:
         st.lnf = e(B, d)
         st.logits = e(B, self.Vp, dt=torch.float32)
         st.token = torch.zeros(B, dtype=torch.int64, device=dev)
-        st.graph = None
+        st.graphs = {}             # token-selection mode (None = greedy | (temperature, top_k, top_p)) -> captured hipGraph
         st.steps = 0
         return st
 
-    def _decode_step(self, cache: KVCache, st):
+    def select_token(self, logits: torch.Tensor, cache: KVCache, mode, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """next token of every row from fp32 logits (B, V): greedy argmax (mode None; reference sampling.py:96-97) or the
+        sampled branch (mode = (temperature, top_k, top_p); :99-107), then the loop bookkeeping (all-eos step, step
+        counter).  Enqueue-only: used inside the captured token step and, eagerly, on the prefill logits."""
+        if mode is None:
+            tok = ops.argmax(logits, out=out)
+        else:
+            tok = ops.sample(logits, mode[0], mode[1], mode[2], cache.seed, cache.sample_state, out=out)
+        ops.sample_finish(tok, cache.eos, cache.sample_state)
+        return tok
+
+    def _decode_step(self, cache: KVCache, st, mode=None):
         """Enqueue one token step for all B sequences (graph-capturable: no
         allocation, no sync, position read from cache.d_pos on the device)."""
         B = cache.B
@@ -464,12 +490,12 @@ class LMEngine:
             x, xn = xn, x
         head = self.head_w8 if w8_on else self.head_dec
         ops.gemm_skinny(x, head, out=st.logits, ln_fold=(head.colsum, self.d, self.eps))
-        ops.argmax(st.logits[:, : self.V], out=st.token)
+        self.select_token(st.logits[:, : self.V], cache, mode, out=st.token)
         ops.advance_pos(cache.d_pos, 1)
 
-    def decode(self, input_ids: torch.Tensor, cache: KVCache, use_graph: bool = True):
-        """One cached step.  Returns (fp32 logits (B,V) view, greedy token (B,) view);
-        both are overwritten by the next step."""
+    def decode(self, input_ids: torch.Tensor, cache: KVCache, use_graph: bool = True, sampling=None):
+        """One cached step.  Returns (fp32 logits (B,V) view, selected token (B,) view: greedy, or sampled when
+        ``sampling = (temperature, top_k, top_p)``); both are overwritten by the next step."""
         if cache.pos >= cache.Smax:
             raise ValueError(f"KV cache full (Smax={cache.Smax}); pass a larger cache_hint / max_steps")
         if cache.B > 16:
@@ -481,17 +507,18 @@ class LMEngine:
                 self._ensure_decode_packs_w8()
             st = cache.decode_state = self._alloc_decode_state(cache)
         st.ids.copy_(input_ids.reshape(cache.B, 1))
+        mode = None if sampling is None else (float(sampling[0]), int(sampling[1]), float(sampling[2]))
         if not use_graph:
-            self._decode_step(cache, st)
-        elif st.graph is not None:
-            st.graph.replay()
+            self._decode_step(cache, st, mode)
+        elif mode in st.graphs:
+            st.graphs[mode].replay()
         elif st.steps == 0:
-            self._decode_step(cache, st)          # first step eager (loads code objects)
+            self._decode_step(cache, st, mode)    # first step eager (loads code objects)
         else:
             g = torch.cuda.CUDAGraph()            # hipGraph on ROCm
             with torch.cuda.graph(g):
-                self._decode_step(cache, st)
-            st.graph = g
+                self._decode_step(cache, st, mode)
+            st.graphs[mode] = g
             g.replay()
         st.steps += 1
         cache.pos += 1

@@ -151,6 +151,8 @@ class GPTJForCausalLM(nn.Module):
         self.invalidate_packed()
         return new_wte
 
+    device_token_selection = True      # forward(..., sampling=, eos_token=, seed=) picks the next token in the HIP engine
+
     # ---- engine plumbing ----
     def invalidate_packed(self):
         """Drop device-layout copies of the weights (after load_state_dict / optimizer steps)."""
@@ -171,11 +173,13 @@ class GPTJForCausalLM(nn.Module):
     def forward(self, input_ids: Optional[torch.Tensor] = None, inputs_embeds: Optional[torch.Tensor] = None,
                 labels: Optional[torch.Tensor] = None, use_cache: bool = False, past_key_values: Any = None,
                 output_hidden_states: bool = False, cache_hint: Optional[int] = None, reuse_cache: bool = False,
-                return_logits: bool = False, **unused) -> LMOutput:
+                return_logits: bool = False, sampling=None, eos_token: Optional[int] = None,
+                seed: Optional[int] = None, **unused) -> LMOutput:
         return self.engine.forward(input_ids=input_ids, inputs_embeds=inputs_embeds, labels=labels,
                                    use_cache=use_cache, past_key_values=past_key_values,
                                    output_hidden_states=output_hidden_states, cache_hint=cache_hint,
-                                   reuse_cache=reuse_cache, return_logits=return_logits)
+                                   reuse_cache=reuse_cache, return_logits=return_logits, sampling=sampling,
+                                   eos_token=eos_token, seed=seed)
 
 
 def get_gptj(gradient_checkpointing: bool = False, from_pretrained: bool = False, device=None,

@@ -372,6 +372,31 @@ def argmax(logits: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Te
     return out
 
 
+def sample(logits: torch.Tensor, temperature: float, top_k: int, top_p: float, seed: Optional[torch.Tensor],
+           state: Optional[torch.Tensor], out: Optional[torch.Tensor] = None, filtered: Optional[torch.Tensor] = None,
+           want_token: bool = True):
+    """reference sampling.py:99-107 on the device: top-k filter, the reference's top-p rule, softmax(logits / temperature)
+    and one multinomial draw per row (Philox stream keyed by ``seed`` at counter (state[0], row)).  ``filtered`` receives
+    the filtered logits (the tensor the reference's filters return) when given."""
+    _need_gpu(logits, seed, state, out, filtered)
+    assert logits.dtype == torch.float32 and logits.ndim == 2 and logits.stride(1) == 1
+    B, V = logits.shape
+    if want_token and out is None:
+        out = torch.empty(B, dtype=torch.int64, device=logits.device)
+    if filtered is not None:
+        assert filtered.dtype == torch.float32 and filtered.shape == logits.shape and filtered.stride(1) == 1
+    check(L.load().mg_sample_f32(logits.data_ptr(), logits.stride(0), B, V, float(temperature), int(top_k), float(top_p),
+                                 _p(seed), _p(state), _p(out) if want_token else None, _p(filtered),
+                                 0 if filtered is None else filtered.stride(0), _stream()), "mg_sample_f32")
+    return out
+
+
+def sample_finish(token: torch.Tensor, eos: int, state: torch.Tensor):
+    _need_gpu(token, state)
+    assert token.dtype == torch.int64 and state.dtype == torch.int32 and state.numel() >= 2
+    check(L.load().mg_sample_finish(token.data_ptr(), token.numel(), int(eos), state.data_ptr(), _stream()), "mg_sample_finish")
+
+
 def advance_pos(d_pos: torch.Tensor, delta: int = 1):
     check(L.load().mg_advance_pos(d_pos.data_ptr(), delta, _stream()), "mg_advance_pos")
 

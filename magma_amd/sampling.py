@@ -3,9 +3,13 @@
 greedy when temperature == 0.0; temperature / top-k / the reference's own
 top-p filter otherwise; early stop when every row emitted EOS).
 
-Differences: greedy argmax runs in the HIP kernel inside the decode
-graph; the per-step ``(next_token == eos).all()`` host sync of the reference
-(:109) is kept but can be disabled with ``stop_on_eos=False`` for timing."""
+Differences: token selection -- greedy argmax AND the sampled branch --
+runs as HIP kernels inside the captured token step (csrc/sampling.hip); the
+per-step ``(next_token == eos).all()`` host sync of the reference (:109) became
+a device-side record read every few steps.  ``top_k_filter`` / ``top_p_filter``
+below are the host statements of the same rules (pinned to the reference's own
+functions, tests/test_oracle_pins.py) and serve LM objects other than the engine."""
+import os
 from typing import List, Union
 
 import torch
@@ -42,7 +46,12 @@ def remove_tokens_after_eos(tensor, eos_token, image_token):
 @torch.no_grad()
 def generate(model, embeddings, max_steps: int = 100, temperature: float = 0.7, top_k: int = 0,
              top_p: float = 0.9, eos_token: int = None, decode: bool = True,
-             stop_on_eos: bool = True) -> Union[List[str], torch.Tensor]:
+             stop_on_eos: bool = True, seed: int = None, eos_check_every: int = None) -> Union[List[str], torch.Tensor]:
+    """reference sampling.py:43-121.  Token selection (argmax, or top-k / the reference's top-p rule / softmax /
+    multinomial) and the ``(next_token == eos).all()`` test run on the device inside the captured token step; the host
+    reads the recorded "first all-eos step" every ``eos_check_every`` steps (default 8, MAGMA_EOS_CHECK_EVERY) instead of
+    synchronising on every token, and cuts the output there -- same result as the reference's per-step break.
+    ``seed`` fixes the sampling stream (default: drawn from torch's CPU generator, so torch.manual_seed reproduces a run)."""
     eos_token = eos_token or model.eos_token
     was_training = model.training
     model.eval()
@@ -53,20 +62,29 @@ def generate(model, embeddings, max_steps: int = 100, temperature: float = 0.7, 
     n = s
     past = None
     greedy = temperature == 0.0
+    mode = None if greedy else (float(temperature), int(top_k), float(top_p))
+    if seed is None and not greedy:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    every = eos_check_every or int(os.environ.get("MAGMA_EOS_CHECK_EVERY", "8"))
+    # the HIP engine selects the token itself; any other LM object gets the reference's call (sampling.py:81-93)
+    on_device = getattr(model.lm, "device_token_selection", False)
+    first_kw = dict(sampling=mode, eos_token=eos_token, seed=seed) if on_device else {}
+    step_kw = dict(sampling=mode) if on_device else {}
     for i in range(max_steps):
         if i == 0:
             outputs = model.lm(inputs_embeds=embeddings, use_cache=True, past_key_values=None, cache_hint=max_steps,
-                               reuse_cache=True)
+                               reuse_cache=True, **first_kw)
         else:
-            outputs = model.lm(input_ids=out[:, n - 1:n], use_cache=True, past_key_values=past)
+            outputs = model.lm(input_ids=out[:, n - 1:n], use_cache=True, past_key_values=past, **step_kw)
         past = outputs.past_key_values
-        if greedy and outputs.get("next_token") is not None:
-            next_token = outputs.next_token.unsqueeze(1)          # argmax kernel inside the decode graph
-        else:
+        if outputs.get("next_token") is not None and (on_device or greedy):   # selected on the device (HIP engine)
+            next_token = outputs.next_token.unsqueeze(1)
+            state = outputs.get("eos_state")
+        else:                                                # any other LM object: the reference's host-side arithmetic
+            state = None
             logits = outputs.logits[:, -1, :].float()
             if greedy:
-                from . import ops
-                next_token = ops.argmax(logits.contiguous()).unsqueeze(1)
+                next_token = torch.argmax(logits, dim=-1, keepdim=True)
             else:
                 if top_k > 0:
                     logits = top_k_filter(logits, k=top_k)
@@ -76,8 +94,15 @@ def generate(model, embeddings, max_steps: int = 100, temperature: float = 0.7, 
                 next_token = torch.multinomial(probs, num_samples=1)
         out[:, n:n + 1] = next_token
         n += 1
-        if stop_on_eos and eos_token is not None and bool((next_token == eos_token).all()):
-            break
+        if stop_on_eos and eos_token is not None:
+            if state is None:
+                if bool((next_token == eos_token).all()):
+                    break
+            elif (i + 1) % every == 0 or i + 1 == max_steps:
+                first = int(state[1])                        # one host sync per `every` steps
+                if first >= 0:
+                    n = s + first + 1                        # tokens after the first all-eos step are dropped again
+                    break
     out = out[:, :n]
     if decode:
         out = [model.tokenizer.decode(remove_tokens_after_eos(row, eos_token, model.image_token)) for row in out]

@@ -6,6 +6,9 @@ skip_until = sys.argv[2] if len(sys.argv) > 2 else None
 for f in glob.glob(os.path.join(root, "**", "*kernel_trace.csv"), recursive=True):
     rows = list(csv.DictReader(open(f)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    if skip_until:      # keep only what was launched after the LAST kernel whose name contains the marker
+        last = max((i for i, r in enumerate(rows) if skip_until in r["Kernel_Name"]), default=-1)
+        rows = rows[last + 1:]
     agg = defaultdict(lambda: [0, 0])
     for r in rows:
         n = r["Kernel_Name"].replace("(anonymous namespace)::", "")
@@ -14,5 +17,5 @@ for f in glob.glob(os.path.join(root, "**", "*kernel_trace.csv"), recursive=True
     tot = sum(v[0] for v in agg.values())
     span = int(rows[-1]["End_Timestamp"]) - int(rows[0]["Start_Timestamp"])
     print(f"== {f}: {len(rows)} launches, busy {tot/1e6:.2f} ms, span {span/1e6:.2f} ms")
-    for n, (t, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:30]:
+    for n, (t, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:int(os.environ.get('TOP', 45))]:
         print(f"{n:72s} calls={c:6d} total_ms={t/1e6:9.3f} avg_us={t/c/1e3:8.2f}")
