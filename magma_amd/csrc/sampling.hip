@@ -9,8 +9,9 @@
 //
 // One workgroup of 1024 threads per row; the row (200 KB of fp32 at V = 50 258) stays in L2 and is swept a few times:
 //   top-k        threshold = the k-th largest logit by MSB-first radix selection on order-preserving 32-bit keys
-//                (4 sweeps, integer histograms in LDS); every logit below it becomes -inf (all ties at the threshold are
-//                kept -- torch.topk keeps an unspecified subset of them).
+//                (4 sweeps, integer histograms in LDS); every logit below it becomes -inf; of the ties AT the threshold the
+//                first ones by index stay, so that exactly k survive (torch.topk keeps an unspecified subset of them --
+//                equal values, so the probability mass the next stage sees is the same).
 //   "top-p"      the reference sorts descending, accumulates softmax probabilities and DROPS every rank r >= 1 whose
 //                preceding mass cum[r-1] is still below 1 - threshold.  No sort is needed for that: an element is dropped
 //                iff it is not the first maximum and the probability mass of the strictly larger logits is < 1 - threshold,
@@ -101,7 +102,8 @@ __global__ __launch_bounds__(ST) void sample_kernel(const SampleParams p) {
   const float* x = p.logits + (int64_t)blockIdx.x * p.ld;
 
   // ---------------- top-k: key of the k-th largest logit ----------------
-  uint32_t tk = 0;                                  // alive(i) = fkey(x[i]) >= tk
+  uint32_t tk = 0;                                  // alive(i) = key > tk || (key == tk && i < k_cut): exactly k survive
+  int k_cut = 0x7fffffff;
   if (p.top_k > 0 && p.top_k < V) {
     uint32_t prefix = 0, mask = 0, remaining = (uint32_t)p.top_k;
     for (int shift = 24; shift >= 0; shift -= 8) {
@@ -118,14 +120,26 @@ __global__ __launch_bounds__(ST) void sample_kernel(const SampleParams p) {
           if (hist32[b] >= rem) { d = b; break; }
           rem -= hist32[b];
         }
-        bc[0] = (uint32_t)d; bc[1] = rem;
+        bc[0] = (uint32_t)d; bc[1] = rem; bc[2] = hist32[d];
       }
       __syncthreads();
       prefix |= bc[0] << shift; mask |= 255u << shift; remaining = bc[1];
+      const uint32_t in_bucket = bc[2];
       __syncthreads();
+      if (shift == 0 && in_bucket > remaining) {     // more ties at the threshold than places left: the first ones by index stay
+        if (tid == 0) {
+          uint32_t seen = 0; int cut = 0x7fffffff;
+          for (int i = 0; i < V; ++i) if (fkey(x[i]) == prefix) { if (seen == remaining) { cut = i; break; } ++seen; }
+          bc[3] = (uint32_t)cut;
+        }
+        __syncthreads();
+        k_cut = (int)bc[3];
+        __syncthreads();
+      }
     }
     tk = prefix;
   }
+  auto alive = [&](int i, uint32_t k) -> bool { return k > tk || (k == tk && i < k_cut); };
 
   // ---------------- first maximum (rank 0 of the reference's sort; never dropped) ----------------
   float mx = -INFINITY;
@@ -141,7 +155,7 @@ __global__ __launch_bounds__(ST) void sample_kernel(const SampleParams p) {
   const double bound = (double)(float)(1.0 - (double)p.top_p);      // tensor < python scalar compares in fp32
   if (p.top_p > 0.f && bound > 0.0) {
     float z = 0.f;
-    for (int i = tid; i < V; i += ST) if (fkey(x[i]) >= tk) z += __expf(x[i] - mx);
+    for (int i = tid; i < V; i += ST) if (alive(i, fkey(x[i]))) z += __expf(x[i] - mx);
     z = blk_sum(z, shf);
     const float rz = 1.0f / z;
     const unsigned long long cfix = (unsigned long long)(bound * FIX);
@@ -153,7 +167,7 @@ __global__ __launch_bounds__(ST) void sample_kernel(const SampleParams p) {
       __syncthreads();
       for (int i = tid; i < V; i += ST) {
         const uint32_t k = fkey(x[i]);
-        if (k >= tk && (k & mask) == prefix) {
+        if (alive(i, k) && (k & mask) == prefix) {
           const unsigned long long q = (unsigned long long)((double)(__expf(x[i] - mx) * rz) * FIX + 0.5);
           atomicAdd(&hist64[(k >> shift) & 255], q);
           atomicAdd(&hist32[(k >> shift) & 255], 1u);
@@ -188,7 +202,7 @@ __global__ __launch_bounds__(ST) void sample_kernel(const SampleParams p) {
     if (m < (int)n_eq) {           // rare: only the first m ties (by index) go -- one thread finds the (m+1)-th tie's index
       if (tid == 0) {
         int seen = 0, cut = 0x7fffffff;
-        for (int i = 0; i < V; ++i) if (fkey(x[i]) == tstar) { if (seen == m) { cut = i; break; } ++seen; }
+        for (int i = 0; i < V; ++i) if (fkey(x[i]) == tstar && alive(i, tstar)) { if (seen == m) { cut = i; break; } ++seen; }
         bc[2] = (uint32_t)cut;
       }
       __syncthreads();
@@ -197,7 +211,7 @@ __global__ __launch_bounds__(ST) void sample_kernel(const SampleParams p) {
   }
   auto kept = [&](int i, float v) -> bool {
     const uint32_t k = fkey(v);
-    if (k < tk) return false;
+    if (!alive(i, k)) return false;
     if (i == imax) return true;
     return !(k > tstar || (k == tstar && i < tie_cut));
   };

@@ -267,7 +267,10 @@ class LMEngine:
             # generate() only reads the last position, so only that row is computed
             out = LMOutput(logits=logits.unsqueeze(1), past_key_values=cache, hidden_states=hs, loss=None)
             if eos_token is not None:     # generate(): first token of the loop selected here, device-side bookkeeping armed
-                cache.eos = int(eos_token)
+                if cache.eos != int(eos_token):        # the eos id is a launch argument of the captured bookkeeping kernel
+                    cache.eos = int(eos_token)
+                    if cache.decode_state is not None:
+                        cache.decode_state.graphs.clear()
                 cache.sample_state.copy_(torch.tensor([0, -1], dtype=torch.int32), non_blocking=True)
                 if seed is not None:
                     cache.seed.fill_(int(seed) & 0x7fffffffffffffff)

@@ -185,10 +185,12 @@ class Magma(nn.Module):
 
     @torch.no_grad()
     def generate(self, embeddings, max_steps: int = 100, temperature: float = 0.7, top_k: int = 0,
-                 top_p: float = 0.9, decode: bool = True, stop_on_eos: bool = True):
+                 top_p: float = 0.9, decode: bool = True, stop_on_eos: bool = True, seed: int = None,
+                 eos_check_every: int = None):
+        """reference magma.py:214-236 (+ stop_on_eos / seed / eos_check_every, see sampling.generate)."""
         torch.cuda.set_device(self.device)
         return generate(self, embeddings=embeddings, max_steps=max_steps, temperature=temperature, top_k=top_k,
-                        top_p=top_p, decode=decode, stop_on_eos=stop_on_eos)
+                        top_p=top_p, decode=decode, stop_on_eos=stop_on_eos, seed=seed, eos_check_every=eos_check_every)
 
     # ------------------------------------------------------------- forward
     def forward(self, images=None, captions=None, output_hidden_states: bool = False, input_embeddings=None,

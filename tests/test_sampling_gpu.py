@@ -61,12 +61,17 @@ def test_filters_full_vocabulary(dev, kind):
         assert torch.equal(torch.isneginf(got) | (got == x), torch.ones_like(got, dtype=torch.bool))   # only -inf or the original value
         diff = (torch.isneginf(got) != torch.isneginf(want)).sum(1)
         if kind == "bf16_ties":
-            # torch.topk / torch.sort keep an unspecified subset of exact ties at a boundary; the kernel keeps all top-k ties
-            # and drops top-p ties in index order: the SETS may differ among equal values only
-            gv, wv = got.clone(), want.clone()
+            # torch.topk / torch.sort keep an unspecified subset of exact ties (at the top-k boundary, at the top-p boundary and
+            # among several maxima: which one is "rank 0"); the kernel resolves each by index order.  The SETS may therefore
+            # differ among EQUAL VALUES only: per distinct value the number of survivors must agree (+-1 at the top-p boundary
+            # for the summation order, as below).
             for b in range(B):
-                d = torch.isneginf(gv[b]) != torch.isneginf(wv[b])
-                assert x[b][d].unique().numel() <= 2, (kind, top_k, top_p, b)
+                d = torch.isneginf(got[b]) != torch.isneginf(want[b])
+                off = 0
+                for v in x[b][d].unique():
+                    sel = x[b] == v
+                    off += abs(int((~torch.isneginf(got[b][sel])).sum()) - int((~torch.isneginf(want[b][sel])).sum()))
+                assert off <= 1, (kind, top_k, top_p, b, off)
         else:
             # summation order (fixed point here, fp32 cumsum there) can move the boundary by one rank at most
             assert int(diff.max()) <= 1, (kind, top_k, top_p, diff.tolist())
