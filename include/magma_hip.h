@@ -331,6 +331,20 @@ int mg_bn_fold_f32(const float* gamma, const float* beta, const float* mean, con
                    float* scale, float* shift, int32_t C, void* stream);
 int mg_im2col_t_bf16(const mg_bf16* x, mg_bf16* out, int64_t ldo, int32_t B, int32_t H, int32_t W, int32_t Cin, void* stream);
 
+/* batch-statistics BatchNorm of the CLIP trunk in training (the reference's tower runs in train mode after its
+ * first eval phase, reference train.py:164,182).  z = raw conv output [M, C] bf16 (M = B*H*W); sum / sumsq = per-channel sums
+ * of z and z*z (mg_colsum_f32).  fold: scale = gamma * rstd, shift = beta - mean * scale, and running_mean / running_var
+ * (may be NULL) updated like nn.BatchNorm2d (momentum, unbiased variance).  apply: y = [relu](z*scale + shift [+ res]).
+ * bwd_dz: dz = gamma * rstd * (g - dbeta/M - xhat * dgamma/M) with xhat = (z - mean) * rstd, dgamma / dbeta = this call's
+ * per-channel sums of g * xhat and g.                                                                                    */
+int mg_bn_batch_fold_f32(const float* sum, const float* sumsq, const float* gamma, const float* beta, int64_t M, float eps,
+                         float momentum, float* running_mean, float* running_var, float* scale, float* shift, float* mean,
+                         float* rstd, int32_t C, void* stream);
+int mg_bn_apply_bf16(const mg_bf16* z, const float* scale, const float* shift, const mg_bf16* res, int32_t relu, mg_bf16* y,
+                     int64_t M, int32_t C, void* stream);
+int mg_bn_bwd_dz_bf16(const mg_bf16* g, const mg_bf16* z, const float* mean, const float* rstd, const float* gamma,
+                      const float* dgamma, const float* dbeta, mg_bf16* dz, int64_t M, int32_t C, void* stream);
+
 /* optimizer (replaces DeepSpeed's fp16 ZeRO-2 step: global-norm clip + AdamW on fp32
  * master copies, reference train.py:96-101, config.py:124-134).                     */
 int mg_sumsq_f32(const float* g, int64_t n, float* out, void* stream);

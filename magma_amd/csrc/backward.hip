@@ -420,6 +420,76 @@ __global__ __launch_bounds__(256) void im2col_t_kernel(const mg_bf16* __restrict
 }
 
 // ---------------------------------------------------------------------------
+// batch-statistics BatchNorm (what the reference's tower runs once train.py:182 has flipped it to train mode).
+// The conv GEMM writes the raw output z; per-channel sums come from colsum_kernel; then:
+//   bn_batch_fold   mean, biased var -> scale = gamma * rstd, shift = beta - mean * scale; running statistics updated as
+//                   nn.BatchNorm2d does (momentum, unbiased variance)
+//   bn_apply        y = [relu](z * scale + shift [+ residual])
+//   bn_bwd_dz       dz = gamma * rstd * (g - dbeta / M - xhat * dgamma / M),  xhat = (z - mean) * rstd
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_batch_fold_kernel(const float* __restrict__ sum, const float* __restrict__ sumsq,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float inv_m, float unbias, float eps, float momentum,
+                                                            float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                            float* __restrict__ scale, float* __restrict__ shift,
+                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out, int C) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float mean = sum[c] * inv_m;
+  const float var = fmaxf(sumsq[c] * inv_m - mean * mean, 0.f);
+  const float rstd = rsqrtf(var + eps);
+  const float sc = gamma[c] * rstd;
+  scale[c] = sc; shift[c] = beta[c] - mean * sc; mean_out[c] = mean; rstd_out[c] = rstd;
+  if (run_mean) run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean;
+  if (run_var) run_var[c] = (1.f - momentum) * run_var[c] + momentum * var * unbias;
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const mg_bf16* __restrict__ z, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, const mg_bf16* __restrict__ res,
+                                                       int relu, mg_bf16* __restrict__ y, int64_t nvec, int cvec) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % cvec) * 8;
+    const u32x4 zv = ((const u32x4*)z)[i];
+    u32x4 rv = (u32x4){0u, 0u, 0u, 0u};
+    if (res) rv = ((const u32x4*)res)[i];
+    u32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float a = bflo(zv[j]) * scale[c + 2 * j] + shift[c + 2 * j] + bflo(rv[j]);
+      float b = bfhi(zv[j]) * scale[c + 2 * j + 1] + shift[c + 2 * j + 1] + bfhi(rv[j]);
+      if (relu) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
+      o[j] = pack2bf(a, b);
+    }
+    ((u32x4*)y)[i] = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_dz_kernel(const mg_bf16* __restrict__ g, const mg_bf16* __restrict__ z,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        const float* __restrict__ gamma, const float* __restrict__ dgamma,
+                                                        const float* __restrict__ dbeta, float inv_m,
+                                                        mg_bf16* __restrict__ dz, int64_t nvec, int cvec) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % cvec) * 8;
+    const u32x4 gv = ((const u32x4*)g)[i], zv = ((const u32x4*)z)[i];
+    u32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float r[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int cc = c + 2 * j + h;
+        const float gg = h ? bfhi(gv[j]) : bflo(gv[j]), zz = h ? bfhi(zv[j]) : bflo(zv[j]);
+        const float xh = (zz - mean[cc]) * rstd[cc];
+        r[h] = gamma[cc] * rstd[cc] * (gg - dbeta[cc] * inv_m - xh * dgamma[cc] * inv_m);
+      }
+      o[j] = pack2bf(r[0], r[1]);
+    }
+    ((u32x4*)dz)[i] = o;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // optimizer: sum of squares (global grad norm) and fused clip + AdamW
 // ---------------------------------------------------------------------------
 // gradient element as fp32: fp32 flat gradients (single GPU) or the bf16 buckets that went through RCCL (DP)
@@ -585,6 +655,36 @@ extern "C" int mg_bn_param_grad_f32(const mg_bf16* g, const mg_bf16* y, const mg
   if (!g || !y || !gamma || !beta || !dgamma || !dbeta || !MG_ALIGNED16(g) || !MG_ALIGNED16(y) || !MG_ALIGNED16(sub)) MG_FAIL(MG_ERR_ALIGN, "mg_bn_param_grad_f32: null/unaligned pointer");
   const int rpb = 256;
   hipLaunchKernelGGL(bn_param_grad_kernel, dim3((C + 511) / 512, (M + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream, g, y, sub, gamma, beta, dgamma, dbeta, M, C, rpb);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
+extern "C" int mg_bn_batch_fold_f32(const float* sum, const float* sumsq, const float* gamma, const float* beta, int64_t M,
+                                    float eps, float momentum, float* running_mean, float* running_var, float* scale,
+                                    float* shift, float* mean, float* rstd, int32_t C, void* stream) {
+  if (!sum || !sumsq || !gamma || !beta || !scale || !shift || !mean || !rstd || C <= 0 || M <= 0) MG_FAIL(MG_ERR_SHAPE, "mg_bn_batch_fold_f32: bad arguments");
+  const float unbias = M > 1 ? (float)((double)M / (double)(M - 1)) : 1.f;
+  hipLaunchKernelGGL(bn_batch_fold_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sum, sumsq, gamma, beta,
+                     (float)(1.0 / (double)M), unbias, eps, momentum, running_mean, running_var, scale, shift, mean, rstd, C);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
+extern "C" int mg_bn_apply_bf16(const mg_bf16* z, const float* scale, const float* shift, const mg_bf16* res, int32_t relu,
+                                mg_bf16* y, int64_t M, int32_t C, void* stream) {
+  if (!z || !scale || !shift || !y || M <= 0 || C <= 0 || (C & 7)) MG_FAIL(MG_ERR_SHAPE, "mg_bn_apply_bf16: need C %% 8 == 0");
+  if (!MG_ALIGNED16(z) || !MG_ALIGNED16(y) || !MG_ALIGNED16(res)) MG_FAIL(MG_ERR_ALIGN, "mg_bn_apply_bf16: 16-byte alignment required");
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(M * (C / 8))), dim3(256), 0, (hipStream_t)stream, z, scale, shift, res, relu, y, M * (C / 8), C / 8);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
+extern "C" int mg_bn_bwd_dz_bf16(const mg_bf16* g, const mg_bf16* z, const float* mean, const float* rstd, const float* gamma,
+                                 const float* dgamma, const float* dbeta, mg_bf16* dz, int64_t M, int32_t C, void* stream) {
+  if (!g || !z || !mean || !rstd || !gamma || !dgamma || !dbeta || !dz || M <= 0 || C <= 0 || (C & 7)) MG_FAIL(MG_ERR_SHAPE, "mg_bn_bwd_dz_bf16: need C %% 8 == 0");
+  if (!MG_ALIGNED16(g) || !MG_ALIGNED16(z) || !MG_ALIGNED16(dz)) MG_FAIL(MG_ERR_ALIGN, "mg_bn_bwd_dz_bf16: 16-byte alignment required");
+  hipLaunchKernelGGL(bn_bwd_dz_kernel, dim3(grid_for(M * (C / 8))), dim3(256), 0, (hipStream_t)stream, g, z, mean, rstd, gamma, dgamma, dbeta,
+                     (float)(1.0 / (double)M), dz, M * (C / 8), C / 8);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }

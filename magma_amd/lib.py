@@ -105,6 +105,9 @@ SYMBOLS = {
     "mg_im2col_t_bf16": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     "mg_sumsq_f32": (C.c_int, [_vp, _i64, _vp, _vp]),
     "mg_adamw_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _vp, _f32, _vp]),
+    "mg_bn_batch_fold_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "mg_bn_apply_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _i64, _i32, _vp]),
+    "mg_bn_bwd_dz_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     "mg_cast_f32_bf16": (C.c_int, [_vp, _vp, _i64, _vp]),
     "mg_sumsq_bf16": (C.c_int, [_vp, _i64, _vp, _vp]),
     "mg_adamw_gbf16_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _vp, _f32, _vp]),

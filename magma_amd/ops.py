@@ -616,6 +616,36 @@ def bn_fold(gamma, beta, mean, var, eps: float):
     return scale, shift
 
 
+def bn_batch_fold(s1, s2, gamma, beta, M: int, eps: float, momentum: float, running_mean=None, running_var=None):
+    """Per-channel batch statistics -> (scale, shift, mean, rstd) fp32 [C]; running statistics updated in place (fp32 tensors)."""
+    _need_gpu(s1, s2, gamma, beta)
+    C_ = s1.numel()
+    scale, shift, mean, rstd = (torch.empty(C_, dtype=torch.float32, device=s1.device) for _ in range(4))
+    check(L.load().mg_bn_batch_fold_f32(s1.data_ptr(), s2.data_ptr(), gamma.data_ptr(), beta.data_ptr(), M, eps, momentum,
+                                        _p(running_mean), _p(running_var), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
+                                        rstd.data_ptr(), C_, _stream()), "mg_bn_batch_fold_f32")
+    return scale, shift, mean, rstd
+
+
+def bn_apply(z, scale, shift, res=None, relu=True):
+    _need_gpu(z, res)
+    assert z.dtype == BF16 and z.ndim == 2 and z.is_contiguous()
+    y = torch.empty_like(z)
+    check(L.load().mg_bn_apply_bf16(z.data_ptr(), scale.data_ptr(), shift.data_ptr(), _p(res), int(bool(relu)), y.data_ptr(),
+                                    z.shape[0], z.shape[1], _stream()), "mg_bn_apply_bf16")
+    return y
+
+
+def bn_bwd_dz(g, z, mean, rstd, gamma, dgamma, dbeta):
+    _need_gpu(g, z)
+    assert g.dtype == BF16 and z.dtype == BF16 and g.shape == z.shape and g.is_contiguous() and z.is_contiguous()
+    dz = torch.empty_like(z)
+    check(L.load().mg_bn_bwd_dz_bf16(g.data_ptr(), z.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                                     dgamma.data_ptr(), dbeta.data_ptr(), dz.data_ptr(), z.shape[0], z.shape[1], _stream()),
+          "mg_bn_bwd_dz_bf16")
+    return dz
+
+
 def conv_weight_relayout(w: torch.Tensor, mode: int, scale: Optional[torch.Tensor] = None) -> torch.Tensor:
     """[Cout, Cin, k, k] bf16 conv weight -> row-major GEMM operand with K zero padded to a multiple of 64.
     mode 0: [Cout, k*k*Cin] in (ky, kx, ci) order; mode 1: [Cin, k*k*Cout] with flipped taps times scale[co] (dgrad)."""

@@ -127,6 +127,11 @@ class MagmaEngine:
         self.fp8 = os.environ.get("MAGMA_TRAIN_FP8", "0") == "1"
         self._fp8_packs = {}
         self._bn_stats = {}
+        # the reference's CLIP tower runs BatchNorm on its frozen statistics until the first eval phase and on
+        # BATCH statistics afterwards (train.py:164,182 flips it to train mode).  Default here = frozen (steps 0 ..
+        # eval_every-1 and inference); MAGMA_BN_BATCH_STATS=1 or train(bn_batch_stats=True) selects the later behaviour.
+        self.bn_batch_stats = os.environ.get("MAGMA_BN_BATCH_STATS", "0") == "1"
+        self._bn_dirty = False
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.gas = max(1, int(self.config.gradient_accumulation_steps))
         self.clip = float(self.config.gradient_clipping or 0.0)
@@ -251,10 +256,25 @@ class MagmaEngine:
     def is_trainable(self, p) -> bool:
         return id(p) in self._where
 
-    def train(self, mode: bool = True):
+    def _flush_bn_stats(self):
+        """fp32 running statistics updated by the batch-statistics mode -> the module's buffers (checkpoints, inference)."""
+        if not self._bn_dirty:
+            return
+        for m in self.module.image_prefix.enc.modules():
+            st = self._bn_stats.get(id(m))
+            if st is not None:
+                m.running_mean.copy_(st[0]); m.running_var.copy_(st[1])
+        self._bn_dirty = False
+        self.module.image_prefix.invalidate_packed()
+
+    def train(self, mode: bool = True, bn_batch_stats: Optional[bool] = None):
+        if bn_batch_stats is not None:
+            self.bn_batch_stats = bool(bn_batch_stats)
+        if not mode:
+            self._flush_bn_stats()
         self.training = mode
         self.module.train(mode)
-        self.module.image_prefix.enc.eval()     # BN statistics stay frozen (first-eval_every-steps behaviour)
+        self.module.image_prefix.enc.eval()     # the module flag stays "eval": the inference path reads the running statistics
         if not mode and self._adapters_dirty:   # inference path reads packed copies of the adapters
             self.module.lm.engine.repack_adapters(self.module.lm)
             self._adapters_dirty = False
@@ -551,12 +571,28 @@ class MagmaEngine:
         else:
             wop = RawWeight(ops.conv_weight_relayout(w, 0), bias=shift, K=9 * cin)
             convarg = (geom[1], geom[2], cin)
+        rec = {"conv": conv, "bn": bn, "a": a, "geom": geom, "kind": kind or ("1x1" if kh == 1 else "3x3"),
+               "gamma": gamma, "beta": beta, "sub": residual}
+        if self.bn_batch_stats:
+            # batch statistics: raw conv output, per-channel sums, fold, normalise (+ residual, ReLU); the running
+            # statistics (fp32 copies) are updated in place with nn.BatchNorm2d's momentum rule
+            z = ops.gemm(a, wop, conv=convarg, layout="rm", use_bias=False)
+            M, C = z.shape
+            sums = torch.zeros(2, C, dtype=F32, device=z.device)
+            ops.colsum(z, sums[0])
+            ops.colsum(z, sums[1], z)
+            st = self._bn_stats[id(bn)]
+            mom = 0.1 if bn.momentum is None else float(bn.momentum)
+            scale, shift, mean, rstd = ops.bn_batch_fold(sums[0], sums[1], gamma, beta, M, bn.eps, mom, st[0], st[1])
+            self._bn_dirty = True
+            y = ops.bn_apply(z, scale, shift, res=residual, relu=relu or residual is not None)
+            rec.update(y=y, z=z, mean=mean, rstd=rstd, scale=None, batch=True)
+            return y, rec
         if residual is None:
             y = ops.gemm(a, wop, scale=scale, act=ops.MG_ACT_RELU if relu else ops.MG_ACT_NONE, conv=convarg, layout="rm")
         else:
             y = ops.gemm(a, wop, scale=scale, residuals=(residual,), act_after=ops.MG_ACT_RELU, conv=convarg, layout="rm")
-        rec = {"conv": conv, "bn": bn, "a": a, "y": y, "geom": geom, "kind": kind or ("1x1" if kh == 1 else "3x3"),
-               "scale": scale, "gamma": gamma, "beta": beta, "sub": residual}
+        rec.update(y=y, scale=scale, batch=False)
         return y, rec
 
     @staticmethod
@@ -614,7 +650,19 @@ class MagmaEngine:
         cout, cin, kh, _ = w.shape
         Bq, hh, ww = rec["geom"]
         a, scale = rec["a"], rec["scale"]
-        ops.bn_param_grad(g, rec["y"], rec["sub"], rec["gamma"], rec["beta"], self.grad_of(bn.weight), self.grad_of(bn.bias))
+        if rec["batch"]:
+            # dbeta = sum g, dgamma = sum g * xhat = rstd * (sum g*z - mean * sum g); then the gradient wrt the raw conv output
+            C = g.shape[1]
+            sums = torch.zeros(2, C, dtype=F32, device=g.device)
+            ops.colsum(g, sums[0])
+            ops.colsum(g, sums[1], rec["z"])
+            dbeta = sums[0]
+            dgamma = rec["rstd"] * (sums[1] - rec["mean"] * dbeta)
+            self.grad_of(bn.weight).add_(dgamma)
+            self.grad_of(bn.bias).add_(dbeta)
+            g = ops.bn_bwd_dz(g, rec["z"], rec["mean"], rec["rstd"], rec["gamma"], dgamma, dbeta)
+        else:
+            ops.bn_param_grad(g, rec["y"], rec["sub"], rec["gamma"], rec["beta"], self.grad_of(bn.weight), self.grad_of(bn.bias))
         gT = _t(g)
         if rec["kind"] == "3x3":
             # im2col^T rows come in the weight's own (ci, ky, kx) order -> dW needs no re-layout
@@ -708,6 +756,7 @@ class MagmaEngine:
     def save_checkpoint(self, save_dir, client_state=None, tag=None):
         """DeepSpeed layout: <dir>/<tag>/mp_rank_00_model_states.pt with {"module": state_dict, ...} + <dir>/latest."""
         tag = tag or f"global_step{self.global_steps}"
+        self._flush_bn_stats()
         if (not dist.is_initialized()) or dist.get_rank() == 0:
             path = Path(save_dir) / tag
             path.mkdir(parents=True, exist_ok=True)

@@ -1,0 +1,29 @@
+"""Token-step time of the full-size MAGMA_v1 decode graph (B = 8) -- for A/B runs of decode tuning knobs (env vars)."""
+import json, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from magma_amd import Magma
+dev = torch.device("cuda:0")
+torch.manual_seed(1234)
+model = Magma("MAGMA_v1", device=dev); model.eval()
+eng = model.lm.engine
+B = int(os.environ.get("DB", 8))
+g = torch.Generator(device=dev).manual_seed(1)
+images = torch.randn(B, 3, 224, 224, device=dev, generator=g).to(torch.bfloat16)
+prompt = torch.randint(0, 50256, (B, 8), device=dev, generator=g)
+emb = model.embed([images, prompt])
+out = model.lm(inputs_embeds=emb, use_cache=True, cache_hint=200)
+cache = out.past_key_values
+tok = out.logits[:, -1].argmax(-1, keepdim=True)
+for _ in range(3):
+    eng.decode(tok, cache)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+res = []
+for rep in range(3):
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(40):
+        eng.decode(tok, cache)
+    e1.record(); torch.cuda.synchronize()
+    res.append(e0.elapsed_time(e1) / 40)
+print(json.dumps({"knobs": {k: v for k, v in os.environ.items() if k.startswith("MAGMA_")}, "token_step_ms": min(res), "all": res,
+                  "hbm_frac": 12.156e9 / (min(res) * 1e-3) / 8e12}))
