@@ -233,12 +233,15 @@ int mg_advance_pos(int32_t* d_pos, int32_t delta, void* stream);
  *   every row produced eos (-1 until then)}: the random stream is Philox4x32-10 keyed by the seed at counter (step, row);
  *   token [B] int64 sampled ids (NULL: filter only); filtered [B, V] optional copy of the filtered logits (-inf where the
  *   reference's filters put -inf).
- * mg_sample_finish is the loop bookkeeping: records the first step with (token == eos).all() (reference sampling.py:109, read
- * by the host every few steps instead of a sync per token) and advances the step counter.                                  */
+ * mg_sample_finish is the loop bookkeeping of a token step in one small launch: records the first step with
+ * (token == eos).all() (reference sampling.py:109, read by the host every few steps instead of a sync per token), advances
+ * the step counter, bumps the KV-cache write position *d_pos by delta (NULL: untouched) and appends the tokens to
+ * history[b * ld_history + step] (NULL: off; the host copies the history once when generate() ends).                       */
 int mg_sample_f32(const float* logits, int64_t ld, int32_t B, int32_t V, float temperature, int32_t top_k, float top_p,
                   const uint64_t* seed, const int32_t* state, int64_t* token, float* filtered, int64_t ld_filtered,
                   void* stream);
-int mg_sample_finish(const int64_t* token, int32_t B, int64_t eos, int32_t* state, void* stream);
+int mg_sample_finish(const int64_t* token, int32_t B, int64_t eos, int32_t* state, int32_t* d_pos, int32_t delta,
+                     int64_t* history, int64_t ld_history, int32_t history_cols, void* stream);
 
 /* K4: 2x2 average pool, NHWC bf16.  x [B,H,W,C] -> y [B,H/2,W/2,C]  (stem pool and the anti-aliased stride of
  * CLIP's ModifiedResNet bottlenecks; trunk selected at reference magma/image_encoders.py:65-74).              */

@@ -208,6 +208,7 @@ struct SkinnyParams {
   // (lane = kq*16 + n: bytes 0-7 = W[n][32*(2j) + 8kq ..], bytes 8-15 = the same columns of k-step 2j+1) and
   // w_scale[n] the per-output-channel scale; the weights are widened to bf16 in registers, so the stream is half as long.
   const float* w_scale;
+  int dbg;   // tuning experiments only (MAGMA_SKINNY_DBG): bit 0 = skip the LayerNorm-fold row statistics (WRONG results)
 };
 
 // Device body: `block` is the workgroup's index inside THIS problem's grid, `lds` a caller-provided
@@ -264,7 +265,7 @@ MG_DEV void skinny_body(const SkinnyParams& p, int block, char* lds) {
       if (!xok) raw = (u32x4){0u, 0u, 0u, 0u};
       xf[i] = __builtin_bit_cast(bf16x8, raw);
     }
-    if (p.ln_colsum) {
+    if (p.ln_colsum && !(p.dbg & 1)) {
 #pragma unroll
       for (int i = 0; i < KC; ++i) {
         const u32x4 raw = __builtin_bit_cast(u32x4, xf[i]);

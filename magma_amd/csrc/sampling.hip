@@ -269,14 +269,22 @@ __global__ __launch_bounds__(ST) void sample_kernel(const SampleParams p) {
   if (total == 0 && tid == 0) p.out[blockIdx.x] = imax == 0x7fffffff ? 0 : imax;   // nothing representable: the maximum
 }
 
-// one thread: (next_token == eos).all() of reference sampling.py:109, recorded as the FIRST step at which it held, and the
-// step counter of the random stream.  state = {step, first_all_eos_step (-1 = not yet)}
-__global__ void sample_finish_kernel(const int64_t* __restrict__ tok, int B, int64_t eos, int32_t* __restrict__ state) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// Loop bookkeeping of one token step in ONE small launch: (next_token == eos).all() of reference sampling.py:109 recorded as
+// the FIRST step at which it held, the step counter of the random stream, the KV-cache write position, and the token
+// history the host reads once at the end of generate() (instead of one small copy per step).
+// state = {step, first_all_eos_step (-1 = not yet)}
+__global__ void sample_finish_kernel(const int64_t* __restrict__ tok, int B, int64_t eos, int32_t* __restrict__ state,
+                                     int32_t* __restrict__ d_pos, int delta, int64_t* __restrict__ history, int64_t ld_hist,
+                                     int hist_cols) {
+  const int step = state[0];
+  if (history && step < hist_cols)
+    for (int b = threadIdx.x; b < B; b += blockDim.x) history[(int64_t)b * ld_hist + step] = tok[b];
+  if (threadIdx.x != 0) return;
   bool all = true;
   for (int b = 0; b < B; ++b) all = all && (tok[b] == eos);
-  if (all && state[1] < 0) state[1] = state[0];
-  state[0] += 1;
+  if (all && state[1] < 0) state[1] = step;
+  state[0] = step + 1;
+  if (d_pos) *d_pos += delta;
 }
 
 }  // namespace
@@ -295,9 +303,12 @@ extern "C" int mg_sample_f32(const float* logits, int64_t ld, int32_t B, int32_t
   return MG_OK;
 }
 
-extern "C" int mg_sample_finish(const int64_t* token, int32_t B, int64_t eos, int32_t* state, void* stream) {
+extern "C" int mg_sample_finish(const int64_t* token, int32_t B, int64_t eos, int32_t* state, int32_t* d_pos, int32_t delta,
+                                int64_t* history, int64_t ld_history, int32_t history_cols, void* stream) {
   if (!token || !state || B <= 0) MG_FAIL(MG_ERR_SHAPE, "mg_sample_finish: bad arguments");
-  hipLaunchKernelGGL(sample_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, token, B, eos, state);
+  if (history && (ld_history < history_cols || history_cols <= 0)) MG_FAIL(MG_ERR_SHAPE, "mg_sample_finish: bad history geometry");
+  hipLaunchKernelGGL(sample_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, token, B, eos, state, d_pos, delta,
+                     history, ld_history, history_cols);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }

@@ -51,6 +51,7 @@ class KVCache:
         self.sample_state = torch.tensor([0, -1], dtype=torch.int32, device=device)
         self.seed = torch.zeros(1, dtype=torch.int64, device=device)
         self.eos = -1
+        self.history = torch.zeros(B, Smax, dtype=torch.int64, device=device)   # token selected at step s of the current loop
         self.B, self.Smax = B, Smax
         self.decode_state = None
 
@@ -249,15 +250,15 @@ class LMEngine:
     def forward(self, input_ids=None, inputs_embeds=None, labels=None, use_cache=False, past_key_values=None,
                 output_hidden_states=False, cache_hint: Optional[int] = None, reuse_cache: bool = False,
                 return_logits: bool = False, sampling=None, eos_token: Optional[int] = None,
-                seed: Optional[int] = None) -> LMOutput:
+                seed: Optional[int] = None, feed_back: bool = False) -> LMOutput:
         if labels is not None:
             if inputs_embeds is None:
                 inputs_embeds = self.embed_ids(input_ids)
             return self.forward_loss(inputs_embeds, labels, output_hidden_states, return_logits)
         if past_key_values is not None:
-            if input_ids is None or input_ids.shape[1] != 1:
+            if not feed_back and (input_ids is None or input_ids.shape[1] != 1):
                 raise NotImplementedError("cached decoding takes one new token id per sequence (reference sampling.py:88-90)")
-            logits, tok = self.decode(input_ids, past_key_values, sampling=sampling)
+            logits, tok = self.decode(None if feed_back else input_ids, past_key_values, sampling=sampling)
             return LMOutput(logits=logits.unsqueeze(1), past_key_values=past_key_values, next_token=tok, loss=None,
                             eos_state=past_key_values.sample_state)
         if inputs_embeds is None:
@@ -274,7 +275,8 @@ class LMEngine:
                 cache.sample_state.copy_(torch.tensor([0, -1], dtype=torch.int32), non_blocking=True)
                 if seed is not None:
                     cache.seed.fill_(int(seed) & 0x7fffffffffffffff)
-                out["next_token"] = self.select_token(logits, cache, sampling)
+                st = self._ensure_decode_state(cache)      # the first token lands where the decode steps read it back
+                out["next_token"] = self.select_token(logits, cache, sampling, out=st.token)
                 out["eos_state"] = cache.sample_state
             return out
         x, hs = self._blocks_prefill(inputs_embeds, None, output_hidden_states)
@@ -397,22 +399,26 @@ class LMEngine:
         st.steps = 0
         return st
 
-    def select_token(self, logits: torch.Tensor, cache: KVCache, mode, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def select_token(self, logits: torch.Tensor, cache: KVCache, mode, out: Optional[torch.Tensor] = None,
+                     advance: bool = False) -> torch.Tensor:
         """next token of every row from fp32 logits (B, V): greedy argmax (mode None; reference sampling.py:96-97) or the
-        sampled branch (mode = (temperature, top_k, top_p); :99-107), then the loop bookkeeping (all-eos step, step
-        counter).  Enqueue-only: used inside the captured token step and, eagerly, on the prefill logits."""
+        sampled branch (mode = (temperature, top_k, top_p); :99-107), then the loop bookkeeping in one small launch
+        (all-eos step, step counter, token history, and -- inside a decode step -- the KV write position).  Enqueue-only:
+        used inside the captured token step and, eagerly, on the prefill logits."""
         if mode is None:
             tok = ops.argmax(logits, out=out)
         else:
             tok = ops.sample(logits, mode[0], mode[1], mode[2], cache.seed, cache.sample_state, out=out)
-        ops.sample_finish(tok, cache.eos, cache.sample_state)
+        ops.sample_finish(tok, cache.eos, cache.sample_state, d_pos=cache.d_pos if advance else None, history=cache.history)
         return tok
 
-    def _decode_step(self, cache: KVCache, st, mode=None):
+    def _decode_step(self, cache: KVCache, st, mode=None, feed_back: bool = False):
         """Enqueue one token step for all B sequences (graph-capturable: no
-        allocation, no sync, position read from cache.d_pos on the device)."""
+        allocation, no sync, position read from cache.d_pos on the device).
+        ``feed_back``: the input ids are the tokens the previous step selected (st.token, still on the device) -- the
+        reference's loop feeds exactly those back (sampling.py:88-90) -- instead of ids copied in from the caller."""
         B = cache.B
-        ops.embedding(st.ids, self.wte, st.xa.view(B, 1, self.d))
+        ops.embedding(st.token.view(B, 1) if feed_back else st.ids, self.wte, st.xa.view(B, 1, self.d))
         x, xn = st.xa, st.xb
         d3 = 3 * self.d
         main = torch.cuda.current_stream()
@@ -493,35 +499,42 @@ class LMEngine:
             x, xn = xn, x
         head = self.head_w8 if w8_on else self.head_dec
         ops.gemm_skinny(x, head, out=st.logits, ln_fold=(head.colsum, self.d, self.eps))
-        self.select_token(st.logits[:, : self.V], cache, mode, out=st.token)
-        ops.advance_pos(cache.d_pos, 1)
+        self.select_token(st.logits[:, : self.V], cache, mode, out=st.token, advance=True)
 
-    def decode(self, input_ids: torch.Tensor, cache: KVCache, use_graph: bool = True, sampling=None):
-        """One cached step.  Returns (fp32 logits (B,V) view, selected token (B,) view: greedy, or sampled when
-        ``sampling = (temperature, top_k, top_p)``); both are overwritten by the next step."""
-        if cache.pos >= cache.Smax:
-            raise ValueError(f"KV cache full (Smax={cache.Smax}); pass a larger cache_hint / max_steps")
-        if cache.B > 16:
-            raise NotImplementedError("decode batch > 16 per GPU is not implemented (weight-streaming kernel is M<=16)")
+    def _ensure_decode_state(self, cache: KVCache):
         st = cache.decode_state
         if st is None:
             self._ensure_decode_packs()
             if self.decode_w8:
                 self._ensure_decode_packs_w8()
             st = cache.decode_state = self._alloc_decode_state(cache)
-        st.ids.copy_(input_ids.reshape(cache.B, 1))
+        return st
+
+    def decode(self, input_ids: Optional[torch.Tensor], cache: KVCache, use_graph: bool = True, sampling=None):
+        """One cached step.  Returns (fp32 logits (B,V) view, selected token (B,) view: greedy, or sampled when
+        ``sampling = (temperature, top_k, top_p)``); both are overwritten by the next step.  ``input_ids=None`` feeds the
+        previously selected tokens back without leaving the device."""
+        if cache.pos >= cache.Smax:
+            raise ValueError(f"KV cache full (Smax={cache.Smax}); pass a larger cache_hint / max_steps")
+        if cache.B > 16:
+            raise NotImplementedError("decode batch > 16 per GPU is not implemented (weight-streaming kernel is M<=16)")
+        st = self._ensure_decode_state(cache)
+        feed_back = input_ids is None
+        if not feed_back:
+            st.ids.copy_(input_ids.reshape(cache.B, 1))
         mode = None if sampling is None else (float(sampling[0]), int(sampling[1]), float(sampling[2]))
+        key = (mode, feed_back)
         if not use_graph:
-            self._decode_step(cache, st, mode)
-        elif mode in st.graphs:
-            st.graphs[mode].replay()
+            self._decode_step(cache, st, mode, feed_back)
+        elif key in st.graphs:
+            st.graphs[key].replay()
         elif st.steps == 0:
-            self._decode_step(cache, st, mode)    # first step eager (loads code objects)
+            self._decode_step(cache, st, mode, feed_back)    # first step eager (loads code objects)
         else:
             g = torch.cuda.CUDAGraph()            # hipGraph on ROCm
             with torch.cuda.graph(g):
-                self._decode_step(cache, st, mode)
-            st.graphs[mode] = g
+                self._decode_step(cache, st, mode, feed_back)
+            st.graphs[key] = g
             g.replay()
         st.steps += 1
         cache.pos += 1

@@ -174,12 +174,12 @@ class GPTJForCausalLM(nn.Module):
                 labels: Optional[torch.Tensor] = None, use_cache: bool = False, past_key_values: Any = None,
                 output_hidden_states: bool = False, cache_hint: Optional[int] = None, reuse_cache: bool = False,
                 return_logits: bool = False, sampling=None, eos_token: Optional[int] = None,
-                seed: Optional[int] = None, **unused) -> LMOutput:
+                seed: Optional[int] = None, feed_back: bool = False, **unused) -> LMOutput:
         return self.engine.forward(input_ids=input_ids, inputs_embeds=inputs_embeds, labels=labels,
                                    use_cache=use_cache, past_key_values=past_key_values,
                                    output_hidden_states=output_hidden_states, cache_hint=cache_hint,
                                    reuse_cache=reuse_cache, return_logits=return_logits, sampling=sampling,
-                                   eos_token=eos_token, seed=seed)
+                                   eos_token=eos_token, seed=seed, feed_back=feed_back)
 
 
 def get_gptj(gradient_checkpointing: bool = False, from_pretrained: bool = False, device=None,

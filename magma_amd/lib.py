@@ -83,7 +83,7 @@ SYMBOLS = {
     "mg_argmax_f32": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp]),
     "mg_advance_pos": (C.c_int, [_vp, _i32, _vp]),
     "mg_sample_f32": (C.c_int, [_vp, _i64, _i32, _i32, _f32, _i32, _f32, _vp, _vp, _vp, _vp, _i64, _vp]),
-    "mg_sample_finish": (C.c_int, [_vp, _i32, _i64, _vp, _vp]),
+    "mg_sample_finish": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _i32, _vp, _i64, _i32, _vp]),
     "mg_avgpool2_nhwc_bf16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mg_stem_im2col_bf16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "mg_build_labels_i64": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i64, _vp]),

@@ -391,10 +391,17 @@ def sample(logits: torch.Tensor, temperature: float, top_k: int, top_p: float, s
     return out
 
 
-def sample_finish(token: torch.Tensor, eos: int, state: torch.Tensor):
-    _need_gpu(token, state)
+def sample_finish(token: torch.Tensor, eos: int, state: torch.Tensor, d_pos: Optional[torch.Tensor] = None, delta: int = 1,
+                  history: Optional[torch.Tensor] = None):
+    """Bookkeeping of one token step: first all-eos step, step counter, (optionally) KV write position += delta and the
+    token history [B, n_steps] int64."""
+    _need_gpu(token, state, d_pos, history)
     assert token.dtype == torch.int64 and state.dtype == torch.int32 and state.numel() >= 2
-    check(L.load().mg_sample_finish(token.data_ptr(), token.numel(), int(eos), state.data_ptr(), _stream()), "mg_sample_finish")
+    if history is not None:
+        assert history.dtype == torch.int64 and history.ndim == 2 and history.stride(1) == 1 and history.shape[0] == token.numel()
+    check(L.load().mg_sample_finish(token.data_ptr(), token.numel(), int(eos), state.data_ptr(), _p(d_pos), delta, _p(history),
+                                    0 if history is None else history.stride(0), 0 if history is None else history.shape[1],
+                                    _stream()), "mg_sample_finish")
 
 
 def advance_pos(d_pos: torch.Tensor, delta: int = 1):

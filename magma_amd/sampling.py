@@ -74,35 +74,36 @@ def generate(model, embeddings, max_steps: int = 100, temperature: float = 0.7, 
         if i == 0:
             outputs = model.lm(inputs_embeds=embeddings, use_cache=True, past_key_values=None, cache_hint=max_steps,
                                reuse_cache=True, **first_kw)
+        elif on_device:      # the token selected by the previous step is fed back on the device: nothing crosses the host
+            outputs = model.lm(input_ids=None, use_cache=True, past_key_values=past, feed_back=True, **step_kw)
         else:
             outputs = model.lm(input_ids=out[:, n - 1:n], use_cache=True, past_key_values=past, **step_kw)
         past = outputs.past_key_values
-        if outputs.get("next_token") is not None and (on_device or greedy):   # selected on the device (HIP engine)
-            next_token = outputs.next_token.unsqueeze(1)
-            state = outputs.get("eos_state")
-        else:                                                # any other LM object: the reference's host-side arithmetic
-            state = None
-            logits = outputs.logits[:, -1, :].float()
-            if greedy:
-                next_token = torch.argmax(logits, dim=-1, keepdim=True)
-            else:
-                if top_k > 0:
-                    logits = top_k_filter(logits, k=top_k)
-                if top_p > 0:
-                    logits = top_p_filter(logits, threshold=top_p)
-                probs = F.softmax(logits / temperature, dim=-1)
-                next_token = torch.multinomial(probs, num_samples=1)
-        out[:, n:n + 1] = next_token
-        n += 1
-        if stop_on_eos and eos_token is not None:
-            if state is None:
-                if bool((next_token == eos_token).all()):
-                    break
-            elif (i + 1) % every == 0 or i + 1 == max_steps:
-                first = int(state[1])                        # one host sync per `every` steps
+        if on_device:
+            n += 1
+            if stop_on_eos and eos_token is not None and ((i + 1) % every == 0 or i + 1 == max_steps):
+                first = int(outputs.eos_state[1])            # one host sync per `every` steps
                 if first >= 0:
                     n = s + first + 1                        # tokens after the first all-eos step are dropped again
                     break
+            continue
+        logits = outputs.logits[:, -1, :].float()            # any other LM object: the reference's host-side arithmetic
+        if greedy:
+            next_token = outputs.next_token.unsqueeze(1) if outputs.get("next_token") is not None else \
+                torch.argmax(logits, dim=-1, keepdim=True)
+        else:
+            if top_k > 0:
+                logits = top_k_filter(logits, k=top_k)
+            if top_p > 0:
+                logits = top_p_filter(logits, threshold=top_p)
+            probs = F.softmax(logits / temperature, dim=-1)
+            next_token = torch.multinomial(probs, num_samples=1)
+        out[:, n:n + 1] = next_token
+        n += 1
+        if stop_on_eos and eos_token is not None and bool((next_token == eos_token).all()):
+            break
+    if on_device:            # one copy of the token history the bookkeeping kernel kept
+        out[:, s:n] = past.history[:, : n - s]
     out = out[:, :n]
     if decode:
         out = [model.tokenizer.decode(remove_tokens_after_eos(row, eos_token, model.image_token)) for row in out]

@@ -17,6 +17,9 @@ cache = out.past_key_values
 tok = out.logits[:, -1].argmax(-1, keepdim=True)
 for _ in range(3):
     eng.decode(tok, cache)
+if os.environ.get("TRACE_MARK") == "1":      # marker for tools/trace_by_grid.py: only the replays below are summarised
+    from magma_amd import ops
+    torch.cuda.synchronize(); ops.cast_f32_bf16(torch.zeros(64, device=dev), torch.zeros(64, dtype=torch.bfloat16, device=dev)); torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 res = []
 for rep in range(3):
