@@ -220,6 +220,33 @@ int mg_attn_decode_fused_bf16(const mg_bf16* qkv, mg_bf16* kcache, mg_bf16* vcac
                               int32_t H, int32_t Smax, const int32_t* d_pos, int32_t rot_dim,
                               const float* sin_t, const float* cos_t, void* stream);
 
+/* ---- persistent decode step -------------------------------------------------------------------------------------------
+ * One launch for a whole cached token step (reference magma/sampling.py:86-93: model.lm(input_ids=..., past_key_values=...)):
+ * the step is described ONCE as a list of ops -- weight-streaming GEMVs (kind 0: mg_skinny_desc, bf16 weights, K % 1024 == 0,
+ * M <= 16) and fused decode attentions (kind 1: the arguments of mg_attn_decode_fused_bf16) -- in execution order.  Every op
+ * owns a completion counter (in the caller's int32 `counters` array of mg_decode_counter_ints(n_ops), bumped once per work item = one
+ * 16-column tile or one (batch, head)) and may wait for up to two earlier ops to complete.  The ops' workgroups
+ * all live in one persistent grid: a consumer first issues its weight loads, then waits for its producers, so the HBM
+ * weight stream does not drain between ops as it does between launches.  Activations that cross ops MUST NOT be read or
+ * written by anything else while the step runs; `counters` must be zero at launch (mg_sample_finish can clear it) and
+ * `err` (one int32, 0) becomes 1 if a wait timed out.
+ *   mg_decode_plan_bytes / mg_decode_plan_build: translate the host op list into the device table (one synchronous copy,
+ *   not capturable -- do it once); mg_decode_step_bf16: enqueue the step (capturable).                                     */
+typedef struct mg_decode_op {
+  int32_t kind;                 /* 0 = GEMV, 1 = decode attention */
+  int32_t dep0, dep1;           /* indices of EARLIER ops of the list this op reads from (-1 = none) */
+  int32_t _pad;
+  mg_skinny_desc gemv;          /* kind 0 */
+  const mg_bf16* qkv; mg_bf16* kcache; mg_bf16* vcache; mg_bf16* attn_out;   /* kind 1 */
+  int32_t B, H, Smax, rot_dim;
+  const int32_t* d_pos; const float* sin_t; const float* cos_t;
+} mg_decode_op;
+int64_t mg_decode_plan_bytes(int32_t n_ops);
+int32_t mg_decode_counter_ints(int32_t n_ops);   /* length of the int32 `counters` array (sharded, one cache line per shard) */
+int mg_decode_plan_build(const mg_decode_op* ops, int32_t n_ops, void* plan_device, int32_t* total_items_out);
+int mg_decode_step_bf16(const void* plan_device, int32_t n_ops, int32_t total_items, int32_t* counters, int32_t* err,
+                        void* stream);
+
 /* K24 greedy (reference magma/sampling.py:96-97, temperature == 0.0): token[b] = argmax_v logits[b, v] (first maximum), int64 out;
  * optionally appends to out_tokens[b*out_ld + *d_pos_out] and bumps *d_pos.  */
 int mg_argmax_f32(const float* logits, int64_t ld, int32_t B, int32_t V, int64_t* token,
@@ -236,12 +263,15 @@ int mg_advance_pos(int32_t* d_pos, int32_t delta, void* stream);
  * mg_sample_finish is the loop bookkeeping of a token step in one small launch: records the first step with
  * (token == eos).all() (reference sampling.py:109, read by the host every few steps instead of a sync per token), advances
  * the step counter, bumps the KV-cache write position *d_pos by delta (NULL: untouched) and appends the tokens to
- * history[b * ld_history + step] (NULL: off; the host copies the history once when generate() ends).                       */
+ * history[b * ld_history + step] (NULL: off; the host copies the history once when generate() ends); `clear` (NULL: off) =
+ * n_clear int32 at clear[i * clear_stride] set to zero for the next step (the sharded completion counters of
+ * mg_decode_step_bf16: one word per 64-byte line).                                                                         */
 int mg_sample_f32(const float* logits, int64_t ld, int32_t B, int32_t V, float temperature, int32_t top_k, float top_p,
                   const uint64_t* seed, const int32_t* state, int64_t* token, float* filtered, int64_t ld_filtered,
                   void* stream);
 int mg_sample_finish(const int64_t* token, int32_t B, int64_t eos, int32_t* state, int32_t* d_pos, int32_t delta,
-                     int64_t* history, int64_t ld_history, int32_t history_cols, void* stream);
+                     int64_t* history, int64_t ld_history, int32_t history_cols, int32_t* clear, int32_t n_clear,
+                     int32_t clear_stride, void* stream);
 
 /* K4: 2x2 average pool, NHWC bf16.  x [B,H,W,C] -> y [B,H/2,W/2,C]  (stem pool and the anti-aliased stride of
  * CLIP's ModifiedResNet bottlenecks; trunk selected at reference magma/image_encoders.py:65-74).              */

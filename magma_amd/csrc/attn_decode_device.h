@@ -2,6 +2,7 @@
 // shared by attention.hip (stand-alone launch) and decode_fused.hip (co-launched with a GEMV).
 #pragma once
 #include "common.h"
+#include "gemm_device.h"
 
 // ---------------------------------------------------------------------------
 // decode attention: one query per (b,h); ctx = *d_pos + 1 keys.  grid B*H, 256 thr.
@@ -24,7 +25,9 @@ struct AttnDecodeParams {
 };
 
 // Device body: `bh` = (batch, head) index, `lds` = ATTN_DEC_LDS bytes of scratch (16-byte aligned).
-template <bool FUSED>
+// COH (persistent decode step): the fused qkv row comes from other workgroups of the same launch and the context row
+// goes to others -- both through the coherent accessors of gemm_device.h.
+template <bool FUSED, bool COH = false>
 MG_DEV void attn_decode_body(const AttnDecodeParams& P, int bh, char* lds) {
   constexpr int DH = 256;
   const mg_bf16* __restrict__ qin = P.qin;
@@ -52,7 +55,9 @@ MG_DEV void attn_decode_body(const AttnDecodeParams& P, int bh, char* lds) {
     const int dmodel = H * DH;
     if (tid < 96) {
       const int which = tid >> 5, c = tid & 31, d0 = c * 8;
-      u32x4 v = *(const u32x4*)(qin + (int64_t)b * 3 * dmodel + which * dmodel + h * DH + d0);
+      u32x4 v;
+      if constexpr (COH) v = ld16_coh(qin + (int64_t)b * 3 * dmodel + which * dmodel + h * DH + d0);
+      else v = *(const u32x4*)(qin + (int64_t)b * 3 * dmodel + which * dmodel + h * DH + d0);
       if (which < 2 && d0 < rot_dim) {
         const int half_rot = rot_dim >> 1;
         const float* sp = sin_t + (int64_t)pos * half_rot + (d0 >> 1);
@@ -132,6 +137,16 @@ MG_DEV void attn_decode_body(const AttnDecodeParams& P, int bh, char* lds) {
   for (int r = 0; r < 4; ++r) red[wave * DH + lane * 4 + r] = acc[r];
   __syncthreads();
   const float v = (red[tid] + red[DH + tid] + red[2 * DH + tid] + red[3 * DH + tid]) * inv;
-  out[(int64_t)bh * DH + tid] = f2bf(v);
+  if constexpr (COH) {      // four dims per lane -> one 8-byte coherent store (lanes 0..63 of wave 0)
+    __syncthreads();
+    red[tid] = v;
+    __syncthreads();
+    if (tid < 64) {
+      u32x2 w; w[0] = pack2bf(red[tid * 4], red[tid * 4 + 1]); w[1] = pack2bf(red[tid * 4 + 2], red[tid * 4 + 3]);
+      st8_coh(out + (int64_t)bh * DH + tid * 4, w);
+    }
+  } else {
+    out[(int64_t)bh * DH + tid] = f2bf(v);
+  }
 }
 

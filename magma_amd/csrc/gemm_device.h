@@ -40,10 +40,53 @@ MG_DEV void epilogue_cols(const mg_epilogue& ep, int n, int N, EpiColsW<W>& c) {
   }
 }
 
+// ---- cross-workgroup hand-offs inside ONE launch (persistent decode step, decode_mega_kernel) ----
+// A CU's vector L1 is never refreshed by another CU's stores and the per-XCD L2s are not coherent with each other
+// (MI355X_MICROARCH.md, inter-workgroup visibility).  Data produced and consumed by different workgroups of the same
+// launch therefore moves through 8-byte agent-scope relaxed atomics on BOTH sides (global_load/store_dwordx2 sc1: L1
+// bypassed, written through), ordered by a completion counter: the valid form "{8-B agent atomics both sides}".
+// (hipcc follows every __hip_atomic_load with a full s_waitcnt vmcnt(0), which would serialise the weight stream around each
+// activation fragment, so the loads are written as asm: `sc1` = the agent-scope form, and ONE wait per batch of loads.)
+MG_DEV u32x2 ld8_coh(const void* p) {
+  u32x2 v;
+  asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+  return v;
+}
+MG_DEV void st8_coh(void* p, u32x2 w) {
+  __hip_atomic_store((unsigned long long*)p, (unsigned long long)w[0] | ((unsigned long long)w[1] << 32), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+MG_DEV u32x4 ld16_coh(const void* p) {
+  u32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+  return v;
+}
+// up to three 8-byte rows (the residual operands of an epilogue) with one wait
+MG_DEV void ld8x3_coh(const void* p0, const void* p1, const void* p2, u32x2& a, u32x2& b, u32x2& c) {
+  asm volatile("global_load_dwordx2 %0, %3, off sc1\n\tglobal_load_dwordx2 %1, %4, off sc1\n\t"
+               "global_load_dwordx2 %2, %5, off sc1\n\ts_waitcnt vmcnt(0)"
+               : "=&v"(a), "=&v"(b), "=&v"(c) : "v"(p0), "v"(p1), "v"(p2) : "memory");
+}
+// eight consecutive 64-byte-spaced 16-byte fragments (one chunk of activation k-steps) with one wait; the wait also
+// retires the weight loads issued before it -- the MFMAs that follow need both
+MG_DEV void ld16x8_coh(const void* p, u32x4 (&v)[8]) {
+  asm volatile("global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %8, off offset:64 sc1\n\t"
+               "global_load_dwordx4 %2, %8, off offset:128 sc1\n\tglobal_load_dwordx4 %3, %8, off offset:192 sc1\n\t"
+               "global_load_dwordx4 %4, %8, off offset:256 sc1\n\tglobal_load_dwordx4 %5, %8, off offset:320 sc1\n\t"
+               "global_load_dwordx4 %6, %8, off offset:384 sc1\n\tglobal_load_dwordx4 %7, %8, off offset:448 sc1\n\t"
+               "s_waitcnt vmcnt(0)"
+               : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+               : "v"(p) : "memory");
+}
+
 // W consecutive bf16 of a row <-> floats (W = 4: one 8-B access, W = 8: one 16-B access; p must be W*2-byte aligned)
-template <int W>
+template <int W, bool COH = false>
 MG_DEV void load_bf16_row(const mg_bf16* p, float* a) {
-  if constexpr (W == 8) {
+  if constexpr (COH) {
+    static_assert(W == 4, "coherent rows are 8-byte accesses");
+    const u32x2 w = ld8_coh(p);
+    a[0] = bflo(w[0]); a[1] = bfhi(w[0]); a[2] = bflo(w[1]); a[3] = bfhi(w[1]);
+  } else if constexpr (W == 8) {
     const u32x4 w = *(const u32x4*)p;
 #pragma unroll
     for (int i = 0; i < 4; ++i) { a[2 * i] = bflo(w[i]); a[2 * i + 1] = bfhi(w[i]); }
@@ -52,9 +95,13 @@ MG_DEV void load_bf16_row(const mg_bf16* p, float* a) {
     a[0] = bflo(w[0]); a[1] = bfhi(w[0]); a[2] = bflo(w[1]); a[3] = bfhi(w[1]);
   }
 }
-template <int W, bool NT>
+template <int W, bool NT, bool COH = false>
 MG_DEV void store_bf16_row(mg_bf16* p, const float* o) {
-  if constexpr (W == 8) {
+  if constexpr (COH) {
+    static_assert(W == 4, "coherent rows are 8-byte accesses");
+    u32x2 w; w[0] = pack2bf(o[0], o[1]); w[1] = pack2bf(o[2], o[3]);
+    st8_coh(p, w);
+  } else if constexpr (W == 8) {
     u32x4 w;
 #pragma unroll
     for (int i = 0; i < 4; ++i) w[i] = pack2bf(o[2 * i], o[2 * i + 1]);
@@ -67,7 +114,7 @@ MG_DEV void store_bf16_row(mg_bf16* p, const float* o) {
 
 // v[W] = accumulators of columns n .. n+W-1 of row m.  NT: non-temporal output stores (large outputs
 // that nobody re-reads soon: keeps the L2 for the operand panels and streams the tile out).
-template <int W, bool NT>
+template <int W, bool NT, bool COH = false>
 MG_DEV void epilogue_apply(const mg_epilogue& ep, const EpiColsW<W>& c, int m, int n, const float* v, int N) {
   const bool full = (n + W - 1 < N);
   float o[W];
@@ -100,13 +147,25 @@ MG_DEV void epilogue_apply(const mg_epilogue& ep, const EpiColsW<W>& c, int m, i
     }
   }
   const mg_bf16* rs[3] = {ep.res0, ep.res1, ep.res2};
+  if constexpr (COH) {       // all residual rows in flight together, one wait (W == 4: 8-byte rows)
+    if (full && (rs[0] || rs[1] || rs[2])) {
+      const mg_bf16* any = rs[0] ? rs[0] : (rs[1] ? rs[1] : rs[2]);
+      u32x2 w[3];
+      ld8x3_coh((rs[0] ? rs[0] : any) + (int64_t)m * ep.ldr + n, (rs[1] ? rs[1] : any) + (int64_t)m * ep.ldr + n,
+                (rs[2] ? rs[2] : any) + (int64_t)m * ep.ldr + n, w[0], w[1], w[2]);
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+        if (rs[t]) { o[0] += bflo(w[t][0]); o[1] += bfhi(w[t][0]); o[2] += bflo(w[t][1]); o[3] += bfhi(w[t][1]); }
+      rs[0] = rs[1] = rs[2] = nullptr;
+    }
+  }
 #pragma unroll
   for (int t = 0; t < 3; ++t) {
     if (rs[t]) {
       const mg_bf16* rp = rs[t] + (int64_t)m * ep.ldr + n;
       if (full) {
         float a[W];
-        load_bf16_row<W>(rp, a);
+        load_bf16_row<W, COH>(rp, a);
 #pragma unroll
         for (int r = 0; r < W; ++r) o[r] += a[r];
       } else {
@@ -133,17 +192,18 @@ MG_DEV void epilogue_apply(const mg_epilogue& ep, const EpiColsW<W>& c, int m, i
     } else for (int r = 0; r < W; ++r) if (n + r < N) cp[r] = o[r];
   } else {
     mg_bf16* cp = (mg_bf16*)ep.C + (int64_t)m * ep.ldc + n;
-    if (full) store_bf16_row<W, NT>(cp, o);
+    if (full) store_bf16_row<W, NT, COH>(cp, o);
     else for (int r = 0; r < W; ++r) if (n + r < N) cp[r] = f2bf(o[r]);
   }
 }
 
+template <bool COH = false>
 MG_DEV void epilogue_store4(const mg_epilogue& ep, int m, int n, f32x4 v, int N) {
   if (n >= N) return;
   EpiCols c;
   epilogue_cols<4>(ep, n, N, c);
   const float vv[4] = {v[0], v[1], v[2], v[3]};
-  epilogue_apply<4, false>(ep, c, m, n, vv, N);
+  epilogue_apply<4, false, COH>(ep, c, m, n, vv, N);
 }
 
 // 16-byte accesses need every row start 16-byte aligned
@@ -226,8 +286,13 @@ MG_DEV bf16x8 fp8x8_to_bf16(uint32_t w0, uint32_t w1) {
   return __builtin_bit_cast(bf16x8, o);
 }
 
-template <int WAVES, int KC, int NT, bool W8 = false>
-MG_DEV void skinny_body(const SkinnyParams& p, int block, char* lds) {
+struct NoWait { MG_DEV void operator()() const {} };
+
+// COH: activations in / out go through the coherent 8-byte accessors (persistent decode step); `wait` is called once,
+// AFTER the first chunk's weight loads have been issued and BEFORE the first activation load: inside the persistent
+// launch it blocks on the producer's completion counter while the weights are already streaming in.
+template <int WAVES, int KC, int NT, bool W8 = false, bool COH = false, class Wait = NoWait>
+MG_DEV void skinny_body(const SkinnyParams& p, int block, char* lds, Wait wait = Wait()) {
   static_assert(!W8 || KC % 2 == 0, "fp8 weights are stored in k-step pairs");
   float* red = (float*)lds;
   const int lane = threadIdx.x & 63;
@@ -244,12 +309,9 @@ MG_DEV void skinny_body(const SkinnyParams& p, int block, char* lds) {
   for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float xs = 0.f, xss = 0.f;   // row statistics of x (LayerNorm fold)
 
-  for (int kc = 0; kc < per_wave; kc += KC) {
-    // Issue the whole chunk's loads before the first MFMA (GEMV recipe: loads
-    // straight to VGPRs, deep queue, late wait): weights first (HBM, non-temporal
-    // -- each byte is read exactly once per step), then the x fragments (L2 hits).
-    constexpr int WL = W8 ? KC / 2 : KC;      // 16-byte loads per n-tile and chunk
-    u32x4 wf[NT][WL];
+  constexpr int WL = W8 ? KC / 2 : KC;      // 16-byte loads per n-tile and chunk
+  u32x4 wf[NT][WL];
+  auto load_w = [&](int kc) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int nt = min(nt0 + t, p.ntiles - 1);
@@ -258,12 +320,28 @@ MG_DEV void skinny_body(const SkinnyParams& p, int block, char* lds) {
 #pragma unroll
       for (int i = 0; i < WL; ++i) wf[t][i] = __builtin_nontemporal_load(wp + i * 64);
     }
+  };
+  constexpr bool AHEAD = !__is_same(Wait, NoWait);     // persistent step: first weight burst before the dependency wait
+  if constexpr (AHEAD) { load_w(0); wait(); }
+  for (int kc = 0; kc < per_wave; kc += KC) {
+    // Issue the whole chunk's loads before the first MFMA (GEMV recipe: loads
+    // straight to VGPRs, deep queue, late wait): weights first (HBM, non-temporal
+    // -- each byte is read exactly once per step), then the x fragments (L2 hits).
+    if (!AHEAD || kc > 0) load_w(kc);
     bf16x8 xf[KC];
+    if constexpr (COH) {
+      static_assert(KC == 8, "the coherent fragment batch is 8 k-steps");
+      u32x4 raw[8];
+      ld16x8_coh(xrow + (int64_t)(ks0 + kc) * 32, raw);
 #pragma unroll
-    for (int i = 0; i < KC; ++i) {
-      u32x4 raw = *(const u32x4*)(xrow + (int64_t)(ks0 + kc + i) * 32);
-      if (!xok) raw = (u32x4){0u, 0u, 0u, 0u};
-      xf[i] = __builtin_bit_cast(bf16x8, raw);
+      for (int i = 0; i < KC; ++i) xf[i] = __builtin_bit_cast(bf16x8, xok ? raw[i] : (u32x4){0u, 0u, 0u, 0u});
+    } else {
+#pragma unroll
+      for (int i = 0; i < KC; ++i) {
+        u32x4 raw = *(const u32x4*)(xrow + (int64_t)(ks0 + kc + i) * 32);
+        if (!xok) raw = (u32x4){0u, 0u, 0u, 0u};
+        xf[i] = __builtin_bit_cast(bf16x8, raw);
+      }
     }
     if (p.ln_colsum && !(p.dbg & 1)) {
 #pragma unroll
@@ -323,8 +401,8 @@ MG_DEV void skinny_body(const SkinnyParams& p, int block, char* lds) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) s[r] = rstd * (s[r] - mean * (n + r < p.N ? p.ln_colsum[n + r] : 0.f));
     }
-    if (p.split_n > 0 && n >= p.split_n) epilogue_store4(p.ep_b, li, n - p.split_n, s, p.N - p.split_n);
-    else epilogue_store4(p.ep, li, n, s, p.split_n > 0 ? p.split_n : p.N);
+    if (p.split_n > 0 && n >= p.split_n) epilogue_store4<COH>(p.ep_b, li, n - p.split_n, s, p.N - p.split_n);
+    else epilogue_store4<COH>(p.ep, li, n, s, p.split_n > 0 ? p.split_n : p.N);
   }
 }
 

@@ -275,8 +275,9 @@ __global__ __launch_bounds__(ST) void sample_kernel(const SampleParams p) {
 // state = {step, first_all_eos_step (-1 = not yet)}
 __global__ void sample_finish_kernel(const int64_t* __restrict__ tok, int B, int64_t eos, int32_t* __restrict__ state,
                                      int32_t* __restrict__ d_pos, int delta, int64_t* __restrict__ history, int64_t ld_hist,
-                                     int hist_cols) {
+                                     int hist_cols, int32_t* __restrict__ clear, int n_clear, int clear_stride) {
   const int step = state[0];
+  for (int i = threadIdx.x; i < n_clear; i += blockDim.x) clear[(int64_t)i * clear_stride] = 0;
   if (history && step < hist_cols)
     for (int b = threadIdx.x; b < B; b += blockDim.x) history[(int64_t)b * ld_hist + step] = tok[b];
   if (threadIdx.x != 0) return;
@@ -304,11 +305,12 @@ extern "C" int mg_sample_f32(const float* logits, int64_t ld, int32_t B, int32_t
 }
 
 extern "C" int mg_sample_finish(const int64_t* token, int32_t B, int64_t eos, int32_t* state, int32_t* d_pos, int32_t delta,
-                                int64_t* history, int64_t ld_history, int32_t history_cols, void* stream) {
+                                int64_t* history, int64_t ld_history, int32_t history_cols, int32_t* clear, int32_t n_clear,
+                                int32_t clear_stride, void* stream) {
   if (!token || !state || B <= 0) MG_FAIL(MG_ERR_SHAPE, "mg_sample_finish: bad arguments");
   if (history && (ld_history < history_cols || history_cols <= 0)) MG_FAIL(MG_ERR_SHAPE, "mg_sample_finish: bad history geometry");
-  hipLaunchKernelGGL(sample_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, token, B, eos, state, d_pos, delta,
-                     history, ld_history, history_cols);
+  hipLaunchKernelGGL(sample_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, token, B, eos, state, d_pos, delta,
+                     history, ld_history, history_cols, clear, clear ? n_clear : 0, clear_stride > 0 ? clear_stride : 1);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }

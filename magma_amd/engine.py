@@ -135,6 +135,11 @@ class LMEngine:
         # GEMVs -> half the bytes per token step.  Changes the numerics (weight quantisation), so it is opt-in.
         self.decode_w8 = os.environ.get("MAGMA_DECODE_W8", "0") == "1"
         self._dec_in_variant = int(os.environ.get("MAGMA_DEC_IN_VARIANT", "0"))   # tuning knob: nt | waves<<4 | kc<<8
+        # persistent decode step (one launch per token instead of ~115 -- csrc/gemm.hip decode_mega_kernel).  Parity-green at
+        # full width but SLOWER than the launch chain on this chip (3.93 vs 2.55 ms per token at B = 8: every dependency level
+        # exposes a ~14 us hand-off chain -- drained stores, counter, poll, L2-served activations -- where a launch boundary
+        # costs ~3 us; without the waits the same structure streams at 2.27 ms).  Opt-in: MAGMA_DECODE_MEGA=1.
+        self.mega = os.environ.get("MAGMA_DECODE_MEGA", "0") == "1"
         self._side_stream = torch.cuda.Stream(device=dev)
         self.group_launches = os.environ.get("MAGMA_DECODE_GROUPED", "1") == "1"
         self.two_streams = os.environ.get("MAGMA_DECODE_STREAMS", "1") == "2"   # measured slower (3.07 vs 2.94 ms/step): off
@@ -397,10 +402,51 @@ class LMEngine:
         st.token = torch.zeros(B, dtype=torch.int64, device=dev)
         st.graphs = {}             # token-selection mode (None = greedy | (temperature, top_k, top_p)) -> captured hipGraph
         st.steps = 0
+        st.plan = self._build_decode_plan(cache, st) if self.mega and not self.decode_w8 else None
         return st
 
+    def _build_decode_plan(self, cache: KVCache, st):
+        """Op list of the persistent token step (csrc/gemm.hip decode_mega_kernel) for the MAGMA_v1 block shape: per layer
+        [ln_1+qkv+gelu(fc_in)] -> {attention, fc_out} -> {out_proj, adapter-down} -> adapter-up(+3 residuals), then
+        [ln_f+lm_head].  Returns None when a block does not have that shape (v2 / parallel adapters, K % 1024 != 0): the
+        launch chain is used then.  The activation buffers are shared by all layers; every reuse is ordered by the
+        dependency chain (a layer's first op waits for the previous layer's last one)."""
+        B, d3 = cache.B, 3 * self.d
+        plan_ops = []
+        x, xn = st.xa, st.xb
+        for li, ly in enumerate(self.layers):
+            ok = (ly.mlp_adapter is not None and ly.attn_adapter is None and ly.mlp_par is None
+                  and all(p.Kp % 1024 == 0 for p in (ly.dec_in, ly.fc_out, ly.out, ly.mlp_adapter[0], ly.mlp_adapter[1])))
+            if not ok:
+                return None
+            t = st.t[:, : ly.mlp_adapter[0].N]
+            plan_ops += [
+                {"name": f"in{li}", "deps": [f"up{li - 1}"] if li else [],
+                 "gemv": (x, ly.dec_in, st.qkv, dict(ln_fold=(ly.dec_in.colsum, self.d, self.eps),
+                                                     split=(d3, st.h, ops.MG_ACT_GELU_NEW, ly.dec_in.bias_b)))},
+                {"name": f"attn{li}", "deps": [f"in{li}"],
+                 "attn": (st.qkv, cache.k[li], cache.v[li], st.ctx, B, self.H, cache.d_pos, self.rot, self.sin_t, self.cos_t)},
+                {"name": f"fco{li}", "deps": [f"in{li}"], "gemv": (st.h, ly.fc_out, st.m, {})},
+                {"name": f"out{li}", "deps": [f"attn{li}"], "gemv": (st.ctx, ly.out, st.a, {})},
+                {"name": f"dn{li}", "deps": [f"fco{li}"], "gemv": (st.m, ly.mlp_adapter[0], t, dict(act=ops.MG_ACT_RELU))},
+                {"name": f"up{li}", "deps": [f"dn{li}", f"out{li}"],
+                 "gemv": (t, ly.mlp_adapter[1], xn, dict(residuals=(st.m, st.a, x)))},
+            ]
+            x, xn = xn, x
+        if self.head_dec.Kp % 1024:
+            return None
+        plan_ops.append({"name": "head", "deps": [f"up{len(self.layers) - 1}"],
+                         "gemv": (x, self.head_dec, st.logits, dict(ln_fold=(self.head_dec.colsum, self.d, self.eps)))})
+        try:
+            return ops.DecodePlan(plan_ops, self.device)
+        except ops.L.MagmaHipError as e:       # shape the persistent kernel does not take: fall back to the launch chain
+            if os.environ.get("MAGMA_DECODE_MEGA_STRICT") == "1":
+                raise
+            self._mega_refused = str(e)
+            return None
+
     def select_token(self, logits: torch.Tensor, cache: KVCache, mode, out: Optional[torch.Tensor] = None,
-                     advance: bool = False) -> torch.Tensor:
+                     advance: bool = False, clear: Optional[torch.Tensor] = None) -> torch.Tensor:
         """next token of every row from fp32 logits (B, V): greedy argmax (mode None; reference sampling.py:96-97) or the
         sampled branch (mode = (temperature, top_k, top_p); :99-107), then the loop bookkeeping in one small launch
         (all-eos step, step counter, token history, and -- inside a decode step -- the KV write position).  Enqueue-only:
@@ -409,8 +455,16 @@ class LMEngine:
             tok = ops.argmax(logits, out=out)
         else:
             tok = ops.sample(logits, mode[0], mode[1], mode[2], cache.seed, cache.sample_state, out=out)
-        ops.sample_finish(tok, cache.eos, cache.sample_state, d_pos=cache.d_pos if advance else None, history=cache.history)
+        ops.sample_finish(tok, cache.eos, cache.sample_state, d_pos=cache.d_pos if advance else None, history=cache.history,
+                          clear=clear, clear_stride=16 if clear is not None else 1)
         return tok
+
+    def check_decode(self, cache: KVCache):
+        """Raise if a wait of the persistent decode step timed out (one device read; generate() calls it once at the end)."""
+        st = cache.decode_state
+        if st is not None and st.plan is not None and int(st.plan.err) != 0:
+            raise ops.L.MagmaHipError("persistent decode step: a dependency wait timed out (results of this call are invalid); "
+                                      "set MAGMA_DECODE_MEGA=0 to use the launch chain")
 
     def _decode_step(self, cache: KVCache, st, mode=None, feed_back: bool = False):
         """Enqueue one token step for all B sequences (graph-capturable: no
@@ -419,6 +473,10 @@ class LMEngine:
         reference's loop feeds exactly those back (sampling.py:88-90) -- instead of ids copied in from the caller."""
         B = cache.B
         ops.embedding(st.token.view(B, 1) if feed_back else st.ids, self.wte, st.xa.view(B, 1, self.d))
+        if st.plan is not None:      # the whole step as ONE persistent launch, then token selection + bookkeeping
+            st.plan.launch()
+            self.select_token(st.logits[:, : self.V], cache, mode, out=st.token, advance=True, clear=st.plan.counters)   # stride 16
+            return
         x, xn = st.xa, st.xb
         d3 = 3 * self.d
         main = torch.cuda.current_stream()

@@ -64,6 +64,17 @@ class SkinnyDesc(C.Structure):
     ]
 
 
+class DecodeOp(C.Structure):
+    """mg_decode_op: one op of the persistent decode step."""
+    _fields_ = [
+        ("kind", C.c_int32), ("dep0", C.c_int32), ("dep1", C.c_int32), ("_pad", C.c_int32),
+        ("gemv", SkinnyDesc),
+        ("qkv", C.c_void_p), ("kcache", C.c_void_p), ("vcache", C.c_void_p), ("attn_out", C.c_void_p),
+        ("B", C.c_int32), ("H", C.c_int32), ("Smax", C.c_int32), ("rot_dim", C.c_int32),
+        ("d_pos", C.c_void_p), ("sin_t", C.c_void_p), ("cos_t", C.c_void_p),
+    ]
+
+
 # every symbol include/magma_hip.h declares: (name, restype, argtypes)
 _i32, _i64, _f32, _vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 SYMBOLS = {
@@ -83,7 +94,11 @@ SYMBOLS = {
     "mg_argmax_f32": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp]),
     "mg_advance_pos": (C.c_int, [_vp, _i32, _vp]),
     "mg_sample_f32": (C.c_int, [_vp, _i64, _i32, _i32, _f32, _i32, _f32, _vp, _vp, _vp, _vp, _i64, _vp]),
-    "mg_sample_finish": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _i32, _vp, _i64, _i32, _vp]),
+    "mg_sample_finish": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _i32, _vp, _i64, _i32, _vp, _i32, _i32, _vp]),
+    "mg_decode_plan_bytes": (C.c_int64, [_i32]),
+    "mg_decode_counter_ints": (C.c_int32, [_i32]),
+    "mg_decode_plan_build": (C.c_int, [C.POINTER(DecodeOp), _i32, _vp, C.POINTER(C.c_int32)]),
+    "mg_decode_step_bf16": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp]),
     "mg_avgpool2_nhwc_bf16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mg_stem_im2col_bf16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "mg_build_labels_i64": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i64, _vp]),

@@ -392,16 +392,59 @@ def sample(logits: torch.Tensor, temperature: float, top_k: int, top_p: float, s
 
 
 def sample_finish(token: torch.Tensor, eos: int, state: torch.Tensor, d_pos: Optional[torch.Tensor] = None, delta: int = 1,
-                  history: Optional[torch.Tensor] = None):
+                  history: Optional[torch.Tensor] = None, clear: Optional[torch.Tensor] = None, clear_stride: int = 1):
     """Bookkeeping of one token step: first all-eos step, step counter, (optionally) KV write position += delta and the
     token history [B, n_steps] int64."""
     _need_gpu(token, state, d_pos, history)
     assert token.dtype == torch.int64 and state.dtype == torch.int32 and state.numel() >= 2
     if history is not None:
         assert history.dtype == torch.int64 and history.ndim == 2 and history.stride(1) == 1 and history.shape[0] == token.numel()
+    if clear is not None:
+        assert clear.dtype == torch.int32 and clear.is_contiguous()
     check(L.load().mg_sample_finish(token.data_ptr(), token.numel(), int(eos), state.data_ptr(), _p(d_pos), delta, _p(history),
                                     0 if history is None else history.stride(0), 0 if history is None else history.shape[1],
-                                    _stream()), "mg_sample_finish")
+                                    _p(clear), 0 if clear is None else clear.numel() // clear_stride, clear_stride, _stream()),
+          "mg_sample_finish")
+
+
+class DecodePlan:
+    """Device table of a persistent decode step (mg_decode_plan_build) + its completion counters and error flag.
+    ``ops`` = list of dicts: {"gemv": (x, w, out, kwargs)} or {"attn": (qkv, kcache, vcache, out, B, H, d_pos, rot, sin, cos)},
+    each with "name", and "deps": names of the ops it reads from."""
+
+    def __init__(self, ops_list, device):
+        n = len(ops_list)
+        arr = (L.DecodeOp * n)()
+        index = {o["name"]: i for i, o in enumerate(ops_list)}
+        for i, o in enumerate(ops_list):
+            d = arr[i]
+            if "gemv" in o:
+                x, w, out, kw = o["gemv"]
+                sd, _ = skinny_desc(x, w, out, **kw)
+                d.kind, d.gemv = 0, sd
+            else:
+                qkv, kc, vc, out, B, H, d_pos, rot, sin_t, cos_t = o["attn"]
+                d.kind = 1
+                d.qkv, d.kcache, d.vcache, d.attn_out = qkv.data_ptr(), kc.data_ptr(), vc.data_ptr(), out.data_ptr()
+                d.B, d.H, d.Smax, d.rot_dim = B, H, kc.shape[2], rot
+                d.d_pos, d.sin_t, d.cos_t = d_pos.data_ptr(), sin_t.data_ptr(), cos_t.data_ptr()
+            deps = [index[nm] for nm in o.get("deps", ())]
+            assert len(deps) <= 2 and all(j < i for j in deps), "an op waits for at most two EARLIER ops"
+            d.dep0 = deps[0] if len(deps) > 0 else -1
+            d.dep1 = deps[1] if len(deps) > 1 else -1
+        lib = L.load()
+        self.n_ops = n
+        self.table = torch.empty(int(lib.mg_decode_plan_bytes(n)), dtype=torch.uint8, device=device)
+        self.counters = torch.zeros(int(lib.mg_decode_counter_ints(n)), dtype=torch.int32, device=device)
+        self.err = torch.zeros(1, dtype=torch.int32, device=device)
+        total = C.c_int32(0)
+        torch.cuda.synchronize(device)
+        check(lib.mg_decode_plan_build(arr, n, self.table.data_ptr(), C.byref(total)), "mg_decode_plan_build")
+        self.total_items = int(total.value)
+
+    def launch(self):
+        check(L.load().mg_decode_step_bf16(self.table.data_ptr(), self.n_ops, self.total_items, self.counters.data_ptr(),
+                                           self.err.data_ptr(), _stream()), "mg_decode_step_bf16")
 
 
 def advance_pos(d_pos: torch.Tensor, delta: int = 1):

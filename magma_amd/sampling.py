@@ -104,6 +104,7 @@ def generate(model, embeddings, max_steps: int = 100, temperature: float = 0.7, 
             break
     if on_device:            # one copy of the token history the bookkeeping kernel kept
         out[:, s:n] = past.history[:, : n - s]
+        model.lm.engine.check_decode(past)
     out = out[:, :n]
     if decode:
         out = [model.tokenizer.decode(remove_tokens_after_eos(row, eos_token, model.image_token)) for row in out]
