@@ -130,6 +130,45 @@ def cpu_baseline(args, budget_s):
                       f"measured in {time.time()-t_used:.0f} s"}
 
 
+def decode_gemv_jobs(eng, st):
+    """Exactly the weight-streaming GEMV launches of one token step, on the real weights of every layer (12.16 GB, far beyond
+    the 256 MiB Infinity Cache): (list of launch thunks, algorithmic weight bytes, [(N, K)] per launch)."""
+    from magma_amd import ops
+    jobs, shapes = [], []
+    d3 = 3 * eng.d
+
+    def add(fn, w):
+        jobs.append(fn)
+        shapes.append((w.N, w.K))
+
+    for ly in eng.layers:
+        add(lambda ly=ly: ops.gemm_skinny(st.xa, ly.dec_in, out=st.qkv, ln_fold=(ly.dec_in.colsum, eng.d, eng.eps),
+                                          split=(d3, st.h, ops.MG_ACT_GELU_NEW, ly.dec_in.bias_b)), ly.dec_in)
+        add(lambda ly=ly: ops.gemm_skinny(st.ctx, ly.out, out=st.a), ly.out)
+        add(lambda ly=ly: ops.gemm_skinny(st.h, ly.fc_out, out=st.m), ly.fc_out)
+        if ly.mlp_adapter:
+            r = ly.mlp_adapter[0].N
+            add(lambda ly=ly, r=r: ops.gemm_skinny(st.m, ly.mlp_adapter[0], out=st.t[:, :r], act=ops.MG_ACT_RELU), ly.mlp_adapter[0])
+            add(lambda ly=ly, r=r: ops.gemm_skinny(st.t[:, :r], ly.mlp_adapter[1], out=st.xb, residuals=(st.m, st.a, st.xa)), ly.mlp_adapter[1])
+    add(lambda: ops.gemm_skinny(st.xa, eng.head_dec, out=st.logits, ln_fold=(eng.head_dec.colsum, eng.d, eng.eps)), eng.head_dec)
+    return jobs, sum(n * k * 2 for n, k in shapes), shapes
+
+
+def pmc_traffic_per_launch(shapes):
+    """HBM bytes per launch of the GEMV sweep from the committed rocprofv3 FETCH_SIZE pass over this very sweep
+    (profiles/r02_decode_gemv_fetch_table.json, tools/pmc_decode_sweep.py: per (N, K) shape, counter x 2 for the gfx950
+    wide-read under-count, MI355X_MICROARCH.md HBM).  None when a shape is missing from the table."""
+    path = os.path.join(ROOT, "profiles", "r02_decode_gemv_fetch_table.json")
+    if not os.path.exists(path):
+        return None, None
+    tab = json.load(open(path))["bytes_per_launch"]
+    try:
+        tot = sum(tab[f"{n}x{k}"] for n, k in shapes)
+    except KeyError:
+        return None, None
+    return tot / len(shapes), os.path.relpath(path, ROOT)
+
+
 def train_flops_per_image(model, res, S, c=1.0):
     """SURVEY 8d, 'no recompute' policy: T = 2G + 3A + W + 3E per image.  c = 1: full-S^2 attention FLOPs, as the
     reference computes them; c = 0.5: the causal tiles the flash kernels actually execute."""
@@ -341,26 +380,8 @@ def main():
         # dominant kernel in isolation: every decode GEMV of the model (all layers + head) launched
         # back to back on the real weights (12.16 GB, far beyond the 256 MiB Infinity Cache), HIP events
         # on the launch stream.  achieved = algorithmic bytes per launch / average launch duration.
-        from magma_amd import ops
         st = cache.decode_state
-        jobs, wbytes = [], 0
-        d3 = 3 * eng.d
-
-        def add(fn, w):
-            nonlocal wbytes
-            jobs.append(fn)
-            wbytes += w.N * w.K * 2
-
-        for ly in eng.layers:     # exactly the GEMV launches of one token step, on the real weights
-            add(lambda ly=ly: ops.gemm_skinny(st.xa, ly.dec_in, out=st.qkv, ln_fold=(ly.dec_in.colsum, eng.d, eng.eps),
-                                              split=(d3, st.h, ops.MG_ACT_GELU_NEW, ly.dec_in.bias_b)), ly.dec_in)
-            add(lambda ly=ly: ops.gemm_skinny(st.ctx, ly.out, out=st.a), ly.out)
-            add(lambda ly=ly: ops.gemm_skinny(st.h, ly.fc_out, out=st.m), ly.fc_out)
-            if ly.mlp_adapter:
-                r = ly.mlp_adapter[0].N
-                add(lambda ly=ly, r=r: ops.gemm_skinny(st.m, ly.mlp_adapter[0], out=st.t[:, :r], act=ops.MG_ACT_RELU), ly.mlp_adapter[0])
-                add(lambda ly=ly, r=r: ops.gemm_skinny(st.t[:, :r], ly.mlp_adapter[1], out=st.xb, residuals=(st.m, st.a, st.xa)), ly.mlp_adapter[1])
-        add(lambda: ops.gemm_skinny(st.xa, eng.head_dec, out=st.logits, ln_fold=(eng.head_dec.colsum, eng.d, eng.eps)), eng.head_dec)
+        jobs, wbytes, shapes = decode_gemv_jobs(eng, st)
 
         def sweep():
             for fn in jobs:
@@ -380,11 +401,12 @@ def main():
         torch.cuda.synchronize()
         ms_sweep = e0.elapsed_time(e1) / 10
         achieved = wbytes / (ms_sweep * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic_per_launch(shapes)
         roof = {"bound": "hbm", "kernel": "skinny_kernel (decode weight-streaming GEMM, M=8)",
                 "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                # PMC (profiles/r01_skinny_fc_in_pmc_*): FETCH_SIZE 65,850 KB/launch at the fc_in shape, x2 for the
-                # gfx950 wide-read under-count (MI355X_MICROARCH.md HBM) = 134.9 MB vs 134.2 MB algorithmic
-                "traffic": 1.005 * wbytes / len(jobs), "bytes_per_launch": wbytes / len(jobs), "launches": len(jobs),
+                # HBM bytes per launch from the PMC pass over this sweep (per GEMV shape), not measured in this run
+                "traffic": traffic, "traffic_source": traffic_src,
+                "bytes_per_launch": wbytes / len(jobs), "launches": len(jobs),
                 "avg_launch_us": ms_sweep * 1e3 / len(jobs),
                 "token_step": {"ms": ms_tok, "decode_tokens_per_s": B / (ms_tok * 1e-3),
                                "hbm_frac_whole_step": wbytes / (ms_tok * 1e-3) / 8e12}}
