@@ -40,6 +40,7 @@ extern "C" {
 #define MG_ACT_NONE 0
 #define MG_ACT_RELU 1
 #define MG_ACT_GELU_NEW 2
+#define MG_ACT_QUICK_GELU 3 /* x * sigmoid(1.702 x): CLIP ViT MLP */
 
 /* auxiliary-operand modes of the epilogue (backward passes, dropout) */
 #define MG_AUX_NONE 0
@@ -272,6 +273,17 @@ int mg_sample_f32(const float* logits, int64_t ld, int32_t B, int32_t V, float t
 int mg_sample_finish(const int64_t* token, int32_t B, int64_t eos, int32_t* state, int32_t* d_pos, int32_t delta,
                      int64_t* history, int64_t ld_history, int32_t history_cols, int32_t* clear, int32_t n_clear,
                      int32_t clear_stride, void* stream);
+
+/* CLIP VisionTransformer front end and attention (encoder_name "clip" = ViT-B/32; reference magma/image_encoders.py:56-63):
+ *   patchify   img [B,3,H,W] bf16 NCHW -> rows [B*(H/P)*(W/P), 3*P*P] in (c, py, px) order = the im2col of the stride-P patch
+ *              conv, which then is mg_gemm_bf16 against conv1.weight.reshape(width, 3*P*P);
+ *   vit_embed  out[b,0,:] = class_embedding + pos[0];  out[b,1+g,:] = patches[b*G+g,:] + pos[1+g]   (fp32 add, bf16 out);
+ *   attn_small non-causal multi-head attention for short sequences (S <= 256, head dim 64): qkv [B*S, 3*H*64] = [q | k | v]
+ *              with the in_proj bias already added, out [B*S, H*64]; fp32 scores / softmax, scale 1/8.              */
+int mg_patchify_bf16(const mg_bf16* img, mg_bf16* out, int32_t B, int32_t H, int32_t W, int32_t P, void* stream);
+int mg_vit_embed_bf16(const mg_bf16* patches, const mg_bf16* class_embedding, const mg_bf16* pos, mg_bf16* out, int32_t B,
+                      int32_t G, int32_t width, void* stream);
+int mg_attn_small_bf16(const mg_bf16* qkv, mg_bf16* out, int32_t B, int32_t S, int32_t H, void* stream);
 
 /* K4: 2x2 average pool, NHWC bf16.  x [B,H,W,C] -> y [B,H/2,W/2,C]  (stem pool and the anti-aliased stride of
  * CLIP's ModifiedResNet bottlenecks; trunk selected at reference magma/image_encoders.py:65-74).              */

@@ -47,6 +47,7 @@ MG_DEV float gelu_new_grad_f(float x) {
 MG_DEV float apply_act(float v, int act) {
   if (act == MG_ACT_RELU) return v > 0.f ? v : 0.f;
   if (act == MG_ACT_GELU_NEW) return gelu_new_f(v);
+  if (act == MG_ACT_QUICK_GELU) return v * __frcp_rn(1.0f + __expf(-1.702f * v));   // CLIP's QuickGELU: x * sigmoid(1.702 x)
   return v;
 }
 

@@ -307,6 +307,95 @@ extern "C" int mg_embedding_bf16(const int64_t* ids, int32_t B, int32_t T, const
   return MG_OK;
 }
 
+// ---------------------------------------------------------------------------
+// CLIP ViT front end + short-sequence attention (see include/magma_hip.h)
+// ---------------------------------------------------------------------------
+namespace {
+// one workgroup per patch; thread -> (c, py) row of P pixels
+__global__ __launch_bounds__(256) void patchify_kernel(const mg_bf16* __restrict__ img, mg_bf16* __restrict__ out, int H, int W, int P) {
+  const int gw = W / P, gh = H / P;
+  const int patch = blockIdx.x, b = patch / (gh * gw), g = patch - b * gh * gw, gy = g / gw, gx = g - gy * gw;
+  mg_bf16* dst = out + (int64_t)patch * (3 * P * P);
+  for (int r = threadIdx.x; r < 3 * P; r += 256) {
+    const int c = r / P, py = r - c * P;
+    const mg_bf16* src = img + (((int64_t)b * 3 + c) * H + gy * P + py) * W + gx * P;
+    for (int px = 0; px < P; ++px) dst[r * P + px] = src[px];
+  }
+}
+
+__global__ __launch_bounds__(256) void vit_embed_kernel(const mg_bf16* __restrict__ patches, const mg_bf16* __restrict__ cls,
+                                                        const mg_bf16* __restrict__ pos, mg_bf16* __restrict__ out, int G, int width) {
+  const int row = blockIdx.x, b = row / (G + 1), t = row - b * (G + 1);
+  const mg_bf16* src = t == 0 ? cls : patches + ((int64_t)b * G + (t - 1)) * width;
+  for (int i = threadIdx.x; i < width; i += 256)
+    out[(int64_t)row * width + i] = f2bf(bf2f(src[i]) + bf2f(pos[(int64_t)t * width + i]));
+}
+
+// one workgroup per (b, h); K and V rows of the head in LDS as fp32; thread = one query row
+constexpr int AS_DH = 64, AS_MAXS = 256;
+__global__ __launch_bounds__(256) void attn_small_kernel(const mg_bf16* __restrict__ qkv, mg_bf16* __restrict__ out, int S, int H) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* ks = (float*)smem;                 // [S][65] (+1: bank skew)
+  float* vs = ks + AS_MAXS * (AS_DH + 1);
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const int w3 = 3 * H * AS_DH;
+  for (int i = threadIdx.x; i < S * AS_DH; i += 256) {
+    const int s = i / AS_DH, d = i - s * AS_DH;
+    const mg_bf16* row = qkv + (int64_t)(b * S + s) * w3 + h * AS_DH + d;
+    ks[s * (AS_DH + 1) + d] = bf2f(row[H * AS_DH]);
+    vs[s * (AS_DH + 1) + d] = bf2f(row[2 * H * AS_DH]);
+  }
+  __syncthreads();
+  const int qi = threadIdx.x;
+  if (qi >= S) return;
+  float q[AS_DH];
+  const mg_bf16* qrow = qkv + (int64_t)(b * S + qi) * w3 + h * AS_DH;
+#pragma unroll
+  for (int d = 0; d < AS_DH; ++d) q[d] = bf2f(qrow[d]) * 0.125f;        // 1 / sqrt(64)
+  float m = -1e30f, l = 0.f, acc[AS_DH];
+#pragma unroll
+  for (int d = 0; d < AS_DH; ++d) acc[d] = 0.f;
+  for (int j = 0; j < S; ++j) {                                         // online softmax, fp32
+    float sc = 0.f;
+#pragma unroll
+    for (int d = 0; d < AS_DH; ++d) sc += q[d] * ks[j * (AS_DH + 1) + d];
+    const float mn = fmaxf(m, sc), a = __expf(m - mn), pj = __expf(sc - mn);
+    l = l * a + pj;
+#pragma unroll
+    for (int d = 0; d < AS_DH; ++d) acc[d] = acc[d] * a + pj * vs[j * (AS_DH + 1) + d];
+    m = mn;
+  }
+  const float inv = 1.0f / l;
+  mg_bf16* orow = out + (int64_t)(b * S + qi) * (H * AS_DH) + h * AS_DH;
+#pragma unroll
+  for (int d = 0; d < AS_DH; ++d) orow[d] = f2bf(acc[d] * inv);
+}
+}  // namespace
+
+extern "C" int mg_patchify_bf16(const mg_bf16* img, mg_bf16* out, int32_t B, int32_t H, int32_t W, int32_t P, void* stream) {
+  if (B <= 0 || P <= 0 || H <= 0 || W <= 0 || H % P || W % P || !img || !out) MG_FAIL(MG_ERR_SHAPE, "mg_patchify_bf16: need H, W multiples of the patch size");
+  hipLaunchKernelGGL(patchify_kernel, dim3(B * (H / P) * (W / P)), dim3(256), 0, (hipStream_t)stream, img, out, H, W, P);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
+extern "C" int mg_vit_embed_bf16(const mg_bf16* patches, const mg_bf16* class_embedding, const mg_bf16* pos, mg_bf16* out,
+                                 int32_t B, int32_t G, int32_t width, void* stream) {
+  if (B <= 0 || G <= 0 || width <= 0 || !patches || !class_embedding || !pos || !out) MG_FAIL(MG_ERR_SHAPE, "mg_vit_embed_bf16: bad arguments");
+  hipLaunchKernelGGL(vit_embed_kernel, dim3(B * (G + 1)), dim3(256), 0, (hipStream_t)stream, patches, class_embedding, pos, out, G, width);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
+extern "C" int mg_attn_small_bf16(const mg_bf16* qkv, mg_bf16* out, int32_t B, int32_t S, int32_t H, void* stream) {
+  if (B <= 0 || H <= 0 || S <= 0 || S > AS_MAXS || !qkv || !out) MG_FAIL(MG_ERR_SHAPE, "mg_attn_small_bf16: need 0 < S <= %d (head dim 64)", AS_MAXS);
+  const int lds = 2 * AS_MAXS * (AS_DH + 1) * 4;
+  if (int rc = mg_allow_dynamic_lds((const void*)attn_small_kernel, lds, "mg_attn_small_bf16")) return rc;
+  hipLaunchKernelGGL(attn_small_kernel, dim3(B * H), dim3(256), lds, (hipStream_t)stream, qkv, out, S, H);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
 extern "C" int mg_avgpool2_nhwc_bf16(const mg_bf16* x, mg_bf16* y, int32_t B, int32_t H, int32_t W, int32_t C, void* stream) {
   if (B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C <= 0 || (C & 7)) MG_FAIL(MG_ERR_SHAPE, "mg_avgpool2_nhwc_bf16: need even H,W and C%%8==0");
   if (!x || !y || !MG_ALIGNED16(x) || !MG_ALIGNED16(y)) MG_FAIL(MG_ERR_ALIGN, "mg_avgpool2_nhwc_bf16: null/unaligned pointer");

@@ -2,8 +2,9 @@
 
 ``clip_resnet_large`` (CLIP RN50x16 trunk with the attention pool replaced by
 ``b d h w -> b (h w) d``) is what the shipped YAMLs select; ``clip_resnet``
-(RN50x4) is the same trunk at another width/depth.  ViT-B/32 and nfresnet50
-raise.  The module tree carries openai/CLIP's
+(RN50x4) is the same trunk at another width/depth; ``clip`` (ViT-B/32) is the
+VisionTransformer below, feeding the pooled ImagePrefix branch.  nfresnet50
+(timm NF-ResNet, no source or stand-in offline) raises.  The module tree carries openai/CLIP's
 parameter names (conv1..3, bn1..3, layer{1..4}.{j}.{conv,bn}{1..3},
 downsample.{0,1}) so reference checkpoints load by name, but the arithmetic is
 NOT torch: forward() drives the HIP kernels -- NHWC activations, every conv an
@@ -154,14 +155,110 @@ class ModifiedResNetTrunk(nn.Module):
         return y.view(B, h * w, -1)   # NHWC rows == "b (h w) d": the rearrange is free
 
 
+class _ViTAttention(nn.Module):
+    """Parameter container with nn.MultiheadAttention's names (in_proj_weight / in_proj_bias / out_proj.*)."""
+
+    def __init__(self, width, **kw):
+        super().__init__()
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * width, width, **kw))
+        self.in_proj_bias = nn.Parameter(torch.empty(3 * width, **kw))
+        self.out_proj = nn.Linear(width, width, **kw)
+
+
+class _ViTBlock(nn.Module):
+    def __init__(self, width, **kw):
+        super().__init__()
+        self.attn = _ViTAttention(width, **kw)
+        self.ln_1 = nn.LayerNorm(width, **kw)
+        self.mlp = nn.Sequential(OrderedDict([("c_fc", nn.Linear(width, 4 * width, **kw)), ("gelu", nn.Identity()),
+                                              ("c_proj", nn.Linear(4 * width, width, **kw))]))
+        self.ln_2 = nn.LayerNorm(width, **kw)
+
+
+class _ViTTransformer(nn.Module):
+    def __init__(self, width, layers, **kw):
+        super().__init__()
+        self.resblocks = nn.Sequential(*[_ViTBlock(width, **kw) for _ in range(layers)])
+
+
+class VisionTransformer(nn.Module):
+    """CLIP VisionTransformer (encoder_name "clip" = ViT-B/32, reference image_encoders.py:56-63), used whole -- ln_post and
+    the 512-d projection included -- so it returns (B, output_dim) and feeds the pooled branch of ImagePrefix.  openai/CLIP
+    parameter names; forward() drives the HIP kernels: patchify + GEMM (the stride-32 patch conv), class/positional embedding,
+    LayerNorm, QKV / out_proj / MLP GEMMs with bias, QuickGELU and residual adds in the epilogues, short-sequence attention."""
+
+    def __init__(self, input_resolution=224, patch_size=32, width=768, layers=12, heads=12, output_dim=512, device=None, dtype=None):
+        super().__init__()
+        if width != heads * 64:
+            raise ValueError("the short-sequence attention kernel is specialised for head dim 64 (CLIP ViT-B)")
+        kw = dict(device=device, dtype=dtype)
+        self.input_resolution, self.patch_size, self.width, self.heads, self.out_dim = input_resolution, patch_size, width, heads, output_dim
+        scale = width ** -0.5
+        self.conv1 = nn.Conv2d(3, width, patch_size, stride=patch_size, bias=False, **kw)
+        self.class_embedding = nn.Parameter(scale * torch.randn(width, **kw))
+        self.positional_embedding = nn.Parameter(scale * torch.randn((input_resolution // patch_size) ** 2 + 1, width, **kw))
+        self.ln_pre = nn.LayerNorm(width, **kw)
+        self.transformer = _ViTTransformer(width, layers, **kw)
+        self.ln_post = nn.LayerNorm(width, **kw)
+        self.proj = nn.Parameter(scale * torch.randn(width, output_dim, **kw))
+        with torch.no_grad():
+            for blk in self.transformer.resblocks:
+                blk.attn.in_proj_weight.normal_(std=scale)
+                blk.attn.in_proj_bias.zero_()
+        self._packed = None
+        self.eval()
+
+    def invalidate_packed(self):
+        self._packed = None
+
+    def _ensure_packed(self):
+        if self._packed is None:
+            f32 = lambda t: t.detach().float().contiguous()  # noqa: E731
+            pk = {"conv1": ops.PackedLinear(self.conv1.weight.detach().reshape(self.width, -1)),
+                  "proj": ops.PackedLinear(self.proj.detach().t().contiguous()),
+                  "ln_pre": (f32(self.ln_pre.weight), f32(self.ln_pre.bias)), "ln_post": (f32(self.ln_post.weight), f32(self.ln_post.bias)),
+                  "blocks": []}
+            for blk in self.transformer.resblocks:
+                pk["blocks"].append({
+                    "ln_1": (f32(blk.ln_1.weight), f32(blk.ln_1.bias)), "ln_2": (f32(blk.ln_2.weight), f32(blk.ln_2.bias)),
+                    "qkv": ops.PackedLinear(blk.attn.in_proj_weight, blk.attn.in_proj_bias),
+                    "out": ops.PackedLinear(blk.attn.out_proj.weight, blk.attn.out_proj.bias),
+                    "c_fc": ops.PackedLinear(blk.mlp.c_fc.weight, blk.mlp.c_fc.bias),
+                    "c_proj": ops.PackedLinear(blk.mlp.c_proj.weight, blk.mlp.c_proj.bias)})
+            self._packed = pk
+        return self._packed
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        pk = self._ensure_packed()
+        P, R = self.patch_size, self.input_resolution
+        if x.ndim != 4 or x.shape[1] != 3 or x.shape[2] != R or x.shape[3] != R:
+            raise ValueError(f"expected (B,3,{R},{R}) (fixed positional embedding), got {tuple(x.shape)}")
+        x = x.to(torch.bfloat16).contiguous()
+        B = x.shape[0]
+        patches = ops.gemm(ops.patchify(x, P), pk["conv1"])                                   # [B*G, width]
+        t = ops.vit_embed(patches, self.class_embedding.detach(), self.positional_embedding.detach(), B)
+        S, w = t.shape[1], self.width
+        t = ops.layernorm(t.view(B * S, w), *pk["ln_pre"], self.ln_pre.eps)
+        for blk, b in zip(self.transformer.resblocks, pk["blocks"]):
+            h = ops.layernorm(t, *b["ln_1"], blk.ln_1.eps)
+            ctx = ops.attn_small(ops.gemm(h, b["qkv"]), B, S, self.heads)
+            t = ops.gemm(ctx, b["out"], residuals=(t,))
+            h = ops.layernorm(t, *b["ln_2"], blk.ln_2.eps)
+            h = ops.gemm(h, b["c_fc"], act=ops.MG_ACT_QUICK_GELU)
+            t = ops.gemm(h, b["c_proj"], residuals=(t,))
+        cls = ops.layernorm(t.view(B, S, w)[:, 0, :], *pk["ln_post"], self.ln_post.eps)       # strided rows: the class tokens
+        return ops.gemm(cls, pk["proj"])                                                      # (B, output_dim)
+
+
 def clip_encoder(device=None, name: str = "clip_resnet_large", dtype=None) -> nn.Module:
     name = _ALIASES.get(name, name)
+    if name in ("clip", "ViT-B/32"):
+        return VisionTransformer(224, 32, 768, 12, 12, 512, device=device, dtype=dtype)
     if name in CLIP_RESNETS:
         layers, width, res = CLIP_RESNETS[name]
         return ModifiedResNetTrunk(layers, width, res, device=device, dtype=dtype)
-    raise NotImplementedError(f"encoder {name!r} is not implemented on the MI355X path (SURVEY 8f row 4): the CLIP ResNet "
-                              "trunks (clip_resnet_large = RN50x16, clip_resnet = RN50x4) are; ViT-B/32 needs a dh=64 "
-                              "attention kernel this build does not have")
+    raise NotImplementedError(f"encoder {name!r} is not implemented on the MI355X path (SURVEY 8f row 4): clip_resnet_large "
+                              "(RN50x16), clip_resnet (RN50x4) and clip (ViT-B/32) are")
 
 
 def get_image_encoder(name: str, device=None, pretrained: bool = False, dtype=None) -> nn.Module:

@@ -22,10 +22,12 @@ class ImagePrefix(nn.Module):
             config.encoder_name, device=device, pretrained=config.pretrained_img_encoder, dtype=dtype)
         self.encoder_out_dim = getattr(self.enc, "out_dim", None) or ENCODER_OUT_DIMS[self.encoder_type]
         self.out_dim = out_dim
-        if self.encoder_type not in ENCODER_SEQ_LENS:
-            raise NotImplementedError("pooled encoders (image_seq_len projection) are out of scope (SURVEY 8f row 4)")
-        self.out_seq_len = ENCODER_SEQ_LENS[self.encoder_type]
-        self.proj = nn.Linear(self.encoder_out_dim, self.out_dim, device=device, dtype=dtype)
+        # encoders with a token grid (CLIP ResNets) project every token; pooled encoders (ViT class token) are projected to
+        # image_seq_len tokens at once (reference image_prefix.py:60-72)
+        self.pooled = self.encoder_type not in ENCODER_SEQ_LENS
+        self.out_seq_len = config.image_seq_len if self.pooled else ENCODER_SEQ_LENS[self.encoder_type]
+        self.proj = nn.Linear(self.encoder_out_dim, self.out_dim * self.out_seq_len if self.pooled else self.out_dim,
+                              device=device, dtype=dtype)
         self.dropout = nn.Dropout(config.image_embed_dropout_prob)
         self.use_layernorm = config.use_image_embed_layernorm
         if self.use_layernorm:
@@ -49,7 +51,21 @@ class ImagePrefix(nn.Module):
     def forward(self, x: torch.Tensor, dropout_mask: torch.Tensor = None) -> torch.Tensor:
         """x (b,c,h,w) -> (b, seq, out_dim) bf16.  ``dropout_mask`` (b,seq,out_dim),
         already scaled by 1/(1-p), is applied in training mode when given."""
-        feats = self.enc(x)                                    # (B, P, enc_dim)
+        feats = self.enc(x)                                    # (B, P, enc_dim), or (B, enc_dim) from a pooled encoder
+        if self.pooled:
+            # reference image_prefix.py:85-101: Linear(enc_dim -> s*d), "b (s d) -> b s d" -- the GEMM output row IS the
+            # (s, d) block, so the rearrange is a view; dropout mask and LayerNorm then act on [B*s, d] rows
+            assert feats.ndim == 2
+            pk = self._ensure_packed()
+            y = ops.gemm(feats, pk["proj"]).reshape(feats.shape[0] * self.out_seq_len, self.out_dim)
+            if self.training and self.dropout.p > 0:
+                if dropout_mask is None:
+                    keep = 1.0 - self.dropout.p
+                    dropout_mask = (torch.rand(y.shape, device=y.device) < keep).to(y.dtype) / keep
+                y = ops.mul(y.contiguous(), dropout_mask.reshape(y.shape).to(y.dtype).contiguous())
+            if self.use_layernorm:
+                y = ops.layernorm(y, pk["ln_g"], pk["ln_b"], self.ln.eps)
+            return y.view(feats.shape[0], self.out_seq_len, self.out_dim)
         assert feats.ndim == 3, "clip resnet encoders return (b, hw, d)"
         B, P, E = feats.shape
         pk = self._ensure_packed()

@@ -13,7 +13,7 @@ from pathlib import Path
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libmagma_hip.so"
 
-MG_ACT_NONE, MG_ACT_RELU, MG_ACT_GELU_NEW = 0, 1, 2
+MG_ACT_NONE, MG_ACT_RELU, MG_ACT_GELU_NEW, MG_ACT_QUICK_GELU = 0, 1, 2, 3
 MG_W_ROWMAJOR, MG_W_FRAGTILED = 0, 1
 MG_A_DENSE, MG_A_CONV3X3 = 0, 1
 MG_AUX_NONE, MG_AUX_RELU_GATE, MG_AUX_GELU_GRAD, MG_AUX_MUL = 0, 1, 2, 3
@@ -99,6 +99,9 @@ SYMBOLS = {
     "mg_decode_counter_ints": (C.c_int32, [_i32]),
     "mg_decode_plan_build": (C.c_int, [C.POINTER(DecodeOp), _i32, _vp, C.POINTER(C.c_int32)]),
     "mg_decode_step_bf16": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp]),
+    "mg_patchify_bf16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "mg_vit_embed_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "mg_attn_small_bf16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "mg_avgpool2_nhwc_bf16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mg_stem_im2col_bf16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "mg_build_labels_i64": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i64, _vp]),

@@ -10,7 +10,7 @@ from typing import Optional, Sequence
 import torch
 
 from . import lib as L
-from .lib import (MG_A_CONV3X3, MG_A_DENSE, MG_ACT_GELU_NEW, MG_ACT_NONE, MG_ACT_RELU, MG_AUX_GELU_GRAD,
+from .lib import (MG_A_CONV3X3, MG_A_DENSE, MG_ACT_GELU_NEW, MG_ACT_NONE, MG_ACT_QUICK_GELU, MG_ACT_RELU, MG_AUX_GELU_GRAD,
                   MG_AUX_MUL, MG_AUX_NONE, MG_AUX_RELU_GATE, MG_W_FRAGTILED, MG_W_ROWMAJOR, Epilogue, GemmDesc,
                   SkinnyDesc, check)
 
@@ -449,6 +449,36 @@ class DecodePlan:
 
 def advance_pos(d_pos: torch.Tensor, delta: int = 1):
     check(L.load().mg_advance_pos(d_pos.data_ptr(), delta, _stream()), "mg_advance_pos")
+
+
+def patchify(img: torch.Tensor, P: int) -> torch.Tensor:
+    """img [B,3,H,W] bf16 -> [B*(H/P)*(W/P), 3*P*P] rows in (c, py, px) order (im2col of the stride-P patch conv)."""
+    _need_gpu(img)
+    assert img.dtype == BF16 and img.is_contiguous() and img.ndim == 4 and img.shape[1] == 3
+    B, _, H, W = img.shape
+    out = torch.empty(B * (H // P) * (W // P), 3 * P * P, dtype=BF16, device=img.device)
+    check(L.load().mg_patchify_bf16(img.data_ptr(), out.data_ptr(), B, H, W, P, _stream()), "mg_patchify_bf16")
+    return out
+
+
+def vit_embed(patches: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor, B: int) -> torch.Tensor:
+    """[class | patches] + positional embedding -> [B, G+1, width] bf16."""
+    _need_gpu(patches, cls, pos)
+    G, width = patches.shape[0] // B, patches.shape[1]
+    assert patches.dtype == BF16 and cls.dtype == BF16 and pos.dtype == BF16 and pos.shape == (G + 1, width)
+    out = torch.empty(B, G + 1, width, dtype=BF16, device=patches.device)
+    check(L.load().mg_vit_embed_bf16(patches.data_ptr(), cls.contiguous().data_ptr(), pos.contiguous().data_ptr(), out.data_ptr(),
+                                     B, G, width, _stream()), "mg_vit_embed_bf16")
+    return out
+
+
+def attn_small(qkv: torch.Tensor, B: int, S: int, H: int) -> torch.Tensor:
+    """Non-causal attention, head dim 64, S <= 256: qkv [B*S, 3*H*64] -> [B*S, H*64]."""
+    _need_gpu(qkv)
+    assert qkv.dtype == BF16 and qkv.is_contiguous() and qkv.shape == (B * S, 3 * H * 64)
+    out = torch.empty(B * S, H * 64, dtype=BF16, device=qkv.device)
+    check(L.load().mg_attn_small_bf16(qkv.data_ptr(), out.data_ptr(), B, S, H, _stream()), "mg_attn_small_bf16")
+    return out
 
 
 def avgpool2(x: torch.Tensor) -> torch.Tensor:

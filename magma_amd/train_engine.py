@@ -117,6 +117,9 @@ class MagmaEngine:
             raise NotImplementedError("freeze_lm: false (training the 6B GPT-J weights, ~100 GB of fp32 optimizer state) is not "
                                       "implemented: no LM weight gradients are computed on this path (SURVEY Q2: adapters, image "
                                       "encoder and prefix train)")
+        if getattr(model.image_prefix, "pooled", False):
+            raise NotImplementedError("training with a pooled image encoder (encoder_name 'clip' = ViT-B/32) is not implemented "
+                                      "(inference only)")
         from .adapters import ParallelAdapter
         if any(isinstance(m, ParallelAdapter) for m in model.modules()):
             raise NotImplementedError("training with parallel / scaled_parallel adapters is not implemented (inference only)")

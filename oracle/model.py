@@ -402,6 +402,97 @@ def _encoder_body(p, cfg, x, _conv_bn):
     return x.permute(0, 2, 3, 1).reshape(B, H * W, C)
 
 
+# ----------------------------------------------------------------------------
+# CLIP VisionTransformer (encoder_name "clip" = ViT-B/32)  [UNVENDORED openai/CLIP model.py VisionTransformer]
+# reference call site: magma/image_encoders.py:56-63 (clip.load(name)[0].visual, used whole: ln_post + proj included),
+# consumed by the pooled branch of ImagePrefix (magma/image_prefix.py:60-72,85-101).
+# Restated from the published CLIP architecture; pinned against the independent statement installed here,
+# HF CLIPVisionModelWithProjection (tests/test_oracle_vs_hf.py).  Parameter names are openai/CLIP's.
+# ----------------------------------------------------------------------------
+@dataclass
+class ViTConfig:
+    width: int = 768
+    layers: int = 12
+    heads: int = 12
+    patch: int = 32
+    resolution: int = 224
+    out_dim: int = 512
+    ln_eps: float = 1e-5
+
+    @property
+    def tokens(self) -> int:
+        return (self.resolution // self.patch) ** 2 + 1
+
+
+def init_vit_params(v: ViTConfig, seed: int = 0, prefix: str = "image_prefix.enc.") -> Params:
+    g = torch.Generator().manual_seed(seed)
+    w, sc = v.width, v.width ** -0.5
+
+    def rn(*shape, std):
+        return torch.randn(*shape, generator=g) * std
+
+    p: Params = {prefix + "conv1.weight": rn(w, 3, v.patch, v.patch, std=(3 * v.patch * v.patch) ** -0.5),
+                 prefix + "class_embedding": rn(w, std=sc), prefix + "positional_embedding": rn(v.tokens, w, std=sc),
+                 prefix + "proj": rn(w, v.out_dim, std=sc)}
+    for name in ("ln_pre", "ln_post"):
+        p[prefix + name + ".weight"] = 1.0 + rn(w, std=0.05)
+        p[prefix + name + ".bias"] = rn(w, std=0.02)
+    for i in range(v.layers):
+        b = f"{prefix}transformer.resblocks.{i}."
+        for name in ("ln_1", "ln_2"):
+            p[b + name + ".weight"] = 1.0 + rn(w, std=0.05)
+            p[b + name + ".bias"] = rn(w, std=0.02)
+        p[b + "attn.in_proj_weight"] = rn(3 * w, w, std=sc)
+        p[b + "attn.in_proj_bias"] = rn(3 * w, std=0.02)
+        p[b + "attn.out_proj.weight"] = rn(w, w, std=sc)
+        p[b + "attn.out_proj.bias"] = rn(w, std=0.02)
+        p[b + "mlp.c_fc.weight"] = rn(4 * w, w, std=sc)
+        p[b + "mlp.c_fc.bias"] = rn(4 * w, std=0.02)
+        p[b + "mlp.c_proj.weight"] = rn(w, 4 * w, std=(4 * w) ** -0.5)
+        p[b + "mlp.c_proj.bias"] = rn(w, std=0.02)
+    return p
+
+
+def vit_encoder_fwd(p: Params, v: ViTConfig, x: torch.Tensor, prefix: str = "image_prefix.enc.") -> torch.Tensor:
+    """(B,3,R,R) -> (B, out_dim): patch conv (stride = kernel), [class | patches] + positional embedding, ln_pre, `layers` x
+    {x += MHA(ln_1 x); x += c_proj(QuickGELU(c_fc(ln_2 x)))}, ln_post on the class token, @ proj."""
+    B = x.shape[0]
+    w, H = v.width, v.heads
+    t = F.conv2d(x, p[prefix + "conv1.weight"], None, stride=v.patch)            # (B, w, g, g)
+    t = t.reshape(B, w, -1).permute(0, 2, 1)
+    cls = p[prefix + "class_embedding"].to(t.dtype).expand(B, 1, w)
+    t = torch.cat((cls, t), dim=1) + p[prefix + "positional_embedding"].to(t.dtype)
+    t = F.layer_norm(t, (w,), p[prefix + "ln_pre.weight"], p[prefix + "ln_pre.bias"], v.ln_eps)
+    S, dh = t.shape[1], w // H
+    for i in range(v.layers):
+        b = f"{prefix}transformer.resblocks.{i}."
+        h = F.layer_norm(t, (w,), p[b + "ln_1.weight"], p[b + "ln_1.bias"], v.ln_eps)
+        qkv = F.linear(h, p[b + "attn.in_proj_weight"], p[b + "attn.in_proj_bias"])
+        q, k, vv = (u.reshape(B, S, H, dh).permute(0, 2, 1, 3) for u in qkv.chunk(3, dim=-1))
+        att = torch.softmax(torch.matmul(q.float(), k.float().transpose(-1, -2)) / math.sqrt(dh), dim=-1).to(vv.dtype)
+        o = torch.matmul(att, vv).permute(0, 2, 1, 3).reshape(B, S, w)
+        t = t + F.linear(o, p[b + "attn.out_proj.weight"], p[b + "attn.out_proj.bias"])
+        h = F.layer_norm(t, (w,), p[b + "ln_2.weight"], p[b + "ln_2.bias"], v.ln_eps)
+        h = F.linear(h, p[b + "mlp.c_fc.weight"], p[b + "mlp.c_fc.bias"])
+        h = h * torch.sigmoid(1.702 * h)                                         # QuickGELU
+        t = t + F.linear(h, p[b + "mlp.c_proj.weight"], p[b + "mlp.c_proj.bias"])
+    c = F.layer_norm(t[:, 0, :], (w,), p[prefix + "ln_post.weight"], p[prefix + "ln_post.bias"], v.ln_eps)
+    return c @ p[prefix + "proj"].to(c.dtype)
+
+
+def pooled_prefix_fwd(p: Params, d_model: int, seq_len: int, feats: torch.Tensor, ln_eps: float = 1e-5,
+                      dropout_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """reference magma/image_prefix.py:85-109 for encoders without a token grid (feats (B, enc_dim)):
+    Linear(enc_dim -> seq_len * d) -> "b (s d) -> b s d" -> dropout -> LayerNorm(d)."""
+    x = F.linear(feats, p["image_prefix.proj.weight"], p["image_prefix.proj.bias"])
+    x = x.reshape(feats.shape[0], seq_len, d_model)
+    if dropout_mask is not None:
+        x = x * dropout_mask
+    if "image_prefix.ln.weight" in p:
+        x = F.layer_norm(x, (d_model,), p["image_prefix.ln.weight"], p["image_prefix.ln.bias"], ln_eps)
+    return x
+
+
 def image_prefix_fwd(p: Params, cfg: OracleConfig, images: torch.Tensor,
                      dropout_mask: Optional[torch.Tensor] = None, bn_train: bool = False) -> torch.Tensor:
     """reference magma/image_prefix.py:78-109: enc -> proj -> dropout -> ln.

@@ -95,3 +95,44 @@ def test_adapter_placement_sequential_after_mlp():
     m = torch.nn.functional.linear(O.gelu_new(torch.nn.functional.linear(ln, p[mp + "c_fc.weight"], p[mp + "c_fc.bias"])), p[mp + "c_proj.weight"], p[mp + "c_proj.bias"])
     want = O.adapter_fwd(p, "lm.transformer.h.0.mlp.1.adapter.", m)
     assert torch.allclose(O.mlp_fwd(p, cfg, 0, ln), want, atol=1e-6)
+
+
+def test_vit_oracle_matches_hf_clip_vision():
+    """oracle.vit_encoder_fwd (CLIP VisionTransformer restated from the published architecture, openai/CLIP parameter
+    names) against HF CLIPVisionModelWithProjection -- an independent implementation of the same model -- on a reduced
+    configuration: patch conv, class / positional embeddings, pre-LN blocks with QuickGELU, ln_post, projection."""
+    from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
+    from oracle.model import ViTConfig, init_vit_params, vit_encoder_fwd
+    v = ViTConfig(width=64, layers=3, heads=4, patch=8, resolution=32, out_dim=24)
+    p = init_vit_params(v, seed=5, prefix="")
+    hf = CLIPVisionModelWithProjection(CLIPVisionConfig(hidden_size=64, intermediate_size=256, num_hidden_layers=3,
+                                                        num_attention_heads=4, image_size=32, patch_size=8, projection_dim=24,
+                                                        hidden_act="quick_gelu", layer_norm_eps=1e-5, attn_implementation="eager"))
+    hf.eval()
+    sd = hf.state_dict()
+    m = {"vision_model.embeddings.patch_embedding.weight": p["conv1.weight"],
+         "vision_model.embeddings.class_embedding": p["class_embedding"],
+         "vision_model.embeddings.position_embedding.weight": p["positional_embedding"],
+         "vision_model.pre_layrnorm.weight": p["ln_pre.weight"], "vision_model.pre_layrnorm.bias": p["ln_pre.bias"],
+         "vision_model.post_layernorm.weight": p["ln_post.weight"], "vision_model.post_layernorm.bias": p["ln_post.bias"],
+         "visual_projection.weight": p["proj"].t().contiguous()}
+    for i in range(v.layers):
+        b, h = f"transformer.resblocks.{i}.", f"vision_model.encoder.layers.{i}."
+        wq, wk, wv = p[b + "attn.in_proj_weight"].chunk(3, 0)
+        bq, bk, bv = p[b + "attn.in_proj_bias"].chunk(3, 0)
+        m.update({h + "self_attn.q_proj.weight": wq, h + "self_attn.k_proj.weight": wk, h + "self_attn.v_proj.weight": wv,
+                  h + "self_attn.q_proj.bias": bq, h + "self_attn.k_proj.bias": bk, h + "self_attn.v_proj.bias": bv,
+                  h + "self_attn.out_proj.weight": p[b + "attn.out_proj.weight"], h + "self_attn.out_proj.bias": p[b + "attn.out_proj.bias"],
+                  h + "layer_norm1.weight": p[b + "ln_1.weight"], h + "layer_norm1.bias": p[b + "ln_1.bias"],
+                  h + "layer_norm2.weight": p[b + "ln_2.weight"], h + "layer_norm2.bias": p[b + "ln_2.bias"],
+                  h + "mlp.fc1.weight": p[b + "mlp.c_fc.weight"], h + "mlp.fc1.bias": p[b + "mlp.c_fc.bias"],
+                  h + "mlp.fc2.weight": p[b + "mlp.c_proj.weight"], h + "mlp.fc2.bias": p[b + "mlp.c_proj.bias"]})
+    missing = [k for k in sd if k not in m and "position_ids" not in k]
+    assert not missing, missing
+    hf.load_state_dict({k: m.get(k, sd[k]) for k in sd})
+    x = torch.randn(2, 3, 32, 32, generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        ref = hf(pixel_values=x).image_embeds
+        got = vit_encoder_fwd(p, v, x, prefix="")
+    assert got.shape == ref.shape == (2, 24)
+    assert torch.allclose(got, ref, atol=2e-5, rtol=1e-4), float((got - ref).abs().max())

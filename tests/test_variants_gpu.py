@@ -171,3 +171,67 @@ def test_magma_import_path(dev):
     from magma.image_input import ImageInput
     import magma_amd
     assert Magma is magma_amd.Magma and ImageInput is magma_amd.ImageInput
+
+
+@pytest.mark.parametrize("geom", ["reduced", "vit_b32"])
+def test_clip_vit_encoder_and_pooled_prefix(dev, geom):
+    """encoder_name "clip" (ViT-B/32, reference image_encoders.py:56-63) + the pooled ImagePrefix branch (image_prefix.py:60-72,
+    85-101) against the oracle (CLIP VisionTransformer restated and pinned to HF CLIPVisionModelWithProjection)."""
+    from magma_amd.image_encoders import VisionTransformer
+    from magma_amd.image_prefix import ImagePrefix
+    from magma_amd.testing import tiny_multimodal_config
+    from oracle.model import ViTConfig, init_vit_params, pooled_prefix_fwd, vit_encoder_fwd
+    v = ViTConfig() if geom == "vit_b32" else ViTConfig(width=128, layers=2, heads=2, patch=8, resolution=32, out_dim=48)
+    p = init_vit_params(v, seed=3)
+    enc = VisionTransformer(v.resolution, v.patch, v.width, v.layers, v.heads, v.out_dim, device=dev, dtype=torch.bfloat16)
+    sd = {k[len("image_prefix.enc."):]: t for k, t in p.items()}
+    missing, unexpected = enc.load_state_dict(sd, strict=True), None
+    enc.invalidate_packed()
+    x = torch.randn(2, 3, v.resolution, v.resolution, generator=torch.Generator().manual_seed(0)).to(torch.bfloat16).float()
+    with torch.no_grad():
+        ref = vit_encoder_fwd(p, v, x)
+        eb = rel(vit_encoder_fwd(bf16_params(p), v, x.to(torch.bfloat16)), ref)
+        got = enc(x.cuda())
+    assert got.shape == ref.shape == (2, v.out_dim)
+    assert rel(got, ref) <= 2 * eb + 5e-3, (rel(got, ref), eb)
+    # pooled prefix: Linear(out_dim -> seq_len * d) + "b (s d) -> b s d" + LayerNorm
+    d, s = 512, 3
+    cfg = tiny_multimodal_config(encoder_name="clip", image_seq_len=s, image_size=v.resolution)
+    ip = ImagePrefix(cfg, out_dim=d, device=dev, dtype=torch.bfloat16, enc=enc)
+    assert ip.pooled and ip.out_seq_len == s and ip.proj.weight.shape == (s * d, v.out_dim)
+    g = torch.Generator().manual_seed(1)
+    pp = dict(p)
+    pp["image_prefix.proj.weight"] = torch.randn(s * d, v.out_dim, generator=g) * v.out_dim ** -0.5
+    pp["image_prefix.proj.bias"] = torch.randn(s * d, generator=g) * 0.02
+    pp["image_prefix.ln.weight"] = 1.0 + torch.randn(d, generator=g) * 0.05
+    pp["image_prefix.ln.bias"] = torch.randn(d, generator=g) * 0.02
+    with torch.no_grad():
+        ip.proj.weight.copy_(pp["image_prefix.proj.weight"]); ip.proj.bias.copy_(pp["image_prefix.proj.bias"])
+        ip.ln.weight.copy_(pp["image_prefix.ln.weight"]); ip.ln.bias.copy_(pp["image_prefix.ln.bias"])
+    ip.invalidate_packed()
+    ip.eval()
+    with torch.no_grad():
+        ref2 = pooled_prefix_fwd(pp, d, s, ref)
+        ppb = bf16_params(pp)
+        eb2 = rel(pooled_prefix_fwd(ppb, d, s, vit_encoder_fwd(ppb, v, x.to(torch.bfloat16))), ref2)
+        got2 = ip(x.cuda())
+    assert got2.shape == (2, s, d)
+    assert rel(got2, ref2) <= 2 * eb2 + 5e-3, (rel(got2, ref2), eb2)
+
+
+def test_magma_with_clip_vit_encoder(dev):
+    """Magma built from a config that selects encoder_name "clip": embed() yields image_seq_len prefix tokens per image."""
+    from magma_amd.config import MultimodalConfig
+    from magma_amd.language_model import GPTJConfig
+    from magma_amd.magma import Magma
+    cfg = MultimodalConfig(batch_size=2, train_steps=1, encoder_name="clip", image_seq_len=4, image_size=224,
+                           adapter_config={"mlp": {"adapter_type": "normal", "downsample_factor": 4}})
+    lm_cfg = GPTJConfig(vocab_size=1056, hidden_size=512, num_layers=2, num_heads=2, rotary_dim=64, intermediate_size=2048,
+                        max_position_embeddings=256)
+    model = Magma(cfg, device=dev, lm_config=lm_cfg)
+    model.eval()
+    assert model.image_prefix.pooled and model.image_prefix_seq_len == 4
+    emb = model.embed([torch.randn(2, 3, 224, 224), torch.randint(0, 1000, (2, 5))])
+    assert emb.shape == (2, 4 + 5, 512) and bool(torch.isfinite(emb.float()).all())
+    toks = model.generate(emb, max_steps=3, temperature=0.0, decode=False, stop_on_eos=False)
+    assert toks.shape == (2, 9 + 3)
