@@ -117,3 +117,64 @@ def test_clip_preprocess_shape_and_stats():
     t = clip_preprocess(384)(img)
     assert t.shape == (1, 3, 384, 384) and t.dtype == torch.float32
     assert abs(float(t.mean())) < 0.5
+
+
+def test_host_side_label_index_matches_build_labels():
+    """MagmaEngine.target_index (the loss head's row / label plumbing, computed on the host so that the training step has no
+    device sync) against the reference's label rule as the oracle states it (reference utils.py:334-364)."""
+    from magma_amd.train_engine import MagmaEngine
+    from oracle.model import build_labels
+    g = torch.Generator().manual_seed(0)
+    for P in (0, 4, 49):
+        S, eos = 96 + P, 7
+        caps = torch.randint(8, 50, (6, S), generator=g)
+        caps[0, :] = 9                    # no eos at all
+        caps[1, 0] = eos                  # eos first
+        caps[2, 5] = eos
+        caps[3, S - P - 1] = eos          # eos in the last kept position
+        caps[4, 3] = eos; caps[4, 10] = eos
+        rows, tgt, first = MagmaEngine.target_index(caps, P, eos, S)
+        lab = build_labels(P, caps, eos)
+        t = lab[:, 1:].reshape(-1)
+        allrows = (torch.arange(6)[:, None] * S + torch.arange(S - 1)[None, :]).reshape(-1)
+        keep = (t != -100).nonzero().squeeze(1)
+        assert torch.equal(rows, allrows[keep]) and torch.equal(tgt, t[keep]), P
+        assert first.tolist()[:5] == [S - P - 1, 0, 5, S - P - 1, 3]
+
+
+def test_lazy_loss_and_magma_alias():
+    from magma_amd.train_loop import LazyLoss
+    x = LazyLoss(torch.tensor(1.25))
+    assert f"{x:.2f}" == "1.25" and float(x) == 1.25 and x.item() == 1.25 and x < 2 and x > 1 and str(x) == "1.25"
+    import magma
+    import magma_amd
+    from magma.image_input import ImageInput
+    assert magma.Magma is magma_amd.Magma and ImageInput is magma_amd.ImageInput
+    from magma import collate_fn, eval_step, inference_step, train_step   # noqa: F401  (reference magma/__init__.py:19-20)
+
+
+def test_img_cpt_dataset_reads_the_reference_layout(tmp_path):
+    """reference magma/datasets/dataset.py:92-160: <dir>/image_data/<shard>/<n>.json records + images relative to <dir>;
+    items (1,3,H,W) / (1,seq_len) right-padded with eos; collate -> (B,3,H,W), (B,seq_len)."""
+    import json
+    import numpy as np
+    import PIL.Image as I
+    from magma_amd.datasets import ImgCptDataset, collate_fn
+    from magma_amd.tokenizer import ByteTokenizer
+    from magma_amd.transforms import clip_preprocess
+    (tmp_path / "image_data" / "00000").mkdir(parents=True)
+    (tmp_path / "images" / "00000").mkdir(parents=True)
+    rng = np.random.RandomState(0)
+    for i in range(3):
+        I.fromarray((rng.rand(50 + i, 70, 3) * 255).astype("uint8")).save(tmp_path / "images" / "00000" / f"{i}.jpg")
+        rec = {"captions": [f"caption {i}"], "metadata": {}}
+        if i != 1:
+            rec["image_path"] = f"images/00000/{i}.jpg"          # record 1: path inferred from the record's own name
+        (tmp_path / "image_data" / "00000" / f"{i}.json").write_text(json.dumps(rec))
+    ds = ImgCptDataset(tmp_path, ByteTokenizer(64), clip_preprocess(32), seq_len=64)
+    assert len(ds) == 3
+    img, cap = ds[1]
+    assert img.shape == (1, 3, 32, 32) and cap.shape == (1, 64) and cap.dtype == torch.int64
+    assert cap[0, :9].tolist() == list(b"caption 1") and bool((cap[0, 9:] == ByteTokenizer.eos_token_id).all())
+    images, caps = collate_fn([ds[i] for i in range(3)], seq_len=64)
+    assert images.shape == (3, 3, 32, 32) and caps.shape == (3, 64)
