@@ -121,6 +121,9 @@ typedef struct mg_gemm_desc {
 } mg_gemm_desc;
 
 int mg_gemm_bf16(const mg_gemm_desc* d, void* stream);
+/* Bytes of split-K scratch mg_gemm_bf16 / mg_gemm_fp8 can use for an M x N x K problem at the largest split the automatic
+ * policy picks (0 when the shape is never split): what a caller that owns all memory should allocate once.  */
+int64_t mg_gemm_workspace_bytes(int32_t M, int32_t N, int32_t K);
 
 /* fp8 operands (BASELINE config 5): A and W hold OCP e4m3 bytes (mg_quantize_rows_fp8), the product
  * runs on v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales) at twice the bf16 MFMA rate with fp32

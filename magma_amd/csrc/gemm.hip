@@ -614,6 +614,15 @@ int gemm_dispatch(const mg_gemm_desc* d, bool fp8, const float* row_scale, hipSt
 }
 }  // namespace
 
+extern "C" int64_t mg_gemm_workspace_bytes(int32_t M, int32_t N, int32_t K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, nkt = (K + BK - 1) / BK;
+  const int tiles = tiles_m * tiles_n;
+  if (tiles >= 192) return 0;                                   // same policy as gemm_dispatch: enough tiles, no split
+  const int want = std::max(1, std::min(std::min(16, nkt / 4), (512 + tiles - 1) / tiles));
+  return want > 1 ? (int64_t)want * M * tiles_n * BN * 4 : 0;
+}
+
 extern "C" int mg_gemm_bf16(const mg_gemm_desc* d, void* stream) {
   return gemm_dispatch(d, false, nullptr, (hipStream_t)stream, "mg_gemm_bf16");
 }

@@ -81,6 +81,7 @@ SYMBOLS = {
     "mg_version": (C.c_char_p, []),
     "mg_last_error": (C.c_char_p, []),
     "mg_gemm_bf16": (C.c_int, [C.POINTER(GemmDesc), _vp]),
+    "mg_gemm_workspace_bytes": (C.c_int64, [_i32, _i32, _i32]),
     "mg_gemm_skinny_bf16": (C.c_int, [C.POINTER(SkinnyDesc), _vp]),
     "mg_gemm_skinny2_bf16": (C.c_int, [C.POINTER(SkinnyDesc), C.POINTER(SkinnyDesc), _vp]),
     "mg_decode_attn_gemv_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp,

@@ -178,3 +178,22 @@ def test_img_cpt_dataset_reads_the_reference_layout(tmp_path):
     assert cap[0, :9].tolist() == list(b"caption 1") and bool((cap[0, 9:] == ByteTokenizer.eos_token_id).all())
     images, caps = collate_fn([ds[i] for i in range(3)], seq_len=64)
     assert images.shape == (3, 3, 32, 32) and caps.shape == (3, 64)
+
+
+def test_workspace_query_is_consistent_with_the_split_policy():
+    """mg_gemm_workspace_bytes (callers own all memory): 0 for shapes that fill the chip, else splits x M x
+    ceil(N/128)*128 fp32 -- pure host arithmetic, callable without a GPU."""
+    import ctypes
+    from magma_amd import lib
+    if not lib.LIB_PATH.exists():
+        pytest.skip("libmagma_hip.so not built")
+    try:
+        dll = ctypes.CDLL(str(lib.LIB_PATH))
+    except OSError as e:
+        pytest.skip(f"cannot dlopen the HIP library here: {e}")
+    f = dll.mg_gemm_workspace_bytes
+    f.restype, f.argtypes = ctypes.c_int64, [ctypes.c_int32] * 3
+    assert f(32768, 16384, 4096) == 0                       # training shape: 32768 tiles
+    assert f(456, 4096, 16384) == 4 * 456 * 4096 * 4        # prefill fc_out: 128 tiles -> 4-way split of 256 K-tiles
+    assert f(456, 1024, 4096) == 16 * 456 * 1024 * 4        # adapter-down: 32 tiles -> 16-way
+    assert f(0, 1, 1) == 0
