@@ -411,6 +411,25 @@ def main():
                 "token_step": {"ms": ms_tok, "decode_tokens_per_s": B / (ms_tok * 1e-3),
                                "hbm_frac_whole_step": wbytes / (ms_tok * 1e-3) / 8e12}}
 
+    # the reference's DEFAULT generate() settings (temperature 0.7, top_p 0.9, magma.py:214-221): the sampled branch -- top-p
+    # rule, softmax, multinomial -- runs inside the same captured token step (csrc/sampling.hip); never the headline
+    gen_s = None
+    try:
+        def sampled_step():
+            emb = model.embed([images, prompt])
+            return model.generate(emb, max_steps=gen, temperature=0.7, top_k=0, top_p=0.9, decode=False, stop_on_eos=False, seed=1)
+        sampled_step()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            sampled_step()
+        sync()
+        dts = (time.perf_counter() - t0) / args.steps
+        gen_s = {"mode": "temperature 0.7, top_p 0.9 (reference defaults), device-side sampling in the decode graph",
+                 "tokens_per_s": world * B * gen / dts, "ms_per_call": dts * 1e3, "vs_greedy": (dt / args.steps) / dts}
+    except Exception as e:  # noqa: BLE001
+        gen_s = {"error": repr(e)[:300]}
+
     gen8 = None
     if args.fp8:
         # BASELINE config[4] on the inference side: e4m3 weights in every decode GEMV (W8A16: bf16 activations, weights
@@ -443,6 +462,7 @@ def main():
                            "parallelism": f"replicas x{world}", "layers": model.lm.config.num_layers,
                            "prefill_len": int(toks.shape[1] - gen)},
                 "roofline": roof}
+        line["generate_sampled"] = gen_s
         if gen8 is not None:
             line["generate_fp8"] = gen8
         line["train"] = None
