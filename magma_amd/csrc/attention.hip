@@ -147,6 +147,8 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(
   const int sw0 = row_swz(krow0);
 
   int sc = 0;
+  MG_USE8(qf);                        // retire the q loads in hipcc's scoreboard: it cannot see the asm DMA waits below and
+                                      // would otherwise wait for "its" loads inside the loop with counts that drain the ring
   for (int t = 0; t < ntiles; ++t) {
     MG_WAIT_VMCNT(8);                 // this wave's pieces of tile t landed (tiles t+1, t+2 may be in flight)
     MG_BARRIER_KEEP_DMA();            // tile t complete; everyone is done with tile t-1
@@ -283,7 +285,7 @@ __global__ __launch_bounds__(256, 1) void attn_prefill32_kernel(
       const int blk = wave * 4 + i;
       const int row = blk * 2 + (lane >> 5);
       const int c = (lane & 31) ^ row_swz(row);
-      glds16(kbase + (int64_t)min(c0 + row, S - 1) * DH + c * 8, st + blk * 1024);
+      glds16a(kbase + (int64_t)min(c0 + row, S - 1) * DH + c * 8, st + blk * 1024);
     }
     const mg_bf16* src = vbase + (int64_t)(c0 >> 5) * (DH * 32);
 #pragma unroll
@@ -291,7 +293,7 @@ __global__ __launch_bounds__(256, 1) void attn_prefill32_kernel(
       const int blk = wave * 4 + i;
       const int row = blk * 16 + (lane >> 2);
       const int c = (lane & 3) ^ t_swz(row);
-      glds16(src + row * 32 + c * 8, st + ROW_TILE + blk * 1024);
+      glds16a(src + row * 32 + c * 8, st + ROW_TILE + blk * 1024);
     }
   };
 #pragma unroll
@@ -410,6 +412,7 @@ __global__ __launch_bounds__(256, 1) void attn_prefill32_kernel(
   };
 
   int sc = 0;
+  MG_USE8(qf); MG_USE8(qf + 8);       // see attn_prefill_kernel
   {
     for (int t = 0; t < ntiles; ++t) {
       MG_WAIT_VMCNT(16);               // tile t landed (this wave's pieces); tiles t+1, t+2 (8 pieces each) may be in flight

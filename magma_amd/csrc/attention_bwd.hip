@@ -114,6 +114,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(
   const int sw0 = row_swz(krow0);
 
   int sc = 0;
+  MG_USE8(qf); MG_USE8(dof);          // retire the ordinary loads in hipcc's scoreboard (see attention.hip)
+  asm volatile("" ::"v"(lse2), "v"(Dq));
   for (int t = 0; t < ntiles; ++t) {
     MG_WAIT_VMCNT(6);                 // this wave's pieces of tile t have landed (tile t+1 may be in flight)
     MG_BARRIER_KEEP_DMA();            // tile t complete; everyone is done with tile t-1
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_kernel(
     dma_rows(st, qb, DH, q0, S, wave, lane);
     if constexpr (DK) dma_rows(st + ROW_TILE, dob, dmodel, q0, S, wave, lane);
     dma_cols(st + T_OFF, tb, ld_t, q0, wave, lane);
-    glds4(ldb + (int64_t)min(q0 + (lane >> 1), S - 1) * 2 + (lane & 1), st + LD_OFF);   // every wave writes the same 256 B
+    glds4a(ldb + (int64_t)min(q0 + (lane >> 1), S - 1) * 2 + (lane & 1), st + LD_OFF);   // every wave writes the same 256 B
   };
 #pragma unroll
   for (int i = 0; i < NST - 1; ++i) issue(t_begin + i, i);
@@ -252,6 +254,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_kernel(
   const uint32_t ls_addr = (uint32_t)(uintptr_t)(mg_lptr_t)(smem + LD_OFF + lq * 64);   // LDS byte address, stage 0
 
   int sc = 0;
+  MG_USE8(kf);                        // retire the ordinary loads in hipcc's scoreboard (see attention.hip)
+  if constexpr (DK) MG_USE8(vf);
   for (int t = t_begin; t < t_end; ++t) {
     if constexpr (DK) { MG_WAIT_VMCNT(7); } else { MG_WAIT_VMCNT(10); }   // (NST-2) later tiles may be in flight
     MG_BARRIER_KEEP_DMA();
@@ -347,6 +351,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_kernel(
     }
   }
 }
+
 
 int set_lds(const void* fn, int bytes) {
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);

@@ -13,29 +13,31 @@ MG_DEV int t_swz(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; }   /
 constexpr int ROW_TILE = 32 * DH * 2;     // 16 KiB
 constexpr int T_TILE = DH * 32 * 2;       // 16 KiB
 
-// One tile = 16 blocks of 1 KiB; wave w (of 8) moves blocks 2w and 2w+1.
+// One tile = 16 blocks of 1 KiB; wave w (of NW) moves blocks w*16/NW .. +16/NW-1.
 // rows [r0, r0+32) of a row-major [*][256] array (row stride in elements), rows clamped to rmax-1
+template <int NW = 8>
 MG_DEV void dma_rows(char* tile, const mg_bf16* base, int64_t row_stride, int r0, int rmax, int wave, int lane) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int blk = wave * 2 + i;
+  for (int i = 0; i < 16 / NW; ++i) {
+    const int blk = wave * (16 / NW) + i;
     const int row = blk * 2 + (lane >> 5);
     const int c = (lane & 31) ^ row_swz(row);
-    glds16(base + (int64_t)min(r0 + row, rmax - 1) * row_stride + c * 8, tile + blk * 1024);
+    glds16a(base + (int64_t)min(r0 + row, rmax - 1) * row_stride + c * 8, tile + blk * 1024);
   }
 }
 // positions [c0, c0+32) (c0 % 32 == 0) of a transposed operand in the column-tiled layout [tile][256][32]: the
 // 16-KiB tile is contiguous, a wave instruction reads 1 KiB of it (16 rows x 64 B), the swizzle permutes 16-byte
 // chunks inside each 64-byte row only
+template <int NW = 8>
 MG_DEV void dma_cols(char* tile, const mg_bf16* base_t, int ld, int c0, int wave, int lane) {
   (void)ld;
   const mg_bf16* src = base_t + (int64_t)(c0 >> 5) * (DH * 32);
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int blk = wave * 2 + i;
+  for (int i = 0; i < 16 / NW; ++i) {
+    const int blk = wave * (16 / NW) + i;
     const int row = blk * 16 + (lane >> 2);
     const int c = (lane & 3) ^ t_swz(row);
-    glds16(src + row * 32 + c * 8, tile + blk * 1024);
+    glds16a(src + row * 32 + c * 8, tile + blk * 1024);
   }
 }
 

@@ -61,11 +61,34 @@ MG_DEV void glds16(const void* g, char* lds_wave_base) {
 MG_DEV void glds4(const void* g, char* lds_wave_base) {   // 64 lanes x 4 B -> 256 B
   __builtin_amdgcn_global_load_lds((mg_gptr_t)g, (mg_lptr_t)lds_wave_base, 4, 0, 0);
 }
+// The same two as inline assembly.  hipcc models the builtin as a FLAT access that may touch LDS; while one is in flight
+// (always, in a DMA ring that is only ever waited on with a counted vmcnt) its scoreboard calls both counters out of
+// order and turns EVERY wait for an ordinary ds_read into s_waitcnt lgkmcnt(0) -- a full LDS round trip in front of each
+// MFMA burst that only needed its oldest fragment.  Issued from assembly the DMA is invisible to that pass, the ds_read
+// waits are counted again, and the ring is ordered by hand (MG_WAIT_VMCNT + barrier), as it already was.  A kernel that
+// uses these must not also use the builtin forms (M0 is written behind the compiler's back).
+MG_DEV void glds16a(const void* g, char* lds_wave_base) {
+  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off"
+               :: "v"(g), "s"(__builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(mg_lptr_t)lds_wave_base)) : "memory");
+}
+MG_DEV void glds4a(const void* g, char* lds_wave_base) {
+  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dword %0, off"
+               :: "v"(g), "s"(__builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(mg_lptr_t)lds_wave_base)) : "memory");
+}
 #define MG_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 // vmcnt(0) through the BUILTIN (gfx9 encoding: vmcnt = 0, expcnt / lgkmcnt untouched): unlike the inline-asm
 // form this one updates hipcc's own scoreboard, so it does not re-wait (vmcnt(0), draining the DMA ring)
 // at the first use of an ordinary load's result inside the pipelined loop.  Use it once, before the loop.
-#define MG_WAIT_VMCNT0_TRACKED() __builtin_amdgcn_s_waitcnt(0x0F70)
+#define MG_WAIT_VMCNT0_TRACKED()            \
+  do {                                     \
+    asm volatile("" ::: "memory");         \
+    __builtin_amdgcn_s_waitcnt(0x0F70);    \
+    asm volatile("" ::: "memory");         \
+  } while (0)
+// "these registers are needed now": hipcc waits (in its own scoreboard) for the ordinary loads that produce them.  Loads
+// through const __restrict__ pointers are invariant loads and float across memory clobbers -- and across the builtin
+// wait above -- so the only way to retire them BEFORE a pipelined loop is to consume their results there.
+#define MG_USE8(f) asm volatile("" ::"v"((f)[0]), "v"((f)[1]), "v"((f)[2]), "v"((f)[3]), "v"((f)[4]), "v"((f)[5]), "v"((f)[6]), "v"((f)[7]))
 // workgroup barrier that does NOT drain in-flight LDS-DMA (a __syncthreads() would emit vmcnt(0)):
 // retire this wave's LDS reads, barrier, and keep the compiler from moving LDS accesses across it
 #define MG_BARRIER_KEEP_DMA()                          \
