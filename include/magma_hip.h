@@ -204,6 +204,13 @@ int mg_rotary_split_bf16(const mg_bf16* qkv, int32_t B, int32_t S, int32_t H, in
                          const int32_t* d_pos, mg_bf16* q_out, mg_bf16* kcache, mg_bf16* vcache,
                          int32_t Smax, mg_bf16* vt, int32_t vt_ld, void* stream);
 
+/* Training form of K9 (positions 0..S-1): q, k, v [B,H,S,256] plus ALL THREE column-tiled transposes vt, qt, kt
+ * [B,H,ld_t/32,256,32] in one pass over qkv -- vt feeds mg_attn_prefill_bf16, qt / kt are the s-contraction operands
+ * of mg_attn_bwd_bf16 (otherwise two more mg_head_transpose_bf16 passes in the backward).                          */
+int mg_rotary_split_train_bf16(const mg_bf16* qkv, int32_t B, int32_t S, int32_t H, int32_t rot_dim,
+                               const float* sin_t, const float* cos_t, mg_bf16* q, mg_bf16* k, mg_bf16* v,
+                               mg_bf16* vt, mg_bf16* qt, mg_bf16* kt, int32_t ld_t, void* stream);
+
 /* K10 prefill/training forward (same attention module; reference call sites magma/magma.py:270-274 and the
  * prefill step magma/sampling.py:81-85): causal flash attention, head dim 256, fp32
  * online softmax, scale 1/16.  q [B,H,S,256]; k rows from kcache [B,H,Smax,256];
@@ -358,6 +365,17 @@ int mg_attn_bwd_bf16(const mg_bf16* q, const mg_bf16* k, const mg_bf16* v, const
                      const mg_bf16* kt, const mg_bf16* dO, const mg_bf16* dOt, const mg_bf16* O,
                      const float* lse, float* D, mg_bf16* dq, mg_bf16* dk, mg_bf16* dv, int32_t B,
                      int32_t H, int32_t S, int32_t ld_t, void* stream);
+
+/* The same backward written straight into the gradient of the fused qkv projection (autograd through
+ * GPTJAttention's rotary + head split, /root/reference call site magma/magma.py:263-276 -> HF modeling_gptj):
+ * dqkv [B*S, 3*H*256] = [dq | dk | dv] per token, the inverse GPT-J rotary R(-theta_s) applied to the first
+ * rot_dim columns of every dq and dk head (sin_t, cos_t fp32 [>= S, rot_dim/2]).  Equals mg_attn_bwd_bf16
+ * followed by mg_rotary_merge_bwd_bf16 with one bf16 rounding instead of two.  dOt is a WORKSPACE
+ * [B,H,ld_t/32,256,32] here: the first launch transposes dO into it while it computes D.               */
+int mg_attn_bwd_merged_bf16(const mg_bf16* q, const mg_bf16* k, const mg_bf16* v, const mg_bf16* qt,
+                            const mg_bf16* kt, const mg_bf16* dO, mg_bf16* dOt, const mg_bf16* O,
+                            const float* lse, float* D, mg_bf16* dqkv, int32_t rot_dim, const float* sin_t,
+                            const float* cos_t, int32_t B, int32_t H, int32_t S, int32_t ld_t, void* stream);
 
 /* CLIP trunk backward helpers */
 int mg_avgpool2_bwd_nhwc_bf16(const mg_bf16* dy, const mg_bf16* gate, mg_bf16* dx, int32_t B, int32_t H, int32_t W, int32_t C, void* stream);

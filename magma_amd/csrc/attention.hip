@@ -20,12 +20,16 @@ namespace {
 // ---------------------------------------------------------------------------
 // rotary + split.  grid (ceil(S/32), B*H), 256 threads.
 // ---------------------------------------------------------------------------
+// QKT: also write the rotated q and k transposed (qt, kt, same column-tiled layout as vt) -- the s-contraction
+// operands of the backward kernels, which otherwise cost two more passes (mg_head_transpose_bf16) over q and k.
+template <bool QKT>
 __global__ __launch_bounds__(256) void rotary_split_kernel(
     const mg_bf16* __restrict__ qkv, int B, int S, int H, int rot_dim,
     const float* __restrict__ sin_t, const float* __restrict__ cos_t, int pos0_host,
     const int* __restrict__ d_pos, mg_bf16* __restrict__ q_out, mg_bf16* __restrict__ kcache,
-    mg_bf16* __restrict__ vcache, int Smax, mg_bf16* __restrict__ vt, int vt_ld) {
-  __shared__ __attribute__((aligned(16))) mg_bf16 vtile[32 * DH];
+    mg_bf16* __restrict__ vcache, int Smax, mg_bf16* __restrict__ vt, int vt_ld, mg_bf16* __restrict__ qt,
+    mg_bf16* __restrict__ kt) {
+  __shared__ __attribute__((aligned(16))) mg_bf16 vtile[(QKT ? 3 : 1) * 32 * DH];
   const int tid = threadIdx.x;
   const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
   const int s0 = blockIdx.x * 32;
@@ -39,7 +43,7 @@ __global__ __launch_bounds__(256) void rotary_split_kernel(
     const int row = ci >> 5, c = ci & 31;
     const int s = s0 + row;
     const int d0 = c * 8;
-    u32x4 vv = (u32x4){0u, 0u, 0u, 0u};
+    u32x4 vv = (u32x4){0u, 0u, 0u, 0u}, qz = vv, kz = vv;
     if (s < S) {
       const mg_bf16* base = qkv + (int64_t)(b * S + s) * (3 * dmodel) + h * DH + d0;
       u32x4 qv = *(const u32x4*)base;
@@ -62,24 +66,34 @@ __global__ __launch_bounds__(256) void rotary_split_kernel(
       *(u32x4*)(q_out + ((int64_t)bh * S + s) * DH + d0) = qv;
       *(u32x4*)(kcache + ((int64_t)bh * Smax + pos) * DH + d0) = kv;
       *(u32x4*)(vcache + ((int64_t)bh * Smax + pos) * DH + d0) = vv;
+      qz = qv; kz = kv;
     }
     if (vt) *(u32x4*)(vtile + row * DH + d0) = vv;   // zero rows beyond S
+    if (QKT) {
+      *(u32x4*)(vtile + 32 * DH + row * DH + d0) = qz;
+      *(u32x4*)(vtile + 64 * DH + row * DH + d0) = kz;
+    }
   }
   if (!vt) return;
   __syncthreads();
-  // thread = one d; gather its 32 keys and write 64 contiguous bytes of V^T
+  // thread = one d; gather its 32 positions and write 64 contiguous bytes of the transposed tile
   const int dd = tid;
-  mg_bf16* dst = vt + (((int64_t)bh * (vt_ld >> 5) + blockIdx.x) * DH + dd) * 32;   // column-tiled: [b,h][tile][256][32]
+  const int64_t toff = (((int64_t)bh * (vt_ld >> 5) + blockIdx.x) * DH + dd) * 32;   // column-tiled: [b,h][tile][256][32]
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    u32x4 o;
+  for (int which = 0; which < (QKT ? 3 : 1); ++which) {
+    mg_bf16* dst = (which == 0 ? vt : which == 1 ? qt : kt) + toff;
+    const mg_bf16* tile = vtile + which * 32 * DH;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      const uint32_t lo = vtile[(g * 8 + w * 2) * DH + dd];
-      const uint32_t hi = vtile[(g * 8 + w * 2 + 1) * DH + dd];
-      o[w] = lo | (hi << 16);
+    for (int g = 0; g < 4; ++g) {
+      u32x4 o;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const uint32_t lo = tile[(g * 8 + w * 2) * DH + dd];
+        const uint32_t hi = tile[(g * 8 + w * 2 + 1) * DH + dd];
+        o[w] = lo | (hi << 16);
+      }
+      *(u32x4*)(dst + g * 8) = o;
     }
-    *(u32x4*)(dst + g * 8) = o;
   }
 }
 
@@ -487,8 +501,25 @@ extern "C" int mg_rotary_split_bf16(const mg_bf16* qkv, int32_t B, int32_t S, in
   }
   if (!d_pos && pos0_host + S > Smax) MG_FAIL(MG_ERR_SHAPE, "mg_rotary_split_bf16: pos0+S exceeds Smax");
   dim3 grid((S + 31) / 32, B * H);
-  hipLaunchKernelGGL(rotary_split_kernel, grid, dim3(256), 0, (hipStream_t)stream, qkv, B, S, H, rot_dim, sin_t,
-                     cos_t, pos0_host, d_pos, q_out, kcache, vcache, Smax, vt, vt_ld);
+  hipLaunchKernelGGL(rotary_split_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, qkv, B, S, H, rot_dim, sin_t,
+                     cos_t, pos0_host, d_pos, q_out, kcache, vcache, Smax, vt, vt_ld, nullptr, nullptr);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
+// training form: positions 0..S-1, q / k / v [B,H,S,256] and all three transposes vt, qt, kt [B,H,ld_t/32,256,32] in one pass
+extern "C" int mg_rotary_split_train_bf16(const mg_bf16* qkv, int32_t B, int32_t S, int32_t H, int32_t rot_dim,
+                                          const float* sin_t, const float* cos_t, mg_bf16* q, mg_bf16* k, mg_bf16* v,
+                                          mg_bf16* vt, mg_bf16* qt, mg_bf16* kt, int32_t ld_t, void* stream) {
+  if (B <= 0 || S <= 0 || H <= 0) MG_FAIL(MG_ERR_SHAPE, "mg_rotary_split_train_bf16: B,S,H must be positive");
+  if (rot_dim < 0 || rot_dim > DH || (rot_dim & 7)) MG_FAIL(MG_ERR_SHAPE, "mg_rotary_split_train_bf16: rot_dim must be a multiple of 8 in [0,256]");
+  if (!qkv || !q || !k || !v || !vt || !qt || !kt || (rot_dim && (!sin_t || !cos_t))) MG_FAIL(MG_ERR_SHAPE, "mg_rotary_split_train_bf16: null pointer");
+  if (!MG_ALIGNED16(qkv) || !MG_ALIGNED16(q) || !MG_ALIGNED16(k) || !MG_ALIGNED16(v) || !MG_ALIGNED16(vt) || !MG_ALIGNED16(qt) || !MG_ALIGNED16(kt))
+    MG_FAIL(MG_ERR_ALIGN, "mg_rotary_split_train_bf16: pointers must be 16-byte aligned");
+  if ((ld_t & 31) || ld_t < ((S + 31) & ~31)) MG_FAIL(MG_ERR_SHAPE, "mg_rotary_split_train_bf16: ld_t must be a multiple of 32 and >= S");
+  dim3 grid((S + 31) / 32, B * H);
+  hipLaunchKernelGGL(rotary_split_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, qkv, B, S, H, rot_dim, sin_t,
+                     cos_t, 0, nullptr, q, k, v, S, vt, ld_t, qt, kt);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }

@@ -34,6 +34,49 @@ namespace {
 
 constexpr int LD_TILE = 256;              // 32 x {lse*log2e, D}
 
+// Where a gradient row goes.  merged == nullptr: out[(bh*S + s)*256 + d] (dq / dk / dv as [B,H,S,256]).  Otherwise the
+// row lands in the gradient of the fused qkv projection, merged[(b*S + s)*3*H*256 + which*H*256 + h*256 + d], with the
+// inverse GPT-J rotary R(-theta_s) applied to the first rot_dim columns of dq and dk (what mg_rotary_merge_bwd_bf16 did
+// in a separate pass over 3 x [B,H,S,256]).
+struct GradOut {
+  mg_bf16* out;
+  mg_bf16* merged;
+  const float* sin_t;
+  const float* cos_t;
+  int which, rot_dim;
+};
+// acc[dt] = columns dt*16 + lq*4 .. +3 of row s (sequence position) of head (b, h)
+MG_DEV void store_grad_row(const GradOut& g, const f32x4 (&acc)[16], int b, int h, int H, int S, int s, int lq) {
+  if (!g.merged) {
+    mg_bf16* op = g.out + (((int64_t)b * H + h) * S + s) * DH + lq * 4;
+#pragma unroll
+    for (int dt = 0; dt < 16; ++dt) {
+      u32x2 w;
+      w[0] = pack2bf(acc[dt][0], acc[dt][1]);
+      w[1] = pack2bf(acc[dt][2], acc[dt][3]);
+      *(u32x2*)(op + dt * 16) = w;
+    }
+    return;
+  }
+  mg_bf16* op = g.merged + ((int64_t)b * S + s) * (3 * H * DH) + (int64_t)g.which * H * DH + h * DH + lq * 4;
+  const int half_rot = g.rot_dim >> 1;
+#pragma unroll
+  for (int dt = 0; dt < 16; ++dt) {
+    float x0 = acc[dt][0], x1 = acc[dt][1], x2 = acc[dt][2], x3 = acc[dt][3];
+    if (g.which < 2 && dt * 16 + lq * 4 < g.rot_dim) {       // rot_dim % 8 == 0: a lane's 4 columns are inside or outside
+      const int pi = (int)((int64_t)s * half_rot) + dt * 8 + lq * 2;
+      const float s0 = g.sin_t[pi], c0 = g.cos_t[pi], s1 = g.sin_t[pi + 1], c1 = g.cos_t[pi + 1];
+      const float y0 = x0 * c0 + x1 * s0, y1 = x1 * c0 - x0 * s0;
+      const float y2 = x2 * c1 + x3 * s1, y3 = x3 * c1 - x2 * s1;
+      x0 = y0; x1 = y1; x2 = y2; x3 = y3;
+    }
+    u32x2 w;
+    w[0] = pack2bf(x0, x1);
+    w[1] = pack2bf(x2, x3);
+    *(u32x2*)(op + dt * 16) = w;
+  }
+}
+
 constexpr int DQ_STAGE = 2 * ROW_TILE + T_TILE;             // K rows | V rows | K^T
 constexpr int DQ_STAGES = 3;
 constexpr int DK_STAGE = 2 * ROW_TILE + T_TILE + LD_TILE;   // Q rows | dO rows | Q^T | lse,D
@@ -62,11 +105,56 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const mg_bf16* __res
   }
 }
 
+// The same statistics computed while dO is transposed: one workgroup per (b, h, 32 positions) reads the dO and O tiles
+// once, writes dO^T in the column-tiled layout of mg_head_transpose_bf16 (zero padded) and ld2 -- the prep pass and the
+// dO transpose of the two-pass form in one.  grid (ceil(S/32), B*H), 256 threads; a row is 32 consecutive lanes.
+__global__ __launch_bounds__(256) void attn_bwd_prep_t_kernel(const mg_bf16* __restrict__ dO, const mg_bf16* __restrict__ O,
+                                                              const float* __restrict__ lse, float* __restrict__ ld2,
+                                                              mg_bf16* __restrict__ dOt, int ld_t, int B, int H, int S) {
+  __shared__ __attribute__((aligned(16))) mg_bf16 tile[32 * DH];
+  const int tid = threadIdx.x;
+  const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+  const int s0 = blockIdx.x * 32;
+  const int64_t dmodel = (int64_t)H * DH;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int ci = tid + it * 256;
+    const int row = ci >> 5, c = ci & 31, sidx = s0 + row;
+    u32x4 a = (u32x4){0u, 0u, 0u, 0u};
+    float dot = 0.f;
+    if (sidx < S) {
+      const int64_t off = ((int64_t)b * S + sidx) * dmodel + h * DH + c * 8;
+      a = *(const u32x4*)(dO + off);
+      const u32x4 o = *(const u32x4*)(O + off);
+#pragma unroll
+      for (int w = 0; w < 4; ++w) dot += bflo(a[w]) * bflo(o[w]) + bfhi(a[w]) * bfhi(o[w]);
+    }
+    *(u32x4*)(tile + row * DH + c * 8) = a;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 32);
+    if (c == 0 && sidx < S) {
+      const int64_t i = ((int64_t)bh * S + sidx);
+      ld2[i * 2] = lse[i] * 1.4426950408889634f;
+      ld2[i * 2 + 1] = dot;
+    }
+  }
+  __syncthreads();
+  mg_bf16* d = dOt + (((int64_t)bh * (ld_t >> 5) + blockIdx.x) * DH + tid) * 32;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    u32x4 o;
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+      o[w] = (uint32_t)tile[(g * 8 + w * 2) * DH + tid] | ((uint32_t)tile[(g * 8 + w * 2 + 1) * DH + tid] << 16);
+    *(u32x4*)(d + g * 8) = o;
+  }
+}
+
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(
     const mg_bf16* __restrict__ q, const mg_bf16* __restrict__ k, const mg_bf16* __restrict__ v,
     const mg_bf16* __restrict__ kt, const mg_bf16* __restrict__ dO, const float* __restrict__ ld2,
-    mg_bf16* __restrict__ dq, int B, int H, int S, int ld_t) {
+    const GradOut gout, int B, int H, int S, int ld_t) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -179,16 +267,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(
     sc = sc == DQ_STAGES - 1 ? 0 : sc + 1;
   }
   MG_WAIT_VMCNT(0);                   // drain the ring's trailing loads before the wave retires
-  if (qrow < S) {
-    mg_bf16* op = dq + ((int64_t)bh * S + qrow) * DH + lq * 4;
-#pragma unroll
-    for (int dt = 0; dt < 16; ++dt) {
-      u32x2 w;
-      w[0] = pack2bf(acc[dt][0], acc[dt][1]);
-      w[1] = pack2bf(acc[dt][2], acc[dt][3]);
-      *(u32x2*)(op + dt * 16) = w;
-    }
-  }
+  if (qrow < S) store_grad_row(gout, acc, b, h, H, S, qrow, lq);
 }
 
 // ---------------------------------------------------------------------------
@@ -199,7 +278,7 @@ template <bool DK>
 __global__ __launch_bounds__(512) void attn_bwd_dkdv_kernel(
     const mg_bf16* __restrict__ q, const mg_bf16* __restrict__ k, const mg_bf16* __restrict__ v,
     const mg_bf16* __restrict__ qt, const mg_bf16* __restrict__ dO, const mg_bf16* __restrict__ dOt,
-    const float* __restrict__ ld2, mg_bf16* __restrict__ dout, int B, int H, int S, int ld_t) {
+    const float* __restrict__ ld2, const GradOut gout, int B, int H, int S, int ld_t) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int STAGE = DK ? DK_STAGE : DV_STAGE;
   constexpr int NST = DK ? DK_STAGES : DV_STAGES;
@@ -341,24 +420,38 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_kernel(
     sc = sc == NST - 1 ? 0 : sc + 1;
   }
   MG_WAIT_VMCNT(0);
-  if (key < S) {
-    mg_bf16* op = dout + ((int64_t)bh * S + key) * DH + lq * 4;
-#pragma unroll
-    for (int dt = 0; dt < 16; ++dt) {
-      u32x2 w;
-      w[0] = pack2bf(acc[dt][0], acc[dt][1]); w[1] = pack2bf(acc[dt][2], acc[dt][3]);
-      *(u32x2*)(op + dt * 16) = w;
-    }
-  }
+  if (key < S) store_grad_row(gout, acc, b, h, H, S, key, lq);
 }
 
 
-int set_lds(const void* fn, int bytes) {
-  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-  if (e != hipSuccess) MG_FAIL(MG_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+}  // namespace
+
+namespace {
+int attn_bwd_launch(const mg_bf16* q, const mg_bf16* k, const mg_bf16* v, const mg_bf16* qt, const mg_bf16* kt,
+                    const mg_bf16* dO, const mg_bf16* dOt, const mg_bf16* O, const float* lse, float* D,
+                    const GradOut& gq, const GradOut& gk, const GradOut& gv, int32_t B, int32_t H, int32_t S, int32_t ld_t,
+                    bool make_dOt, hipStream_t s, const char* who) {
+  if (B <= 0 || H <= 0 || S <= 0 || (ld_t & 31) || ld_t < ((S + 31) & ~31)) MG_FAIL(MG_ERR_SHAPE, "%s: ld_t must be a multiple of 32 and >= S", who);
+  const void* ptrs[] = {q, k, v, qt, kt, dO, dOt, O, lse, D};
+  for (const void* p : ptrs) {
+    if (!p) MG_FAIL(MG_ERR_SHAPE, "%s: null pointer", who);
+    if (!MG_ALIGNED16(p)) MG_FAIL(MG_ERR_ALIGN, "%s: pointers must be 16-byte aligned", who);
+  }
+  if (int rc = mg_allow_dynamic_lds((const void*)attn_bwd_dq_kernel, DQ_STAGES * DQ_STAGE, who)) return rc;
+  if (int rc = mg_allow_dynamic_lds((const void*)attn_bwd_dkdv_kernel<true>, DK_STAGES * DK_STAGE, who)) return rc;
+  if (int rc = mg_allow_dynamic_lds((const void*)attn_bwd_dkdv_kernel<false>, DV_STAGES * DV_STAGE, who)) return rc;
+  const int64_t rows = (int64_t)B * S * H;
+  const dim3 grid((unsigned)(((S + 127) / 128) * B * H));
+  if (make_dOt)
+    hipLaunchKernelGGL(attn_bwd_prep_t_kernel, dim3((S + 31) / 32, B * H), dim3(256), 0, s, dO, O, lse, D, (mg_bf16*)dOt, ld_t, B, H, S);
+  else
+    hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, dO, O, lse, D, B, H, S);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(512), DQ_STAGES * DQ_STAGE, s, q, k, v, kt, dO, D, gq, B, H, S, ld_t);
+  hipLaunchKernelGGL(attn_bwd_dkdv_kernel<false>, grid, dim3(512), DV_STAGES * DV_STAGE, s, q, k, v, qt, dO, dOt, D, gv, B, H, S, ld_t);
+  hipLaunchKernelGGL(attn_bwd_dkdv_kernel<true>, grid, dim3(512), DK_STAGES * DK_STAGE, s, q, k, v, qt, dO, dOt, D, gk, B, H, S, ld_t);
+  MG_CHECK_LAUNCH();
   return MG_OK;
 }
-
 }  // namespace
 
 // q,k,v [B,H,S,256]; kt,qt,dOt column-tiled transposed [B,H,ld_t/32,256,32] (mg_head_transpose_bf16; zero padded);
@@ -367,22 +460,23 @@ extern "C" int mg_attn_bwd_bf16(const mg_bf16* q, const mg_bf16* k, const mg_bf1
                                 const mg_bf16* kt, const mg_bf16* dO, const mg_bf16* dOt, const mg_bf16* O,
                                 const float* lse, float* D, mg_bf16* dq, mg_bf16* dk, mg_bf16* dv, int32_t B,
                                 int32_t H, int32_t S, int32_t ld_t, void* stream) {
-  if (B <= 0 || H <= 0 || S <= 0 || (ld_t & 31) || ld_t < ((S + 31) & ~31)) MG_FAIL(MG_ERR_SHAPE, "mg_attn_bwd_bf16: ld_t must be a multiple of 32 and >= S");
-  const void* ptrs[] = {q, k, v, qt, kt, dO, dOt, O, lse, D, dq, dk, dv};
-  for (const void* p : ptrs) {
-    if (!p) MG_FAIL(MG_ERR_SHAPE, "mg_attn_bwd_bf16: null pointer");
-    if (!MG_ALIGNED16(p)) MG_FAIL(MG_ERR_ALIGN, "mg_attn_bwd_bf16: pointers must be 16-byte aligned");
-  }
-  if (int rc = mg_allow_dynamic_lds((const void*)attn_bwd_dq_kernel, DQ_STAGES * DQ_STAGE, "mg_attn_bwd_bf16")) return rc;
-  if (int rc = mg_allow_dynamic_lds((const void*)attn_bwd_dkdv_kernel<true>, DK_STAGES * DK_STAGE, "mg_attn_bwd_bf16")) return rc;
-  if (int rc = mg_allow_dynamic_lds((const void*)attn_bwd_dkdv_kernel<false>, DV_STAGES * DV_STAGE, "mg_attn_bwd_bf16")) return rc;
-  hipStream_t s = (hipStream_t)stream;
-  const int64_t rows = (int64_t)B * S * H;
-  const dim3 grid((unsigned)(((S + 127) / 128) * B * H));
-  hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, dO, O, lse, D, B, H, S);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(512), DQ_STAGES * DQ_STAGE, s, q, k, v, kt, dO, D, dq, B, H, S, ld_t);
-  hipLaunchKernelGGL(attn_bwd_dkdv_kernel<false>, grid, dim3(512), DV_STAGES * DV_STAGE, s, q, k, v, qt, dO, dOt, D, dv, B, H, S, ld_t);
-  hipLaunchKernelGGL(attn_bwd_dkdv_kernel<true>, grid, dim3(512), DK_STAGES * DK_STAGE, s, q, k, v, qt, dO, dOt, D, dk, B, H, S, ld_t);
-  MG_CHECK_LAUNCH();
-  return MG_OK;
+  if (!dq || !dk || !dv) MG_FAIL(MG_ERR_SHAPE, "mg_attn_bwd_bf16: null pointer");
+  if (!MG_ALIGNED16(dq) || !MG_ALIGNED16(dk) || !MG_ALIGNED16(dv)) MG_FAIL(MG_ERR_ALIGN, "mg_attn_bwd_bf16: pointers must be 16-byte aligned");
+  const GradOut gq{dq, nullptr, nullptr, nullptr, 0, 0}, gk{dk, nullptr, nullptr, nullptr, 1, 0}, gv{dv, nullptr, nullptr, nullptr, 2, 0};
+  return attn_bwd_launch(q, k, v, qt, kt, dO, dOt, O, lse, D, gq, gk, gv, B, H, S, ld_t, false, (hipStream_t)stream, "mg_attn_bwd_bf16");
+}
+
+// Same backward, written straight into the gradient of the fused qkv projection: dqkv [B*S, 3*H*256] = [dq | dk | dv]
+// per row, with the inverse GPT-J rotary (angles of position s, tables sin_t / cos_t [>= S, rot_dim/2]) applied to the
+// first rot_dim columns of every dq and dk head -- mg_attn_bwd_bf16 followed by mg_rotary_merge_bwd_bf16 in one pass.
+// dOt is a WORKSPACE here ([B,H,ld_t/32,256,32]): the first launch transposes dO into it while it computes D.
+extern "C" int mg_attn_bwd_merged_bf16(const mg_bf16* q, const mg_bf16* k, const mg_bf16* v, const mg_bf16* qt,
+                                       const mg_bf16* kt, const mg_bf16* dO, mg_bf16* dOt, const mg_bf16* O,
+                                       const float* lse, float* D, mg_bf16* dqkv, int32_t rot_dim, const float* sin_t,
+                                       const float* cos_t, int32_t B, int32_t H, int32_t S, int32_t ld_t, void* stream) {
+  if (!dqkv || !MG_ALIGNED16(dqkv)) MG_FAIL(MG_ERR_ALIGN, "mg_attn_bwd_merged_bf16: dqkv must be a 16-byte aligned pointer");
+  if (rot_dim < 0 || rot_dim > 256 || (rot_dim & 7)) MG_FAIL(MG_ERR_SHAPE, "mg_attn_bwd_merged_bf16: rot_dim must be a multiple of 8 in [0,256]");
+  if (rot_dim && (!sin_t || !cos_t)) MG_FAIL(MG_ERR_SHAPE, "mg_attn_bwd_merged_bf16: rotary tables missing");
+  const GradOut gq{nullptr, dqkv, sin_t, cos_t, 0, rot_dim}, gk{nullptr, dqkv, sin_t, cos_t, 1, rot_dim}, gv{nullptr, dqkv, sin_t, cos_t, 2, 0};
+  return attn_bwd_launch(q, k, v, qt, kt, dO, dOt, O, lse, D, gq, gk, gv, B, H, S, ld_t, true, (hipStream_t)stream, "mg_attn_bwd_merged_bf16");
 }

@@ -339,6 +339,14 @@ def rotary_split(qkv, B, S, H, rot_dim, sin_t, cos_t, q_out, kcache, vcache, *, 
           "mg_rotary_split_bf16")
 
 
+def rotary_split_train(qkv, B, S, H, rot_dim, sin_t, cos_t, q, k, v, vt, qt, kt):
+    """Training form of rotary_split: q, k, v [B,H,S,256] and the three transposes [B,H,ld/32,256,32] in one pass."""
+    _need_gpu(qkv)
+    check(L.load().mg_rotary_split_train_bf16(qkv.data_ptr(), B, S, H, rot_dim, sin_t.data_ptr(), cos_t.data_ptr(),
+                                              q.data_ptr(), k.data_ptr(), v.data_ptr(), vt.data_ptr(), qt.data_ptr(),
+                                              kt.data_ptr(), vt.shape[2] * 32, _stream()), "mg_rotary_split_train_bf16")
+
+
 def attn_prefill(q, kcache, vt, out, B, H, S, lse: Optional[torch.Tensor] = None):
     _need_gpu(q)
     check(L.load().mg_attn_prefill_bf16(q.data_ptr(), kcache.data_ptr(), vt.data_ptr(), out.data_ptr(), _p(lse),
@@ -611,6 +619,21 @@ def attn_bwd(q, k, v, qt, kt, dO, dOt, O, lse, B, H, S):
                                     dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, H, S, qt.shape[2] * 32, _stream()),
           "mg_attn_bwd_bf16")
     return dq, dk, dv
+
+
+def attn_bwd_merged(q, k, v, qt, kt, dO, O, lse, B, H, S, rot_dim, sin_t, cos_t):
+    """dO transpose + attn_bwd + rotary_merge_bwd in one call: -> dqkv [B*S, 3*H*256] (gradient of the fused qkv
+    projection)."""
+    _need_gpu(q)
+    dev = q.device
+    D = torch.empty(B, H, S, 2, dtype=torch.float32, device=dev)
+    dOt = torch.empty_like(qt)                                       # workspace, filled by the first launch
+    dqkv = torch.empty(B * S, 3 * H * 256, dtype=BF16, device=dev)
+    check(L.load().mg_attn_bwd_merged_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), qt.data_ptr(), kt.data_ptr(),
+                                           dO.data_ptr(), dOt.data_ptr(), O.data_ptr(), lse.data_ptr(), D.data_ptr(),
+                                           dqkv.data_ptr(), rot_dim, sin_t.data_ptr(), cos_t.data_ptr(), B, H, S,
+                                           qt.shape[2] * 32, _stream()), "mg_attn_bwd_merged_bf16")
+    return dqkv
 
 
 def avgpool2_bwd(dy: torch.Tensor, B, H, W, Cc, gate: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -397,11 +397,14 @@ class MagmaEngine:
             q = torch.empty(B, H, S, 256, dtype=BF16, device=dev)
             k = torch.empty(B, H, S, 256, dtype=BF16, device=dev)
             v = torch.empty(B, H, S, 256, dtype=BF16, device=dev)
-            ops.rotary_split(qkv, B, S, H, eng.rot, eng.sin_t, eng.cos_t, q, k, v, pos0=0, vt=vt)
+            # q^T / k^T (the s-contraction operands of the attention backward) come out of the same pass as q, k, v, V^T
+            qt = torch.empty(B, H, vt_ld // 32, 256, 32, dtype=BF16, device=dev)
+            kt = torch.empty(B, H, vt_ld // 32, 256, 32, dtype=BF16, device=dev)
+            ops.rotary_split_train(qkv, B, S, H, eng.rot, eng.sin_t, eng.cos_t, q, k, v, vt, qt, kt)
             ctx = torch.empty(M, d, dtype=BF16, device=dev)
             lse = torch.empty(B, H, S, dtype=F32, device=dev)
             ops.attn_prefill(q, k, vt, ctx, B, H, S, lse=lse)
-            sv.update(q=q, k=k, v=v, ctx=ctx, lse=lse)
+            sv.update(q=q, k=k, v=v, qt=qt, kt=kt, ctx=ctx, lse=lse)
             a = self._fgemm((li, "out"), ctx, ly.out)
             if ly.attn_adapter is not None:
                 dn, up = self._adapter_ops(blk.attn.adapter)
@@ -497,12 +500,7 @@ class MagmaEngine:
                 da = g
             dctx = self._fgemm((li, "out_t"), da, pk["out_t"])
             q, k, v = sv["q"], sv["k"], sv["v"]
-            hs = H * S * 256
-            qt = ops.head_transpose(q, B, H, S, sb=hs, ss=256, sh=S * 256)
-            kt = ops.head_transpose(k, B, H, S, sb=hs, ss=256, sh=S * 256)
-            dOt = ops.head_transpose(dctx, B, H, S, sb=S * d, ss=d, sh=256)
-            dq, dk, dv = ops.attn_bwd(q, k, v, qt, kt, dctx, dOt, sv["ctx"], sv["lse"], B, H, S)
-            dqkv = ops.rotary_merge_bwd(dq, dk, dv, B, S, H, eng.rot, eng.sin_t, eng.cos_t)
+            dqkv = ops.attn_bwd_merged(q, k, v, sv["qt"], sv["kt"], dctx, sv["ctx"], sv["lse"], B, H, S, eng.rot, eng.sin_t, eng.cos_t)
             dln = self._fgemm((li, "qkv_t"), dqkv, pk["qkv_t"], residuals=(dln_mlp,))
             g = ops.layernorm_bwd(dln, sv["x"], ly.ln_g, eng.eps, res=g)
             tape["layers"][li] = None     # free this layer's activations

@@ -132,6 +132,61 @@ def test_attention_backward(dev, B, H, S):
             assert rel(got, ref) < 1.5e-2, (name, rel(got, ref))
 
 
+@pytest.mark.parametrize("B,H,S", [(2, 2, 57), (1, 2, 300)])
+def test_attention_backward_merged_output(dev, B, H, S):
+    """mg_attn_bwd_merged_bf16 (gradients written straight into dqkv with the inverse rotary) == mg_attn_bwd_bf16 +
+    mg_rotary_merge_bwd_bf16, up to the second bf16 rounding the two-pass form has."""
+    from magma_amd import ops
+    d = H * 256
+    q = rnd(B, H, S, 256, dev=dev, seed=30, scale=0.5).to(BF16)
+    k = rnd(B, H, S, 256, dev=dev, seed=31, scale=0.5).to(BF16)
+    v = rnd(B, H, S, 256, dev=dev, seed=32).to(BF16)
+    dO = rnd(B * S, d, dev=dev, seed=33).to(BF16)
+    vt = ops.head_transpose(v, B, H, S, sb=H * S * 256, ss=256, sh=S * 256)
+    out = torch.empty(B * S, d, dtype=BF16, device=dev)
+    lse = torch.empty(B, H, S, dtype=torch.float32, device=dev)
+    ops.attn_prefill(q, k, vt, out, B, H, S, lse=lse)
+    qt = ops.head_transpose(q, B, H, S, sb=H * S * 256, ss=256, sh=S * 256)
+    kt = ops.head_transpose(k, B, H, S, sb=H * S * 256, ss=256, sh=S * 256)
+    dOt = ops.head_transpose(dO, B, H, S, sb=S * d, ss=d, sh=256)
+    rot = 64
+    inv = 1.0 / (10000 ** (torch.arange(0, rot, 2, dtype=torch.float32, device=dev) / rot))
+    ang = torch.arange(S + 3, dtype=torch.float32, device=dev)[:, None] * inv[None, :]
+    sin_t, cos_t = ang.sin().contiguous(), ang.cos().contiguous()
+    dq, dk, dv = ops.attn_bwd(q, k, v, qt, kt, dO, dOt, out, lse, B, H, S)
+    two_pass = ops.rotary_merge_bwd(dq, dk, dv, B, S, H, rot, sin_t, cos_t)
+    merged = ops.attn_bwd_merged(q, k, v, qt, kt, dO, out, lse, B, H, S, rot, sin_t, cos_t)   # transposes dO itself
+    assert merged.shape == two_pass.shape == (B * S, 3 * d)
+    assert torch.equal(merged[:, 2 * d:], two_pass[:, 2 * d:])                     # dv: no rotary, same rounding
+    for name, sl in (("dq", slice(0, d)), ("dk", slice(d, 2 * d))):
+        a, b = merged[:, sl].view(B * S, H, 256), two_pass[:, sl].view(B * S, H, 256)
+        # columns outside the rotary: same arithmetic except the summation order of D = rowsum(dO o O) (fused prep)
+        assert rel(a[..., rot:], b[..., rot:]) < 2e-3, (name, rel(a[..., rot:], b[..., rot:]))
+        assert rel(a[..., :rot], b[..., :rot]) < 6e-3, (name, rel(a[..., :rot], b[..., :rot]))
+
+
+def test_rotary_split_train_emits_all_transposes(dev):
+    """mg_rotary_split_train_bf16 == mg_rotary_split_bf16 + two mg_head_transpose_bf16, bit for bit."""
+    from magma_amd import ops
+    B, H, S, rot = 2, 3, 75, 64
+    d = H * 256
+    qkv = rnd(B * S, 3 * d, dev=dev, seed=40).to(BF16)
+    inv = 1.0 / (10000 ** (torch.arange(0, rot, 2, dtype=torch.float32, device=dev) / rot))
+    ang = torch.arange(S + 5, dtype=torch.float32, device=dev)[:, None] * inv[None, :]
+    sin_t, cos_t = ang.sin().contiguous(), ang.cos().contiguous()
+    ld = ops.ceil_to(S, 32)
+    mk = lambda: torch.empty(B, H, S, 256, dtype=BF16, device=dev)
+    mt = lambda: torch.full((B, H, ld // 32, 256, 32), 7.0, dtype=BF16, device=dev)
+    q0, k0, v0, vt0 = mk(), mk(), mk(), mt()
+    ops.rotary_split(qkv, B, S, H, rot, sin_t, cos_t, q0, k0, v0, pos0=0, vt=vt0)
+    qt0 = ops.head_transpose(q0, B, H, S, sb=H * S * 256, ss=256, sh=S * 256)
+    kt0 = ops.head_transpose(k0, B, H, S, sb=H * S * 256, ss=256, sh=S * 256)
+    q1, k1, v1, vt1, qt1, kt1 = mk(), mk(), mk(), mt(), mt(), mt()
+    ops.rotary_split_train(qkv, B, S, H, rot, sin_t, cos_t, q1, k1, v1, vt1, qt1, kt1)
+    for a, b, name in ((q1, q0, "q"), (k1, k0, "k"), (v1, v0, "v"), (vt1, vt0, "vt"), (qt1, qt0, "qt"), (kt1, kt0, "kt")):
+        assert torch.equal(a, b), name
+
+
 def test_rotary_merge_bwd(dev):
     from magma_amd import ops
     from oracle.model import apply_rotary, rotary_tables
