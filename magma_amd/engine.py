@@ -198,9 +198,14 @@ class LMEngine:
             if ly.attn_adapter is not None:
                 ad = blk.attn.adapter
                 ly.attn_adapter = (ops.PackedLinear(ad[0].weight, ad[0].bias), ops.PackedLinear(ad[2].weight, ad[2].bias))
+                if ly.attn_par is not None:           # scaled_parallel: the scale is a trained parameter too
+                    ly.attn_par = torch.full((self.d,), blk.attn.scale_value(), dtype=torch.float32, device=ly.attn_par.device)
             if ly.mlp_adapter is not None:
-                ad = blk.mlp[1].adapter
+                par = ly.mlp_par is not None
+                ad = blk.mlp.adapter if par else blk.mlp[1].adapter
                 ly.mlp_adapter = (ops.PackedLinear(ad[0].weight, ad[0].bias), ops.PackedLinear(ad[2].weight, ad[2].bias))
+                if par:
+                    ly.mlp_par = torch.full((self.d,), blk.mlp.scale_value(), dtype=torch.float32, device=ly.mlp_par.device)
             ly.fp8 = {}
             ly.__dict__.pop("up_cat", None)
 

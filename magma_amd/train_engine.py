@@ -41,7 +41,7 @@ class FlatGroup:
         self.offsets, n = [], 0
         for p in params:
             self.offsets.append(n)
-            n += (p.numel() + 3) // 4 * 4          # keep every view 16-byte aligned
+            n += (p.numel() + 7) // 8 * 8          # keep every view 16-byte aligned in the bf16 copy as well
         self.n = n
         self.master = torch.zeros(n, dtype=F32, device=device)
         self.m = torch.zeros(n, dtype=F32, device=device)
@@ -120,9 +120,6 @@ class MagmaEngine:
         if getattr(model.image_prefix, "pooled", False):
             raise NotImplementedError("training with a pooled image encoder (encoder_name 'clip' = ViT-B/32) is not implemented "
                                       "(inference only)")
-        from .adapters import ParallelAdapter
-        if any(isinstance(m, ParallelAdapter) for m in model.modules()):
-            raise NotImplementedError("training with parallel / scaled_parallel adapters is not implemented (inference only)")
         self.betas, self.eps = betas, eps
         self.truncate = truncate or os.environ.get("MAGMA_TRUNCATE", "0") == "1"
         # BASELINE config[4]: the frozen-weight block GEMMs (qkv, out_proj, fc_in, fc_out; forward and dgrad) on the fp8
@@ -319,9 +316,7 @@ class MagmaEngine:
             eng = self.module.lm.engine
             packs = []
             for ly, blk in zip(eng.layers, self.module.lm.transformer.h):
-                attn = blk.attn.attn_block if hasattr(blk.attn, "attn_block") else blk.attn
-                a = attn.attention
-                mlp = blk.mlp[0] if isinstance(blk.mlp, torch.nn.Sequential) else blk.mlp
+                a, mlp = ly._src          # the wrapped GPT-J attention / MLP modules, whatever adapter type wraps them
                 pk = {
                     "qkv_t": PackedLinear(torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0).t().contiguous()),
                     "out_t": PackedLinear(a.out_proj.weight.t().contiguous()),
@@ -340,6 +335,21 @@ class MagmaEngine:
         dn, up = ad[0], ad[2]
         return (RawWeight(dn.weight.data, bias=self.master_of(dn.bias)),
                 RawWeight(up.weight.data, bias=self.master_of(up.bias)))
+
+    def _par_adapter_ops(self, wrapper):
+        """(down, up, scale vector or None) of a ParallelAdapter / ParallelAdapterWrapper on the live parameters.  The GEMM
+        epilogue computes acc * scale[n] + bias[n]; the reference (acc + b_up) * adapter_scale, so the up bias handed to the
+        epilogue is pre-multiplied by the (device-resident, trainable) scale."""
+        ad = wrapper.adapter
+        dn, up = ad[0], ad[2]
+        dnw = RawWeight(dn.weight.data, bias=self.master_of(dn.bias))
+        sp = wrapper.adapter_scale
+        if not torch.is_tensor(sp):
+            assert float(sp) == 1.0
+            return dnw, RawWeight(up.weight.data, bias=self.master_of(up.bias)), None
+        sval = self.master_of(sp) if self.is_trainable(sp) else sp.detach().float()
+        sc = sval.reshape(1).to(F32).expand(up.weight.shape[0]).contiguous()
+        return dnw, RawWeight(up.weight.data, bias=(self.master_of(up.bias) * sc).contiguous()), sc
 
     def _fgemm(self, key, x, lin, xq=None, **kw):
         """GEMM against a FROZEN packed weight: bf16 tile GEMM, or (self.fp8) the fp8 MFMA on a per-row quantised x."""
@@ -406,7 +416,13 @@ class MagmaEngine:
             ops.attn_prefill(q, k, vt, ctx, B, H, S, lse=lse)
             sv.update(q=q, k=k, v=v, qt=qt, kt=kt, ctx=ctx, lse=lse)
             a = self._fgemm((li, "out"), ctx, ly.out)
-            if ly.attn_adapter is not None:
+            if ly.attn_adapter is not None and ly.attn_par is not None:
+                # parallel / scaled_parallel (reference adapters.py:42-92): the adapter reads the attention INPUT (ln_1 output)
+                dn, up, sc = self._par_adapter_ops(blk.attn)
+                ta = ops.gemm(ln, dn, act=ops.MG_ACT_RELU, layout="rm")
+                a = ops.gemm(ta, up, scale=sc, residuals=(a,), layout="rm")
+                sv.update(ta=ta)
+            elif ly.attn_adapter is not None:
                 dn, up = self._adapter_ops(blk.attn.adapter)
                 ta = ops.gemm(a, dn, act=ops.MG_ACT_RELU, layout="rm")
                 a2 = ops.gemm(ta, up, residuals=(a,), layout="rm")
@@ -415,7 +431,13 @@ class MagmaEngine:
             hpre = torch.empty(M, ly.fc_in.N, dtype=BF16, device=dev)
             h = self._fgemm((li, "fc_in"), ln, ly.fc_in, lnq, act=ops.MG_ACT_GELU_NEW, out2=hpre)
             sv["hpre"] = hpre
-            if ly.mlp_adapter is not None:
+            if ly.mlp_adapter is not None and ly.mlp_par is not None:
+                dn, up, sc = self._par_adapter_ops(blk.mlp)
+                m = self._fgemm((li, "fc_out"), h, ly.fc_out)
+                t = ops.gemm(ln, dn, act=ops.MG_ACT_RELU, layout="rm")
+                x = ops.gemm(t, up, scale=sc, residuals=(m, a, x), layout="rm")
+                sv.update(t=t)
+            elif ly.mlp_adapter is not None:
                 dn, up = self._adapter_ops(blk.mlp[1].adapter)
                 m = self._fgemm((li, "fc_out"), h, ly.fc_out)
                 t = ops.gemm(m, dn, act=ops.MG_ACT_RELU, layout="rm")
@@ -470,6 +492,36 @@ class MagmaEngine:
         self._acc_wgrad(dn.weight, _t(dt), _t(x_in))
         return dt, _t(dn.weight.data)
 
+    def _par_adapter_backward(self, wrapper, g, x_in, t):
+        """y = f(x_in) + s * (Wup relu(Wdn x_in + bdn) + bup)  (reference adapters.py:59-63, :84-91).  Given g = dL/dy:
+        accumulates the adapter's parameter gradients (and ds = <g, z>, z the unscaled adapter output, computed from the
+        unscaled weight / bias gradients: <g^T t, Wup> + <colsum g, bup>) and returns (dt, Wdn^T): dL/dx_in through the
+        adapter is dt Wdn, added by the caller."""
+        ad = wrapper.adapter
+        dn, up = ad[0], ad[2]
+        sp = wrapper.adapter_scale
+        scaled = torch.is_tensor(sp)
+        N = up.weight.shape[0]
+        sc = None
+        if scaled:
+            sval = self.master_of(sp) if self.is_trainable(sp) else sp.detach().float()
+            sc = sval.reshape(1).to(F32).expand(N).contiguous()
+        gb = torch.zeros(N, dtype=F32, device=g.device)
+        ops.colsum(g, gb)                                                  # unscaled d b_up
+        gw = ops.gemm(_t(g).rm, _t(t), out_dtype=F32, layout="rm", use_bias=False)     # unscaled d W_up [N, K]
+        gview = self.grad_of(up.weight).view(N, -1)
+        ops.scale_rows_acc(gview, gw[:, : gview.shape[1]], sc)
+        self.grad_of(up.bias).add_(gb * sc if scaled else gb)
+        if scaled and self.is_trainable(sp):
+            ds = (gw[:, : gview.shape[1]] * up.weight.data.float()).sum() + (gb * self.master_of(up.bias)).sum()
+            self.grad_of(sp).add_(ds.reshape(self.grad_of(sp).shape))
+        K = up.weight.shape[1]
+        dt = ops.gemm(g, _t(up.weight.data), aux=t, aux_mode=ops.MG_AUX_RELU_GATE, layout="rm", use_bias=False,
+                      scale=None if sc is None else sc[:K].contiguous())
+        ops.colsum(dt, self.grad_of(dn.bias))
+        self._acc_wgrad(dn.weight, _t(dt), _t(x_in))
+        return dt, _t(dn.weight.data)
+
     def _lm_backward(self, tape):
         eng = self.module.lm.engine
         dev = self.device
@@ -484,7 +536,14 @@ class MagmaEngine:
         for li in range(len(eng.layers) - 1, -1, -1):
             ly, blk, pk, sv = eng.layers[li], self.module.lm.transformer.h[li], packs[li], tape["layers"][li]
             # ---- MLP branch ----
-            if ly.mlp_adapter is not None:
+            par = ly.mlp_par is not None or ly.attn_par is not None
+            ln = ops.layernorm(sv["x"], ly.ln_g, ly.ln_b, eng.eps) if par else None   # the parallel adapters' input, recomputed
+            extra = []                                                                 # dL/d ln through the parallel adapters
+            if ly.mlp_adapter is not None and ly.mlp_par is not None:
+                dt, dn_t = self._par_adapter_backward(blk.mlp, g, ln, sv["t"])
+                extra.append(ops.gemm(dt, dn_t, layout="rm", use_bias=False))
+                dm = g
+            elif ly.mlp_adapter is not None:
                 dt, dn_t = self._adapter_backward(blk.mlp[1].adapter, g, sv["m"], sv["t"])
                 dm = ops.gemm(dt, dn_t, residuals=(g,), layout="rm", use_bias=False)
             else:
@@ -493,7 +552,11 @@ class MagmaEngine:
             dln_mlp = self._fgemm((li, "fc_in_t"), dhpre, pk["fc_in_t"])
             del dhpre, dm
             # ---- attention branch ----
-            if ly.attn_adapter is not None:
+            if ly.attn_adapter is not None and ly.attn_par is not None:
+                dta, dn_t = self._par_adapter_backward(blk.attn, g, ln, sv["ta"])
+                extra.append(ops.gemm(dta, dn_t, layout="rm", use_bias=False))
+                da = g
+            elif ly.attn_adapter is not None:
                 dta, dn_t = self._adapter_backward(blk.attn.adapter, g, sv["a"], sv["ta"])
                 da = ops.gemm(dta, dn_t, residuals=(g,), layout="rm", use_bias=False)
             else:
@@ -501,7 +564,7 @@ class MagmaEngine:
             dctx = self._fgemm((li, "out_t"), da, pk["out_t"])
             q, k, v = sv["q"], sv["k"], sv["v"]
             dqkv = ops.attn_bwd_merged(q, k, v, sv["qt"], sv["kt"], dctx, sv["ctx"], sv["lse"], B, H, S, eng.rot, eng.sin_t, eng.cos_t)
-            dln = self._fgemm((li, "qkv_t"), dqkv, pk["qkv_t"], residuals=(dln_mlp,))
+            dln = self._fgemm((li, "qkv_t"), dqkv, pk["qkv_t"], residuals=(dln_mlp, *extra))
             g = ops.layernorm_bwd(dln, sv["x"], ly.ln_g, eng.eps, res=g)
             tape["layers"][li] = None     # free this layer's activations
             self._reduce_params_async([p for p in blk.parameters() if p.requires_grad])

@@ -74,6 +74,79 @@ def test_parallel_adapters_vs_oracle(dev, mlp_type, attn_type):
         assert rel(full.logits, lm_forward(lm, cfg, inputs_embeds=emb)["logits"]) < 2e-2
 
 
+@pytest.mark.parametrize("mlp_type,attn_type", [("parallel", None), ("scaled_parallel", "scaled_parallel")])
+def test_parallel_adapters_train_gradients(dev, mlp_type, attn_type):
+    """Training with parallel / scaled_parallel adapters: gradients of every trainable tensor (adapter weights and biases,
+    the adapter_scale scalars, prefix, trunk) from the explicit HIP backward against autograd through the fp32 oracle.
+    Tolerance as tests/test_train_gpu.py: err(HIP) <= 2 x err(bf16 autograd) + 3e-2 per tensor, cosine > 0.999."""
+    from magma_amd.train_engine import MagmaEngine
+    from oracle.model import OracleConfig, init_params, magma_forward
+    cfg = OracleConfig.tiny(mlp_adapter_hidden=128, attn_adapter_hidden=64 if attn_type else 0,
+                            mlp_adapter_type=mlp_type, attn_adapter_type=attn_type or "normal")
+    params = init_params(cfg, seed=23)
+    for k in params:
+        if ".adapter." in k:
+            params[k] = params[k] * 20
+    model = _build(dev, mlp_type, attn_type)
+    missing, unexpected = model.load_checkpoint_state(params)
+    assert not unexpected and not missing, (missing, unexpected)
+    model.config.gradient_accumulation_steps = 1
+    eng = MagmaEngine(model)
+    eng.train()
+    g = torch.Generator().manual_seed(3)
+    B, S = 2, model.seq_len
+    images = torch.randn(B, 3, 64, 64, generator=g)
+    caps = torch.full((B, S), cfg.eos_token, dtype=torch.int64)
+    caps[0, :23] = torch.randint(0, 1000, (23,), generator=g)
+    caps[1, :11] = torch.randint(0, 1000, (11,), generator=g)
+    mask = (torch.rand(B, 4, cfg.d_model, generator=g) < 0.9).float() / 0.9
+
+    def oracle_grads(dtype):
+        p = {k: (v.detach().to(dtype).clone() if v.is_floating_point() else v) for k, v in params.items()}
+        names = [k for k in p if (".adapter." in k or "adapter_scale" in k or k.startswith("image_prefix.")) and "running_" not in k]
+        for k in names:
+            p[k].requires_grad_(True)
+        out = magma_forward(p, cfg, images.to(dtype), caps, dropout_mask=mask.to(dtype))
+        out["loss"].backward()
+        return float(out["loss"]), {k: p[k].grad.float() for k in names}
+
+    loss_ref, g_ref = oracle_grads(torch.float32)
+    loss_bf, g_bf = oracle_grads(torch.bfloat16)
+    out = eng(images.to(dev), caps.to(dev), dropout_mask=mask.to(dev))
+    assert abs(float(out.loss) - loss_ref) <= 2 * abs(loss_bf - loss_ref) + 3e-3 * abs(loss_ref)
+    eng.backward(out.loss)
+    name_of = {id(p): n for n, p in model.named_parameters()}
+    dots = n1 = n2 = 0.0
+    seen = set()
+    bad, scal = [], []
+    for grp in eng.groups:
+        for p in grp.params:
+            n = name_of[id(p)]
+            n = "lm." + n if n.startswith("transformer.") else n
+            if n in seen or n not in g_ref:
+                continue
+            seen.add(n)
+            got, ref = eng.grad_of(p).float().cpu().reshape(-1), g_ref[n].reshape(-1)
+            e_hip, e_bf = rel(got, ref), rel(g_bf[n].reshape(-1), ref)
+            if "adapter_scale" in n:      # scalars (a sum of 260k signed products each): judged together as one vector below
+                scal.append((float(got), float(ref), float(g_bf[n])))
+            elif e_hip > 2 * e_bf + 3e-2:
+                bad.append((n, e_hip, e_bf))
+            dots += float((got * ref).sum()); n1 += float((got * got).sum()); n2 += float((ref * ref).sum())
+    assert not bad, bad
+    if scal:
+        t = torch.tensor(scal)
+        e_hip, e_bf = rel(t[:, 0], t[:, 1]), rel(t[:, 2], t[:, 1])
+        print("adapter_scale gradients (hip, fp32 oracle, bf16 oracle):", scal)
+        assert e_hip <= 2 * e_bf + 3e-2, (e_hip, e_bf, scal)
+    assert len(seen) == len(g_ref), set(g_ref) - seen
+    assert any("adapter_scale" in n for n in seen) == (mlp_type == "scaled_parallel")
+    assert dots / (n1 ** 0.5 * n2 ** 0.5) > 0.999
+    eng.step()                                   # the step runs, and the inference engine sees the new scale afterwards
+    eng.eval()
+    assert torch.isfinite(eng(images.to(dev), caps.to(dev)).loss)
+
+
 def test_adapter_as_a_module(dev):
     """reference adapters.py:38-39: Adapter.forward(x) = adapter(x) + x, callable on its own."""
     from magma_amd.adapters import Adapter
