@@ -110,6 +110,46 @@ def test_gradients_and_step(dev, variant):
     assert torch.isfinite(out2.loss)
 
 
+def test_frozen_image_encoder(dev):
+    """config.freeze_img_encoder = true (the reference's default, magma.py:98-100; the shipped YAMLs set false): the trunk
+    runs the inference path, owns no optimizer state, and the adapter / prefix gradients equal those of the run that also
+    trains the trunk (same weights, same arithmetic upstream of the trunk)."""
+    from magma_amd.testing import build_reduced_magma
+    from magma_amd.train_engine import MagmaEngine
+    g = torch.Generator().manual_seed(11)
+    images = torch.randn(2, 3, 64, 64, generator=g).to(dev)
+    res = {}
+    for frozen in (False, True):
+        torch.manual_seed(0)
+        model = build_reduced_magma(dev, n_positions=128)
+        caps = torch.full((2, 128), model.eos_token, dtype=torch.int64)
+        caps[0, :20] = torch.randint(0, 1000, (20,), generator=torch.Generator().manual_seed(1))
+        caps[1, :9] = torch.randint(0, 1000, (9,), generator=torch.Generator().manual_seed(2))
+        model.config.gradient_accumulation_steps = 1
+        model.image_prefix.dropout.p = 0.0
+        if frozen:
+            model.config.freeze_img_encoder = True
+            for p in model.image_prefix.enc.parameters():
+                p.requires_grad = False
+        eng = MagmaEngine(model)
+        eng.train()
+        enc_ids = {id(p) for p in model.image_prefix.enc.parameters()}
+        owned = {id(p) for grp in eng.groups for p in grp.params}
+        assert bool(owned & enc_ids) == (not frozen)
+        out = eng(images, caps.to(dev))
+        eng.backward(out.loss)
+        names = {id(p): n for n, p in model.named_parameters()}
+        res[frozen] = (float(out.loss), {names[id(p)]: eng.grad_of(p).float().cpu().clone() for grp in eng.groups
+                                         for p in grp.params if id(p) not in enc_ids})
+        eng.step()
+        assert torch.isfinite(eng(images, caps.to(dev)).loss)
+    (l0, g0), (l1, g1) = res[False], res[True]
+    assert abs(l0 - l1) <= 2e-3 * abs(l0), (l0, l1)       # the two trunk paths (training units vs inference engine) differ in bf16 rounding
+    assert set(g0) == set(g1) and len(g1) > 4
+    for n in g1:
+        assert rel(g1[n], g0[n]) < 3e-2, (n, rel(g1[n], g0[n]))
+
+
 def test_truncation_is_exact(dev):
     """truncating to the longest caption leaves loss and grads unchanged."""
     from magma_amd.testing import build_reduced_magma
