@@ -71,6 +71,13 @@ MG_DEV void glds16a(const void* g, char* lds_wave_base) {
   asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off"
                :: "v"(g), "s"(__builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(mg_lptr_t)lds_wave_base)) : "memory");
 }
+// SGPR base + 32-bit per-lane BYTE offset: no 64-bit address VGPRs (which hipcc otherwise hoists out of the K loop, one
+// pair per DMA piece, and spills when the kernel is at its register limit)
+MG_DEV void glds16s(const void* base_uniform, uint32_t byte_off, char* lds_wave_base) {
+  asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1"
+               :: "v"(byte_off), "s"(base_uniform),
+                  "s"(__builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(mg_lptr_t)lds_wave_base)) : "memory");
+}
 MG_DEV void glds4a(const void* g, char* lds_wave_base) {
   asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dword %0, off"
                :: "v"(g), "s"(__builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(mg_lptr_t)lds_wave_base)) : "memory");

@@ -324,7 +324,10 @@ static_assert(G256_LDS >= 2 * G256_BUF, "LDS must hold two K-tiles");
 #define MG_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define MG_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
-template <int WLAYOUT, bool LATE_LGKM>
+// FP8: as in gemm128_kernel the operands are e4m3 bytes counted in pairs; a K-tile is 128 fp8 values per row (the same 128
+// bytes), its two 16-byte k-substep fragments form ONE 8-register operand of v_mfma_scale_f32_16x16x128_f8f6f4 -- half the
+// MFMA instructions per phase, each twice as long, twice the flops per byte staged.
+template <int WLAYOUT, bool LATE_LGKM, bool FP8 = false>
 __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -354,21 +357,25 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
         b_off[h][j] = (int)(((int64_t)nt * (p.ldw >> 5) + j) * 512 + lane * 8);   // j = k-step inside the tile
       }
     }
+  // the K-tile advance goes into the (scalar) base, the per-lane part stays a 32-bit byte offset: see glds16s
 #define MG_DMA_A(kt, h)                                                                                  \
   {                                                                                                      \
     char* dst_ = smem + ((kt) & 1) * G256_BUF + ((h) * 128 + wave * 16) * 128;                           \
-    glds16(p.A + (int64_t)(kt) * 64 + a_off[h][0], dst_);                                                \
-    glds16(p.A + (int64_t)(kt) * 64 + a_off[h][1], dst_ + 1024);                                         \
+    const mg_bf16* src_ = p.A + (int64_t)(kt) * 64;                                                      \
+    glds16s(src_, (uint32_t)a_off[h][0] * 2u, dst_);                                                     \
+    glds16s(src_, (uint32_t)a_off[h][1] * 2u, dst_ + 1024);                                              \
   }
 #define MG_DMA_B(kt, h)                                                                                  \
   {                                                                                                      \
     char* base_ = smem + ((kt) & 1) * G256_BUF + G256_TILE;                                              \
     if (WLAYOUT == MG_W_ROWMAJOR) {                                                                      \
-      glds16(p.W + (int64_t)(kt) * 64 + b_off[h][0], base_ + ((h) * 128 + wave * 16) * 128);             \
-      glds16(p.W + (int64_t)(kt) * 64 + b_off[h][1], base_ + ((h) * 128 + wave * 16 + 8) * 128);         \
+      const mg_bf16* src_ = p.W + (int64_t)(kt) * 64;                                                    \
+      glds16s(src_, (uint32_t)b_off[h][0] * 2u, base_ + ((h) * 128 + wave * 16) * 128);                  \
+      glds16s(src_, (uint32_t)b_off[h][1] * 2u, base_ + ((h) * 128 + wave * 16 + 8) * 128);              \
     } else {                                                                                             \
-      glds16(p.W + (int64_t)(kt) * 1024 + b_off[h][0], base_ + (((h) * 8 + wave) * 2) * 1024);           \
-      glds16(p.W + (int64_t)(kt) * 1024 + b_off[h][1], base_ + (((h) * 8 + wave) * 2 + 1) * 1024);       \
+      const mg_bf16* src_ = p.W + (int64_t)(kt) * 1024;                                                  \
+      glds16s(src_, (uint32_t)b_off[h][0] * 2u, base_ + (((h) * 8 + wave) * 2) * 1024);                  \
+      glds16s(src_, (uint32_t)b_off[h][1] * 2u, base_ + (((h) * 8 + wave) * 2 + 1) * 1024);              \
     }                                                                                                    \
   }
 
@@ -379,24 +386,25 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
                                                 : G256_TILE + (wc * 8) * 1024 + lane * 16;
   constexpr int B_NT = (WLAYOUT == MG_W_ROWMAJOR) ? 16 * 128 : 2 * 1024;
   constexpr int B_KS = (WLAYOUT == MG_W_ROWMAJOR) ? 0 : 1024;           // row-major: substep via XOR 64
-  bf16x8 af[4][2];                 // current m-half: [m-tile][k-substep]
-  bf16x8 bw[2][2][2];              // both n-halves:  [n-half][n-tile][k-substep]
+  // fragments as 8-register tuples: halves [0..3] / [4..7] = k-substeps 0 / 1 (two bf16 MFMA operands, or one fp8 operand)
+  i32x8 af[4];                     // current m-half: [m-tile]
+  i32x8 bw[2][2];                  // both n-halves:  [n-half][n-tile]
 #define MG_READ_A(par, mh)                                                                               \
   {                                                                                                      \
     const char* sb_ = smem + (par) * G256_BUF;                                                           \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                   \
-      af[i_][0] = *(const bf16x8*)(sb_ + a_rd0 + ((mh) * 4 + i_) * 2048);                                \
-      af[i_][1] = *(const bf16x8*)(sb_ + (a_rd0 ^ 64) + ((mh) * 4 + i_) * 2048);                         \
-    }                                                                                                    \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                     \
+      af[i_] = __builtin_shufflevector(*(const i32x4*)(sb_ + a_rd0 + ((mh) * 4 + i_) * 2048),            \
+                                       *(const i32x4*)(sb_ + (a_rd0 ^ 64) + ((mh) * 4 + i_) * 2048), 0, 1, 2, 3, 4, 5, 6, 7); \
   }
 #define MG_READ_B(par, nh)                                                                               \
   {                                                                                                      \
     const char* sb_ = smem + (par) * G256_BUF;                                                           \
-    _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                                   \
-      bw[nh][j_][0] = *(const bf16x8*)(sb_ + b_rd0 + ((nh) * 2 + j_) * B_NT);                            \
-      bw[nh][j_][1] = *(const bf16x8*)(sb_ + ((WLAYOUT == MG_W_ROWMAJOR) ? (b_rd0 ^ 64) : (b_rd0 + B_KS)) + ((nh) * 2 + j_) * B_NT); \
-    }                                                                                                    \
+    _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                     \
+      bw[nh][j_] = __builtin_shufflevector(                                                              \
+          *(const i32x4*)(sb_ + b_rd0 + ((nh) * 2 + j_) * B_NT),                                         \
+          *(const i32x4*)(sb_ + ((WLAYOUT == MG_W_ROWMAJOR) ? (b_rd0 ^ 64) : (b_rd0 + B_KS)) + ((nh) * 2 + j_) * B_NT), 0, 1, 2, 3, 4, 5, 6, 7); \
   }
+#define MG_HALF(v, s_) __builtin_bit_cast(bf16x8, (s_) ? __builtin_shufflevector(v, v, 4, 5, 6, 7) : __builtin_shufflevector(v, v, 0, 1, 2, 3))
 
   f32x4 acc[8][4];
 #pragma unroll
@@ -410,7 +418,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
       _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                   \
         _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                 \
           acc[(mh) * 4 + i_][(nh) * 2 + j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                   \
-              bw[nh][j_][s_], af[i_][s_], acc[(mh) * 4 + i_][(nh) * 2 + j_], 0, 0, 0);                   \
+              MG_HALF(bw[nh][j_], s_), MG_HALF(af[i_], s_), acc[(mh) * 4 + i_][(nh) * 2 + j_], 0, 0, 0); \
     __builtin_amdgcn_s_setprio(0);                                                                       \
   }
 #define MG_BAR() __builtin_amdgcn_s_barrier()
@@ -425,9 +433,43 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
     MG_MMA(MH, NH);                                                                                      \
     MG_BAR();                                                                                            \
   }
+  // FP8 phases: the 8-register operands leave no room for four A and four W fragments next to 128 accumulators, so a
+  // phase is one m-QUARTER (two m-tiles) against all four n-tiles: W is read once per K-tile (q0), A two tiles per phase.
+  // Same DMA schedule; the W regions of a buffer are last read in q0 and the A regions in q3 of the group that owns
+  // them (A_lo = rows of group 0, A_hi = group 1), both before the next DMA into them (W_hi at q0, A_lo / A_hi at q1 / q2
+  // of the NEXT tile of that parity, W_lo at q3 one barrier after the last q0 read).
+#define MG_READ_AQ(par, mq)                                                                              \
+  {                                                                                                      \
+    const char* sb_ = smem + (par) * G256_BUF;                                                           \
+    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                                     \
+      af[i_] = __builtin_shufflevector(*(const i32x4*)(sb_ + a_rd0 + ((mq) * 2 + i_) * 2048),            \
+                                       *(const i32x4*)(sb_ + (a_rd0 ^ 64) + ((mq) * 2 + i_) * 2048), 0, 1, 2, 3, 4, 5, 6, 7); \
+  }
+#define MG_MMAQ(mq)                                                                                      \
+  {                                                                                                      \
+    __builtin_amdgcn_s_setprio(1);                                                                       \
+    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                                     \
+      _Pragma("unroll") for (int n_ = 0; n_ < 4; ++n_)                                                   \
+        acc[(mq) * 2 + i_][n_] = mfma_fp8_k128(bw[n_ >> 1][n_ & 1], af[i_], acc[(mq) * 2 + i_][n_]);     \
+    __builtin_amdgcn_s_setprio(0);                                                                       \
+  }
+#define MG_PHASEQ(READS, DMA, MQ)                                                                        \
+  {                                                                                                      \
+    READS;                                                                                               \
+    DMA;                                                                                                 \
+    MG_WAIT_LGKM0();                                                                                     \
+    MG_BAR();                                                                                            \
+    MG_MMAQ(MQ);                                                                                         \
+    MG_BAR();                                                                                            \
+  }
   // K-tile t with buffer parity PAR; NXT: tile t+1 exists, NXT2: tile t+2 exists
 #define MG_G256_TILE(t, PAR, NXT, NXT2)                                                                  \
-  {                                                                                                      \
+  if constexpr (FP8) {                                                                                   \
+    MG_PHASEQ({ MG_READ_AQ(PAR, 0); MG_READ_B(PAR, 0); MG_READ_B(PAR, 1); }, { if (NXT) MG_DMA_B((t) + 1, 1); }, 0); \
+    MG_PHASEQ({ MG_READ_AQ(PAR, 1); }, { if (NXT) MG_DMA_A((t) + 1, 0); }, 1);                            \
+    MG_PHASEQ({ MG_READ_AQ(PAR, 2); }, { if (NXT) MG_DMA_A((t) + 1, 1); }, 2);                            \
+    MG_PHASEQ({ MG_READ_AQ(PAR, 3); }, { if (NXT2) { MG_DMA_B((t) + 2, 0); MG_WAIT_VM(2); } else { MG_WAIT_VM(0); } }, 3); \
+  } else {                                                                                               \
     MG_PHASE({ MG_READ_A(PAR, 0); MG_READ_B(PAR, 0); }, { if (NXT) MG_DMA_B((t) + 1, 1); }, 0, 0);       \
     MG_PHASE({ MG_READ_B(PAR, 1); }, { if (NXT) MG_DMA_A((t) + 1, 0); }, 0, 1);                           \
     MG_PHASE({ MG_READ_A(PAR, 1); }, { if (NXT) MG_DMA_A((t) + 1, 1); }, 1, 1);                           \
@@ -450,10 +492,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   MG_G256_TILE(t + 1, 1, false, false)
   if (wr == 0) MG_BAR();
 #undef MG_G256_TILE
+#undef MG_PHASEQ
+#undef MG_MMAQ
+#undef MG_READ_AQ
 #undef MG_PHASE
 #undef MG_MMA
 #undef MG_READ_A
 #undef MG_READ_B
+#undef MG_HALF
 #undef MG_DMA_A
 #undef MG_DMA_B
 
@@ -518,11 +564,11 @@ int launch_gemm(const GemmParams& gp, hipStream_t s) {
   return MG_OK;
 }
 
-template <int WLAYOUT, bool LATE_LGKM>
+template <int WLAYOUT, bool LATE_LGKM, bool FP8 = false>
 int launch_gemm256(GemmParams gp, hipStream_t s) {
-  if (int rc = mg_allow_dynamic_lds((const void*)gemm256_kernel<WLAYOUT, LATE_LGKM>, G256_LDS, "mg_gemm")) return rc;
+  if (int rc = mg_allow_dynamic_lds((const void*)gemm256_kernel<WLAYOUT, LATE_LGKM, FP8>, G256_LDS, "mg_gemm")) return rc;
   gp.tiles_m = (gp.M + 255) / 256; gp.tiles_n = (gp.N + 255) / 256;
-  hipLaunchKernelGGL((gemm256_kernel<WLAYOUT, LATE_LGKM>), dim3(gp.tiles_m * gp.tiles_n), dim3(512), G256_LDS, s, gp);
+  hipLaunchKernelGGL((gemm256_kernel<WLAYOUT, LATE_LGKM, FP8>), dim3(gp.tiles_m * gp.tiles_n), dim3(512), G256_LDS, s, gp);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }
@@ -579,12 +625,12 @@ int gemm_dispatch(const mg_gemm_desc* d, bool fp8, const float* row_scale, hipSt
   const bool rm = d->w_layout == MG_W_ROWMAJOR;
   // large dense shapes go to the deep-pipelined 256x256 kernel (tile_hint: 0 auto, 128 / 256 force)
   const int64_t wgs256 = (int64_t)((d->M + 255) / 256) * ((d->N + 255) / 256);
-  const bool can256 = !fp8 && d->a_mode == MG_A_DENSE && (gp.K % 128) == 0;   // fp8: 128x128 kernel only (the 8-register
-                                                                              // operands do not fit the 256x256 kernel's budget)
+  const bool can256 = d->a_mode == MG_A_DENSE && (gp.K % 128) == 0;           // gp.K counts PAIRS of fp8 values on the fp8 path
   const bool want256 = d->tile_hint == 256 || d->tile_hint == 257 || (d->tile_hint == 0 && wgs256 >= 192 && d->M >= 1024 && d->N >= 512);
   if (can256 && want256) {
-    if (d->tile_hint == 257)   // experiment: LDS-read wait after the barrier
+    if (d->tile_hint == 257 && !fp8)   // experiment: LDS-read wait after the barrier
       return rm ? launch_gemm256<MG_W_ROWMAJOR, true>(gp, s) : launch_gemm256<MG_W_FRAGTILED, true>(gp, s);
+    if (fp8) return rm ? launch_gemm256<MG_W_ROWMAJOR, false, true>(gp, s) : launch_gemm256<MG_W_FRAGTILED, false, true>(gp, s);
     return rm ? launch_gemm256<MG_W_ROWMAJOR, false>(gp, s) : launch_gemm256<MG_W_FRAGTILED, false>(gp, s);
   }
   if (d->tile_hint == 256 && !can256) MG_FAIL(MG_ERR_UNSUPPORTED, "%s: the 256x256 kernel needs dense A and K %% %d == 0", who, 128 * epb);

@@ -827,8 +827,10 @@ class PackedLinearFP8:
 def gemm_fp8(aq: torch.Tensor, a_scale: torch.Tensor, w: PackedLinearFP8, out: Optional[torch.Tensor] = None, *,
              act: int = MG_ACT_NONE, residuals: Sequence[torch.Tensor] = (), act_after: int = MG_ACT_NONE,
              use_bias: bool = True, out_dtype=BF16, layout: Optional[str] = None, split_k: int = 0,
-             aux=None, aux_mode: int = MG_AUX_NONE, aux_after: bool = False, out2: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out[M,N] = epilogue((aq @ wq^T) * a_scale[m] * w.scale[n]) on the fp8 MFMA (fp32 accumulate)."""
+             aux=None, aux_mode: int = MG_AUX_NONE, aux_after: bool = False, out2: Optional[torch.Tensor] = None,
+             tile: int = 0) -> torch.Tensor:
+    """out[M,N] = epilogue((aq @ wq^T) * a_scale[m] * w.scale[n]) on the fp8 MFMA (fp32 accumulate).
+    ``tile``: 0 lets the library choose between the 128x128 and the 256x256 kernel, 128 / 256 force one."""
     _need_gpu(aq)
     assert aq.dtype == torch.uint8 and aq.ndim == 2 and aq.stride(1) == 1 and aq.shape[1] >= w.K
     M = aq.shape[0]
@@ -844,6 +846,7 @@ def gemm_fp8(aq: torch.Tensor, a_scale: torch.Tensor, w: PackedLinearFP8, out: O
         d.W, d.ldw, d.w_layout = w.rm.data_ptr(), w.rm.stride(0), MG_W_ROWMAJOR
     d.M, d.N, d.K = M, w.N, w.K
     d.a_mode = MG_A_DENSE
+    d.tile_hint = tile
     d.zero_page = zero_page(aq.device).data_ptr()
     d.split_k = split_k
     if split_k != 1:

@@ -132,6 +132,24 @@ def main():
                 fl = 2.0 * M * N * K
                 emit(kind="fp8", tag=tag, M=M, N=N, K=K, bf16_ms=ms16, fp8_ms=ms8, quant_ms=msq, bf16_tflops=fl / ms16 / 1e9,
                      fp8_tflops=fl / ms8 / 1e9)
+    if which == "fp8tile":   # fp8 GEMM: 128x128 kernel vs 256x256 kernel vs bf16 256x256, training shapes, with a numerics check
+        M = 32768
+        for (N, K, tag) in [(12288, 4096, "qkv"), (4096, 4096, "out_proj"), (16384, 4096, "fc_in"), (4096, 16384, "fc_out")]:
+            a = torch.randn(M, K, device=dev).to(BF16)
+            w = (torch.randn(N, K, device=dev) * 0.05).to(BF16)
+            lin, lin8 = ops.PackedLinear(w), ops.PackedLinearFP8(w)
+            aq, asc = ops.quantize_rows_fp8(a)
+            o128 = ops.gemm_fp8(aq, asc, lin8, tile=128)
+            o256 = ops.gemm_fp8(aq, asc, lin8, tile=256)
+            diff = float((o128.float() - o256.float()).abs().max()), float(o128.float().abs().max())
+            out = torch.empty(M, N, dtype=BF16, device=dev)
+            fl = 2.0 * M * N * K
+            r = {"kind": "fp8tile", "tag": tag, "M": M, "N": N, "K": K, "max_abs_diff_128_vs_256": diff[0], "max_abs": diff[1]}
+            for name, fn in (("bf16_256", lambda i: ops.gemm(a, lin, out=out)), ("fp8_128", lambda i: ops.gemm_fp8(aq, asc, lin8, out=out, tile=128)),
+                             ("fp8_256", lambda i: ops.gemm_fp8(aq, asc, lin8, out=out, tile=256))):
+                ms = timeit(fn, 5)
+                r[name + "_ms"] = ms; r[name + "_tflops"] = fl / ms / 1e9
+            emit(**r)
     if which == "prefill":   # M = 8 x 57 rows: weights rotate so they stream from HBM as in a real prefill
         for (N, K, tag) in [(12288, 4096, "qkv"), (16384, 4096, "fc_in"), (4096, 4096, "out_proj"),
                             (4096, 16384, "fc_out"), (1024, 4096, "adapter_dn"), (4096, 1024, "adapter_up")]:
