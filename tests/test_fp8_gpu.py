@@ -61,6 +61,27 @@ def test_gemm_fp8(dev, layout, M, N, K):
     assert rel(plain, full) < 0.06, rel(plain, full)
 
 
+@pytest.mark.parametrize("layout", ["rm", "ft"])
+@pytest.mark.parametrize("M,N,K", [(1024, 512, 256), (1100, 1056, 1024), (4096, 12288, 4096)])
+def test_gemm_fp8_256x256_kernel(dev, layout, M, N, K):
+    """gemm256_kernel<..., FP8> (forced with tile=256; the library picks it by itself from M >= 1024 and >= 192 tiles) against
+    the exact restatement of the arithmetic, ragged M / N included, and bit-identical to the 128x128 fp8 kernel."""
+    from magma_amd import ops
+    g = torch.Generator(device=dev).manual_seed(M + N + K)
+    a = torch.randn(M, K, device=dev, generator=g).to(BF16)
+    w = (torch.randn(N, K, device=dev, generator=g) * 0.05).to(BF16)
+    bias = torch.randn(N, device=dev, generator=g)
+    res = torch.randn(M, ops.ceil_to(N, 8), device=dev, generator=g).to(BF16)
+    lin = ops.PackedLinearFP8(w, bias=bias, tiled=True, rowmajor=True)
+    aq, asc = ops.quantize_rows_fp8(a)
+    aqf = aq[:, :K].view(torch.float8_e4m3fn).float()
+    ref = F.gelu((aqf @ lin.dequant().t()) * asc[:, None] + bias, approximate="tanh") + res[:, :N].float()
+    kw = dict(layout=layout, act=ops.MG_ACT_GELU_NEW, residuals=(res,), out_dtype=torch.float32, split_k=1)
+    o256 = ops.gemm_fp8(aq, asc, lin, tile=256, **kw)
+    assert rel(o256, ref) < 1e-4, rel(o256, ref)
+    assert torch.equal(o256, ops.gemm_fp8(aq, asc, lin, tile=128, **kw))
+
+
 @pytest.mark.parametrize("mode", ["attn", "all"])
 def test_model_forward_in_fp8_stays_close_to_bf16(dev, mode):
     """config 5 at model level: the fp8 projections change logits / loss only at the e4m3 quantisation level
