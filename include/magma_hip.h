@@ -47,6 +47,7 @@ extern "C" {
 #define MG_AUX_RELU_GATE 1 /* v *= (aux > 0)            -- ReLU backward            */
 #define MG_AUX_GELU_GRAD 2 /* v *= gelu_new'(aux)       -- aux = saved pre-activation */
 #define MG_AUX_MUL 3       /* v *= aux                  -- dropout mask (pre-scaled)  */
+#define MG_AUX_QUICK_GELU_GRAD 4 /* v *= d/dx [x sigmoid(1.702 x)](aux) -- CLIP ViT MLP backward, aux = saved pre-activation */
 
 /* weight layouts for the B operand of the GEMMs */
 #define MG_W_ROWMAJOR 0 /* W[n*ldw + k], k zero-padded to a multiple of 64   */
@@ -294,6 +295,10 @@ int mg_patchify_bf16(const mg_bf16* img, mg_bf16* out, int32_t B, int32_t H, int
 int mg_vit_embed_bf16(const mg_bf16* patches, const mg_bf16* class_embedding, const mg_bf16* pos, mg_bf16* out, int32_t B,
                       int32_t G, int32_t width, void* stream);
 int mg_attn_small_bf16(const mg_bf16* qkv, mg_bf16* out, int32_t B, int32_t S, int32_t H, void* stream);
+/* Backward of mg_attn_small_bf16 (training the CLIP ViT encoder; autograd through nn.MultiheadAttention in the reference's
+ * CLIP dependency): qkv [B*S, 3*H*64] as in the forward, d_out [B*S, H*64] -> d_qkv [B*S, 3*H*64].  Recomputes the
+ * probabilities (fp32) per (b, h); S <= 64.                                                                         */
+int mg_attn_small_bwd_bf16(const mg_bf16* qkv, const mg_bf16* d_out, mg_bf16* d_qkv, int32_t B, int32_t S, int32_t H, void* stream);
 
 /* K4: 2x2 average pool, NHWC bf16.  x [B,H,W,C] -> y [B,H/2,W/2,C]  (stem pool and the anti-aliased stride of
  * CLIP's ModifiedResNet bottlenecks; trunk selected at reference magma/image_encoders.py:65-74).              */

@@ -38,6 +38,10 @@ MG_DEV float gelu_new_f(float x) {
   const float u = k0 * (x + k1 * x * x * x);
   return x * __frcp_rn(1.0f + __expf(-2.0f * u));
 }
+MG_DEV float quick_gelu_grad_f(float x) {      // d/dx [x * sigmoid(1.702 x)]
+  const float sg = 1.0f / (1.0f + __expf(-1.702f * x));
+  return sg * (1.0f + 1.702f * x * (1.0f - sg));
+}
 MG_DEV float gelu_new_grad_f(float x) {
   const float k0 = 0.7978845608028654f, k1 = 0.044715f;
   const float sg = __frcp_rn(1.0f + __expf(-2.0f * k0 * (x + k1 * x * x * x)));   // 0.5 (1 + tanh u)

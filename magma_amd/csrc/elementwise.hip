@@ -370,7 +370,80 @@ __global__ __launch_bounds__(256) void attn_small_kernel(const mg_bf16* __restri
 #pragma unroll
   for (int d = 0; d < AS_DH; ++d) orow[d] = f2bf(acc[d] * inv);
 }
+// Backward of attn_small_kernel.  One workgroup per (b, h), everything of the head in LDS as fp32 (S <= 64):
+//   P = softmax(q k^T / 8)            dV = P^T dO            dP = dO V^T
+//   dS = P o (dP - rowsum(P o dP)) / 8        dQ = dS K        dK = dS^T Q
+// The sequences are tens of tokens (CLIP ViT-B/32: 50): plain fp32 FMAs, no MFMA -- 12 heads x B workgroups of ~1 MFLOP.
+constexpr int ASB_MAXS = 64;
+__global__ __launch_bounds__(256) void attn_small_bwd_kernel(const mg_bf16* __restrict__ qkv, const mg_bf16* __restrict__ dout,
+                                                             mg_bf16* __restrict__ dqkv, int S, int H) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int LD = AS_DH + 1;
+  float* qs = (float*)smem;            // [S][65]
+  float* ks = qs + ASB_MAXS * LD;
+  float* vs = ks + ASB_MAXS * LD;
+  float* gs = vs + ASB_MAXS * LD;      // dO
+  float* ps = gs + ASB_MAXS * LD;      // [S][S+1]  P, then dS
+  float* ds = ps + ASB_MAXS * (ASB_MAXS + 1);   // [S][S+1]  dP
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const int w = H * AS_DH, w3 = 3 * w, tid = threadIdx.x, LP = S + 1;
+  for (int i = tid; i < S * AS_DH; i += 256) {
+    const int s = i / AS_DH, d = i - s * AS_DH;
+    const mg_bf16* row = qkv + (int64_t)(b * S + s) * w3 + h * AS_DH + d;
+    qs[s * LD + d] = bf2f(row[0]);
+    ks[s * LD + d] = bf2f(row[w]);
+    vs[s * LD + d] = bf2f(row[2 * w]);
+    gs[s * LD + d] = bf2f(dout[(int64_t)(b * S + s) * w + h * AS_DH + d]);
+  }
+  __syncthreads();
+  for (int idx = tid; idx < S * S; idx += 256) {           // scores and dP
+    const int i = idx / S, j = idx - i * S;
+    float sc = 0.f, dp = 0.f;
+#pragma unroll 8
+    for (int d = 0; d < AS_DH; ++d) { sc += qs[i * LD + d] * ks[j * LD + d]; dp += gs[i * LD + d] * vs[j * LD + d]; }
+    ps[i * LP + j] = sc * 0.125f;
+    ds[i * LP + j] = dp;
+  }
+  __syncthreads();
+  if (tid < S) {                                           // row softmax, then dS = P (dP - D) / 8 in place
+    float* pr = ps + tid * LP;
+    const float* dr = ds + tid * LP;
+    float m = -1e30f;
+    for (int j = 0; j < S; ++j) m = fmaxf(m, pr[j]);
+    float l = 0.f;
+    for (int j = 0; j < S; ++j) { const float e = __expf(pr[j] - m); pr[j] = e; l += e; }
+    const float inv = 1.0f / l;
+    float D = 0.f;
+    for (int j = 0; j < S; ++j) { pr[j] *= inv; D += pr[j] * dr[j]; }
+    float* dsr = ds + tid * LP;
+    for (int j = 0; j < S; ++j) dsr[j] = pr[j] * (dr[j] - D) * 0.125f;     // ds <- dS; ps keeps P for dV
+  }
+  __syncthreads();
+  for (int idx = tid; idx < S * AS_DH; idx += 256) {
+    const int s = idx / AS_DH, d = idx - s * AS_DH;
+    float dq = 0.f, dk = 0.f, dv = 0.f;
+    for (int j = 0; j < S; ++j) {
+      dq += ds[s * LP + j] * ks[j * LD + d];               // dQ[s] = sum_j dS[s][j] K[j]
+      dk += ds[j * LP + s] * qs[j * LD + d];               // dK[s] = sum_i dS[i][s] Q[i]
+      dv += ps[j * LP + s] * gs[j * LD + d];               // dV[s] = sum_i P[i][s] dO[i]
+    }
+    mg_bf16* row = dqkv + (int64_t)(b * S + s) * w3 + h * AS_DH + d;
+    row[0] = f2bf(dq);
+    row[w] = f2bf(dk);
+    row[2 * w] = f2bf(dv);
+  }
+}
 }  // namespace
+
+extern "C" int mg_attn_small_bwd_bf16(const mg_bf16* qkv, const mg_bf16* d_out, mg_bf16* d_qkv, int32_t B, int32_t S, int32_t H,
+                                      void* stream) {
+  if (B <= 0 || H <= 0 || S <= 0 || S > ASB_MAXS || !qkv || !d_out || !d_qkv) MG_FAIL(MG_ERR_SHAPE, "mg_attn_small_bwd_bf16: need 0 < S <= %d (head dim 64)", ASB_MAXS);
+  const int lds = (4 * ASB_MAXS * (AS_DH + 1) + 2 * ASB_MAXS * (ASB_MAXS + 1)) * 4;
+  if (int rc = mg_allow_dynamic_lds((const void*)attn_small_bwd_kernel, lds, "mg_attn_small_bwd_bf16")) return rc;
+  hipLaunchKernelGGL(attn_small_bwd_kernel, dim3(B * H), dim3(256), lds, (hipStream_t)stream, qkv, d_out, d_qkv, S, H);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
 
 extern "C" int mg_patchify_bf16(const mg_bf16* img, mg_bf16* out, int32_t B, int32_t H, int32_t W, int32_t P, void* stream) {
   if (B <= 0 || P <= 0 || H <= 0 || W <= 0 || H % P || W % P || !img || !out) MG_FAIL(MG_ERR_SHAPE, "mg_patchify_bf16: need H, W multiples of the patch size");

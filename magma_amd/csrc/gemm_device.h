@@ -140,7 +140,8 @@ MG_DEV void epilogue_apply(const mg_epilogue& ep, const EpiColsW<W>& c, int m, i
 #pragma unroll
     for (int r = 0; r < W; ++r)
       ax[r] = ep.aux_mode == MG_AUX_RELU_GATE ? (a[r] > 0.f ? 1.f : 0.f)
-            : ep.aux_mode == MG_AUX_GELU_GRAD ? gelu_new_grad_f(a[r]) : a[r];
+            : ep.aux_mode == MG_AUX_GELU_GRAD ? gelu_new_grad_f(a[r])
+            : ep.aux_mode == MG_AUX_QUICK_GELU_GRAD ? quick_gelu_grad_f(a[r]) : a[r];
     if (!ep.aux_after) {
 #pragma unroll
       for (int r = 0; r < W; ++r) o[r] *= ax[r];

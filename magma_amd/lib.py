@@ -16,7 +16,7 @@ LIB_PATH = _HERE / "libmagma_hip.so"
 MG_ACT_NONE, MG_ACT_RELU, MG_ACT_GELU_NEW, MG_ACT_QUICK_GELU = 0, 1, 2, 3
 MG_W_ROWMAJOR, MG_W_FRAGTILED = 0, 1
 MG_A_DENSE, MG_A_CONV3X3 = 0, 1
-MG_AUX_NONE, MG_AUX_RELU_GATE, MG_AUX_GELU_GRAD, MG_AUX_MUL = 0, 1, 2, 3
+MG_AUX_NONE, MG_AUX_RELU_GATE, MG_AUX_GELU_GRAD, MG_AUX_MUL, MG_AUX_QUICK_GELU_GRAD = 0, 1, 2, 3, 4
 
 
 class MagmaHipError(RuntimeError):
@@ -104,6 +104,7 @@ SYMBOLS = {
     "mg_patchify_bf16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mg_vit_embed_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "mg_attn_small_bf16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
+    "mg_attn_small_bwd_bf16": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "mg_avgpool2_nhwc_bf16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mg_stem_im2col_bf16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "mg_build_labels_i64": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i64, _vp]),

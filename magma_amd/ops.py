@@ -11,7 +11,7 @@ import torch
 
 from . import lib as L
 from .lib import (MG_A_CONV3X3, MG_A_DENSE, MG_ACT_GELU_NEW, MG_ACT_NONE, MG_ACT_QUICK_GELU, MG_ACT_RELU, MG_AUX_GELU_GRAD,
-                  MG_AUX_MUL, MG_AUX_NONE, MG_AUX_RELU_GATE, MG_W_FRAGTILED, MG_W_ROWMAJOR, Epilogue, GemmDesc,
+                  MG_AUX_MUL, MG_AUX_NONE, MG_AUX_QUICK_GELU_GRAD, MG_AUX_RELU_GATE, MG_W_FRAGTILED, MG_W_ROWMAJOR, Epilogue, GemmDesc,
                   SkinnyDesc, check)
 
 BF16 = torch.bfloat16
@@ -487,6 +487,16 @@ def attn_small(qkv: torch.Tensor, B: int, S: int, H: int) -> torch.Tensor:
     out = torch.empty(B * S, H * 64, dtype=BF16, device=qkv.device)
     check(L.load().mg_attn_small_bf16(qkv.data_ptr(), out.data_ptr(), B, S, H, _stream()), "mg_attn_small_bf16")
     return out
+
+
+def attn_small_bwd(qkv: torch.Tensor, d_out: torch.Tensor, B: int, S: int, H: int) -> torch.Tensor:
+    """Backward of attn_small: qkv [B*S, 3*H*64], d_out [B*S, H*64] -> d_qkv [B*S, 3*H*64] (S <= 64)."""
+    _need_gpu(qkv, d_out)
+    assert qkv.dtype == BF16 and qkv.is_contiguous() and qkv.shape == (B * S, 3 * H * 64)
+    assert d_out.dtype == BF16 and d_out.is_contiguous() and d_out.shape == (B * S, H * 64)
+    dqkv = torch.empty_like(qkv)
+    check(L.load().mg_attn_small_bwd_bf16(qkv.data_ptr(), d_out.data_ptr(), dqkv.data_ptr(), B, S, H, _stream()), "mg_attn_small_bwd_bf16")
+    return dqkv
 
 
 def avgpool2(x: torch.Tensor) -> torch.Tensor:

@@ -117,9 +117,6 @@ class MagmaEngine:
             raise NotImplementedError("freeze_lm: false (training the 6B GPT-J weights, ~100 GB of fp32 optimizer state) is not "
                                       "implemented: no LM weight gradients are computed on this path (SURVEY Q2: adapters, image "
                                       "encoder and prefix train)")
-        if getattr(model.image_prefix, "pooled", False):
-            raise NotImplementedError("training with a pooled image encoder (encoder_name 'clip' = ViT-B/32) is not implemented "
-                                      "(inference only)")
         self.betas, self.eps = betas, eps
         self.truncate = truncate or os.environ.get("MAGMA_TRUNCATE", "0") == "1"
         # BASELINE config[4]: the frozen-weight block GEMMs (qkv, out_proj, fc_in, fc_out; forward and dgrad) on the fp8
@@ -573,6 +570,8 @@ class MagmaEngine:
     # ---- image prefix + CLIP trunk -------------------------------------------------
     def _prefix_forward(self, images, dropout_mask):
         ip = self.module.image_prefix
+        if ip.pooled:
+            return self._pooled_prefix_forward(images, dropout_mask)
         feats, etape = self._encoder_forward(images)
         B, P, E = feats.shape
         proj = RawWeight(ip.proj.weight.data, bias=self.master_of(ip.proj.bias)) if self.is_trainable(ip.proj.weight) \
@@ -594,6 +593,8 @@ class MagmaEngine:
 
     def _prefix_backward(self, pt, d_prefix):
         ip = self.module.image_prefix
+        if ip.pooled:
+            return self._pooled_prefix_backward(pt, d_prefix)
         B, P = pt["B"], pt["P"]
         g = d_prefix.reshape(B * P, ip.out_dim)
         if ip.use_layernorm:
@@ -612,6 +613,130 @@ class MagmaEngine:
         d_feats = ops.gemm(g, _t(ip.proj.weight.data), aux=pt["feats"], aux_mode=ops.MG_AUX_RELU_GATE, layout="rm",
                            use_bias=False)
         self._encoder_backward(pt["enc"], d_feats)
+
+    # ---- pooled prefix over the CLIP ViT (encoder_name "clip"; reference image_prefix.py:60-72, 85-109) ------------
+    def _lin(self, weight, bias):
+        """GEMM operand on a live [N, K] parameter (fp32 master bias), or the frozen tensors when it is not trained."""
+        if self.is_trainable(weight):
+            return RawWeight(weight.data, bias=None if bias is None else self.master_of(bias))
+        return RawWeight(weight.data, bias=None if bias is None else bias.detach().float().contiguous())
+
+    def _vec(self, p):
+        return self.master_of(p) if self.is_trainable(p) else p.detach().float().contiguous()
+
+    def _ln_bwd(self, ln, dy, x, res=None):
+        """LayerNorm backward with its parameter gradients: returns dL/dx (+ res)."""
+        if self.is_trainable(ln.weight):
+            dx, xhat = ops.layernorm_bwd(dy, x, self._vec(ln.weight), ln.eps, res=res, want_xhat=True)
+            ops.colsum(dy, self.grad_of(ln.weight), xhat)
+            ops.colsum(dy, self.grad_of(ln.bias))
+            return dx
+        return ops.layernorm_bwd(dy, x, self._vec(ln.weight), ln.eps, res=res)
+
+    def _lin_bwd(self, weight, bias, g, x_in, want_dx=True, **kw):
+        """y = x_in W^T + b: accumulates dW, db and returns dL/dx_in = g W (epilogue options in kw)."""
+        if self.is_trainable(weight):
+            if bias is not None:
+                ops.colsum(g, self.grad_of(bias))
+            self._acc_wgrad(weight, _t(g), _t(x_in))
+        if not want_dx:
+            return None
+        return ops.gemm(g, _t(weight.data.view(weight.shape[0], -1)), layout="rm", use_bias=False, **kw)
+
+    def _vit_forward(self, images):
+        """Taped forward of image_encoders.VisionTransformer.forward (same kernels, live parameters)."""
+        enc = self.module.image_prefix.enc
+        if not any(self.is_trainable(p) for p in enc.parameters()):
+            return enc(images), None
+        Pz, w, Hh = enc.patch_size, enc.width, enc.heads
+        x = images.to(BF16).contiguous()
+        B = x.shape[0]
+        patches = ops.patchify(x, Pz)                                           # [B*G, 3*P*P]
+        pe = ops.gemm(patches, RawWeight(enc.conv1.weight.data.view(w, -1)), layout="rm", use_bias=False)
+        emb = ops.vit_embed(pe, enc.class_embedding.data, enc.positional_embedding.data, B)
+        S = emb.shape[1]
+        emb = emb.view(B * S, w)
+        t = ops.layernorm(emb, self._vec(enc.ln_pre.weight), self._vec(enc.ln_pre.bias), enc.ln_pre.eps)
+        blocks = []
+        for blk in enc.transformer.resblocks:
+            h1 = ops.layernorm(t, self._vec(blk.ln_1.weight), self._vec(blk.ln_1.bias), blk.ln_1.eps)
+            qkv = ops.gemm(h1, self._lin(blk.attn.in_proj_weight, blk.attn.in_proj_bias), layout="rm")
+            ctx = ops.attn_small(qkv, B, S, Hh)
+            tm = ops.gemm(ctx, self._lin(blk.attn.out_proj.weight, blk.attn.out_proj.bias), residuals=(t,), layout="rm")
+            h2 = ops.layernorm(tm, self._vec(blk.ln_2.weight), self._vec(blk.ln_2.bias), blk.ln_2.eps)
+            fpre = torch.empty(B * S, 4 * w, dtype=BF16, device=self.device)
+            f = ops.gemm(h2, self._lin(blk.mlp.c_fc.weight, blk.mlp.c_fc.bias), act=ops.MG_ACT_QUICK_GELU, out2=fpre, layout="rm")
+            tn = ops.gemm(f, self._lin(blk.mlp.c_proj.weight, blk.mlp.c_proj.bias), residuals=(tm,), layout="rm")
+            blocks.append({"t": t, "h1": h1, "qkv": qkv, "ctx": ctx, "tm": tm, "h2": h2, "fpre": fpre, "f": f})
+            t = tn
+        cls = t.view(B, S, w)[:, 0, :].contiguous()
+        cln = ops.layernorm(cls, self._vec(enc.ln_post.weight), self._vec(enc.ln_post.bias), enc.ln_post.eps)
+        out = ops.gemm(cln, RawWeight(ops.transpose(enc.proj.data)), layout="rm", use_bias=False)     # (B, out_dim)
+        return out, {"patches": patches, "emb": emb, "blocks": blocks, "cls": cls, "cln": cln, "B": B, "S": S}
+
+    def _vit_backward(self, vt, d_out):
+        enc = self.module.image_prefix.enc
+        B, S, w, Hh = vt["B"], vt["S"], enc.width, enc.heads
+        # out = cln @ proj  (proj is stored [width, out_dim])
+        if self.is_trainable(enc.proj):
+            self._acc_wgrad(enc.proj, _t(vt["cln"]), _t(d_out))
+        d_cln = ops.gemm(d_out, RawWeight(enc.proj.data), layout="rm", use_bias=False)                # [B, width]
+        d_cls = self._ln_bwd(enc.ln_post, d_cln, vt["cls"])
+        g = torch.zeros(B, S, w, dtype=BF16, device=self.device)
+        g[:, 0, :] = d_cls
+        g = g.view(B * S, w)
+        for blk, sv in zip(reversed(list(enc.transformer.resblocks)), reversed(vt["blocks"])):
+            # tn = tm + c_proj(QuickGELU(c_fc(ln_2 tm)))
+            d_fpre = self._lin_bwd(blk.mlp.c_proj.weight, blk.mlp.c_proj.bias, g, sv["f"], aux=sv["fpre"],
+                                   aux_mode=ops.MG_AUX_QUICK_GELU_GRAD)
+            d_h2 = self._lin_bwd(blk.mlp.c_fc.weight, blk.mlp.c_fc.bias, d_fpre, sv["h2"])
+            gm = self._ln_bwd(blk.ln_2, d_h2, sv["tm"], res=g)
+            # tm = t + out_proj(attn(in_proj(ln_1 t)))
+            d_ctx = self._lin_bwd(blk.attn.out_proj.weight, blk.attn.out_proj.bias, gm, sv["ctx"])
+            d_qkv = ops.attn_small_bwd(sv["qkv"], d_ctx, B, S, Hh)
+            d_h1 = self._lin_bwd(blk.attn.in_proj_weight, blk.attn.in_proj_bias, d_qkv, sv["h1"])
+            g = self._ln_bwd(blk.ln_1, d_h1, sv["t"], res=gm)
+            self._reduce_params_async([p for p in blk.parameters() if self.is_trainable(p)])
+        d_emb = self._ln_bwd(enc.ln_pre, g, vt["emb"]).view(B, S, w)
+        if self.is_trainable(enc.positional_embedding):
+            self.grad_of(enc.positional_embedding).add_(d_emb.float().sum(0))
+        if self.is_trainable(enc.class_embedding):
+            self.grad_of(enc.class_embedding).add_(d_emb[:, 0, :].float().sum(0))
+        if self.is_trainable(enc.conv1.weight):
+            d_pe = d_emb[:, 1:, :].reshape(B * (S - 1), w).contiguous()
+            self._acc_wgrad(enc.conv1.weight, _t(d_pe), _t(vt["patches"]))
+        self._reduce_params_async([p for p in enc.parameters() if self.is_trainable(p)])
+
+    def _pooled_prefix_forward(self, images, dropout_mask):
+        ip = self.module.image_prefix
+        feats, vtape = self._vit_forward(images)                                 # (B, enc_dim)
+        B, s, d = feats.shape[0], ip.out_seq_len, ip.out_dim
+        y0 = ops.gemm(feats.contiguous(), self._lin(ip.proj.weight, ip.proj.bias), layout="rm").reshape(B * s, d)
+        mask = None
+        if ip.dropout.p > 0:
+            if dropout_mask is None:
+                keep = 1.0 - ip.dropout.p
+                dropout_mask = (torch.rand(B * s, d, device=self.device) < keep).to(BF16) / keep
+            mask = dropout_mask.reshape(B * s, d).to(BF16).contiguous()
+            y1 = ops.mul(y0.contiguous(), mask)
+        else:
+            y1 = y0.contiguous()
+        y2 = ops.layernorm(y1, self._vec(ip.ln.weight), self._vec(ip.ln.bias), ip.ln.eps) if ip.use_layernorm else y1
+        return y2.view(B, s, d), {"vit": vtape, "feats": feats, "mask": mask, "y1": y1, "B": B}
+
+    def _pooled_prefix_backward(self, pt, d_prefix):
+        ip = self.module.image_prefix
+        B, s, d = pt["B"], ip.out_seq_len, ip.out_dim
+        g = d_prefix.reshape(B * s, d).contiguous()
+        if ip.use_layernorm:
+            g = self._ln_bwd(ip.ln, g, pt["y1"])
+        if pt["mask"] is not None:
+            g = ops.mul(g, pt["mask"])
+        g = g.view(B, s * d)
+        d_feats = self._lin_bwd(ip.proj.weight, ip.proj.bias, g, pt["feats"], want_dx=pt["vit"] is not None)
+        self._reduce_params_async([p for n, p in ip.named_parameters() if not n.startswith("enc.")])
+        if pt["vit"] is not None:
+            self._vit_backward(pt["vit"], d_feats)
 
     # The trunk is executed unit by unit; a unit = conv (+ frozen-statistics BN) (+ ReLU).
     def _bn_vectors(self, bn):

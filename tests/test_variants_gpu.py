@@ -292,6 +292,107 @@ def test_clip_vit_encoder_and_pooled_prefix(dev, geom):
     assert rel(got2, ref2) <= 2 * eb2 + 5e-3, (rel(got2, ref2), eb2)
 
 
+def test_vit_pooled_prefix_train_gradients(dev):
+    """Training with encoder_name "clip" (CLIP ViT-B/32, all 12 blocks trainable) and the pooled image prefix: loss and the
+    gradient of every trainable tensor -- patch conv, class / positional embedding, every LayerNorm, in_proj / out_proj /
+    MLP weights and biases, the 512-d projection, prefix Linear + LayerNorm, LM adapters -- against autograd through the
+    fp32 oracle (vit_encoder_fwd pinned to HF CLIP, tests/test_oracle_vs_hf.py).  Tolerance as tests/test_train_gpu.py."""
+    from magma_amd.config import MultimodalConfig
+    from magma_amd.language_model import GPTJConfig
+    from magma_amd.magma import Magma
+    from magma_amd.train_engine import MagmaEngine
+    from oracle.model import (OracleConfig, ViTConfig, build_labels, init_params, init_vit_params, lm_forward,
+                              pooled_prefix_fwd, vit_encoder_fwd)
+    import torch.nn.functional as F
+    s_img, d = 4, 512
+    mcfg = MultimodalConfig(batch_size=2, train_steps=1, encoder_name="clip", image_seq_len=s_img, image_size=224,
+                            freeze_img_encoder=False, use_image_embed_layernorm=True, image_embed_dropout_prob=0.1,
+                            adapter_config={"mlp": {"adapter_type": "normal", "downsample_factor": 4}},
+                            image_enc_lr=2.0e-6, lr_decay_iters=1000)
+    lm_cfg = GPTJConfig(vocab_size=1056, hidden_size=d, num_layers=2, num_heads=2, rotary_dim=64, intermediate_size=2048,
+                        max_position_embeddings=128)
+    model = Magma(mcfg, device=dev, lm_config=lm_cfg)
+    cfg = OracleConfig.tiny(n_positions=128)
+    v = ViTConfig()
+    params = {k: t for k, t in init_params(cfg, seed=31).items() if not k.startswith("image_prefix.")}
+    for k in params:
+        if ".adapter." in k:
+            params[k] = params[k] * 20
+    params.update(init_vit_params(v, seed=5))
+    g = torch.Generator().manual_seed(9)
+    params["image_prefix.proj.weight"] = torch.randn(s_img * d, v.out_dim, generator=g) * v.out_dim ** -0.5
+    params["image_prefix.proj.bias"] = torch.randn(s_img * d, generator=g) * 0.02
+    params["image_prefix.ln.weight"] = 1.0 + torch.randn(d, generator=g) * 0.05
+    params["image_prefix.ln.bias"] = torch.randn(d, generator=g) * 0.02
+    missing, unexpected = model.load_checkpoint_state(params)
+    assert not unexpected and not missing, (missing, unexpected)
+    model.config.gradient_accumulation_steps = 1
+    eng = MagmaEngine(model)
+    eng.train()
+    B, S = 2, model.seq_len
+    images = torch.randn(B, 3, 224, 224, generator=g).to(torch.bfloat16).float()
+    caps = torch.full((B, S), cfg.eos_token, dtype=torch.int64)
+    caps[0, :23] = torch.randint(0, 1000, (23,), generator=g)
+    caps[1, :11] = torch.randint(0, 1000, (11,), generator=g)
+    mask = (torch.rand(B, s_img, d, generator=g) < 0.9).float() / 0.9
+    names = [k for k in params if ".adapter." in k or k.startswith("image_prefix.")]
+
+    def oracle(dtype):
+        p = {k: (t.detach().to(dtype).clone() if t.is_floating_point() else t) for k, t in params.items()}
+        for k in names:
+            p[k].requires_grad_(True)
+        prefix = pooled_prefix_fwd(p, d, s_img, vit_encoder_fwd(p, v, images.to(dtype)), dropout_mask=mask.to(dtype))
+        labels = build_labels(s_img, caps, cfg.eos_token)
+        words = F.embedding(caps, p["lm.transformer.wte.weight"]).to(prefix.dtype)
+        out = lm_forward(p, cfg, inputs_embeds=torch.cat((prefix, words[:, : S - s_img, :]), dim=1), labels=labels)
+        out["loss"].backward()
+        return float(out["loss"].detach()), {k: p[k].grad.float() for k in names}
+
+    loss_ref, g_ref = oracle(torch.float32)
+    loss_bf, g_bf = oracle(torch.bfloat16)
+    out = eng(images.to(dev), caps.to(dev), dropout_mask=mask.to(dev))
+    assert abs(float(out.loss) - loss_ref) <= 2 * abs(loss_bf - loss_ref) + 3e-3 * abs(loss_ref), (float(out.loss), loss_ref, loss_bf)
+    eng.backward(out.loss)
+    name_of = {id(p): n for n, p in model.named_parameters()}
+    seen, bad = set(), []
+    dots = n1 = n2 = bd = b1 = 0.0
+    for grp in eng.groups:
+        for p in grp.params:
+            n = name_of[id(p)]
+            n = "lm." + n if n.startswith("transformer.") else n
+            if n in seen or n not in g_ref:
+                continue
+            seen.add(n)
+            got, ref, gb = eng.grad_of(p).float().cpu().reshape(-1), g_ref[n].reshape(-1), g_bf[n].reshape(-1)
+            e_hip, e_bf = rel(got, ref), rel(gb, ref)
+            if e_hip > 2 * e_bf + 3e-2:
+                bad.append((n, e_hip, e_bf))
+            dots += float((got * ref).sum()); n1 += float((got * got).sum()); n2 += float((ref * ref).sum())
+            bd += float((gb * ref).sum()); b1 += float((gb * gb).sum())
+    assert len(seen) == len(g_ref) and len(seen) > 150, (len(seen), len(g_ref), sorted(set(g_ref) - seen)[:5])
+    assert not bad, bad[:8]
+    cos_hip, cos_bf = dots / (n1 ** 0.5 * n2 ** 0.5), bd / (b1 ** 0.5 * n2 ** 0.5)
+    assert 1 - cos_hip <= 2 * (1 - cos_bf) + 1e-3, (cos_hip, cos_bf)
+    eng.step()
+    eng.eval()
+    assert torch.isfinite(eng(images.to(dev), caps.to(dev)).loss)
+
+
+def test_attn_small_backward(dev):
+    """mg_attn_small_bwd_bf16 against autograd through fp32 softmax attention (non-causal, head dim 64)."""
+    from magma_amd import ops
+    for (B, S, H) in [(2, 50, 12), (1, 7, 2), (3, 64, 1)]:
+        g = torch.Generator(device=dev).manual_seed(S)
+        qkv = (torch.randn(B * S, 3 * H * 64, device=dev, generator=g) * 0.7).to(torch.bfloat16)
+        do = torch.randn(B * S, H * 64, device=dev, generator=g).to(torch.bfloat16)
+        x = qkv.float().requires_grad_(True)
+        q, k, vv = (u.reshape(B, S, H, 64).permute(0, 2, 1, 3) for u in x.chunk(3, dim=-1))
+        o = (torch.softmax(q @ k.transpose(-1, -2) / 8.0, -1) @ vv).permute(0, 2, 1, 3).reshape(B * S, H * 64)
+        o.backward(do.float())
+        got = ops.attn_small_bwd(qkv, do, B, S, H)
+        assert rel(got, x.grad) < 1e-2, (B, S, H, rel(got, x.grad))
+
+
 def test_magma_with_clip_vit_encoder(dev):
     """Magma built from a config that selects encoder_name "clip": embed() yields image_seq_len prefix tokens per image."""
     from magma_amd.config import MultimodalConfig
