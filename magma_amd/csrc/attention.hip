@@ -133,9 +133,10 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(
 
   const int kv_end = min(S, qt0 + 128);          // causal: keys <= last query of the block
   const int ntiles = (kv_end + 31) >> 5;
+  const uint32_t smem_u = lds_u32(smem);
   auto issue = [&](int t, int buf) {
     const int c0 = min(t, ntiles - 1) * 32;
-    char* st = smem + buf * FA_STAGE;
+    const uint32_t st = smem_u + (uint32_t)(buf * FA_STAGE);
     dma_rows(st, kbase, DH, c0, S, wave, lane);
     dma_cols(st + ROW_TILE, vbase, vt_ld, c0, wave, lane);
   };

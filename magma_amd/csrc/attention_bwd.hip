@@ -173,9 +173,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(
 
   const int kv_end = min(S, qt0 + 128);
   const int ntiles = (kv_end + 31) >> 5;
+  const uint32_t smem_u = lds_u32(smem);
   auto issue = [&](int t, int buf) {
     const int c0 = min(t, ntiles - 1) * 32;
-    char* st = smem + buf * DQ_STAGE;
+    const uint32_t st = smem_u + (uint32_t)(buf * DQ_STAGE);
     dma_rows(st, kb, DH, c0, S, wave, lane);
     dma_rows(st + ROW_TILE, vb, DH, c0, S, wave, lane);
     dma_cols(st + 2 * ROW_TILE, ktb, ld_t, c0, wave, lane);
@@ -300,13 +301,14 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_kernel(
 
   const int t_begin = k0 >> 5;                 // first query tile that can see key k0
   const int t_end = (S + 31) >> 5;
+  const uint32_t smem_u = lds_u32(smem);
   auto issue = [&](int t, int buf) {
     const int q0 = min(t, t_end - 1) * 32;
-    char* st = smem + buf * STAGE;
+    const uint32_t st = smem_u + (uint32_t)(buf * STAGE);
     dma_rows(st, qb, DH, q0, S, wave, lane);
     if constexpr (DK) dma_rows(st + ROW_TILE, dob, dmodel, q0, S, wave, lane);
     dma_cols(st + T_OFF, tb, ld_t, q0, wave, lane);
-    glds4a(ldb + (int64_t)min(q0 + (lane >> 1), S - 1) * 2 + (lane & 1), st + LD_OFF);   // every wave writes the same 256 B
+    glds4au(ldb + (int64_t)min(q0 + (lane >> 1), S - 1) * 2 + (lane & 1), st + LD_OFF);   // every wave writes the same 256 B
   };
 #pragma unroll
   for (int i = 0; i < NST - 1; ++i) issue(t_begin + i, i);

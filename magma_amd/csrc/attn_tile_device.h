@@ -41,6 +41,30 @@ MG_DEV void dma_cols(char* tile, const mg_bf16* base_t, int ld, int c0, int wave
   }
 }
 
+// the same two with the destination tile given as a 32-bit LDS address (see lds_u32)
+template <int NW = 8>
+MG_DEV void dma_rows(uint32_t tile, const mg_bf16* base, int64_t row_stride, int r0, int rmax, int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < 16 / NW; ++i) {
+    const int blk = wave * (16 / NW) + i;
+    const int row = blk * 2 + (lane >> 5);
+    const int c = (lane & 31) ^ row_swz(row);
+    glds16au(base + (int64_t)min(r0 + row, rmax - 1) * row_stride + c * 8, tile + blk * 1024);
+  }
+}
+template <int NW = 8>
+MG_DEV void dma_cols(uint32_t tile, const mg_bf16* base_t, int ld, int c0, int wave, int lane) {
+  (void)ld;
+  const mg_bf16* src = base_t + (int64_t)(c0 >> 5) * (DH * 32);
+#pragma unroll
+  for (int i = 0; i < 16 / NW; ++i) {
+    const int blk = wave * (16 / NW) + i;
+    const int row = blk * 16 + (lane >> 2);
+    const int c = (lane & 3) ^ t_swz(row);
+    glds16au(src + row * 32 + c * 8, tile + blk * 1024);
+  }
+}
+
 // fragment bursts: 8 x ds_read_b128 of one operand, and the 8 MFMAs of a 16x16 tile over d = 256
 #define MG_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #ifndef MG_ATTN_MFMA_PRIO

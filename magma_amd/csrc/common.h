@@ -82,6 +82,15 @@ MG_DEV void glds16s(const void* base_uniform, uint32_t byte_off, char* lds_wave_
                :: "v"(byte_off), "s"(base_uniform),
                   "s"(__builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(mg_lptr_t)lds_wave_base)) : "memory");
 }
+// the same with the LDS destination as a plain 32-bit LDS address (lds_u32 of the dynamic-LDS base, once per kernel, plus
+// integer offsets): a generic char* destination costs a 64-bit add and a null check (s_cmp_lg_u64 / s_cselect) per piece
+MG_DEV uint32_t lds_u32(const void* p) { return __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(mg_lptr_t)p); }
+MG_DEV void glds16au(const void* g, uint32_t lds_addr) {
+  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(g), "s"(lds_addr) : "memory");
+}
+MG_DEV void glds4au(const void* g, uint32_t lds_addr) {
+  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dword %0, off" :: "v"(g), "s"(lds_addr) : "memory");
+}
 MG_DEV void glds4a(const void* g, char* lds_wave_base) {
   asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dword %0, off"
                :: "v"(g), "s"(__builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(mg_lptr_t)lds_wave_base)) : "memory");
