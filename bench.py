@@ -453,11 +453,13 @@ def main():
             eng.decode_w8, eng.fp8_mode = False, None
             eng._cache_pool.clear()
     if rank == 0:
-        line = {"metric": "generate tokens/sec (MAGMA_v1, batch-8 images, 32 new tokens, greedy)",
+        cname = os.path.splitext(os.path.basename(str(args.config)))[0]
+        adapters = "MLP adapters" if cname == "MAGMA_v1" else ("attention + MLP adapters" if cname == "MAGMA_v2" else "adapters per config")
+        line = {"metric": f"generate tokens/sec ({cname}, batch-{B} images, {gen} new tokens, greedy)",
                 "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "bf16", "data": "synthetic",
-                "config": {"workload": f"MAGMA_v1 (CLIP RN50x16 + GPT-J-6B + MLP adapters) bf16 inference: batch {B} "
+                "config": {"workload": f"{cname} (CLIP RN50x16 + GPT-J-6B + {adapters}) bf16 inference: batch {B} "
                                        f"{args.res}x{args.res} images + {args.prompt}-token prompt -> {gen} greedy tokens",
                            "parallelism": f"replicas x{world}", "layers": model.lm.config.num_layers,
                            "prefill_len": int(toks.shape[1] - gen)},
