@@ -152,9 +152,13 @@ __global__ __launch_bounds__(256) void gemm128_kernel(const GemmParams p) {
     }
   }
 
+  // LDS-DMA from inline asm with 32-bit LDS destinations (common.h glds16au): hipcc then counts the waits of the fragment
+  // reads instead of draining them (lgkmcnt(0)) in front of every MFMA burst; the DMA itself is retired by hand
+  // (MG_WAIT_VM(0) in front of the barrier that publishes a stage).
+  const uint32_t smem_u = lds_u32(smem);
   auto stage = [&](int kt, int buf) {
-    char* abase = smem + buf * STAGE_BYTES;
-    char* bbase = abase + TILE_BYTES;
+    const uint32_t abase = smem_u + (uint32_t)(buf * STAGE_BYTES);
+    const uint32_t bbase = abase + TILE_BYTES;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const mg_bf16* src;
@@ -172,17 +176,17 @@ __global__ __launch_bounds__(256) void gemm128_kernel(const GemmParams p) {
         while (cc >= cpt) { cc -= cpt; ++tp; }
         cv_cc[j] = cc; cv_tap[j] = tp;
       }
-      glds16(src, abase + (wave * 32 + j * 8) * 128);
+      glds16au(src, abase + (wave * 32 + j * 8) * 128);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const mg_bf16* src;
       if (WLAYOUT == MG_W_ROWMAJOR) {
         src = (kt * BK + b_k[j] < p.K) ? b_src[j] + kt * BK : p.zero;
-        glds16(src, bbase + (wave * 32 + j * 8) * 128);
+        glds16au(src, bbase + (wave * 32 + j * 8) * 128);
       } else {
         src = b_src[j] + (int64_t)kt * 1024;   // 2 k-steps * 512 elements
-        glds16(src, bbase + (wave * 4 + j) * 1024);
+        glds16au(src, bbase + (wave * 4 + j) * 1024);
       }
     }
   };
@@ -208,7 +212,8 @@ __global__ __launch_bounds__(256) void gemm128_kernel(const GemmParams p) {
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   stage(kt0, 0);
-  __syncthreads();  // hipcc drains the LDS-DMA (vmcnt(0)) in front of the barrier
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
   int cur = 0;
   for (int kt = kt0; kt < kt1; ++kt) {
     if (kt + 1 < kt1) stage(kt + 1, cur ^ 1);
@@ -240,7 +245,8 @@ __global__ __launch_bounds__(256) void gemm128_kernel(const GemmParams p) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
       }
     }
-    __syncthreads();  // next tile landed (vmcnt(0)) + everyone done reading `cur`
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tile landed
+    __syncthreads();                                   // ... for everyone, and everyone is done reading `cur`
     cur ^= 1;
   }
 
