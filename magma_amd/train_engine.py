@@ -113,15 +113,17 @@ class MagmaEngine:
         self.config = config or model.config
         self.device = model.device
         torch.cuda.set_device(self.device)      # kernels launch on the current device (ops._need_gpu)
-        if not self.config.freeze_lm:
-            raise NotImplementedError("freeze_lm: false (training the 6B GPT-J weights, ~100 GB of fp32 optimizer state) is not "
-                                      "implemented: no LM weight gradients are computed on this path (SURVEY Q2: adapters, image "
-                                      "encoder and prefix train)")
+        # freeze_lm: false -- every GPT-J tensor trains as well (what the published reference in fact does: magma.py:93-96
+        # never sets requires_grad = False on the LM; the configs of this repo keep the paper's trainable set).
+        # fp32 master + Adam moments + gradient = 16 B per parameter: ~100 GB on top of the activations at full size.
+        self.lm_trainable = not self.config.freeze_lm
         self.betas, self.eps = betas, eps
         self.truncate = truncate or os.environ.get("MAGMA_TRUNCATE", "0") == "1"
         # BASELINE config[4]: the frozen-weight block GEMMs (qkv, out_proj, fc_in, fc_out; forward and dgrad) on the fp8
         # MFMA -- activations / gradients quantised per row to e4m3, weights per output channel.  Off by default.
         self.fp8 = os.environ.get("MAGMA_TRAIN_FP8", "0") == "1"
+        if self.fp8 and self.lm_trainable:
+            raise NotImplementedError("MAGMA_TRAIN_FP8 quantises the FROZEN block weights once; with freeze_lm: false they change every step")
         self._fp8_packs = {}
         self._bn_stats = {}
         # the reference's CLIP tower runs BatchNorm on its frozen statistics until the first eval phase and on
@@ -383,6 +385,8 @@ class MagmaEngine:
         emb = torch.empty(B, S, eng.d, dtype=BF16, device=dev)
         emb[:, :P] = prefix
         ops.embedding(captions[:, : S - P].contiguous(), eng.wte, emb, row_off=P)
+        if self.lm_trainable:
+            tape["caption_ids"] = captions
         loss = self._lm_forward(emb, labels[:, :S].contiguous(), tape)
         self._tape = tape
         return LMOutput(loss=loss, logits=None, labels=labels)
@@ -428,6 +432,8 @@ class MagmaEngine:
             hpre = torch.empty(M, ly.fc_in.N, dtype=BF16, device=dev)
             h = self._fgemm((li, "fc_in"), ln, ly.fc_in, lnq, act=ops.MG_ACT_GELU_NEW, out2=hpre)
             sv["hpre"] = hpre
+            if self.lm_trainable:
+                sv["h"] = h                    # operand of the fc_out weight gradient
             if ly.mlp_adapter is not None and ly.mlp_par is not None:
                 dn, up, sc = self._par_adapter_ops(blk.mlp)
                 m = self._fgemm((li, "fc_out"), h, ly.fc_out)
@@ -456,6 +462,8 @@ class MagmaEngine:
         _, head_t = self._lm_packs()
         loss, dlogits = ops.cross_entropy_fwd_bwd(logits[:, : eng.V], tgt, head_t.K)
         tape.update(xr=xr, dlogits=dlogits, M=M)
+        if self.lm_trainable:
+            tape["xl"] = xl
         return loss
 
     # ---- backward ----------------------------------------------------------------
@@ -467,6 +475,11 @@ class MagmaEngine:
         d_emb = self._lm_backward(tape)
         B, S, P = tape["B"], tape["S"], tape["P"]
         d_prefix = d_emb.view(B, S, -1)[:, :P].contiguous()
+        if self.lm_trainable:       # word embedding rows of the caption tokens (positions P .. S-1)
+            wte = self.module.lm.transformer.wte.weight
+            ids = tape["caption_ids"][:, : S - P].reshape(-1)
+            self.grad_of(wte).index_add_(0, ids, d_emb.view(B, S, -1)[:, P:].reshape(ids.shape[0], -1).float())
+            self._reduce_params_async([wte, *self.module.lm.transformer.ln_f.parameters(), *self.module.lm.lm_head.parameters()])
         self._prefix_backward(tape["prefix"], d_prefix)
         self._tape = None
         self.micro_steps += 1
@@ -526,8 +539,19 @@ class MagmaEngine:
         B, S, M = tape["B"], tape["S"], tape["M"]
         H, d = eng.H, eng.d
         # loss head: dlogits -> dxl -> ln_f backward -> scatter to the target rows
+        lm = self.module.lm
         dxl = ops.gemm(tape["dlogits"], head_t)
-        dxr = ops.layernorm_bwd(dxl, tape["xr"], eng.lnf_g, eng.eps)
+        if self.lm_trainable:
+            V = lm.lm_head.weight.shape[0]
+            dlT = ops.transpose(tape["dlogits"])                       # [Vp, R]
+            self._acc_wgrad(lm.lm_head.weight, RawWeight(dlT[:V]), _t(tape["xl"]))
+            if lm.lm_head.bias is not None:
+                cs = torch.zeros(tape["dlogits"].shape[1], dtype=F32, device=dev)
+                ops.colsum(tape["dlogits"], cs)
+                self.grad_of(lm.lm_head.bias).add_(cs[:V])
+            dxr = self._ln_bwd(lm.transformer.ln_f, dxl, tape["xr"])
+        else:
+            dxr = ops.layernorm_bwd(dxl, tape["xr"], eng.lnf_g, eng.eps)
         g = torch.zeros(M, d, dtype=BF16, device=dev)
         g.index_copy_(0, tape["rows"], dxr)
         for li in range(len(eng.layers) - 1, -1, -1):
@@ -547,6 +571,14 @@ class MagmaEngine:
                 dm = g
             dhpre = self._fgemm((li, "fc_out_t"), dm, pk["fc_out_t"], aux=sv["hpre"], aux_mode=ops.MG_AUX_GELU_GRAD)
             dln_mlp = self._fgemm((li, "fc_in_t"), dhpre, pk["fc_in_t"])
+            if self.lm_trainable:
+                a_mod, mlp_mod = ly._src
+                if ln is None:
+                    ln = ops.layernorm(sv["x"], ly.ln_g, ly.ln_b, eng.eps)
+                ops.colsum(dm, self.grad_of(mlp_mod.c_proj.bias))
+                self._acc_wgrad(mlp_mod.c_proj.weight, _t(dm), _t(sv["h"]))
+                ops.colsum(dhpre, self.grad_of(mlp_mod.c_fc.bias))
+                self._acc_wgrad(mlp_mod.c_fc.weight, _t(dhpre), _t(ln))
             del dhpre, dm
             # ---- attention branch ----
             if ly.attn_adapter is not None and ly.attn_par is not None:
@@ -562,7 +594,14 @@ class MagmaEngine:
             q, k, v = sv["q"], sv["k"], sv["v"]
             dqkv = ops.attn_bwd_merged(q, k, v, sv["qt"], sv["kt"], dctx, sv["ctx"], sv["lse"], B, H, S, eng.rot, eng.sin_t, eng.cos_t)
             dln = self._fgemm((li, "qkv_t"), dqkv, pk["qkv_t"], residuals=(dln_mlp, *extra))
-            g = ops.layernorm_bwd(dln, sv["x"], ly.ln_g, eng.eps, res=g)
+            if self.lm_trainable:
+                self._acc_wgrad(a_mod.out_proj.weight, _t(da), _t(sv["ctx"]))
+                dqkvT, lnT, dd = ops.transpose(dqkv), _t(ln), d
+                for i3, prj in enumerate((a_mod.q_proj, a_mod.k_proj, a_mod.v_proj)):
+                    self._acc_wgrad(prj.weight, RawWeight(dqkvT[i3 * dd:(i3 + 1) * dd]), lnT)
+                g = self._ln_bwd(blk.ln_1, dln, sv["x"], res=g)
+            else:
+                g = ops.layernorm_bwd(dln, sv["x"], ly.ln_g, eng.eps, res=g)
             tape["layers"][li] = None     # free this layer's activations
             self._reduce_params_async([p for p in blk.parameters() if p.requires_grad])
         return g
@@ -927,6 +966,10 @@ class MagmaEngine:
         self.lr_scheduler.step()
         self.module.image_prefix.invalidate_packed()
         self._adapters_dirty = True
+        if self.lm_trainable:       # the forward / dgrad operands are packed COPIES of the LM weights: rebuild them from the new values
+            self.module.lm.invalidate_packed()
+            self._lm_train_packs = None
+            self._adapters_dirty = False
 
     def grad_norm(self) -> float:
         return float(torch.sqrt(self._norm_sq)) / self.gas / self.world

@@ -110,6 +110,76 @@ def test_gradients_and_step(dev, variant):
     assert torch.isfinite(out2.loss)
 
 
+def test_freeze_lm_false_trains_every_gptj_tensor(dev):
+    """config.freeze_lm = false: gradients of EVERY tensor -- q/k/v/out projections, MLP weights and biases, ln_1, ln_f,
+    lm_head weight and bias, the word embedding, plus adapters / trunk / prefix -- against autograd through the fp32 oracle;
+    then an optimizer step after which the forward runs on the updated (re-packed) LM weights."""
+    from magma_amd.testing import build_reduced_magma
+    from magma_amd.train_engine import MagmaEngine
+    from oracle.model import OracleConfig, init_params, magma_forward
+    cfg = OracleConfig.tiny(n_positions=128)
+    params = init_params(cfg, seed=27)
+    for k in params:
+        if ".adapter." in k:
+            params[k] = params[k] * 20
+    model = build_reduced_magma(dev, n_positions=128)
+    model.load_checkpoint_state(params)
+    model.config.freeze_lm = False
+    for p in model.lm.parameters():
+        p.requires_grad = True
+    model.config.gradient_accumulation_steps = 1
+    eng = MagmaEngine(model)
+    eng.train()
+    g = torch.Generator().manual_seed(4)
+    B, S = 2, model.seq_len
+    images = torch.randn(B, 3, 64, 64, generator=g)
+    caps = torch.full((B, S), cfg.eos_token, dtype=torch.int64)
+    caps[0, :23] = torch.randint(0, 1000, (23,), generator=g)
+    caps[1, :11] = torch.randint(0, 1000, (11,), generator=g)
+    mask = (torch.rand(B, 4, cfg.d_model, generator=g) < 0.9).float() / 0.9
+
+    def oracle(dtype):
+        p = {k: (v.detach().to(dtype).clone() if v.is_floating_point() else v) for k, v in params.items()}
+        names = [k for k in p if p[k].is_floating_point() and "running_" not in k and "num_batches" not in k]
+        for k in names:
+            p[k].requires_grad_(True)
+        out = magma_forward(p, cfg, images.to(dtype), caps, dropout_mask=mask.to(dtype))
+        out["loss"].backward()
+        return float(out["loss"].detach()), {k: p[k].grad.float() for k in names if p[k].grad is not None}
+
+    loss_ref, g_ref = oracle(torch.float32)
+    loss_bf, g_bf = oracle(torch.bfloat16)
+    out = eng(images.to(dev), caps.to(dev), dropout_mask=mask.to(dev))
+    assert abs(float(out.loss) - loss_ref) <= 2 * abs(loss_bf - loss_ref) + 3e-3 * abs(loss_ref)
+    eng.backward(out.loss)
+    name_of = {id(p): n for n, p in model.named_parameters()}
+    seen, bad = set(), []
+    for grp in eng.groups:
+        for p in grp.params:
+            n = name_of[id(p)]
+            n = "lm." + n if n.startswith("transformer.") else ("lm.transformer.wte.weight" if n == "word_embedding.weight" else n)
+            if n in seen or n not in g_ref:
+                continue
+            seen.add(n)
+            e_hip, e_bf = rel(eng.grad_of(p), g_ref[n]), rel(g_bf[n], g_ref[n])
+            if e_hip > 2 * e_bf + 3e-2:
+                bad.append((n, e_hip, e_bf))
+    missing = set(g_ref) - seen
+    assert not missing, sorted(missing)[:10]
+    assert any("q_proj" in n for n in seen) and any("lm_head" in n for n in seen) and any("wte" in n for n in seen)
+    assert not bad, bad[:8]
+    qw = model.lm.transformer.h[0].attn.attention.q_proj.weight
+    before = eng.master_of(qw).clone()
+    eng.step()                                                                # WarmupDecayLR: lr(step 0) = warmup_min_lr = 0
+    out2 = eng(images.to(dev), caps.to(dev), dropout_mask=mask.to(dev))       # runs on the re-packed LM weights
+    assert torch.isfinite(out2.loss)
+    eng.backward(out2.loss)
+    eng.step()
+    assert float((eng.master_of(qw) - before).abs().max()) > 0                # the fp32 master of an LM weight moved
+    eng.eval()
+    assert torch.isfinite(eng(images.to(dev), caps.to(dev)).loss)
+
+
 def test_frozen_image_encoder(dev):
     """config.freeze_img_encoder = true (the reference's default, magma.py:98-100; the shipped YAMLs set false): the trunk
     runs the inference path, owns no optimizer state, and the adapter / prefix gradients equal those of the run that also
