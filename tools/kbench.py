@@ -150,6 +150,18 @@ def main():
                 ms = timeit(fn, 5)
                 r[name + "_ms"] = ms; r[name + "_tflops"] = fl / ms / 1e9
             emit(**r)
+    if which == "wgrad":   # adapter weight-gradient shapes of the training step: the contraction runs over M = B*S = 32768 rows
+        for (M, N, K) in [(4096, 1024, 32768), (1024, 4096, 32768)]:
+            a = torch.randn(M, K, device=dev).to(BF16)
+            w = ops.RawWeight((torch.randn(N, K, device=dev) * 0.05).to(BF16))
+            out = torch.empty(M, N, dtype=torch.float32, device=dev)
+            ref = None
+            for sk in (1, 0, 2, 4, 8):
+                ms = timeit(lambda i: ops.gemm(a, w, out=out, out_dtype=torch.float32, layout="rm", use_bias=False, split_k=sk), 10)
+                if ref is None:
+                    ref = out.clone()
+                emit(kind="wgrad", M=M, N=N, K=K, split_k=sk, ms=ms, tflops=2.0 * M * N * K / ms / 1e9,
+                     rel_vs_split1=float((out - ref).norm() / ref.norm()))
     if which == "prefill":   # M = 8 x 57 rows: weights rotate so they stream from HBM as in a real prefill
         for (N, K, tag) in [(12288, 4096, "qkv"), (16384, 4096, "fc_in"), (4096, 4096, "out_proj"),
                             (4096, 16384, "fc_out"), (1024, 4096, "adapter_dn"), (4096, 1024, "adapter_up")]:
