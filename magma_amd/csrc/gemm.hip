@@ -28,6 +28,7 @@
 // so consecutive lanes own consecutive columns.  The tile kernels park the accumulators in LDS
 // and run the epilogue row-wise with 16-byte accesses (gemm_device.h: epilogue_rows).
 #include "common.h"
+#include <type_traits>
 
 #include <algorithm>
 #include <string.h>
@@ -512,8 +513,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   // ---- epilogue: two passes of 128 tile rows (each wave's upper / lower 64) through LDS ----
   const bool wide = epilogue_wide_ok(p.ep);   // 16-byte accesses when every row start allows it
   __syncthreads();
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
+  // (a generic lambda called with two compile-time halves: a `for (h)` loop around this much code is not unrolled by
+  //  hipcc any more, and acc[h * 4 + i] with a run-time h puts the 128 accumulators in scratch)
+  auto pass = [&](auto hc) {
+    constexpr int h = decltype(hc)::value;
     if (h) __syncthreads();   // pass 0 has been read
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -525,7 +528,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
     if (!wide) epilogue_rows<256, EPI256_ROWB, 4, false>(p.ep, smem, 128, 8, wave, lane, mb, 128, n0, p.M, p.N, p.row_scale);
     else if (p.nt) epilogue_rows<256, EPI256_ROWB, 8, true>(p.ep, smem, 128, 8, wave, lane, mb, 128, n0, p.M, p.N, p.row_scale);
     else epilogue_rows<256, EPI256_ROWB, 8, false>(p.ep, smem, 128, 8, wave, lane, mb, 128, n0, p.M, p.N, p.row_scale);
-  }
+  };
+  pass(std::integral_constant<int, 0>{});
+  pass(std::integral_constant<int, 1>{});
 }
 
 template <int WAVES, int KC, int NT, bool W8 = false>

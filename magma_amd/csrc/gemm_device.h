@@ -112,10 +112,31 @@ MG_DEV void store_bf16_row(mg_bf16* p, const float* o) {
   }
 }
 
+// Residual / aux operands of one full row piece, loaded ahead of the arithmetic: epilogue_rows fetches them for several
+// rows before it stores anything (output and residual pointers may alias as far as the compiler knows, so a load written
+// after a store is never hoisted above it -- one row in flight, 2 TB/s on a three-residual epilogue).
+// (kept as raw bf16 words: W/2 registers per operand and row)
+template <int W> struct EpiPre { uint32_t aux[W / 2]; uint32_t res[3][W / 2]; };
+template <int W>
+MG_DEV void epi_raw_load(const mg_bf16* p, uint32_t (&w)[W / 2]) {
+  if constexpr (W == 8) { const u32x4 t = *(const u32x4*)p; w[0] = t[0]; w[1] = t[1]; w[2] = t[2]; w[3] = t[3]; }
+  else { const u32x2 t = *(const u32x2*)p; w[0] = t[0]; w[1] = t[1]; }
+}
+template <int W>
+MG_DEV void epilogue_prefetch(const mg_epilogue& ep, int m, int n, EpiPre<W>& p) {
+#pragma unroll
+  for (int r = 0; r < W / 2; ++r) { p.aux[r] = 0u; p.res[0][r] = 0u; p.res[1][r] = 0u; p.res[2][r] = 0u; }
+  if (ep.aux_mode != MG_AUX_NONE) epi_raw_load<W>(ep.aux + (int64_t)m * ep.ldaux + n, p.aux);
+  if (ep.res0) epi_raw_load<W>(ep.res0 + (int64_t)m * ep.ldr + n, p.res[0]);
+  if (ep.res1) epi_raw_load<W>(ep.res1 + (int64_t)m * ep.ldr + n, p.res[1]);
+  if (ep.res2) epi_raw_load<W>(ep.res2 + (int64_t)m * ep.ldr + n, p.res[2]);
+}
+
 // v[W] = accumulators of columns n .. n+W-1 of row m.  NT: non-temporal output stores (large outputs
 // that nobody re-reads soon: keeps the L2 for the operand panels and streams the tile out).
-template <int W, bool NT, bool COH = false>
-MG_DEV void epilogue_apply(const mg_epilogue& ep, const EpiColsW<W>& c, int m, int n, const float* v, int N) {
+template <int W, bool NT, bool COH, bool PRE>
+MG_DEV void epilogue_apply_impl(const mg_epilogue& ep, const EpiColsW<W>& c, int m, int n, const float* v, int N,
+                                const EpiPre<W>& pre) {
   const bool full = (n + W - 1 < N);
   float o[W];
 #pragma unroll
@@ -135,7 +156,10 @@ MG_DEV void epilogue_apply(const mg_epilogue& ep, const EpiColsW<W>& c, int m, i
     float a[W];
 #pragma unroll
     for (int r = 0; r < W; ++r) a[r] = 0.f;
-    if (full) load_bf16_row<W>(ap, a);
+    if constexpr (PRE) {
+#pragma unroll
+      for (int r = 0; r < W / 2; ++r) { a[2 * r] = bflo(pre.aux[r]); a[2 * r + 1] = bfhi(pre.aux[r]); }
+    } else if (full) load_bf16_row<W>(ap, a);
     else for (int r = 0; r < W; ++r) if (n + r < N) a[r] = bf2f(ap[r]);
 #pragma unroll
     for (int r = 0; r < W; ++r)
@@ -164,7 +188,10 @@ MG_DEV void epilogue_apply(const mg_epilogue& ep, const EpiColsW<W>& c, int m, i
   for (int t = 0; t < 3; ++t) {
     if (rs[t]) {
       const mg_bf16* rp = rs[t] + (int64_t)m * ep.ldr + n;
-      if (full) {
+      if constexpr (PRE) {
+#pragma unroll
+        for (int r = 0; r < W / 2; ++r) { o[2 * r] += bflo(pre.res[t][r]); o[2 * r + 1] += bfhi(pre.res[t][r]); }
+      } else if (full) {
         float a[W];
         load_bf16_row<W, COH>(rp, a);
 #pragma unroll
@@ -198,6 +225,12 @@ MG_DEV void epilogue_apply(const mg_epilogue& ep, const EpiColsW<W>& c, int m, i
   }
 }
 
+template <int W, bool NT, bool COH = false>
+MG_DEV void epilogue_apply(const mg_epilogue& ep, const EpiColsW<W>& c, int m, int n, const float* v, int N) {
+  const EpiPre<W> none{};
+  epilogue_apply_impl<W, NT, COH, false>(ep, c, m, n, v, N, none);
+}
+
 template <bool COH = false>
 MG_DEV void epilogue_store4(const mg_epilogue& ep, int m, int n, f32x4 v, int N) {
   if (n >= N) return;
@@ -229,21 +262,51 @@ MG_DEV void epilogue_rows(const mg_epilogue& ep, const char* lds, int rows, int 
   if (n >= N) return;
   EpiColsW<W> c;
   epilogue_cols<W>(ep, n, N, c);
+  auto acc_row = [&](int r, float (&v)[W], int m) {
+#pragma unroll
+    for (int g = 0; g < W; g += 4) {
+      const f32x4 t = *(const f32x4*)(lds + r * ROWB + (cl * W + g) * 4);
+      v[g] = t[0]; v[g + 1] = t[1]; v[g + 2] = t[2]; v[g + 3] = t[3];
+    }
+    if (row_scale) {   // fp8 operands: per-row activation scale (the per-column weight scale is ep.scale)
+      const float rs = row_scale[m];
+#pragma unroll
+      for (int g = 0; g < W; ++g) v[g] *= rs;
+    }
+  };
+  const int step = nwaves * RPI;
+  int r = wave * RPI + lane / LPR;
+  const bool extra = ep.aux_mode != MG_AUX_NONE || ep.res0 || ep.res1 || ep.res2;
+  if (extra && n + W - 1 < N) {
+    // rows in batches of 4: all aux / residual loads of the batch first, then the arithmetic and the stores
+    // (four named structs, not an array: an indexed array of them ends up in scratch)
+    auto row_m = [&](int rr) { return m_base + (rr >> 6) * hi_stride + (rr & 63); };
+    auto finish = [&](int rr, int m, const EpiPre<W>& pre) {
+      if (m < M) {
+        float v[W];
+        acc_row(rr, v, m);
+        epilogue_apply_impl<W, NT, false, true>(ep, c, m, n, v, N, pre);
+      }
+    };
+    for (; r + 3 * step < rows; r += 4 * step) {
+      const int m0 = row_m(r), m1 = row_m(r + step), m2 = row_m(r + 2 * step), m3 = row_m(r + 3 * step);
+      EpiPre<W> p0, p1, p2, p3;
+      epilogue_prefetch<W>(ep, min(m0, M - 1), n, p0);
+      epilogue_prefetch<W>(ep, min(m1, M - 1), n, p1);
+      epilogue_prefetch<W>(ep, min(m2, M - 1), n, p2);
+      epilogue_prefetch<W>(ep, min(m3, M - 1), n, p3);
+      finish(r, m0, p0);
+      finish(r + step, m1, p1);
+      finish(r + 2 * step, m2, p2);
+      finish(r + 3 * step, m3, p3);
+    }
+  }
 #pragma unroll 2
-  for (int r = wave * RPI + lane / LPR; r < rows; r += nwaves * RPI) {
+  for (; r < rows; r += step) {
     const int m = m_base + (r >> 6) * hi_stride + (r & 63);
     if (m < M) {
       float v[W];
-#pragma unroll
-      for (int g = 0; g < W; g += 4) {
-        const f32x4 t = *(const f32x4*)(lds + r * ROWB + (cl * W + g) * 4);
-        v[g] = t[0]; v[g + 1] = t[1]; v[g + 2] = t[2]; v[g + 3] = t[3];
-      }
-      if (row_scale) {   // fp8 operands: per-row activation scale (the per-column weight scale is ep.scale)
-        const float rs = row_scale[m];
-#pragma unroll
-        for (int g = 0; g < W; ++g) v[g] *= rs;
-      }
+      acc_row(r, v, m);
       epilogue_apply<W, NT>(ep, c, m, n, v, N);
     }
   }

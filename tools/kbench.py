@@ -150,6 +150,18 @@ def main():
                 ms = timeit(fn, 5)
                 r[name + "_ms"] = ms; r[name + "_tflops"] = fl / ms / 1e9
             emit(**r)
+    if which == "shortk":   # adapter up-projection (K = 1024) with three residual reads: epilogue-bound; 128x128 vs 256x256 kernel
+        M, N, K = 32768, 4096, 1024
+        a = torch.randn(M, K, device=dev).to(BF16)
+        w = ops.RawWeight((torch.randn(N, K, device=dev) * 0.05).to(BF16), bias=torch.randn(N, device=dev))
+        r1, r2, r3 = (torch.randn(M, N, device=dev).to(BF16) for _ in range(3))
+        out = torch.empty(M, N, dtype=BF16, device=dev)
+        for nres in (3, 1, 0):
+            for tile in (256, 128):
+                res = (r1, r2, r3)[:nres]
+                ms = timeit(lambda i: ops.gemm(a, w, out=out, layout="rm", residuals=res, tile=tile), 10)
+                emit(kind="shortk", M=M, N=N, K=K, residuals=nres, tile=tile, ms=ms, tflops=2.0 * M * N * K / ms / 1e9,
+                     gbps=(M * N * 2 * (1 + nres) + M * K * 2) / ms / 1e6)
     if which == "wgrad":   # adapter weight-gradient shapes of the training step: the contraction runs over M = B*S = 32768 rows
         for (M, N, K) in [(4096, 1024, 32768), (1024, 4096, 32768)]:
             a = torch.randn(M, K, device=dev).to(BF16)
