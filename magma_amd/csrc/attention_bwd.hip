@@ -45,35 +45,36 @@ struct GradOut {
   const float* cos_t;
   int which, rot_dim;
 };
-// acc[dt] = columns dt*16 + lq*4 .. +3 of row s (sequence position) of head (b, h)
+// acc[dt] = columns dt*16 + lq*4 .. +3 of row s (sequence position) of head (b, h).  A lane's 4 columns are 8 bytes; stored
+// like that the epilogue is 16 dwordx2 stores per lane and store-ISSUE-bound (MI355X_MICROARCH.md, attention epilogue store
+// tail).  v_permlane16_swap trades halves between the lane groups lq and lq^1 (same row): even groups end up with 8
+// consecutive columns of tile dt, odd groups with 8 of tile dt+1 -- 8 dwordx4 stores per lane instead.
 MG_DEV void store_grad_row(const GradOut& g, const f32x4 (&acc)[16], int b, int h, int H, int S, int s, int lq) {
-  if (!g.merged) {
-    mg_bf16* op = g.out + (((int64_t)b * H + h) * S + s) * DH + lq * 4;
-#pragma unroll
-    for (int dt = 0; dt < 16; ++dt) {
-      u32x2 w;
-      w[0] = pack2bf(acc[dt][0], acc[dt][1]);
-      w[1] = pack2bf(acc[dt][2], acc[dt][3]);
-      *(u32x2*)(op + dt * 16) = w;
-    }
-    return;
-  }
-  mg_bf16* op = g.merged + ((int64_t)b * S + s) * (3 * H * DH) + (int64_t)g.which * H * DH + h * DH + lq * 4;
+  uint32_t wlo[16], whi[16];
+  const bool rot = g.merged && g.which < 2;
   const int half_rot = g.rot_dim >> 1;
 #pragma unroll
   for (int dt = 0; dt < 16; ++dt) {
     float x0 = acc[dt][0], x1 = acc[dt][1], x2 = acc[dt][2], x3 = acc[dt][3];
-    if (g.which < 2 && dt * 16 + lq * 4 < g.rot_dim) {       // rot_dim % 8 == 0: a lane's 4 columns are inside or outside
+    if (rot && dt * 16 + lq * 4 < g.rot_dim) {       // rot_dim % 8 == 0: a lane's 4 columns are inside or outside
       const int pi = (int)((int64_t)s * half_rot) + dt * 8 + lq * 2;
       const float s0 = g.sin_t[pi], c0 = g.cos_t[pi], s1 = g.sin_t[pi + 1], c1 = g.cos_t[pi + 1];
       const float y0 = x0 * c0 + x1 * s0, y1 = x1 * c0 - x0 * s0;
       const float y2 = x2 * c1 + x3 * s1, y3 = x3 * c1 - x2 * s1;
       x0 = y0; x1 = y1; x2 = y2; x3 = y3;
     }
-    u32x2 w;
-    w[0] = pack2bf(x0, x1);
-    w[1] = pack2bf(x2, x3);
-    *(u32x2*)(op + dt * 16) = w;
+    wlo[dt] = pack2bf(x0, x1);
+    whi[dt] = pack2bf(x2, x3);
+  }
+  mg_bf16* row = g.merged ? g.merged + ((int64_t)b * S + s) * (3 * H * DH) + (int64_t)g.which * H * DH + h * DH
+                          : g.out + (((int64_t)b * H + h) * S + s) * DH;
+  const int odd = lq & 1;
+#pragma unroll
+  for (int dt = 0; dt < 16; dt += 2) {
+    const auto r0 = __builtin_amdgcn_permlane16_swap(wlo[dt], wlo[dt + 1], false, false);
+    const auto r1 = __builtin_amdgcn_permlane16_swap(whi[dt], whi[dt + 1], false, false);
+    const u32x4 w = {r0[0], r1[0], r0[1], r1[1]};
+    *(u32x4*)(row + (dt + odd) * 16 + (lq - odd) * 4) = w;
   }
 }
 
