@@ -267,7 +267,8 @@ int mg_advance_pos(int32_t* d_pos, int32_t delta, void* stream);
 
 /* K24 sampled (reference magma/sampling.py:99-107: top_k_filter :22-30, top_p_filter :7-19 -- the reference's own rule, SURVEY Q6 --
  * softmax(logits / temperature), multinomial) as one launch per token step, graph-capturable (csrc/sampling.hip).
- *   logits [B, V] fp32 (row stride ld); top_k == 0 / top_p == 0 disable the respective filter;
+ *   logits [B, V] fp32 (row stride ld); top_k == 0 / top_p == 0 disable the respective filter; top_p is a DOUBLE: the reference
+ *   compares fp32 probabilities with the Python scalar (1 - threshold), i.e. with fp32(double(1) - double(threshold));
  *   seed  device uint64 (read at run time: a new seed needs no re-capture), state device int32[2] = {step, first step at which
  *   every row produced eos (-1 until then)}: the random stream is Philox4x32-10 keyed by the seed at counter (step, row);
  *   token [B] int64 sampled ids (NULL: filter only); filtered [B, V] optional copy of the filtered logits (-inf where the
@@ -278,7 +279,7 @@ int mg_advance_pos(int32_t* d_pos, int32_t delta, void* stream);
  * history[b * ld_history + step] (NULL: off; the host copies the history once when generate() ends); `clear` (NULL: off) =
  * n_clear int32 at clear[i * clear_stride] set to zero for the next step (the sharded completion counters of
  * mg_decode_step_bf16: one word per 64-byte line).                                                                         */
-int mg_sample_f32(const float* logits, int64_t ld, int32_t B, int32_t V, float temperature, int32_t top_k, float top_p,
+int mg_sample_f32(const float* logits, int64_t ld, int32_t B, int32_t V, float temperature, int32_t top_k, double top_p,
                   const uint64_t* seed, const int32_t* state, int64_t* token, float* filtered, int64_t ld_filtered,
                   void* stream);
 int mg_sample_finish(const int64_t* token, int32_t B, int64_t eos, int32_t* state, int32_t* d_pos, int32_t delta,

@@ -81,7 +81,7 @@ MG_DEV void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
 
 struct SampleParams {
   const float* logits; int64_t ld; int V;
-  float temperature; int top_k; float top_p;
+  float temperature; int top_k; double top_p;
   const uint64_t* seed;       // device: 64-bit seed (may change between graph replays)
   const int32_t* state;       // device: [0] = step counter (read here, advanced by sample_finish_kernel)
   int64_t* out;               // [B] sampled token (nullptr: filter only)
@@ -152,8 +152,10 @@ __global__ __launch_bounds__(ST) void sample_kernel(const SampleParams p) {
   // ---------------- the reference's top-p rule ----------------
   uint32_t tstar = 0xffffffffu;    // dropped(i) = alive && i != imax && (key > tstar || (key == tstar && i < tie_cut))
   int tie_cut = 0;
-  const double bound = (double)(float)(1.0 - (double)p.top_p);      // tensor < python scalar compares in fp32
-  if (p.top_p > 0.f && bound > 0.0) {
+  // the reference compares an fp32 tensor with the PYTHON scalar (1 - threshold): the scalar is evaluated in double, then cast
+  // to fp32 for the comparison -- top_p arrives as a double so that exactly that value is formed (0.1f for 0.9, not 0.10000002f)
+  const double bound = (double)(float)(1.0 - p.top_p);
+  if (p.top_p > 0.0 && bound > 0.0) {
     float z = 0.f;
     for (int i = tid; i < V; i += ST) if (alive(i, fkey(x[i]))) z += __expf(x[i] - mx);
     z = blk_sum(z, shf);
@@ -276,7 +278,12 @@ __global__ __launch_bounds__(ST) void sample_kernel(const SampleParams p) {
 __global__ void sample_finish_kernel(const int64_t* __restrict__ tok, int B, int64_t eos, int32_t* __restrict__ state,
                                      int32_t* __restrict__ d_pos, int delta, int64_t* __restrict__ history, int64_t ld_hist,
                                      int hist_cols, int32_t* __restrict__ clear, int n_clear, int clear_stride) {
-  const int step = state[0];
+  // every thread needs the step BEFORE thread 0 bumps it: one read, broadcast through LDS (rows beyond the first wave would
+  // otherwise race with the increment below)
+  __shared__ int s_step;
+  if (threadIdx.x == 0) s_step = state[0];
+  __syncthreads();
+  const int step = s_step;
   for (int i = threadIdx.x; i < n_clear; i += blockDim.x) clear[(int64_t)i * clear_stride] = 0;
   if (history && step < hist_cols)
     for (int b = threadIdx.x; b < B; b += blockDim.x) history[(int64_t)b * ld_hist + step] = tok[b];
@@ -291,12 +298,12 @@ __global__ void sample_finish_kernel(const int64_t* __restrict__ tok, int B, int
 }  // namespace
 
 extern "C" int mg_sample_f32(const float* logits, int64_t ld, int32_t B, int32_t V, float temperature, int32_t top_k,
-                             float top_p, const uint64_t* seed, const int32_t* state, int64_t* token, float* filtered,
+                             double top_p, const uint64_t* seed, const int32_t* state, int64_t* token, float* filtered,
                              int64_t ld_filtered, void* stream) {
   if (B <= 0 || V <= 0 || !logits || ld < V) MG_FAIL(MG_ERR_SHAPE, "mg_sample_f32: bad logits / B / V / ld");
   if (!token && !filtered) MG_FAIL(MG_ERR_SHAPE, "mg_sample_f32: nothing to produce (token and filtered are both null)");
   if (token && (!state || !(temperature > 0.f))) MG_FAIL(MG_ERR_SHAPE, "mg_sample_f32: sampling needs temperature > 0 and a state buffer (greedy decoding is mg_argmax_f32)");
-  if (top_k < 0 || top_p < 0.f || top_p > 1.f) MG_FAIL(MG_ERR_SHAPE, "mg_sample_f32: need top_k >= 0 and 0 <= top_p <= 1");
+  if (top_k < 0 || top_p < 0.0 || top_p > 1.0) MG_FAIL(MG_ERR_SHAPE, "mg_sample_f32: need top_k >= 0 and 0 <= top_p <= 1");
   if (filtered && ld_filtered < V) MG_FAIL(MG_ERR_SHAPE, "mg_sample_f32: ld_filtered < V");
   SampleParams p{logits, ld, V, temperature, top_k, top_p, seed, state, token, filtered, ld_filtered};
   hipLaunchKernelGGL(sample_kernel, dim3(B), dim3(ST), 0, (hipStream_t)stream, p);

@@ -82,6 +82,42 @@ class SyntheticImgCptDataset(torch.utils.data.Dataset):
         return img, cap
 
 
+def load_img_cpt_datasets(dataset_dir, tokenizer, transforms, seq_len: int = 2048, synthetic=None):
+    """reference train.py:34-42 ``_load_img_cpt_datasets``: a list / tuple of directories -> ConcatDataset of their
+    datasets, a str -> ImgCptDataset (a missing directory RAISES -- a typo must not train on noise), anything else ->
+    TypeError.  The one extension: the literal string "synthetic" selects ``synthetic()`` (a callable returning a
+    SyntheticImgCptDataset), which is what the shipped placeholder configs name."""
+    if isinstance(dataset_dir, (list, tuple)):
+        return torch.utils.data.ConcatDataset(
+            [load_img_cpt_datasets(d, tokenizer, transforms, seq_len, synthetic) for d in dataset_dir])
+    if isinstance(dataset_dir, str):
+        if dataset_dir == "synthetic":
+            if synthetic is None:
+                raise ValueError("dataset 'synthetic' requested but no synthetic dataset factory was given")
+            return synthetic()
+        if not Path(dataset_dir).is_dir():
+            raise FileNotFoundError(f"dataset directory {dataset_dir!r} does not exist "
+                                    "(use the literal 'synthetic' for random image-caption pairs)")
+        return ImgCptDataset(dataset_dir, tokenizer, transforms, seq_len=seq_len)
+    raise TypeError("dataset dir wrong type")
+
+
+def get_pretraining_datasets(config, tokenizer, transforms, seq_len: int = 2048, synthetic_train=None, synthetic_eval=None,
+                             split_seed=None):
+    """reference train.py:45-66: the train set from ``config.train_dataset_dir`` (str or list); the eval set from
+    ``config.eval_dataset_dir``, or -- when that is None -- ``eval_dataset_pct`` of the train set split off at random."""
+    train = load_img_cpt_datasets(config.train_dataset_dir, tokenizer, transforms, seq_len, synthetic_train)
+    if config.eval_dataset_dir is None:
+        eval_len = int(len(train) * config.eval_dataset_pct)
+        train_len = len(train) - eval_len
+        print(f"Randomly splitting train_dataset into two datasets of length {train_len} and {eval_len}")
+        g = None if split_seed is None else torch.Generator().manual_seed(split_seed)   # the same split on every rank
+        train, evals = torch.utils.data.random_split(train, [train_len, eval_len], generator=g)
+    else:
+        evals = load_img_cpt_datasets(config.eval_dataset_dir, tokenizer, transforms, seq_len, synthetic_eval)
+    return train, evals
+
+
 def collate_fn(batch_data, seq_len=2048):
     images, captions = list(zip(*batch_data))
     return torch.cat(images), torch.cat([i[:, :seq_len] for i in captions])

@@ -95,7 +95,7 @@ SYMBOLS = {
     "mg_attn_decode_fused_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp]),
     "mg_argmax_f32": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp]),
     "mg_advance_pos": (C.c_int, [_vp, _i32, _vp]),
-    "mg_sample_f32": (C.c_int, [_vp, _i64, _i32, _i32, _f32, _i32, _f32, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "mg_sample_f32": (C.c_int, [_vp, _i64, _i32, _i32, _f32, _i32, C.c_double, _vp, _vp, _vp, _vp, _i64, _vp]),
     "mg_sample_finish": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _i32, _vp, _i64, _i32, _vp, _i32, _i32, _vp]),
     "mg_decode_plan_bytes": (C.c_int64, [_i32]),
     "mg_decode_counter_ints": (C.c_int32, [_i32]),

@@ -55,11 +55,33 @@ class FlatGroup:
         # re-point the module parameters at the flat bf16 buffer (zero-copy operands)
         for p, o in zip(params, self.offsets):
             p.data = self.model[o:o + p.numel()].view(p.shape)
+        self.index = {id(p): k for k, p in enumerate(params)}      # parameter -> slot, O(1) (was a list scan per lookup)
 
     def view(self, buf: torch.Tensor, p: torch.nn.Parameter) -> torch.Tensor:
-        i = next(k for k, q in enumerate(self.params) if q is p)
-        o = self.offsets[i]
+        o = self.offsets[self.index[id(p)]]
         return buf[o:o + p.numel()].view(p.shape)
+
+    def state_by_name(self, names: Dict[int, str]) -> dict:
+        """Optimizer state as UNPADDED per-parameter slices keyed by the parameter's state-dict name: the checkpoint does
+        not depend on the flat buffers' padding / ordering (which changed between rounds: 4 -> 8 element alignment)."""
+        out = {}
+        for p, o in zip(self.params, self.offsets):
+            n = p.numel()
+            out[names[id(p)]] = {"master": self.master[o:o + n].cpu().clone(), "m": self.m[o:o + n].cpu().clone(),
+                                 "v": self.v[o:o + n].cpu().clone()}
+        return out
+
+    def load_state_by_name(self, state: dict, names: Dict[int, str]) -> List[str]:
+        missing = []
+        for p, o in zip(self.params, self.offsets):
+            s = state.get(names[id(p)])
+            if s is None or s["master"].numel() != p.numel():
+                missing.append(names[id(p)])
+                continue
+            n = p.numel()
+            self.master[o:o + n].copy_(s["master"].reshape(-1)); self.m[o:o + n].copy_(s["m"].reshape(-1))
+            self.v[o:o + n].copy_(s["v"].reshape(-1))
+        return missing
 
 
 class LRScheduler:
@@ -196,7 +218,7 @@ class MagmaEngine:
                 continue
             gi, _ = self._where[id(p)]
             g = self.groups[gi]
-            i = next(k for k, q in enumerate(g.params) if q is p)
+            i = g.index[id(p)]
             lo = g.offsets[i]
             hi = g.offsets[i + 1] if i + 1 < len(g.offsets) else g.n
             a, b = spans.get(gi, (lo, hi))
@@ -985,6 +1007,9 @@ class MagmaEngine:
         return DataLoader(dataset, batch_size=bs, sampler=sampler, shuffle=False,
                           collate_fn=collate_fn or partial(default_collate, seq_len=self.module.seq_len))
 
+    def _param_names(self) -> Dict[int, str]:
+        return {id(p): n for n, p in self.module.named_parameters()}
+
     def save_checkpoint(self, save_dir, client_state=None, tag=None):
         """DeepSpeed layout: <dir>/<tag>/mp_rank_00_model_states.pt with {"module": state_dict, ...} + <dir>/latest."""
         tag = tag or f"global_step{self.global_steps}"
@@ -993,7 +1018,8 @@ class MagmaEngine:
             path = Path(save_dir) / tag
             path.mkdir(parents=True, exist_ok=True)
             sd = {"module": {k: v.detach().cpu() for k, v in self.module.state_dict().items()},
-                  "optimizer": [{"master": g.master.cpu(), "m": g.m.cpu(), "v": g.v.cpu()} for g in self.groups],
+                  "optimizer": {"format": "per_parameter_v1",
+                                "state": {k: v for g in self.groups for k, v in g.state_by_name(self._param_names()).items()}},
                   "lr_scheduler": self.lr_scheduler.state_dict(), "global_steps": self.global_steps,
                   "micro_steps": self.micro_steps}
             sd.update(client_state or {})
@@ -1018,8 +1044,20 @@ class MagmaEngine:
             for p, o in zip(g.params, g.offsets):
                 g.master[o:o + p.numel()].copy_(p.data.reshape(-1).float())
         if load_optimizer_states and "optimizer" in sd:
-            for g, s in zip(self.groups, sd["optimizer"]):
-                g.master.copy_(s["master"]); g.m.copy_(s["m"]); g.v.copy_(s["v"])
+            opt = sd["optimizer"]
+            if isinstance(opt, dict) and opt.get("format") == "per_parameter_v1":
+                names = self._param_names()
+                missing = [n for g in self.groups for n in g.load_state_by_name(opt["state"], names)]
+                if missing:
+                    raise RuntimeError(f"optimizer state of the checkpoint lacks / mismatches {len(missing)} trainable tensors "
+                                       f"(first: {missing[:3]}); pass load_optimizer_states=False to restart the optimizer")
+            else:      # rounds 1-2 wrote the padded flat buffers verbatim: usable only if the layout still matches
+                for g, s in zip(self.groups, opt):
+                    if s["master"].numel() != g.master.numel():
+                        raise RuntimeError("optimizer state in the legacy flat layout does not match this build's buffer "
+                                           "layout; pass load_optimizer_states=False to restart the optimizer")
+                    g.master.copy_(s["master"]); g.m.copy_(s["m"]); g.v.copy_(s["v"])
+            for g in self.groups:
                 g.model.copy_(g.master)
             self.global_steps = sd.get("global_steps", 0)
             self.micro_steps = sd.get("micro_steps", 0)

@@ -103,12 +103,17 @@ def clip_preprocess(n_px, use_pad=False, device=None):
     mean = torch.tensor(CLIP_MEAN).view(3, 1, 1)
     std = torch.tensor(CLIP_STD).view(3, 1, 1)
 
+    on_gpu = device is not None and torch.device(device).type == "cuda"
+
     def fn(image):
-        if device is not None and torch.device(device).type == "cuda" and image.mode == "RGB" and min(image.size) >= 2:
+        if on_gpu and image.mode == "RGB" and min(image.size) >= 2:
             return _device_pipeline(image, n_px, device)
         image = _center_crop(_resize_short_side(image, n_px), n_px).convert("RGB")
         t = torch.from_numpy(np.asarray(image, dtype=np.uint8).copy()).permute(2, 0, 1).float() / 255.0
-        return maybe_add_batch_dim((t - mean) / std)
+        out = maybe_add_batch_dim((t - mean) / std)
+        # one transform -> one device: grey / palette / alpha images take the PIL branch but must land where the RGB
+        # ones do, or collate_fn's torch.cat over a mixed batch raises (reference dataset.py:155-160)
+        return out.to(device) if on_gpu else out
 
     return fn
 

@@ -142,7 +142,7 @@ def bn_name_for(conv_name: str) -> str:
 
 
 def init_params(cfg: OracleConfig, seed: int = 0, dtype=torch.float32,
-                lm_std: float = 0.02, randomize_bn: bool = True) -> Params:
+                lm_std: float = 0.02, randomize_bn: bool = True, layer_seeds: bool = False) -> Params:
     """Seeded synthetic weights: N(0, lm_std) for LM/proj, Kaiming for
     convs, adapters per reference magma/adapters.py:28-33 (N(0,1e-3) clamped to
     +-2e-3).  BatchNorm statistics are randomised (not the identity) so that
@@ -159,8 +159,7 @@ def init_params(cfg: OracleConfig, seed: int = 0, dtype=torch.float32,
             p[f"{prefix}{idx}.weight"] = normal(o, i_, std=1e-3).clamp_(-2e-3, 2e-3)
             p[f"{prefix}{idx}.bias"] = normal(o, std=1e-3).clamp_(-2e-3, 2e-3)
 
-    p["lm.transformer.wte.weight"] = normal(cfg.vocab_in, d, std=lm_std)
-    for i in range(cfg.n_layer):
+    def block(i, normal, adapter):
         h = f"lm.transformer.h.{i}."
         p[h + "ln_1.weight"] = 1.0 + normal(d, std=0.05)
         p[h + "ln_1.bias"] = normal(d, std=0.02)
@@ -180,6 +179,31 @@ def init_params(cfg: OracleConfig, seed: int = 0, dtype=torch.float32,
             adapter(h + "attn.adapter.", cfg.attn_adapter_hidden)
             if cfg.attn_adapter_type == "scaled_parallel":
                 p[h + "attn.adapter_scale"] = 1.0 + normal(1, std=0.3)
+
+    p["lm.transformer.wte.weight"] = normal(cfg.vocab_in, d, std=lm_std)
+    if layer_seeds:
+        # full-depth fixtures (28 x 0.2 B values): one generator per block, blocks drawn concurrently (torch.randn is
+        # single-threaded per call and releases the GIL) -- a different stream than the sequential default, which the
+        # margin-searched fixtures of tests/fullwidth_common.py depend on and which therefore stays as it was
+        from concurrent.futures import ThreadPoolExecutor
+
+        def one(i):
+            gi = torch.Generator().manual_seed(seed * 1000003 + 7919 * (i + 1))
+
+            def normal_i(*shape, std):
+                return torch.randn(*shape, generator=gi, dtype=torch.float32) * std
+
+            def adapter_i(prefix, hidden):
+                for idx, (o, i_) in (("0", (hidden, d)), ("2", (d, hidden))):
+                    p[f"{prefix}{idx}.weight"] = normal_i(o, i_, std=1e-3).clamp_(-2e-3, 2e-3)
+                    p[f"{prefix}{idx}.bias"] = normal_i(o, std=1e-3).clamp_(-2e-3, 2e-3)
+            block(i, normal_i, adapter_i)
+
+        with ThreadPoolExecutor(max_workers=min(16, max(1, cfg.n_layer))) as ex:
+            list(ex.map(one, range(cfg.n_layer)))
+    else:
+        for i in range(cfg.n_layer):
+            block(i, normal, adapter)
     p["lm.transformer.ln_f.weight"] = 1.0 + normal(d, std=0.05)
     p["lm.transformer.ln_f.bias"] = normal(d, std=0.02)
     p["lm.lm_head.weight"] = normal(cfg.vocab_out, d, std=lm_std)

@@ -34,6 +34,17 @@ def full_width_params(cfg, seed: int = WEIGHT_SEED, adapter_gain: float = 20.0):
     return p
 
 
+def full_depth_params(cfg, seed: int = WEIGHT_SEED, adapter_gain: float = 20.0):
+    """Weights of the full-DEPTH fixtures (28 blocks = 5.9 B values): as full_width_params but one random stream per
+    block, drawn concurrently (oracle.model.init_params(layer_seeds=True): ~20 s instead of ~140 s)."""
+    from oracle.model import init_params
+    p = init_params(cfg, seed=seed, layer_seeds=True)
+    for k in p:
+        if ".adapter." in k:
+            p[k] = p[k] * adapter_gain
+    return p
+
+
 def lm_only(params):
     return {k: v for k, v in params.items() if k.startswith("lm.")}
 
@@ -57,3 +68,6 @@ def oracle_greedy_margins(params, cfg, emb, steps: int):
 
 
 GREEDY_INPUT_SEED = 1692
+# tests/test_fulldepth_gpu.py: 28 blocks, free-running greedy for FULLDEPTH_STEPS steps (tools/find_margin_seed.py ... 28 8)
+FULLDEPTH_STEPS = 8
+FULLDEPTH_INPUT_SEED = 3

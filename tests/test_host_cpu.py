@@ -180,6 +180,75 @@ def test_img_cpt_dataset_reads_the_reference_layout(tmp_path):
     assert images.shape == (3, 3, 32, 32) and caps.shape == (3, 64)
 
 
+def _write_dataset(root, n, modes=("RGB",)):
+    import json
+    import numpy as np
+    import PIL.Image as I
+    (root / "image_data" / "00000").mkdir(parents=True)
+    (root / "images" / "00000").mkdir(parents=True)
+    rng = np.random.RandomState(0)
+    for i in range(n):
+        mode = modes[i % len(modes)]
+        arr = (rng.rand(40 + i, 56) * 255).astype("uint8") if mode == "L" else (rng.rand(40 + i, 56, 3) * 255).astype("uint8")
+        I.fromarray(arr).save(root / "images" / "00000" / f"{i}.png")
+        rec = {"captions": [f"caption {i}"], "image_path": f"images/00000/{i}.png"}
+        (root / "image_data" / "00000" / f"{i}.json").write_text(json.dumps(rec))
+
+
+def test_mixed_mode_images_collate(tmp_path):
+    """A greyscale image next to an RGB one (common in COCO / CC3M) through the dataset + collate_fn: both branches of
+    the transform must land on one device and in one shape (reference transforms.py:121-134 converts AFTER the resize)."""
+    from magma_amd.datasets import ImgCptDataset, collate_fn
+    from magma_amd.tokenizer import ByteTokenizer
+    from magma_amd.transforms import clip_preprocess
+    _write_dataset(tmp_path, 4, modes=("RGB", "L"))
+    ds = ImgCptDataset(tmp_path, ByteTokenizer(32), clip_preprocess(24), seq_len=32)
+    items = [ds[i] for i in range(4)]
+    assert len({it[0].device for it in items}) == 1
+    images, caps = collate_fn(items, seq_len=32)
+    assert images.shape == (4, 3, 24, 24) and caps.shape == (4, 32)
+    grey = items[1][0]          # a grey image: the three normalised channels are the same pixel values
+    from magma_amd.transforms import CLIP_MEAN, CLIP_STD
+    back = [grey[0, c] * CLIP_STD[c] + CLIP_MEAN[c] for c in range(3)]
+    assert torch.allclose(back[0], back[1], atol=1e-6) and torch.allclose(back[1], back[2], atol=1e-6)
+
+
+def test_pretraining_datasets_follow_the_reference_rules(tmp_path):
+    """reference train.py:34-66: list -> ConcatDataset, eval_dataset_dir None -> eval_dataset_pct split of the train set,
+    wrong type -> TypeError; a missing directory raises instead of silently training on noise; only the literal
+    'synthetic' selects synthetic data."""
+    from types import SimpleNamespace
+    from magma_amd.datasets import SyntheticImgCptDataset, get_pretraining_datasets, load_img_cpt_datasets
+    from magma_amd.tokenizer import ByteTokenizer
+    from magma_amd.transforms import clip_preprocess
+    a, b = tmp_path / "a", tmp_path / "b"
+    a.mkdir(), b.mkdir()
+    _write_dataset(a, 6)
+    _write_dataset(b, 4)
+    tok, tf = ByteTokenizer(32), clip_preprocess(16)
+    cfg = SimpleNamespace(train_dataset_dir=[str(a), str(b)], eval_dataset_dir=None, eval_dataset_pct=0.2)
+    train, evals = get_pretraining_datasets(cfg, tok, tf, seq_len=32, split_seed=0)
+    assert len(train) == 8 and len(evals) == 2
+    t2, e2 = get_pretraining_datasets(cfg, tok, tf, seq_len=32, split_seed=0)
+    assert list(evals.indices) == list(e2.indices)                         # same split on every rank
+    assert isinstance(train.dataset, torch.utils.data.ConcatDataset)
+    assert train[0][0].shape == (1, 3, 16, 16)
+    cfg = SimpleNamespace(train_dataset_dir=str(a), eval_dataset_dir=str(b), eval_dataset_pct=0.1)
+    train, evals = get_pretraining_datasets(cfg, tok, tf, seq_len=32)
+    assert len(train) == 6 and len(evals) == 4
+    with pytest.raises(FileNotFoundError):
+        load_img_cpt_datasets(str(tmp_path / "typo"), tok, tf)
+    with pytest.raises(TypeError):
+        load_img_cpt_datasets(3, tok, tf)
+    with pytest.raises(ValueError):
+        load_img_cpt_datasets("synthetic", tok, tf)
+    syn = load_img_cpt_datasets("synthetic", tok, tf, synthetic=lambda: SyntheticImgCptDataset(5, 16, 32))
+    assert len(syn) == 5
+    cfg = SimpleNamespace(train_dataset_dir="synthetic", eval_dataset_dir=None, eval_dataset_pct=0.1)
+    train, evals = get_pretraining_datasets(cfg, tok, tf, 32, synthetic_train=lambda: SyntheticImgCptDataset(50, 16, 32))
+    assert len(train) == 45 and len(evals) == 5
+
+
 def test_workspace_query_is_consistent_with_the_split_policy():
     """mg_gemm_workspace_bytes (callers own all memory): 0 for shapes that fill the chip, else splits x M x
     ceil(N/128)*128 fp32 -- pure host arithmetic, callable without a GPU."""

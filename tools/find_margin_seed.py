@@ -18,9 +18,13 @@ if __name__ == "__main__":
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 400
     if len(sys.argv) > 3:
         F.SEARCH_MARGIN = float(sys.argv[3])
-    cfg = F.full_width_config()
+    # optional: depth and step count (tests/test_fulldepth_gpu.py: 28 layers, FULLDEPTH_STEPS steps)
+    n_layer = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+    if len(sys.argv) > 5:
+        F.GREEDY_STEPS = int(sys.argv[5])
+    cfg = F.full_width_config(n_layer=n_layer)
     t0 = time.time()
-    params = F.lm_only(F.full_width_params(cfg))
+    params = F.lm_only(F.full_width_params(cfg) if n_layer == 1 else F.full_depth_params(cfg))
     print(f"weights in {time.time()-t0:.0f} s", flush=True)
     best = (-1, -1.0)
     with torch.no_grad():

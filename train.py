@@ -2,8 +2,9 @@
 """train.py -- entry point with the reference's CLI (reference train.py:72-193):
     python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 train.py --config configs/MAGMA_v1.yml
 (the reference used the `deepspeed` launcher; here one process per GPU, RCCL over xGMI).
-Dataset directories in the reference's image_data/*.json layout are read by magma_amd.datasets.ImgCptDataset;
-"synthetic" (or a missing directory) selects SyntheticImgCptDataset."""
+Dataset directories in the reference's image_data/*.json layout are read by magma_amd.datasets.ImgCptDataset (a list
+of directories -> ConcatDataset, eval_dataset_dir: null -> eval_dataset_pct of the train set, reference train.py:34-66);
+only the literal "synthetic" selects SyntheticImgCptDataset -- a missing directory raises."""
 import os
 import sys
 
@@ -11,7 +12,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from magma_amd import Magma  # noqa: E402
-from magma_amd.datasets import ImgCptDataset, SyntheticImgCptDataset  # noqa: E402
+from magma_amd.datasets import SyntheticImgCptDataset, get_pretraining_datasets  # noqa: E402
 from magma_amd.train_engine import initialize  # noqa: E402
 from magma_amd.train_loop import eval_step, inference_step, train_step  # noqa: E402
 from magma_amd.utils import (configure_param_groups, cycle, init_distributed, load_model, parse_args, print_main,  # noqa: E402
@@ -29,14 +30,13 @@ if __name__ == "__main__":
         config.deepspeed_config_params["gradient_accumulation_steps"] = args.grad_accum
     trainable_parameters = configure_param_groups(model, config)
 
-    def make_dataset(directory, n, seed):
-        if directory in (None, "synthetic") or not os.path.isdir(str(directory)):
-            return SyntheticImgCptDataset(n, image_size=config.image_size, seq_len=model.seq_len, eos=model.eos_token,
-                                          vocab=model.eos_token, seed=seed + 1000 * rank)
-        return ImgCptDataset(directory, tokenizer, transforms, seq_len=model.seq_len)   # reference train.py:43-60
+    def synthetic(n, seed):
+        return lambda: SyntheticImgCptDataset(n, image_size=config.image_size, seq_len=model.seq_len, eos=model.eos_token,
+                                              vocab=model.eos_token, seed=seed + 1000 * rank)
 
-    train_dataset = make_dataset(config.train_dataset_dir, 1 << 16, 1234)
-    eval_dataset = make_dataset(config.eval_dataset_dir, 1 << 10, 4321)
+    train_dataset, eval_dataset = get_pretraining_datasets(        # reference train.py:45-66
+        config, tokenizer, transforms, seq_len=model.seq_len, synthetic_train=synthetic(1 << 16, 1234),
+        synthetic_eval=synthetic(1 << 10, 4321), split_seed=0)
     print_main(f"Loaded train dataset with {len(train_dataset)} samples")
     print_main(f"Loaded eval dataset with {len(eval_dataset)} samples")
 
