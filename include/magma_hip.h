@@ -313,6 +313,25 @@ int mg_avgpool2_nhwc_bf16(const mg_bf16* x, mg_bf16* y, int32_t B, int32_t H, in
 int mg_stem_im2col_bf16(const mg_bf16* img_nchw, mg_bf16* out, int32_t B, int32_t H, int32_t W,
                         void* stream);
 
+/* NF-ResNet-50 image encoder (encoder_name "nfresnet50"; reference magma/image_encoders.py:31-45 = timm nf_resnet50 minus its
+ * classifier + AdaptiveAvgPool2d((1,1)), feeding the pooled ImagePrefix branch magma/image_prefix.py:17,67-72,96-101).  The
+ * convolutions are mg_gemm_bf16; these are the pieces around them (csrc/nfnet.hip):
+ *   weight_standardize  timm ScaledStdConv2d's weight transform: out[o, :] = (w[o, :] - mean_o) * rsqrt(var_o + eps) * gain[o] * scale
+ *                       (biased variance over the cin*kh*kw fan-in; scale = gamma * fan_in^-0.5 from the caller), w [cout, cin, kh, kw]
+ *                       bf16 -> out [cout, ldo] bf16 zero padded; to_khwc = 1 permutes the columns to (ky, kx, cin), the order of the
+ *                       implicit-im2col 3x3 A loader (MG_A_CONV3X3), 0 keeps (cin, ky, kx) (1x1 convs, mg_im2col_nchw_bf16).
+ *   im2col_nchw         img [B, C, H, W] bf16 -> rows [B*Ho*Wo, ldo], column (c*k + ky)*k + kx, zero padded (the 7x7 / stride-2 stem).
+ *   maxpool3x3s2        MaxPool2d(3, stride 2, padding 1) on NHWC: x [B,H,W,C] -> y [B,(H-1)/2+1,(W-1)/2+1,C].
+ *   subsample2          y[b,i,j,:] = x[b,2i,2j,:] (a stride-2, padding-1 3x3 conv = its stride-1 output at the even positions).
+ *   relu_mean_rows      y[b, c] = mean_p relu(x[b, p, c]), x [B, HW, C]: final_act + AdaptiveAvgPool2d((1,1)).                          */
+int mg_weight_standardize_bf16(const mg_bf16* w, const mg_bf16* gain, mg_bf16* out, int32_t cout, int32_t cin, int32_t kh,
+                               int32_t kw, int64_t ldo, int32_t to_khwc, float scale, float eps, void* stream);
+int mg_im2col_nchw_bf16(const mg_bf16* img, mg_bf16* out, int32_t B, int32_t C, int32_t H, int32_t W, int32_t k, int32_t stride,
+                        int32_t pad, int32_t ldo, void* stream);
+int mg_maxpool3x3s2_nhwc_bf16(const mg_bf16* x, mg_bf16* y, int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
+int mg_subsample2_nhwc_bf16(const mg_bf16* x, mg_bf16* y, int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
+int mg_relu_mean_rows_bf16(const mg_bf16* x, mg_bf16* y, int32_t B, int32_t HW, int32_t C, void* stream);
+
 /* K20 (integer, exact): reference magma/utils.py:334-364 build_labels.
  * labels[b, :P] = -100; labels[b, P+t] = captions[b, t] up to and including
  * the first eos of the row; -100 after.  captions/labels [B, S] int64.       */

@@ -407,7 +407,7 @@ class LMEngine:
         st.token = torch.zeros(B, dtype=torch.int64, device=dev)
         st.graphs = {}             # token-selection mode (None = greedy | (temperature, top_k, top_p)) -> captured hipGraph
         st.steps = 0
-        st.plan = self._build_decode_plan(cache, st) if self.mega and not self.decode_w8 else None
+        st.plan = self._build_decode_plan(cache, st) if self.mega and not self.decode_w8 and B <= 16 else None
         return st
 
     def _build_decode_plan(self, cache: KVCache, st):
@@ -487,15 +487,27 @@ class LMEngine:
         main = torch.cuda.current_stream()
         side = self._side_stream if self.two_streams else None
         w8_on = self.decode_w8
+        # B > 16 (the weight-streaming GEMV kernels take M <= 16): the same block, every projection through the tile GEMM
+        # on the prefill operands -- weights are still read once per step for the whole batch (reference sampling.py:43-121
+        # has no batch limit).  LayerNorm is a launch of its own there (the fold lives in the GEMV kernel).
+        wide = B > 16
+        G = ops.gemm if wide else ops.gemm_skinny
+        if wide and w8_on:
+            raise NotImplementedError("W8A16 decode covers batches of at most 16 sequences")
         for li, ly in enumerate(self.layers):
             src = ly.w8 if w8_on else ly                 # e4m3 or bf16 operands (same launches)
-            # ln_1 + qkv + fc_in(+gelu) in ONE weight-streaming launch
-            ops.gemm_skinny(x, src.dec_in, out=st.qkv, ln_fold=(src.dec_in.colsum, self.d, self.eps),
-                            split=(d3, st.h, ops.MG_ACT_GELU_NEW, src.dec_in.bias_b), variant=self._dec_in_variant)
+            if wide:
+                ops.layernorm(x, ly.ln_g, ly.ln_b, self.eps, out=st.ln)
+                ops.gemm(st.ln, ly.qkv, out=st.qkv)
+                ops.gemm(st.ln, ly.fc_in, out=st.h, act=ops.MG_ACT_GELU_NEW)
+            else:
+                # ln_1 + qkv + fc_in(+gelu) in ONE weight-streaming launch
+                ops.gemm_skinny(x, src.dec_in, out=st.qkv, ln_fold=(src.dec_in.colsum, self.d, self.eps),
+                                split=(d3, st.h, ops.MG_ACT_GELU_NEW, src.dec_in.bias_b), variant=self._dec_in_variant)
             # attention branch (latency-bound, 128 workgroups) runs on a second HIP stream
             # underneath the MLP branch's weight streaming; both join at the adapter-up GEMV
             par = ly.mlp_par is not None or ly.attn_par is not None
-            grouped = (self.group_launches and not par and ly.mlp_adapter is not None and ly.attn_adapter is None
+            grouped = (not wide and self.group_launches and not par and ly.mlp_adapter is not None and ly.attn_adapter is None
                        and ly.fc_out.Kp % 128 == 0 and ly.out.Kp % 128 == 0 and ly.mlp_adapter[0].Kp % 128 == 0)
             if grouped:
                 # launch 2: attention workgroups + fc_out GEMV workgroups in one grid (they are independent
@@ -511,7 +523,7 @@ class LMEngine:
                 continue
             if w8_on:
                 raise NotImplementedError("W8A16 decode covers the grouped MAGMA_v1 step (mlp adapters, K % 128 == 0) only")
-            up_cat = self._adapter_up_cat(ly) if self.group_launches and not par else None
+            up_cat = self._adapter_up_cat(ly) if self.group_launches and not par and not wide else None
             if up_cat is not None:
                 # MAGMA_v2 (attention AND mlp adapters): 5 launches.  x' = up_m(t) + up_a(ta) + m + a + x is ONE GEMV over
                 # the concatenated bottlenecks [t | ta] against [W_up_m | W_up_a] (the adapter outputs only ever appear summed).
@@ -529,45 +541,50 @@ class LMEngine:
                 torch.cuda.set_stream(side)
             ops.attn_decode_fused(st.qkv, cache.k[li], cache.v[li], st.ctx, B, self.H, cache.d_pos, self.rot,
                                   self.sin_t, self.cos_t)
-            a = ops.gemm_skinny(st.ctx, ly.out, out=st.a)
-            if par:      # parallel adapters read ln_1(x): the one decode configuration that needs the LayerNorm as a tensor
+            a = G(st.ctx, ly.out, out=st.a)
+            if par and not wide:      # parallel adapters read ln_1(x): the one decode configuration that needs the LayerNorm as a tensor
                 ops.layernorm(x, ly.ln_g, ly.ln_b, self.eps, out=st.ln)
             if ly.attn_adapter is not None:
                 ta = st.ta[:, : ly.attn_adapter[0].N]
                 if ly.attn_par is not None:
                     sc, up = self._par_up(ly.attn_adapter[1], ly.attn_par)
-                    ops.gemm_skinny(st.ln, ly.attn_adapter[0], out=ta, act=ops.MG_ACT_RELU)
-                    a = ops.gemm_skinny(ta, up, out=st.a2, scale=sc, residuals=(a,))
+                    G(st.ln, ly.attn_adapter[0], out=ta, act=ops.MG_ACT_RELU)
+                    a = G(ta, up, out=st.a2, scale=sc, residuals=(a,))
                 else:
-                    ops.gemm_skinny(a, ly.attn_adapter[0], out=ta, act=ops.MG_ACT_RELU)
-                    a = ops.gemm_skinny(ta, ly.attn_adapter[1], out=st.a2, residuals=(a,))
+                    G(a, ly.attn_adapter[0], out=ta, act=ops.MG_ACT_RELU)
+                    a = G(ta, ly.attn_adapter[1], out=st.a2, residuals=(a,))
             if side is not None:
                 torch.cuda.set_stream(main)
             if ly.mlp_adapter is not None:
-                ops.gemm_skinny(st.h, ly.fc_out, out=st.m)
+                G(st.h, ly.fc_out, out=st.m)
                 t = st.t[:, : ly.mlp_adapter[0].N]
                 if side is not None:
                     main.wait_stream(side)
                 if ly.mlp_par is not None:
                     sc, up = self._par_up(ly.mlp_adapter[1], ly.mlp_par)
-                    ops.gemm_skinny(st.ln, ly.mlp_adapter[0], out=t, act=ops.MG_ACT_RELU)
-                    ops.gemm_skinny(t, up, out=xn, scale=sc, residuals=(st.m, a, x))
+                    G(st.ln, ly.mlp_adapter[0], out=t, act=ops.MG_ACT_RELU)
+                    G(t, up, out=xn, scale=sc, residuals=(st.m, a, x))
                 else:
-                    ops.gemm_skinny(st.m, ly.mlp_adapter[0], out=t, act=ops.MG_ACT_RELU)
-                    ops.gemm_skinny(t, ly.mlp_adapter[1], out=xn, residuals=(st.m, a, x))
+                    G(st.m, ly.mlp_adapter[0], out=t, act=ops.MG_ACT_RELU)
+                    G(t, ly.mlp_adapter[1], out=xn, residuals=(st.m, a, x))
             else:
                 if side is not None:
                     main.wait_stream(side)
-                ops.gemm_skinny(st.h, ly.fc_out, out=xn, residuals=(a, x))
+                G(st.h, ly.fc_out, out=xn, residuals=(a, x))
             x, xn = xn, x
-        head = self.head_w8 if w8_on else self.head_dec
-        ops.gemm_skinny(x, head, out=st.logits, ln_fold=(head.colsum, self.d, self.eps))
+        if wide:
+            ops.layernorm(x, self.lnf_g, self.lnf_b, self.eps, out=st.lnf)
+            ops.gemm(st.lnf, self.head, out=st.logits)
+        else:
+            head = self.head_w8 if w8_on else self.head_dec
+            ops.gemm_skinny(x, head, out=st.logits, ln_fold=(head.colsum, self.d, self.eps))
         self.select_token(st.logits[:, : self.V], cache, mode, out=st.token, advance=True)
 
     def _ensure_decode_state(self, cache: KVCache):
         st = cache.decode_state
         if st is None:
-            self._ensure_decode_packs()
+            if cache.B <= 16:           # larger batches run the tile GEMM on the prefill operands (no LayerNorm-folded packs)
+                self._ensure_decode_packs()
             if self.decode_w8:
                 self._ensure_decode_packs_w8()
             st = cache.decode_state = self._alloc_decode_state(cache)
@@ -580,7 +597,7 @@ class LMEngine:
         if cache.pos >= cache.Smax:
             raise ValueError(f"KV cache full (Smax={cache.Smax}); pass a larger cache_hint / max_steps")
         if cache.B > 16:
-            raise NotImplementedError("decode batch > 16 per GPU is not implemented (weight-streaming kernel is M<=16)")
+            use_graph = False       # the tile-GEMM step of large batches is launched eagerly (split-K scratch is per stream)
         st = self._ensure_decode_state(cache)
         feed_back = input_ids is None
         if not feed_back:

@@ -519,6 +519,59 @@ def stem_im2col(img: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def weight_standardize(w: torch.Tensor, gain: torch.Tensor, scale: float, eps: float, to_khwc: bool = False,
+                       ldo: Optional[int] = None) -> torch.Tensor:
+    """timm ScaledStdConv2d weight transform: w [cout,cin,kh,kw] bf16, gain [cout(,1,1,1)] -> [cout, ldo] bf16 GEMM operand."""
+    _need_gpu(w, gain)
+    assert w.dtype == BF16 and gain.dtype == BF16 and w.ndim == 4 and w.is_contiguous() and gain.numel() == w.shape[0]
+    cout, cin, kh, kw = w.shape
+    ldo = ceil_to(cin * kh * kw, 8) if ldo is None else ldo
+    out = torch.empty(cout, ldo, dtype=BF16, device=w.device)
+    check(L.load().mg_weight_standardize_bf16(w.data_ptr(), gain.contiguous().data_ptr(), out.data_ptr(), cout, cin, kh, kw, ldo,
+                                              int(bool(to_khwc)), float(scale), float(eps), _stream()), "mg_weight_standardize_bf16")
+    return out
+
+
+def im2col_nchw(img: torch.Tensor, k: int, stride: int, pad: int, ldo: int) -> torch.Tensor:
+    """img [B,C,H,W] bf16 NCHW -> [B*Ho*Wo, ldo], column (c*k + ky)*k + kx (small-Cin strided stem convs)."""
+    _need_gpu(img)
+    assert img.dtype == BF16 and img.is_contiguous() and img.ndim == 4
+    B, Cc, H, W = img.shape
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    out = torch.empty(B * Ho * Wo, ldo, dtype=BF16, device=img.device)
+    check(L.load().mg_im2col_nchw_bf16(img.data_ptr(), out.data_ptr(), B, Cc, H, W, k, stride, pad, ldo, _stream()), "mg_im2col_nchw_bf16")
+    return out
+
+
+def _pool_s2(fn_name: str, x: torch.Tensor) -> torch.Tensor:
+    _need_gpu(x)
+    assert x.dtype == BF16 and x.is_contiguous() and x.ndim == 4
+    B, H, W, Cc = x.shape
+    y = torch.empty(B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cc, dtype=BF16, device=x.device)
+    check(getattr(L.load(), fn_name)(x.data_ptr(), y.data_ptr(), B, H, W, Cc, _stream()), fn_name)
+    return y
+
+
+def maxpool3x3s2(x: torch.Tensor) -> torch.Tensor:
+    """MaxPool2d(3, stride 2, padding 1) on [B,H,W,C] NHWC bf16."""
+    return _pool_s2("mg_maxpool3x3s2_nhwc_bf16", x)
+
+
+def subsample2(x: torch.Tensor) -> torch.Tensor:
+    """x[:, ::2, ::2, :] of an NHWC bf16 map as a contiguous tensor."""
+    return _pool_s2("mg_subsample2_nhwc_bf16", x)
+
+
+def relu_mean_rows(x: torch.Tensor) -> torch.Tensor:
+    """[B, HW, C] bf16 -> [B, C]: mean over the positions of relu(x)."""
+    _need_gpu(x)
+    assert x.dtype == BF16 and x.is_contiguous() and x.ndim == 3
+    B, HW, Cc = x.shape
+    y = torch.empty(B, Cc, dtype=BF16, device=x.device)
+    check(L.load().mg_relu_mean_rows_bf16(x.data_ptr(), y.data_ptr(), B, HW, Cc, _stream()), "mg_relu_mean_rows_bf16")
+    return y
+
+
 def build_labels(captions: torch.Tensor, prefix_len: int, eos: int) -> torch.Tensor:
     _need_gpu(captions)
     assert captions.dtype == torch.int64 and captions.ndim == 2 and captions.is_contiguous()

@@ -38,11 +38,21 @@ def test_device_preprocess_bit_exact(dev, H, W, n_px):
 
 
 def test_non_rgb_images_take_the_host_path(dev):
+    """Grey / palette / alpha images are resized IN THEIR OWN MODE by PIL and converted afterwards (reference
+    transforms.py:121-134), so they take the host arithmetic -- but land on the transform's device like the RGB ones, or a
+    mixed batch could not be collated (reference dataset.py:155-160)."""
+    from magma_amd.datasets import collate_fn
     from magma_amd.transforms import clip_preprocess
-    grey = PilImage.fromarray(np.random.default_rng(1).integers(0, 256, (50, 70), dtype=np.uint8), mode="L")
-    out = clip_preprocess(224, device=dev)(grey)
-    assert not out.is_cuda and out.shape == (1, 3, 224, 224)
-    assert torch.equal(out, clip_preprocess(224)(grey))
+    rng = np.random.default_rng(1)
+    grey = PilImage.fromarray(rng.integers(0, 256, (50, 70), dtype=np.uint8), mode="L")
+    rgb = PilImage.fromarray(rng.integers(0, 256, (50, 70, 3), dtype=np.uint8), mode="RGB")
+    tf = clip_preprocess(224, device=dev)
+    out = tf(grey)
+    assert out.is_cuda and out.shape == (1, 3, 224, 224)
+    assert torch.equal(out.cpu(), clip_preprocess(224)(grey))
+    cap = torch.zeros(1, 8, dtype=torch.int64)
+    images, _ = collate_fn([(tf(rgb), cap), (out, cap)], seq_len=8)
+    assert images.is_cuda and images.shape == (2, 3, 224, 224)
 
 
 def test_errors_are_loud(dev):
