@@ -3,8 +3,8 @@
 ``clip_resnet_large`` (CLIP RN50x16 trunk with the attention pool replaced by
 ``b d h w -> b (h w) d``) is what the shipped YAMLs select; ``clip_resnet``
 (RN50x4) is the same trunk at another width/depth; ``clip`` (ViT-B/32) is the
-VisionTransformer below, feeding the pooled ImagePrefix branch.  nfresnet50
-(timm NF-ResNet, no source or stand-in offline) raises.  The module tree carries openai/CLIP's
+VisionTransformer below, feeding the pooled ImagePrefix branch; ``nfresnet50`` is
+timm's NF-ResNet-50 (NFResNet50 below, same pooled branch).  The CLIP module trees carry openai/CLIP's
 parameter names (conv1..3, bn1..3, layer{1..4}.{j}.{conv,bn}{1..3},
 downsample.{0,1}) so reference checkpoints load by name, but the arithmetic is
 NOT torch: forward() drives the HIP kernels -- NHWC activations, every conv an
@@ -250,6 +250,154 @@ class VisionTransformer(nn.Module):
         return ops.gemm(cls, pk["proj"])                                                      # (B, output_dim)
 
 
+class ScaledStdConv2d(nn.Module):
+    """Parameter container with timm ScaledStdConv2d's names: weight [cout,cin,k,k], bias [cout], gain [cout,1,1,1]."""
+
+    def __init__(self, cin, cout, k, **kw):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(cout, cin, k, k, **kw))
+        self.bias = nn.Parameter(torch.zeros(cout, **kw))
+        self.gain = nn.Parameter(torch.ones(cout, 1, 1, 1, **kw))
+        self.k = k
+
+
+class _NFDownsample(nn.Module):
+    def __init__(self, cin, cout, **kw):
+        super().__init__()
+        self.conv = ScaledStdConv2d(cin, cout, 1, **kw)
+
+
+class NormFreeBlock(nn.Module):
+    def __init__(self, cin, cout, mid, stride, beta, **kw):
+        super().__init__()
+        self.downsample = _NFDownsample(cin, cout, **kw) if (cin != cout or stride != 1) else None
+        self.conv1 = ScaledStdConv2d(cin, mid, 1, **kw)
+        self.conv2 = ScaledStdConv2d(mid, mid, 3, **kw)
+        self.conv3 = ScaledStdConv2d(mid, cout, 1, **kw)
+        self.stride, self.beta = stride, beta
+
+
+class NFResNet50(nn.Module):
+    """timm ``nf_resnet50`` as the reference wraps it (image_encoders.py:31-45):
+    ``Sequential(Sequential(stem, stages, final_conv, final_act), AdaptiveAvgPool2d((1,1)))`` -> state-dict keys
+    ``0.0.conv.*`` (stem), ``0.1.{stage}.{block}.{conv1,conv2,conv3,downsample.conv}.*`` -- kept, so a reference checkpoint loads
+    by name.  (B,3,H,W) -> (B, 2048) for the pooled ImagePrefix branch.
+
+    Published architecture (Brock et al. 2021; timm models/nfnet.py ``_nfres_cfg(depths=(3,4,6,3))``, layers/std_conv.py):
+    scaled-weight-standardised convs (no BatchNorm), 7x7/2 stem + 3x3/2 max pool, 16 pre-activation bottlenecks
+    ``y = alpha * conv3(relu(conv2(relu(conv1(relu(x) * beta))))) + shortcut`` with alpha 0.2, ReLU, global average pool.
+    ``timm`` is not installed here: the arithmetic is checked against the restatement in oracle/nfnet.py (parity unpinned).
+
+    forward() drives the HIP kernels: NHWC bf16 activations; every conv an MFMA GEMM over the standardised weights
+    (mg_weight_standardize_bf16, re-done only when the weights change); the stem through an explicit im2col of the NCHW image
+    (K = 147 -> 160); beta, alpha, the conv bias and the residual add in the GEMM epilogues; max pool, the stride-2 sampling
+    of the three strided 3x3 convs, ReLU and ReLU + global mean as small HBM-bound kernels."""
+
+    ALPHA, EPS, GAMMA = 0.2, 1e-5, 1.7139588594436646
+    DEPTHS, CHANNELS, STEM = (3, 4, 6, 3), (256, 512, 1024, 2048), 64
+
+    def __init__(self, input_resolution=256, device=None, dtype=None, depths=None, channels=None, stem_chs=None):
+        super().__init__()
+        kw = dict(device=device, dtype=dtype)
+        depths, channels = tuple(depths or self.DEPTHS), tuple(channels or self.CHANNELS)
+        stem_chs = stem_chs or self.STEM
+        self.input_resolution = input_resolution
+        self.out_dim = channels[-1]
+        stem = nn.Sequential(OrderedDict([("conv", ScaledStdConv2d(3, stem_chs, 7, **kw)), ("pool", nn.Identity())]))
+        stages, prev, expected_var = [], stem_chs, 1.0
+        for si, depth in enumerate(depths):
+            blocks = []
+            for bi in range(depth):
+                stride = 2 if (bi == 0 and si > 0) else 1
+                blocks.append(NormFreeBlock(prev, channels[si], channels[si] // 4, stride, expected_var ** -0.5, **kw))
+                if bi == 0:
+                    expected_var = 1.0
+                expected_var += self.ALPHA ** 2
+                prev = channels[si]
+            stages.append(nn.Sequential(*blocks))
+        inner = nn.Sequential(stem, nn.Sequential(*stages), nn.Identity(), nn.Identity())   # stem, stages, final_conv, final_act
+        self.add_module("0", inner)
+        self.add_module("1", nn.Identity())                                                 # AdaptiveAvgPool2d((1, 1))
+        self._packed = None
+        self.eval()
+
+    @property
+    def stem_conv(self):
+        return getattr(self, "0")[0].conv
+
+    @property
+    def stages(self):
+        return getattr(self, "0")[1]
+
+    def invalidate_packed(self):
+        self._packed = None
+
+    def _pack(self, conv: ScaledStdConv2d, scale_mul: float = 1.0, khwc: bool = False, ldo=None, scale_bias: bool = False):
+        """(PackedLinear over the standardised weights, per-channel epilogue scale): out = acc * scale_mul + bias, the bias
+        multiplied by scale_mul as well when ``scale_bias`` (alpha * (W t + b)); not for beta, which scales the conv INPUT."""
+        cout, cin, k, _ = conv.weight.shape
+        w = ops.weight_standardize(conv.weight.detach().to(torch.bfloat16).contiguous(), conv.gain.detach().to(torch.bfloat16).reshape(-1),
+                                   self.GAMMA * (cin * k * k) ** -0.5, self.EPS, to_khwc=khwc, ldo=ldo)
+        bias = conv.bias.detach().float() * (scale_mul if scale_bias else 1.0)
+        scale = torch.full((cout,), scale_mul, dtype=torch.float32, device=w.device)
+        return ops.PackedLinear(w, bias=bias), scale
+
+    def _ensure_packed(self):
+        if self._packed is None:
+            pk = {"stem": self._pack(self.stem_conv, ldo=160)}
+            for si, stage in enumerate(self.stages):
+                for bi, blk in enumerate(stage):
+                    pre = f"{si}.{bi}."
+                    pk[pre + "conv1"] = self._pack(blk.conv1, blk.beta)           # conv1(relu(x) * beta) = beta * (W relu(x)) + b
+                    pk[pre + "conv2"] = self._pack(blk.conv2, khwc=True)
+                    pk[pre + "conv3"] = self._pack(blk.conv3, self.ALPHA, scale_bias=True)     # alpha * (W t + b) + shortcut
+                    if blk.downsample is not None:
+                        pk[pre + "down"] = self._pack(blk.downsample.conv, blk.beta)
+            c = max(self.CHANNELS[-1], self.out_dim)
+            pk["one"] = torch.ones(c, dtype=torch.float32, device=self.stem_conv.weight.device)
+            pk["zero"] = torch.zeros(c, dtype=torch.float32, device=self.stem_conv.weight.device)
+            self._packed = pk
+        return self._packed
+
+    @staticmethod
+    def _conv(a, packed, relu=False, conv=None, residual=None):
+        lin, scale = packed
+        # epilogue: act(acc * scale[n] + bias[n]) (+ residual)
+        return ops.gemm(a, lin, scale=scale, act=ops.MG_ACT_RELU if relu else ops.MG_ACT_NONE, conv=conv,
+                        residuals=() if residual is None else (residual,))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        pk = self._ensure_packed()
+        if x.ndim != 4 or x.shape[1] != 3 or x.shape[2] % 64 or x.shape[3] % 64:
+            raise ValueError(f"expected (B,3,H,W) with H,W multiples of 64 (even maps at every stage), got {tuple(x.shape)}")
+        x = x.to(torch.bfloat16).contiguous()
+        B, _, H, W = x.shape
+        h, w = H // 2, W // 2
+        y = self._conv(ops.im2col_nchw(x, 7, 2, 3, 160), pk["stem"])                     # [B*h*w, 64], no activation
+        y = ops.maxpool3x3s2(y.view(B, h, w, -1))
+        h, w = y.shape[1], y.shape[2]
+        y = y.view(B * h * w, -1)
+        for si, stage in enumerate(self.stages):
+            for bi, blk in enumerate(stage):
+                pre = f"{si}.{bi}."
+                c = y.shape[1]
+                r = ops.bn_apply(y, pk["one"][:c], pk["zero"][:c], relu=True)            # relu(x); beta rides in the epilogues
+                shortcut = y
+                if blk.downsample is not None:
+                    s = r
+                    if blk.stride > 1:
+                        s = ops.avgpool2(r.view(B, h, w, c)).view(B * (h // 2) * (w // 2), c)
+                    shortcut = self._conv(s, pk[pre + "down"])
+                out = self._conv(r, pk[pre + "conv1"], relu=True)                        # relu feeds conv2
+                out = self._conv(out, pk[pre + "conv2"], relu=True, conv=(h, w, out.shape[1]))   # relu feeds conv3
+                if blk.stride > 1:     # 3x3, stride 2, padding 1 == the stride-1 map at the even positions (ReLU commutes)
+                    out = ops.subsample2(out.view(B, h, w, -1))
+                    h, w = out.shape[1], out.shape[2]
+                    out = out.view(B * h * w, -1)
+                y = self._conv(out, pk[pre + "conv3"], residual=shortcut)
+        return ops.relu_mean_rows(y.view(B, h * w, -1))                                   # final_act + global average pool
+
+
 def clip_encoder(device=None, name: str = "clip_resnet_large", dtype=None) -> nn.Module:
     name = _ALIASES.get(name, name)
     if name in ("clip", "ViT-B/32"):
@@ -261,7 +409,19 @@ def clip_encoder(device=None, name: str = "clip_resnet_large", dtype=None) -> nn
                               "(RN50x16), clip_resnet (RN50x4) and clip (ViT-B/32) are")
 
 
-def get_image_encoder(name: str, device=None, pretrained: bool = False, dtype=None) -> nn.Module:
+def nfresnet50(device=None, pretrained: bool = False, dtype=None, input_resolution: int = 256) -> nn.Module:
+    """reference image_encoders.py:31-45.  ``pretrained`` would download timm weights: no network here -- weights come from
+    the MAGMA checkpoint (Magma.from_checkpoint) like every other tensor."""
+    if pretrained:
+        raise RuntimeError("pretrained nf_resnet50 weights need timm + network access; load a MAGMA checkpoint instead "
+                           "(pretrained_img_encoder: false)")
+    return NFResNet50(input_resolution, device=device, dtype=dtype)
+
+
+def get_image_encoder(name: str, device=None, pretrained: bool = False, dtype=None, image_size: int = 256) -> nn.Module:
+    """reference image_encoders.py:78-91."""
+    if name == "nfresnet50":
+        return nfresnet50(device=device, pretrained=pretrained, dtype=dtype, input_resolution=image_size)
     if "clip" in name:
         return clip_encoder(device=device, name=name, dtype=dtype)
-    raise NotImplementedError(f"image encoder {name!r} is out of scope for the MI355X path (SURVEY 8f row 4)")
+    raise ValueError(f"image encoder {name} not recognized")

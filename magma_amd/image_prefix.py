@@ -19,7 +19,8 @@ class ImagePrefix(nn.Module):
         self.config = config
         self.encoder_type = config.encoder_name
         self.enc = enc if enc is not None else get_image_encoder(
-            config.encoder_name, device=device, pretrained=config.pretrained_img_encoder, dtype=dtype)
+            config.encoder_name, device=device, pretrained=config.pretrained_img_encoder, dtype=dtype,
+            image_size=config.image_size)
         self.encoder_out_dim = getattr(self.enc, "out_dim", None) or ENCODER_OUT_DIMS[self.encoder_type]
         self.out_dim = out_dim
         # encoders with a token grid (CLIP ResNets) project every token; pooled encoders (ViT class token) are projected to

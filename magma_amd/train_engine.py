@@ -709,6 +709,9 @@ class MagmaEngine:
         enc = self.module.image_prefix.enc
         if not any(self.is_trainable(p) for p in enc.parameters()):
             return enc(images), None
+        if not hasattr(enc, "patch_size"):
+            raise NotImplementedError(f"training the {type(enc).__name__} image encoder is not implemented (its inference path "
+                                      "is): set freeze_img_encoder: true to train the prefix and the adapters on top of it")
         Pz, w, Hh = enc.patch_size, enc.width, enc.heads
         x = images.to(BF16).contiguous()
         B = x.shape[0]

@@ -118,10 +118,78 @@ def clip_preprocess(n_px, use_pad=False, device=None):
     return fn
 
 
+def pad_to_size(x, size=256):
+    """reference transforms.py:8-18 (PIL ImageOps.expand by the missing margin; a larger image is cropped by the negative one)."""
+    from PIL import ImageOps
+    delta_w, delta_h = size - x.size[0], size - x.size[1]
+    padding = (delta_w // 2, delta_h // 2, delta_w - (delta_w // 2), delta_h - (delta_h // 2))
+    return ImageOps.expand(x, padding)
+
+
+def _random_crop(img, size):
+    """torchvision T.RandomCrop(size) on a PIL image: offsets from torch.randint, as torchvision draws them."""
+    w, h = img.size
+    th = tw = size
+    if w == tw and h == th:
+        return img
+    i = int(torch.randint(0, h - th + 1, size=(1,)).item())
+    j = int(torch.randint(0, w - tw + 1, size=(1,)).item())
+    return img.crop((j, i, j + tw, i + th))
+
+
+def _resize_bilinear_short_side(img, size):
+    """torchvision T.Resize(size) on a PIL image: short side -> size, BILINEAR (PIL's antialiased resampler)."""
+    w, h = img.size
+    if (w <= h and w == size) or (h <= w and h == size):
+        return img
+    nw, nh = (size, int(size * h / w)) if w <= h else (int(size * w / h), size)
+    return img.resize((nw, nh), PilImage.BILINEAR)
+
+
+class RandCropResize:
+    """reference transforms.py:42-62: pad to the target size, random square crop, random resize to [9/8, 12/8] x target, random
+    crop to the target -- the augmentation of the non-CLIP encoders (nfresnet50).  Host-side (PIL), as in the reference."""
+
+    def __init__(self, target_size):
+        self.target_size = target_size
+
+    def __call__(self, img):
+        import random
+        img = pad_to_size(img, self.target_size)
+        d_min = min(img.size)
+        img = _random_crop(img, d_min)
+        t_min = min(d_min, round(9 / 8 * self.target_size))
+        t_max = min(d_min, round(12 / 8 * self.target_size))
+        t = random.randint(t_min, t_max + 1)
+        img = _resize_bilinear_short_side(img, t)
+        if min(img.size) < 256:
+            img = _resize_bilinear_short_side(img, 256)
+        return _random_crop(img, self.target_size)
+
+
+def base_transforms(image_size, use_extra_transforms=False, device=None):
+    """reference transforms.py:71-84: RGB -> RandCropResize -> RandomHorizontalFlip(0.5) -> ToTensor -> batch dim."""
+    if use_extra_transforms:
+        raise NotImplementedError("use_extra_transforms (torchvision ColorJitter) is not reproduced; no shipped config sets it")
+    crop = RandCropResize(image_size)
+    on_gpu = device is not None and torch.device(device).type == "cuda"
+
+    def fn(img):
+        img = img.convert("RGB") if img.mode != "RGB" else img
+        img = crop(img)
+        if float(torch.rand(1)) < 0.5:
+            img = img.transpose(PilImage.FLIP_LEFT_RIGHT)
+        t = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).float() / 255.0
+        t = maybe_add_batch_dim(t)
+        return t.to(device) if on_gpu else t
+
+    return fn
+
+
 def get_transforms(image_size, encoder_name, input_resolution=None, use_extra_transforms=False, device=None):
-    """reference magma/transforms.py:87-111.  Only the clip branch is in scope
-    (both shipped YAMLs use clip_resnet_large)."""
+    """reference magma/transforms.py:65-84: the CLIP encoders take clip_preprocess at their input resolution; every other
+    encoder (nfresnet50) the random crop / resize / flip pipeline at ``image_size``."""
     if "clip" in encoder_name:
         assert input_resolution is not None
         return clip_preprocess(input_resolution, device=device)
-    raise NotImplementedError(f"transforms for encoder {encoder_name!r} are out of scope (SURVEY 8f row 4)")
+    return base_transforms(image_size, use_extra_transforms, device=device)

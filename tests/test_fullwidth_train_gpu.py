@@ -8,7 +8,7 @@ merged dqkv epilogue (inverse rotary), the rotary split that also emits q^T / k^
 rows -- the reduced-width tests (tests/test_train_gpu.py) never reach those variants.
 
 Tolerance: per tensor  err(HIP bf16, oracle fp32) <= 2 x err(oracle autograd in bf16 on the CPU, oracle fp32)
-+ 3e-2 rel-L2;  global cosine no further from 1 than twice the bf16 oracle's + 1e-3;  loss within 2 x the bf16 oracle's deviation + 3e-3 relative."""
++ 1e-2 rel-L2;  global cosine no further from 1 than twice the bf16 oracle's + 1e-3;  loss within 2 x the bf16 oracle's deviation + 3e-3 relative."""
 import os
 import sys
 
@@ -74,7 +74,7 @@ def test_gradients_full_width_s2048(dev):
             got, ref = eng.grad_of(p).float().cpu().reshape(-1), g_ref[n].reshape(-1)
             e_hip, e_bf = rel(got, ref), rel(g_bf[n], ref)
             worst.append((e_hip - 2 * e_bf, n, e_hip, e_bf))
-            if e_hip > 2 * e_bf + 3e-2:
+            if e_hip > 2 * e_bf + 1e-2:
                 bad.append((n, e_hip, e_bf))
             dots += float((got * ref).sum()); n1 += float((got * got).sum()); n2 += float((ref * ref).sum())
             gb = g_bf[n].reshape(-1)

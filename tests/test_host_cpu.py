@@ -249,6 +249,45 @@ def test_pretraining_datasets_follow_the_reference_rules(tmp_path):
     assert len(train) == 45 and len(evals) == 5
 
 
+def test_nfresnet50_structure_matches_timm_constants():
+    """nf_resnet50 as the reference wraps it (image_encoders.py:31-45): 53 scaled-std convs, 25,557,032 parameters with timm's
+    2048 -> 1000 classifier (the published count of timm nf_resnet50), 2048 output channels (image_prefix.py:17); the
+    product module's state-dict keys are exactly the oracle's, i.e. the reference's ``0.0.conv.*`` / ``0.1.{s}.{b}.*`` names."""
+    from magma_amd.image_encoders import NFResNet50
+    from oracle.nfnet import NFResNetConfig, block_plan, conv_specs, encoder_fwd, init_params
+    c = NFResNetConfig()
+    specs = conv_specs(c)
+    assert len(specs) == 53
+    assert sum(cin * cout * k * k + 2 * cout for _, cin, cout, k in specs) + 2048 * 1000 + 1000 == 25_557_032
+    p = init_params(c, seed=0, prefix="")
+    enc = NFResNet50(256)
+    assert set(enc.state_dict().keys()) == set(p.keys())
+    assert all(enc.state_dict()[k].shape == p[k].shape for k in p)
+    betas = [round(b, 4) for _, _, _, b in block_plan(c)]
+    assert betas[:4] == [1.0, 0.9806, 0.9623, 0.9449] and betas[7] == 0.9285      # stage boundaries keep the running variance
+    for (_, _, _, b), blk in zip(block_plan(c), [blk for st in enc.stages for blk in st]):
+        assert abs(b - blk.beta) < 1e-12
+    y = encoder_fwd(init_params(c, seed=1), c, torch.randn(1, 3, 64, 64))
+    assert y.shape == (1, 2048) and bool((y >= 0).all())
+
+
+def test_base_transforms_contract():
+    """reference transforms.py:65-84 (non-CLIP encoders): any mode / size -> (1, 3, image_size, image_size) in [0, 1]."""
+    import numpy as np
+    import PIL.Image as I
+    from magma_amd.transforms import get_transforms, pad_to_size
+    tf = get_transforms(128, "nfresnet50")
+    rng = np.random.default_rng(0)
+    for shape, mode in [((200, 300, 3), "RGB"), ((90, 70), "L"), ((400, 130, 3), "RGB")]:
+        img = I.fromarray(rng.integers(0, 256, shape, dtype=np.uint8), mode=mode)
+        t = tf(img)
+        assert t.shape == (1, 3, 128, 128) and t.dtype == torch.float32 and 0.0 <= float(t.min()) and float(t.max()) <= 1.0
+    assert pad_to_size(I.new("RGB", (100, 60)), 128).size == (128, 128)
+    torch.manual_seed(0); import random; random.seed(0)
+    a = tf(I.fromarray(rng.integers(0, 256, (150, 150, 3), dtype=np.uint8)))
+    assert a.shape == (1, 3, 128, 128)
+
+
 def test_workspace_query_is_consistent_with_the_split_policy():
     """mg_gemm_workspace_bytes (callers own all memory): 0 for shapes that fill the chip, else splits x M x
     ceil(N/128)*128 fp32 -- pure host arithmetic, callable without a GPU."""
