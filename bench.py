@@ -252,15 +252,21 @@ def bench_train(model, args, rank, world, dev):
     if args.fp8:
         out["forward_only_fp8"] = _forward_fp8(model, images, caps, args.fp8, sync, dtf, f_fwd)
     eng.train()
+    exposed_comm_ms = overlapped = None
     for trunc in ([False, True] if args.train_truncate else [False]):
         eng.truncate = trunc
         step()
         sync()
+        eng.time_comm = not trunc
+        eng.exposed_comm_ms()
         t0 = time.perf_counter()
         for _ in range(args.train_steps):
             loss = step()
         sync()
         dt = (time.perf_counter() - t0) / args.train_steps
+        if not trunc:
+            exposed_comm_ms, overlapped = eng.exposed_comm_ms(), getattr(eng, "last_overlapped_elems", None)
+        eng.time_comm = False
         if world > 1:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -301,8 +307,13 @@ def bench_train(model, args, rank, world, dev):
             eng.fp8 = False
     out["policy"] = "no recompute; bf16; adapters+CLIP trunk+prefix trainable; clip 1.0 + AdamW in the timed region"
     out["per_gpu_batch"], out["seq_len"] = B, S
+    n_train = sum(g.n for g in eng.groups)
     out["data_parallel"] = {"ranks": world, "backend": "RCCL (torch.distributed nccl)" if world > 1 else None,
+                            "rccl_ranks": torch.distributed.get_world_size() if world > 1 else None,
                             "gradient_exchange": ("bf16 buckets" if eng.exchange_bf16 else "fp32") if world > 1 else None,
+                            "exchanged_elements": n_train if world > 1 else None,
+                            "elements_handed_over_during_backward": overlapped if world > 1 else None,
+                            "exposed_comm_ms_per_step": exposed_comm_ms,
                             "global_batch": world * B}
     out["max_memory_allocated_GB"] = torch.cuda.max_memory_allocated() / 2 ** 30
     return out

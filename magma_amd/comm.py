@@ -1,11 +1,14 @@
 """Data-parallel exchange step: one gradient all-reduce per optimizer step over
 the flat fp32 gradient blocks (383.8 M elements for MAGMA_v1), through
 torch.distributed -- backend "nccl" IS RCCL on ROCm, over xGMI inside a node;
-"gloo" on CPU for the world_size-2 tests.  Large blocks are cut into buckets so
-several ring all-reduces are in flight (xGMI is point-to-point, 7 links/GPU: one
-ring uses one link per direction, so concurrent buckets matter more than on
-NVSwitch).  Semantics preserved from DeepSpeed ZeRO-2 [UNVENDORED]: gradients are
-SUMMED here and divided by world size inside the fused AdamW kernel (mean)."""
+"gloo" on CPU for the world_size-2 tests.  Large blocks are cut into buckets of at most
+BUCKET_ELEMS so that the first one can leave while the later ones are still being cast; on ONE
+process group the buckets are issued to one RCCL stream and run back to back (they do not
+overlap each other -- what overlaps is the exchange with the backward pass, see
+MagmaEngine._reduce_params_async).  Driving several xGMI links at once is RCCL's own business
+(its channels / rings inside one all-reduce), not this file's.  Semantics preserved from
+DeepSpeed ZeRO-2 [UNVENDORED]: gradients are SUMMED here and divided by world size inside the
+fused AdamW kernel (mean)."""
 from __future__ import annotations
 
 from typing import List

@@ -726,6 +726,54 @@ __global__ __launch_bounds__(256) void decode_attn_gemv_kernel(const AttnDecodeP
   if ((int)blockIdx.x < n_attn) attn_decode_body<true>(ap, blockIdx.x, lds);
   else skinny_body<4, KC, 1, W8>(sp, blockIdx.x - n_attn, lds);
 }
+
+// The same launch with a SECOND GEMV that consumes the attention output (out_proj of the block): its workgroups start
+// together with everything else, issue their first burst of weight loads, and only then wait -- off the critical path --
+// for the B*H attention workgroups of this launch to publish the context rows (coherent 8-byte stores, drained, then one
+// relaxed agent-scope increment of a sharded arrival counter; the readers use sc1 loads, so no L1 / cross-XCD L2 line can
+// be stale).  While they wait the independent GEMV (fc_out, 134 MB) keeps the HBM stream saturated, so the hand-off
+// latency that sank the persistent token step (negative result 1: ~14 us per DEPENDENCY LEVEL on the critical
+// path) is hidden here: the launch ends when both streams are done, and the block loses one launch boundary and one
+// under-filled launch.  Deadlock freedom: the waiters need the attention workgroups to RUN, nothing else; the host entry
+// refuses grids that are not co-resident at 3 workgroups per CU (then every workgroup of the launch is resident at once
+// and dispatch order is irrelevant), and every spin is bounded: on time-out *err is set and the workgroup runs on.
+constexpr int CTX_SHARDS = 8, CTX_SHARD_STRIDE = 16;      // ints: one 64-byte line per shard
+constexpr int CTX_SPIN_LIMIT = 1 << 20;
+struct CtxWait {
+  const int* counter; int n_attn; int* err;
+  MG_DEV void operator()() const {
+    if (threadIdx.x < CTX_SHARDS) {
+      const int sh = threadIdx.x;
+      const int target = n_attn / CTX_SHARDS + (sh < (n_attn % CTX_SHARDS) ? 1 : 0);    // arrivals with bid % 8 == sh
+      const int* c = counter + sh * CTX_SHARD_STRIDE;
+      int spins = 0;
+      while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > CTX_SPIN_LIMIT) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      }
+    }
+    __syncthreads();
+  }
+};
+template <int KC>
+__global__ __launch_bounds__(256) void decode_attn_2gemv_kernel(const AttnDecodeParams ap, int n_attn, const SkinnyParams spa,
+                                                                int ga, const SkinnyParams spb, int* __restrict__ counter,
+                                                                int* __restrict__ err) {
+  constexpr int LDS = ATTN_DEC_LDS > skinny_lds_bytes<4, 1>() ? ATTN_DEC_LDS : skinny_lds_bytes<4, 1>();
+  __shared__ __attribute__((aligned(16))) char lds[LDS];
+  const int bid = blockIdx.x;
+  if (bid < n_attn) {
+    attn_decode_body<true, true>(ap, bid, lds);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the coherent context stores have left before the counter moves
+    __syncthreads();
+    if (threadIdx.x == 0)
+      __hip_atomic_fetch_add(counter + (bid % CTX_SHARDS) * CTX_SHARD_STRIDE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else if (bid < n_attn + ga) {
+    skinny_body<4, KC, 1>(spa, bid - n_attn, lds);
+  } else {
+    skinny_body<4, 8, 1, false, true, CtxWait>(spb, bid - n_attn - ga, lds, CtxWait{counter, n_attn, err});
+  }
+}
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -908,6 +956,50 @@ extern "C" int mg_decode_attn_gemv_bf16(const mg_bf16* qkv, mg_bf16* kcache, mg_
   else if (sp.ksteps % 16 == 0) hipLaunchKernelGGL((decode_attn_gemv_kernel<4>), dim3(grid), dim3(256), 0, s, ap, n_attn, sp);
   else if (sp.ksteps % 4 == 0) hipLaunchKernelGGL((decode_attn_gemv_kernel<1>), dim3(grid), dim3(256), 0, s, ap, n_attn, sp);
   else MG_FAIL(MG_ERR_UNSUPPORTED, "mg_decode_attn_gemv_bf16: K of the GEMV must be a multiple of 128");
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
+// The same co-launch plus a second GEMV that READS the attention output (out_proj): see decode_attn_2gemv_kernel.
+// counter: CTX_SHARDS x 16 int32 (one 64-byte line per shard), ZERO on entry (mg_sample_finish's `clear` re-arms it at the
+// end of the token step); err: int32 set to 1 if a bounded wait timed out (results of the step are then invalid).
+extern "C" int32_t mg_decode_ctx_counter_ints(void) { return CTX_SHARDS * CTX_SHARD_STRIDE; }
+extern "C" int mg_decode_attn_2gemv_bf16(const mg_bf16* qkv, mg_bf16* kcache, mg_bf16* vcache, mg_bf16* attn_out, int32_t B,
+                                         int32_t H, int32_t Smax, const int32_t* d_pos, int32_t rot_dim, const float* sin_t,
+                                         const float* cos_t, const mg_skinny_desc* gemv_indep, const mg_skinny_desc* gemv_ctx,
+                                         int32_t* counter, int32_t* err, void* stream) {
+  const char* who = "mg_decode_attn_2gemv_bf16";
+  if (B <= 0 || H <= 0 || Smax <= 0 || Smax > DEC_MAX_CTX) MG_FAIL(MG_ERR_SHAPE, "%s: need 0 < Smax <= %d", who, DEC_MAX_CTX);
+  if (rot_dim < 0 || rot_dim > 256 || (rot_dim & 7)) MG_FAIL(MG_ERR_SHAPE, "%s: rot_dim must be a multiple of 8 in [0,256]", who);
+  if (!qkv || !kcache || !vcache || !attn_out || !d_pos || !counter || !err || (rot_dim && (!sin_t || !cos_t))) MG_FAIL(MG_ERR_SHAPE, "%s: null pointer", who);
+  if (!MG_ALIGNED16(qkv) || !MG_ALIGNED16(kcache) || !MG_ALIGNED16(vcache) || !MG_ALIGNED16(attn_out) || ((uintptr_t)counter & 63)) MG_FAIL(MG_ERR_ALIGN, "%s: pointers must be 16-byte aligned (counter: 64-byte)", who);
+  SkinnyParams spa, spb;
+  if (int rc = fill_skinny(gemv_indep, spa, who)) return rc;
+  if (int rc = fill_skinny(gemv_ctx, spb, who)) return rc;
+  if (spa.w_scale || spb.w_scale) MG_FAIL(MG_ERR_UNSUPPORTED, "%s: bf16 weights only", who);
+  if (spb.X != attn_out) MG_FAIL(MG_ERR_SHAPE, "%s: the dependent GEMV must read the attention output", who);
+  if (spb.ksteps % 32 != 0) MG_FAIL(MG_ERR_UNSUPPORTED, "%s: K of the dependent GEMV must be a multiple of 1024", who);
+  if (spb.ln_colsum || spb.split_n) MG_FAIL(MG_ERR_UNSUPPORTED, "%s: the dependent GEMV takes neither a LayerNorm fold nor a split output", who);
+  const int n_attn = B * H, grid = n_attn + spa.ntiles + spb.ntiles;
+  // every workgroup of the launch must be resident at once (a waiter must never keep an attention workgroup from starting)
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+    MG_FAIL(MG_ERR_HIP, "%s: cannot query the CU count", who);
+  hipStream_t s = (hipStream_t)stream;
+#define MG_L2(KC_)                                                                                                     \
+  {                                                                                                                    \
+    static int per_cu = -1;      /* occupancy of this instantiation, queried once */                                   \
+    if (per_cu < 0 && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_attn_2gemv_kernel<KC_>, 256, 0) != hipSuccess) per_cu = 0; \
+    if ((int64_t)(per_cu > 1 ? per_cu - 1 : 0) * cus < grid)   /* one block per CU of margin (MI355X_MICROARCH: the query may be one high) */ \
+      MG_FAIL(MG_ERR_UNSUPPORTED, "%s: %d workgroups are not co-resident (%d per CU x %d CUs)", who, grid, per_cu, cus); \
+    hipLaunchKernelGGL((decode_attn_2gemv_kernel<KC_>), dim3(grid), dim3(256), 0, s, ap, n_attn, spa, spa.ntiles, spb, counter, err); \
+  }
+  AttnDecodeParams ap{qkv, kcache, vcache, attn_out, H, Smax, d_pos, rot_dim, sin_t, cos_t};
+  if (spa.ksteps % 64 == 0) MG_L2(16)
+  else if (spa.ksteps % 16 == 0) MG_L2(4)
+  else if (spa.ksteps % 4 == 0) MG_L2(1)
+  else MG_FAIL(MG_ERR_UNSUPPORTED, "%s: K of the independent GEMV must be a multiple of 128", who);
+#undef MG_L2
   MG_CHECK_LAUNCH();
   return MG_OK;
 }

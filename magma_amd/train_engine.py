@@ -184,6 +184,8 @@ class MagmaEngine:
                 g.comm = torch.zeros(g.n, dtype=BF16, device=self.device)
         self._reduced = [[] for _ in self.groups]     # per group: (lo, hi) ranges already handed to RCCL this step
         self._works = []
+        self.time_comm, self._comm_events = False, []
+        self.overlapped_elems = 0                     # gradient elements handed over DURING backward in the last step
         if self._dist and self.world > 1:
             # every replica starts from rank 0's model: trainable masters, FROZEN parameters (a random-init GPT-J differs
             # per process unless seeded) and BatchNorm statistics -- what deepspeed.initialize does for the reference
@@ -235,6 +237,18 @@ class MagmaEngine:
                 self._comm_stream.wait_event(ev)
                 self._works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True))
             self._reduced[gi].append((lo, hi))
+            self.overlapped_elems += hi - lo
+
+    def exposed_comm_ms(self, reset: bool = True) -> Optional[float]:
+        """Mean time per optimizer step the compute stream spent in / waiting for the gradient exchange after backward (the
+        part of the all-reduce that was NOT hidden), over the steps taken since the last call; needs time_comm = True and
+        a device synchronisation by the caller.  None without a process group."""
+        if not self._comm_events:
+            return None
+        ms = sum(a.elapsed_time(b) for a, b in self._comm_events) / len(self._comm_events)
+        if reset:
+            self._comm_events = []
+        return ms
 
     def _exchange_view(self, gi, lo, hi):
         """The tensor RCCL sums for flat-gradient range [lo, hi) of group gi: the bf16 bucket (filled here from the fp32
@@ -249,6 +263,7 @@ class MagmaEngine:
         if not self._dist:
             return
         from .comm import allreduce_grads
+        self.last_overlapped_elems, self.overlapped_elems = self.overlapped_elems, 0
         for gi, g in enumerate(self.groups):
             done = sorted(self._reduced[gi])
             pos, rest = 0, []
@@ -935,8 +950,15 @@ class MagmaEngine:
         return ops.gemm(g, wop, layout="rm", use_bias=False, residuals=residuals, **aux_kw)
 
     def _encoder_backward(self, et, g_out):
-        """g_out: gradient wrt the trunk output, already gated by (out > 0)."""
+        """g_out: gradient wrt the trunk output, already gated by (out > 0).  Each stage's parameters (layer4 first, the
+        stem last) are handed to the gradient exchange as soon as its first block has been back-propagated, so the trunk's
+        136 M-element bucket travels under the rest of the trunk's backward instead of in step()."""
         blocks = et["blocks"]
+        enc = self.module.image_prefix.enc
+        stage_start, n = {}, 0
+        for li in range(1, 5):
+            stage_start[n] = li
+            n += len(getattr(enc, f"layer{li}"))
         g3 = g_out
         for bi in range(len(blocks) - 1, -1, -1):
             br = blocks[bi]
@@ -960,6 +982,8 @@ class MagmaEngine:
             g1 = self._unit_bwd(br["u2"], g2, gate=br["u1"]["y"])
             g3 = self._unit_bwd(br["u1"], g1, gate=x if prev_is_relu else None, residuals=(d_id,), gate_after=True)
             blocks[bi] = None
+            if bi in stage_start:
+                self._reduce_params_async([p for p in getattr(enc, f"layer{stage_start[bi]}").parameters() if self.is_trainable(p)])
         # stem: avgpool -> conv3 -> conv2 -> conv1
         units = et["units"]
         B, h, w = units[2]["geom"]
@@ -967,6 +991,8 @@ class MagmaEngine:
         g = self._unit_bwd(units[2], g, gate=units[1]["y"])
         g = self._unit_bwd(units[1], g, gate=units[0]["y"])
         self._unit_bwd(units[0], g, need_dgrad=False)
+        self._reduce_params_async([p for m in (enc.conv1, enc.bn1, enc.conv2, enc.bn2, enc.conv3, enc.bn3)
+                                   for p in m.parameters() if self.is_trainable(p)])
 
     # ---- optimizer step ----------------------------------------------------------------
     def step(self):
@@ -978,7 +1004,13 @@ class MagmaEngine:
         if self._dist:
             # gradient average over ranks (DeepSpeed ZeRO-2 reduce-scatter semantics: mean), RCCL over xGMI;
             # most buckets were launched from backward() and have been running under it
+            if self.time_comm:       # exposed exchange time: what of the all-reduce backward did NOT cover (bench.py reads it)
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
             self._finish_reduce()
+            if self.time_comm:
+                ev[1].record()
+                self._comm_events.append(ev)
             grad_scale /= self.world
         self._norm_sq.zero_()
         grads = [g.comm if self.exchange_bf16 else g.grad for g in self.groups]    # what came back from the exchange
