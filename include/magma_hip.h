@@ -182,6 +182,20 @@ int mg_decode_attn_gemv_bf16(const mg_bf16* qkv, mg_bf16* kcache, mg_bf16* vcach
                              const float* sin_t, const float* cos_t, const mg_skinny_desc* gemv,
                              void* stream);
 
+/* The same co-launch plus a SECOND weight-streaming GEMV that READS the attention output (out_proj, reference GPT-J block:
+ * attn_outputs = out_proj(context)): its workgroups start with the launch, issue their first weight loads and wait -- off
+ * the critical path, while gemv_indep keeps the HBM stream busy -- for the B*H attention workgroups of this launch
+ * (coherent stores + sharded arrival counter).  gemv_ctx->X must be attn_out, K % 1024 == 0, no LayerNorm fold / split.
+ *   counter  mg_decode_ctx_counter_ints() int32, 64-byte aligned, ZERO on entry (re-armed by mg_sample_finish's `clear`);
+ *   err      int32, set to 1 if a (bounded) wait timed out -- the step's results are invalid then.
+ * Refuses grids whose workgroups cannot all be resident at once (MG_ERR_UNSUPPORTED): the caller falls back to
+ * mg_decode_attn_gemv_bf16 + mg_gemm_skinny2_bf16.                                                                        */
+int32_t mg_decode_ctx_counter_ints(void);
+int mg_decode_attn_2gemv_bf16(const mg_bf16* qkv, mg_bf16* kcache, mg_bf16* vcache, mg_bf16* attn_out, int32_t B, int32_t H,
+                              int32_t Smax, const int32_t* d_pos, int32_t rot_dim, const float* sin_t, const float* cos_t,
+                              const mg_skinny_desc* gemv_indep, const mg_skinny_desc* gemv_ctx, int32_t* counter,
+                              int32_t* err, void* stream);
+
 /* K8/K17 + ImagePrefix LN: y = (x-mean)/sqrt(var+eps)*gamma+beta, fp32 stats.  Replaces nn.LayerNorm at reference
  * magma/image_prefix.py:58-60,106-107 and ln_1 / ln_f of the GPT-J blocks built at magma/language_model.py:12-45
  * (arithmetic in the un-vendored transformers fork).                                                        */

@@ -142,6 +142,10 @@ class LMEngine:
         self.mega = os.environ.get("MAGMA_DECODE_MEGA", "0") == "1"
         self._side_stream = torch.cuda.Stream(device=dev)
         self.group_launches = os.environ.get("MAGMA_DECODE_GROUPED", "1") == "1"
+        # MAGMA_v1 block in FOUR launches with out_proj inside the attention || fc_out launch (its workgroups wait in-kernel
+        # for the attention workgroups, off the critical path) and the adapter-down GEMV alone in the third: one
+        # under-filled launch fewer per block.  MAGMA_DECODE_CTXWAIT=0 restores attention || fc_out, out_proj || adapter-down.
+        self.ctx_wait = os.environ.get("MAGMA_DECODE_CTXWAIT", "1") == "1"
         self.two_streams = os.environ.get("MAGMA_DECODE_STREAMS", "1") == "2"   # measured slower (3.07 vs 2.94 ms/step): off
 
     def _ensure_decode_packs(self):
@@ -367,6 +371,8 @@ class LMEngine:
         x, hs = self._blocks_prefill(embeds, cache, want_hidden)
         cache.pos = S
         cache.d_pos.fill_(S)
+        if cache.decode_state is not None:       # a token step that raised mid-way may have left arrivals behind
+            cache.decode_state.ctx_counters.zero_()
         last = x.view(B, S, self.d)[:, S - 1, :]                 # strided rows, no copy
         xl = ops.layernorm(last, self.lnf_g, self.lnf_b, self.eps)
         logits = self._head(xl)
@@ -405,6 +411,12 @@ class LMEngine:
         st.lnf = e(B, d)
         st.logits = e(B, self.Vp, dt=torch.float32)
         st.token = torch.zeros(B, dtype=torch.int64, device=dev)
+        # arrival counters of the in-launch attention -> out_proj hand-off (one set of 64-byte lines per layer, re-armed by
+        # the bookkeeping launch at the end of every token step) and the time-out flag of its bounded waits
+        n_ctx = ops.decode_ctx_counter_ints()
+        st.ctx_counters = torch.zeros(len(self.layers) * n_ctx, dtype=torch.int32, device=dev)
+        st.ctx_err = torch.zeros(1, dtype=torch.int32, device=dev)
+        st.ctx_wait = self.ctx_wait and not self.decode_w8 and B <= 16
         st.graphs = {}             # token-selection mode (None = greedy | (temperature, top_k, top_p)) -> captured hipGraph
         st.steps = 0
         st.plan = self._build_decode_plan(cache, st) if self.mega and not self.decode_w8 and B <= 16 else None
@@ -467,6 +479,11 @@ class LMEngine:
     def check_decode(self, cache: KVCache):
         """Raise if a wait of the persistent decode step timed out (one device read; generate() calls it once at the end)."""
         st = cache.decode_state
+        if st is not None and st.ctx_wait and int(st.ctx_err) != 0:
+            st.ctx_err.zero_()
+            st.ctx_counters.zero_()
+            raise ops.L.MagmaHipError("decode step: the in-launch wait for the attention workgroups timed out (results of this "
+                                      "call are invalid); set MAGMA_DECODE_CTXWAIT=0 to use separate launches")
         if st is not None and st.plan is not None and int(st.plan.err) != 0:
             raise ops.L.MagmaHipError("persistent decode step: a dependency wait timed out (results of this call are invalid); "
                                       "set MAGMA_DECODE_MEGA=0 to use the launch chain")
@@ -509,6 +526,18 @@ class LMEngine:
             par = ly.mlp_par is not None or ly.attn_par is not None
             grouped = (not wide and self.group_launches and not par and ly.mlp_adapter is not None and ly.attn_adapter is None
                        and ly.fc_out.Kp % 128 == 0 and ly.out.Kp % 128 == 0 and ly.mlp_adapter[0].Kp % 128 == 0)
+            if grouped and st.ctx_wait and ly.out.Kp % 1024 == 0:
+                # launch 2: attention || fc_out || out_proj (the out_proj workgroups wait in-kernel for the context rows)
+                n_ctx = st.ctx_counters.numel() // len(self.layers)
+                ops.decode_attn_2gemv(st.qkv, cache.k[li], cache.v[li], st.ctx, B, self.H, cache.d_pos, self.rot, self.sin_t,
+                                      self.cos_t, (st.h, ly.fc_out, st.m, {}), (st.ctx, ly.out, st.a, {}),
+                                      st.ctx_counters[li * n_ctx: (li + 1) * n_ctx], st.ctx_err)
+                # launch 3: adapter-down alone; launch 4: adapter-up + the block's three residuals
+                t = st.t[:, : ly.mlp_adapter[0].N]
+                ops.gemm_skinny(st.m, ly.mlp_adapter[0], out=t, act=ops.MG_ACT_RELU)
+                ops.gemm_skinny(t, ly.mlp_adapter[1], out=xn, residuals=(st.m, st.a, x))
+                x, xn = xn, x
+                continue
             if grouped:
                 # launch 2: attention workgroups + fc_out GEMV workgroups in one grid (they are independent
                 # branches of the parallel block; the latency-bound attention hides under the weight stream)
@@ -578,7 +607,8 @@ class LMEngine:
         else:
             head = self.head_w8 if w8_on else self.head_dec
             ops.gemm_skinny(x, head, out=st.logits, ln_fold=(head.colsum, self.d, self.eps))
-        self.select_token(st.logits[:, : self.V], cache, mode, out=st.token, advance=True)
+        self.select_token(st.logits[:, : self.V], cache, mode, out=st.token, advance=True,
+                          clear=st.ctx_counters if st.ctx_wait else None)
 
     def _ensure_decode_state(self, cache: KVCache):
         st = cache.decode_state

@@ -86,6 +86,9 @@ SYMBOLS = {
     "mg_gemm_skinny2_bf16": (C.c_int, [C.POINTER(SkinnyDesc), C.POINTER(SkinnyDesc), _vp]),
     "mg_decode_attn_gemv_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp,
                                           C.POINTER(SkinnyDesc), _vp]),
+    "mg_decode_ctx_counter_ints": (C.c_int32, []),
+    "mg_decode_attn_2gemv_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp,
+                                           C.POINTER(SkinnyDesc), C.POINTER(SkinnyDesc), _vp, _vp, _vp]),
     "mg_layernorm_bf16": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp]),
     "mg_embedding_bf16": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _i64, _i32, _vp]),
     "mg_rotary_split_bf16": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp]),

@@ -292,6 +292,26 @@ def decode_attn_gemv(qkv, kcache, vcache, attn_out, B, H, d_pos, rot_dim, sin_t,
     return attn_out, og
 
 
+def decode_ctx_counter_ints() -> int:
+    return int(L.load().mg_decode_ctx_counter_ints())
+
+
+def decode_attn_2gemv(qkv, kcache, vcache, attn_out, B, H, d_pos, rot_dim, sin_t, cos_t, gemv_indep: tuple, gemv_ctx: tuple,
+                      counter: torch.Tensor, err: torch.Tensor):
+    """Decode attention co-launched with an independent GEMV (fc_out) AND a GEMV that reads the attention output (out_proj,
+    x must be ``attn_out``): one launch, the dependent workgroups wait in-kernel for the attention workgroups.  ``counter``
+    (decode_ctx_counter_ints() int32, zero) and ``err`` (int32[1]) as in include/magma_hip.h."""
+    _need_gpu(qkv, counter, err)
+    assert counter.dtype == torch.int32 and err.dtype == torch.int32 and gemv_ctx[0].data_ptr() == attn_out.data_ptr()
+    da, oa = skinny_desc(gemv_indep[0], gemv_indep[1], gemv_indep[2], **gemv_indep[3])
+    db, ob = skinny_desc(gemv_ctx[0], gemv_ctx[1], gemv_ctx[2], **gemv_ctx[3])
+    check(L.load().mg_decode_attn_2gemv_bf16(qkv.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), attn_out.data_ptr(),
+                                             B, H, kcache.shape[2], d_pos.data_ptr(), rot_dim, sin_t.data_ptr(),
+                                             cos_t.data_ptr(), C.byref(da), C.byref(db), counter.data_ptr(), err.data_ptr(),
+                                             _stream()), "mg_decode_attn_2gemv_bf16")
+    return attn_out, oa, ob
+
+
 def fold_layernorm(weight: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor):
     """LN(x) W^T + b  ==  rstd*(x W'^T - mean*colsum) + b'  with  W' = W*gamma (bf16),
     colsum[n] = sum_k W'[n][k] (of the rounded W'), b' = b + W beta.  One-off weight prep."""

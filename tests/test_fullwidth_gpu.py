@@ -181,3 +181,34 @@ def test_persistent_decode_step_equals_launch_chain(full):
     assert rel(l1, l0) < 2e-3
     same = (t0 == t1).all(1)
     assert int(same.sum()) >= 6, (t0, t1)         # rows may only part ways at a near-tie of the two summation orders
+
+
+@pytest.mark.parametrize("B", [8, 16])
+def test_ctx_wait_block_equals_separate_launches(full, B):
+    """The default MAGMA_v1 token step runs out_proj INSIDE the attention || fc_out launch (csrc/gemm.hip
+    decode_attn_2gemv_kernel: its workgroups wait in-kernel for the attention workgroups' context rows).  Against the
+    separate-launch block (attention || fc_out, then out_proj || adapter-down): the same arithmetic in the same summation
+    order per output, so identical tokens and logits equal up to the bf16 rounding of the out_proj rows' store path; no wait
+    timed out.  B = 16 is the largest batch of the launch (768 workgroups = 3 per CU, the kernel's residency)."""
+    cfg, p, model = full
+    from magma_amd.engine import LMEngine
+    emb = F.greedy_inputs(cfg, F.GREEDY_INPUT_SEED, B=B).to(torch.bfloat16).cuda()
+
+    def run(ctx_wait):
+        eng = LMEngine(model.lm)
+        eng.ctx_wait = ctx_wait
+        out = eng.forward(inputs_embeds=emb, use_cache=True, cache_hint=12, eos_token=cfg.eos_token)
+        cache, toks = out.past_key_values, [out.next_token.clone()]
+        assert cache.decode_state.ctx_wait == ctx_wait
+        for _ in range(9):            # eager step, graph capture, graph replays (the counters re-arm inside the graph)
+            _, tk = eng.decode(None, cache)
+            toks.append(tk.clone())
+        eng.check_decode(cache)
+        assert int(cache.decode_state.ctx_counters.abs().sum()) == 0      # re-armed by the bookkeeping launch
+        return torch.stack(toks, 1).cpu(), cache.decode_state.logits[:, :50258].float().cpu()
+
+    t0, l0 = run(False)
+    t1, l1 = run(True)
+    assert rel(l1, l0) < 1e-3, rel(l1, l0)
+    same = (t0 == t1).all(1)
+    assert int(same.sum()) >= B - 1, (t0, t1)         # rows may only part ways at a near-tie
