@@ -142,10 +142,12 @@ class LMEngine:
         self.mega = os.environ.get("MAGMA_DECODE_MEGA", "0") == "1"
         self._side_stream = torch.cuda.Stream(device=dev)
         self.group_launches = os.environ.get("MAGMA_DECODE_GROUPED", "1") == "1"
-        # MAGMA_v1 block in FOUR launches with out_proj inside the attention || fc_out launch (its workgroups wait in-kernel
-        # for the attention workgroups, off the critical path) and the adapter-down GEMV alone in the third: one
-        # under-filled launch fewer per block.  MAGMA_DECODE_CTXWAIT=0 restores attention || fc_out, out_proj || adapter-down.
-        self.ctx_wait = os.environ.get("MAGMA_DECODE_CTXWAIT", "1") == "1"
+        # MAGMA_DECODE_CTXWAIT=1: out_proj inside the attention || fc_out launch (its workgroups wait in-kernel for the
+        # attention workgroups, off the critical path), adapter-down alone in the third launch.  Parity-green at full width
+        # (tests/test_fullwidth_gpu.py) and SLOWER on this chip: 2.66 vs 2.56 ms per token at B = 8 -- the merged launch takes
+        # 39.0 us against 28.6 + 13.0 for the two it replaces, but the adapter-down GEMV alone costs 7.2 us (launch floor) and
+        # the coherent-load out_proj stream runs on after fc_out has finished (profiles/r03_decode_ctxwait_*).  Opt-in.
+        self.ctx_wait = os.environ.get("MAGMA_DECODE_CTXWAIT", "0") == "1"
         self.two_streams = os.environ.get("MAGMA_DECODE_STREAMS", "1") == "2"   # measured slower (3.07 vs 2.94 ms/step): off
 
     def _ensure_decode_packs(self):

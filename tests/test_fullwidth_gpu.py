@@ -185,11 +185,11 @@ def test_persistent_decode_step_equals_launch_chain(full):
 
 @pytest.mark.parametrize("B", [8, 16])
 def test_ctx_wait_block_equals_separate_launches(full, B):
-    """The default MAGMA_v1 token step runs out_proj INSIDE the attention || fc_out launch (csrc/gemm.hip
-    decode_attn_2gemv_kernel: its workgroups wait in-kernel for the attention workgroups' context rows).  Against the
-    separate-launch block (attention || fc_out, then out_proj || adapter-down): the same arithmetic in the same summation
-    order per output, so identical tokens and logits equal up to the bf16 rounding of the out_proj rows' store path; no wait
-    timed out.  B = 16 is the largest batch of the launch (768 workgroups = 3 per CU, the kernel's residency)."""
+    """MAGMA_DECODE_CTXWAIT=1 runs out_proj INSIDE the attention || fc_out launch (csrc/gemm.hip decode_attn_2gemv_kernel: its
+    workgroups wait in-kernel for the attention workgroups' context rows; opt-in, measured slower -- engine.py).  Against
+    the default block (attention || fc_out, then out_proj || adapter-down): the same arithmetic, identical tokens and
+    logits equal up to the summation order of the K split; no wait timed out; the counters re-arm inside the graph.
+    B = 16 is the largest batch of the launch (768 workgroups = 3 per CU, the kernel's residency)."""
     cfg, p, model = full
     from magma_amd.engine import LMEngine
     emb = F.greedy_inputs(cfg, F.GREEDY_INPUT_SEED, B=B).to(torch.bfloat16).cuda()
