@@ -55,6 +55,9 @@ def parse():
                     help="also time BASELINE config[4]: fp8 (e4m3) MFMA for QKV/out_proj/adapter GEMMs ('attn') or every "
                          "block GEMM ('all'), W8A16 decode and the fp8 training step; reported in extra objects "
                          "('generate_fp8', 'train.forward_only_fp8', 'train.full_S2048_fp8'), never in 'value'")
+    ap.add_argument("--variants", action=argparse.BooleanOptionalAction, default=True,
+                    help="N = 1 only: also time BASELINE config[3] (MAGMA_v2: attention + MLP adapters) and the model-native 384^2 "
+                         "images as extra objects ('magma_v2', 'generate_res384'); never in 'value'")
     args = ap.parse_args()
     if args.fp8 == "off":
         args.fp8 = None
@@ -319,6 +322,64 @@ def bench_train(model, args, rank, world, dev):
     return out
 
 
+def variant_generate(model, args, dev, res):
+    """The headline call at another image resolution (384^2 = the model's own: 144 prefix tokens, prefill S0 = 152)."""
+    B, gen = args.batch, args.gen
+    g = torch.Generator(device=dev).manual_seed(4321)
+    images = torch.randn(B, 3, res, res, device=dev, generator=g).to(torch.bfloat16)
+    prompt = torch.randint(0, 50256, (B, args.prompt), device=dev, generator=g)
+
+    def call():
+        return model.generate(model.embed([images, prompt]), max_steps=gen, temperature=0.0, decode=False, stop_on_eos=False)
+    toks = call()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        call()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    return {"tokens_per_s": B * gen / dt, "ms_per_call": dt * 1e3, "prefill_len": int(toks.shape[1] - gen), "resolution": res}
+
+
+def variant_v2(args, dev):
+    """BASELINE config[3]: MAGMA_v2.yml (attention AND MLP adapters, downsample 8) -- the same generate call and training step."""
+    import gc
+    from magma_amd import Magma
+    from magma_amd.datasets import synthetic_batch
+    from magma_amd.train_engine import MagmaEngine
+    gc.collect()
+    torch.cuda.empty_cache()
+    torch.manual_seed(1234)
+    model = Magma("MAGMA_v2", device=dev)
+    model.eval()
+    out = {"generate": variant_generate(model, args, dev, args.res)}
+    if args.train_steps > 0:
+        model.config.gradient_accumulation_steps = 1
+        eng = MagmaEngine(model)
+        eng.train()
+        B, S = args.train_batch, model.seq_len
+        images, caps = synthetic_batch(B, args.res, S, model.eos_token, 50256, 1234, device=dev, dtype=torch.bfloat16)
+        caps_host = caps.cpu()
+
+        def step():
+            o = eng(images, caps, captions_host=caps_host)
+            eng.backward(o.loss)
+            eng.step()
+            return o.loss
+        step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.train_steps):
+            loss = step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.train_steps
+        fl = train_flops_per_image(model, args.res, S) * B
+        out["train_full_S2048"] = {"images_per_s": B / dt, "ms_per_step": dt * 1e3, "loss": float(loss),
+                                   "mfma_frac_of_2.5PF": fl / dt / 2.5e15,
+                                   "mfma_frac_executed": train_flops_per_image(model, args.res, S, c=0.5) * B / dt / 2.5e15}
+    return out
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", 0))
@@ -518,6 +579,20 @@ def main():
                 line["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
             except Exception as e:  # noqa: BLE001
                 line["cpu_baseline"] = {"error": str(e)[:200]}
+        if args.variants and world == 1 and args.layers is None:
+            # BASELINE config[3] and the model-native resolution, driver-visible: each in its own try (the headline line must
+            # survive), after the headline model has been released (the training step peaks at ~176 GB)
+            cname = os.path.splitext(os.path.basename(str(args.config)))[0]
+            try:
+                line["generate_res384"] = variant_generate(model, args, dev, 384)
+            except Exception as e:  # noqa: BLE001
+                line["generate_res384"] = {"error": repr(e)[:300]}
+            if cname == "MAGMA_v1":
+                del model, eng
+                try:
+                    line["magma_v2"] = variant_v2(args, dev)
+                except Exception as e:  # noqa: BLE001
+                    line["magma_v2"] = {"error": repr(e)[:300]}
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

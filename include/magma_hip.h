@@ -36,6 +36,7 @@ extern "C" {
 #define MG_ERR_ALIGN (-2)
 #define MG_ERR_HIP (-3)
 #define MG_ERR_UNSUPPORTED (-4)
+#define MG_ERR_COMM (-5)          /* RCCL missing or an RCCL call failed (mg_comm_*) */
 
 #define MG_ACT_NONE 0
 #define MG_ACT_RELU 1
@@ -345,6 +346,25 @@ int mg_im2col_nchw_bf16(const mg_bf16* img, mg_bf16* out, int32_t B, int32_t C, 
 int mg_maxpool3x3s2_nhwc_bf16(const mg_bf16* x, mg_bf16* y, int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
 int mg_subsample2_nhwc_bf16(const mg_bf16* x, mg_bf16* y, int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
 int mg_relu_mean_rows_bf16(const mg_bf16* x, mg_bf16* y, int32_t B, int32_t HW, int32_t C, void* stream);
+
+/* Data-parallel exchange step over RCCL / xGMI (csrc/comm.hip): the seam that replaces DeepSpeed's gradient reduction
+ * (reference magma/train_loop.py:18-19 model_engine.backward / .step, train.py:103-111 deepspeed.initialize, magma/utils.py:26-34
+ * reduce_losses).  One communicator per process (= per GPU; mg_comm_init binds the CURRENT HIP device):
+ *   mg_comm_unique_id   rank 0 draws the 128-byte id, the caller hands it to every rank over any side channel;
+ *   mg_comm_init        collective over all ranks; *comm_out = opaque handle;
+ *   mg_comm_allreduce_sum  in-place SUM over the ranks, count elements of dtype MG_COMM_F32 / MG_COMM_BF16, enqueued on
+ *                       `stream` (the mean of the reference's ZeRO-2 reduction is the 1/world folded into mg_adamw_*);
+ *   mg_comm_broadcast   in-place from `root` (whole-model broadcast at engine construction; MG_COMM_BYTES = raw bytes);
+ *   mg_comm_destroy.
+ * RCCL is loaded with dlopen at the first call (the copy already in the process if there is one): MG_ERR_COMM if absent. */
+#define MG_COMM_F32 0
+#define MG_COMM_BF16 1
+#define MG_COMM_BYTES 2
+int mg_comm_unique_id(uint8_t* id128);
+int mg_comm_init(void** comm_out, const uint8_t* id128, int32_t rank, int32_t world);
+int mg_comm_allreduce_sum(void* comm, void* buf, int64_t count, int32_t dtype, void* stream);
+int mg_comm_broadcast(void* comm, void* buf, int64_t count, int32_t dtype, int32_t root, void* stream);
+int mg_comm_destroy(void* comm);
 
 /* K20 (integer, exact): reference magma/utils.py:334-364 build_labels.
  * labels[b, :P] = -100; labels[b, P+t] = captions[b, t] up to and including

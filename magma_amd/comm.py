@@ -19,16 +19,93 @@ import torch.distributed as dist
 BUCKET_ELEMS = 32 * 1024 * 1024      # 128 MiB of fp32 per bucket
 
 
-def allreduce_grads(flat: List[torch.Tensor], async_op: bool = False):
+class TorchExchange:
+    """Default transport: torch.distributed (backend nccl = RCCL on a GPU, gloo on the CPU tests)."""
+    name = "torch.distributed"
+
+    def all_reduce(self, t: torch.Tensor):
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)       # work handle (stream-side wait)
+
+    def broadcast(self, t: torch.Tensor, src: int = 0):
+        dist.broadcast(t, src=src)
+
+    def close(self):
+        pass
+
+
+class RcclExchange:
+    """The same exchange through the C ABI (include/magma_hip.h mg_comm_*: RCCL reached from libmagma_hip.so itself), the
+    seam a reference maintainer binds in place of DeepSpeed.  MAGMA_DP_BACKEND=rccl selects it; torch.distributed is then
+    used once, as the side channel for the 128-byte unique id.  Collectives are enqueued on the CURRENT stream."""
+    name = "mg_comm (RCCL via the C ABI)"
+
+    def __init__(self, device):
+        import ctypes as C
+        from . import lib as L
+        self._L, self._C = L, C
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        ident = [None]
+        if self.rank == 0:
+            buf = (C.c_uint8 * 128)()
+            L.check(L.load().mg_comm_unique_id(buf), "mg_comm_unique_id")
+            ident[0] = bytes(buf)
+        dist.broadcast_object_list(ident, src=0)
+        torch.cuda.set_device(device)
+        h = C.c_void_p()
+        idbuf = (C.c_uint8 * 128).from_buffer_copy(ident[0])
+        L.check(L.load().mg_comm_init(C.byref(h), idbuf, self.rank, self.world), "mg_comm_init")
+        self._h = h
+
+    @staticmethod
+    def _dtype(t):
+        if t.dtype == torch.float32:
+            return 0
+        if t.dtype == torch.bfloat16:
+            return 1
+        raise TypeError(f"mg_comm exchanges fp32 / bf16 gradients, not {t.dtype}")
+
+    def all_reduce(self, t: torch.Tensor):
+        assert t.is_cuda and t.is_contiguous()
+        self._L.check(self._L.load().mg_comm_allreduce_sum(self._h, t.data_ptr(), t.numel(), self._dtype(t),
+                                                           torch.cuda.current_stream().cuda_stream), "mg_comm_allreduce_sum")
+        return None                                   # ordered by the stream it was enqueued on
+
+    def broadcast(self, t: torch.Tensor, src: int = 0):
+        assert t.is_cuda and t.is_contiguous()
+        self._L.check(self._L.load().mg_comm_broadcast(self._h, t.data_ptr(), t.numel() * t.element_size(), 2, src,
+                                                       torch.cuda.current_stream().cuda_stream), "mg_comm_broadcast")
+
+    def close(self):
+        if self._h:
+            self._L.load().mg_comm_destroy(self._h)
+            self._h = None
+
+
+def make_exchange(device):
+    import os
+    kind = os.environ.get("MAGMA_DP_BACKEND", "torch")
+    if kind == "rccl":
+        if device.type != "cuda":
+            raise ValueError("MAGMA_DP_BACKEND=rccl needs a GPU")
+        return RcclExchange(device)
+    if kind != "torch":
+        raise ValueError(f"MAGMA_DP_BACKEND must be 'torch' or 'rccl', got {kind!r}")
+    return TorchExchange()
+
+
+def allreduce_grads(flat: List[torch.Tensor], async_op: bool = False, exchange=None, always: bool = False):
     """In-place SUM all-reduce of every tensor in ``flat`` (bucketed).  Returns the
     list of work handles when async_op, else waits."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not always):
         return []
+    ex = exchange or TorchExchange()
     works = []
     for t in flat:
         n = t.numel()
         for s in range(0, n, BUCKET_ELEMS):
-            works.append(dist.all_reduce(t[s:min(n, s + BUCKET_ELEMS)], op=dist.ReduceOp.SUM, async_op=True))
+            w = ex.all_reduce(t[s:min(n, s + BUCKET_ELEMS)])
+            if w is not None:
+                works.append(w)
     if async_op:
         return works
     for w in works:

@@ -86,6 +86,11 @@ SYMBOLS = {
     "mg_gemm_skinny2_bf16": (C.c_int, [C.POINTER(SkinnyDesc), C.POINTER(SkinnyDesc), _vp]),
     "mg_decode_attn_gemv_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp,
                                           C.POINTER(SkinnyDesc), _vp]),
+    "mg_comm_unique_id": (C.c_int, [_vp]),
+    "mg_comm_init": (C.c_int, [C.POINTER(C.c_void_p), _vp, _i32, _i32]),
+    "mg_comm_allreduce_sum": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
+    "mg_comm_broadcast": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
+    "mg_comm_destroy": (C.c_int, [_vp]),
     "mg_decode_ctx_counter_ints": (C.c_int32, []),
     "mg_decode_attn_2gemv_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp,
                                            C.POINTER(SkinnyDesc), C.POINTER(SkinnyDesc), _vp, _vp, _vp]),

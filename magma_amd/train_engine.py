@@ -176,6 +176,9 @@ class MagmaEngine:
         self._norm_sq = torch.zeros(1, dtype=F32, device=self.device)
         self._dist = dist.is_initialized()            # a 1-rank process group still exercises the overlap path
         self._comm_stream = torch.cuda.Stream(device=self.device) if self._dist else None
+        if self._dist:
+            from .comm import make_exchange
+            self._exchange = make_exchange(self.device)       # torch.distributed (default) or the C-ABI mg_comm_* (RCCL)
         # gradient exchange dtype: bf16 buckets (0.77 GB per step for MAGMA_v1; the reference's ZeRO-2 reduces its fp16
         # gradients the same way) or the fp32 flat buffers themselves (MAGMA_DP_GRAD_DTYPE=fp32, 1.54 GB)
         self.exchange_bf16 = self._dist and os.environ.get("MAGMA_DP_GRAD_DTYPE", "bf16") != "fp32"
@@ -191,14 +194,14 @@ class MagmaEngine:
             # per process unless seeded) and BatchNorm statistics -- what deepspeed.initialize does for the reference
             # (train.py:103-111 broadcasts every module parameter).  One-off 12.9 GB over xGMI.
             for g in self.groups:
-                dist.broadcast(g.master, src=0)
+                self._exchange.broadcast(g.master, src=0)
                 g.model.copy_(g.master)
             for p in model.parameters():
                 if id(p) not in self._where and p.device.type == "cuda":
-                    dist.broadcast(p.data, src=0)
+                    self._exchange.broadcast(p.data, src=0)
             for buf in model.buffers():
                 if buf.is_floating_point() and buf.device.type == "cuda":
-                    dist.broadcast(buf, src=0)
+                    self._exchange.broadcast(buf, src=0)
         model.invalidate_packed()
         self._lm_train_packs = None
         self._adapters_dirty = False
@@ -235,7 +238,9 @@ class MagmaEngine:
         for (gi, lo, hi), buf in zip(todo, bufs):
             with torch.cuda.stream(self._comm_stream):
                 self._comm_stream.wait_event(ev)
-                self._works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True))
+                w = self._exchange.all_reduce(buf)
+                if w is not None:
+                    self._works.append(w)
             self._reduced[gi].append((lo, hi))
             self.overlapped_elems += hi - lo
 
@@ -273,7 +278,7 @@ class MagmaEngine:
                 pos = max(pos, b)
             if pos < g.n:
                 rest.append(self._exchange_view(gi, pos, g.n))
-            allreduce_grads(rest)
+            allreduce_grads(rest, exchange=self._exchange, always=True)
             self._reduced[gi] = []
         for w in self._works:
             w.wait()                      # stream-side join (no host block for the RCCL backend)

@@ -17,6 +17,8 @@ def _grads(dev, with_group):
     model.config.gradient_accumulation_steps = 2
     eng = MagmaEngine(model)
     assert eng._dist == with_group
+    if with_group:
+        assert eng._exchange.name.startswith("mg_comm") == (os.environ.get("MAGMA_DP_BACKEND") == "rccl")
     eng.train()
     g = torch.Generator().manual_seed(1)
     out = []
@@ -35,10 +37,14 @@ def _grads(dev, with_group):
     return out, [grp.master.clone() for grp in eng.groups]
 
 
-def test_overlapped_allreduce_single_rank(dev):
+@pytest.mark.parametrize("backend", ["torch", "rccl"])
+def test_overlapped_allreduce_single_rank(dev, backend, monkeypatch):
+    """backend "rccl": the same exchange through the C ABI (mg_comm_unique_id / _init / _allreduce_sum / _destroy over the RCCL
+    library, include/magma_hip.h) instead of torch.distributed's collectives."""
     g0, m0 = _grads(dev, False)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29541")
+    monkeypatch.setenv("MAGMA_DP_BACKEND", backend)
     dist.init_process_group("nccl", rank=0, world_size=1)
     try:
         g1, m1 = _grads(dev, True)
@@ -50,3 +56,29 @@ def test_overlapped_allreduce_single_rank(dev):
         assert float((a - b).norm() / (a.norm() + 1e-20)) < 1e-5
     for a, b in zip(m0, m1):
         assert float((a - b).norm() / (a.norm() + 1e-20)) < 1e-5
+
+
+def test_mg_comm_collectives_single_rank(dev):
+    """The comm entry points on their own: a 1-rank communicator (SUM over one rank = identity, broadcast from rank 0 = identity),
+    fp32 and bf16, then destroy; a bad dtype / root is refused with MG_ERR_SHAPE."""
+    import ctypes as C
+    from magma_amd import lib as L
+    dll = L.load()
+    ident = (C.c_uint8 * 128)()
+    L.check(dll.mg_comm_unique_id(ident), "mg_comm_unique_id")
+    h = C.c_void_p()
+    torch.cuda.set_device(dev)
+    L.check(dll.mg_comm_init(C.byref(h), ident, 0, 1), "mg_comm_init")
+    try:
+        s = torch.cuda.current_stream().cuda_stream
+        for dt, code in ((torch.float32, 0), (torch.bfloat16, 1)):
+            x = torch.randn(1 << 16, device=dev).to(dt)
+            ref = x.clone()
+            L.check(dll.mg_comm_allreduce_sum(h, x.data_ptr(), x.numel(), code, s), "mg_comm_allreduce_sum")
+            L.check(dll.mg_comm_broadcast(h, x.data_ptr(), x.numel() * x.element_size(), 2, 0, s), "mg_comm_broadcast")
+            torch.cuda.synchronize()
+            assert torch.equal(x, ref)
+        assert dll.mg_comm_allreduce_sum(h, x.data_ptr(), x.numel(), 7, s) == -1
+        assert dll.mg_comm_broadcast(h, x.data_ptr(), 16, 2, 3, s) == -1
+    finally:
+        L.check(dll.mg_comm_destroy(h), "mg_comm_destroy")
