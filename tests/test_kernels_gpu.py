@@ -350,11 +350,13 @@ def test_skinny_layernorm_fold_and_split(dev):
     assert_close(o32, ref, 1e-2, "ln-fold fp32")
 
 
+@pytest.mark.parametrize("tile", [256, 258, 259])
 @pytest.mark.parametrize("layout", ["rm", "ft"])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (1000, 520, 256), (512, 1056, 1024), (2048, 4096, 4096)])
-def test_gemm256_deep_pipeline(dev, layout, M, N, K):
+def test_gemm256_deep_pipeline(dev, layout, M, N, K, tile):
     """The 256x256 staggered / counted-vmcnt kernel against fp32 and against the 128x128 kernel;
-    repeated launches on fresh data to screen for LDS-DMA races."""
+    repeated launches on fresh data to screen for LDS-DMA races.  tile 258 / 259 force its 32x32x16 / 16x16x32 MFMA
+    forms (256 = the library's default form)."""
     from magma_amd import ops
     for rep in range(3):
         a = rnd(M, K, dev=dev, seed=300 + rep).to(BF16)
@@ -362,7 +364,7 @@ def test_gemm256_deep_pipeline(dev, layout, M, N, K):
         bias = rnd(N, dev=dev, seed=320 + rep)
         res = rnd(M, N, dev=dev, seed=330 + rep).to(BF16)
         lin = ops.PackedLinear(w, bias=bias, tiled=True, rowmajor=True)
-        out = ops.gemm(a, lin, layout=layout, residuals=(res,), tile=256)
+        out = ops.gemm(a, lin, layout=layout, residuals=(res,), tile=tile)
         ref = a.float() @ w.float().t() + bias + res.float()
         assert_close(out, ref, GEMM_TOL, f"gemm256 {layout} {M}x{N}x{K} rep{rep}")
         out128 = ops.gemm(a, lin, layout=layout, residuals=(res,), tile=128)

@@ -150,6 +150,28 @@ def main():
                 ms = timeit(fn, 5)
                 r[name + "_ms"] = ms; r[name + "_tflops"] = fl / ms / 1e9
             emit(**r)
+    if which == "mfma":   # 256x256 bf16 kernel: 16x16x32 MFMA (tile 259) vs 32x32x16 (tile 258), interleaved A/B, random data
+        shapes = [(32768, 12288, 4096, "qkv"), (32768, 4096, 4096, "out_proj"), (32768, 16384, 4096, "fc_in"),
+                  (32768, 4096, 16384, "fc_out"), (32768, 1024, 4096, "adapter_dn"), (32768, 4096, 1024, "adapter_up"),
+                  (4096, 4096, 4096, "square4k"), (8192, 8192, 8192, "square8k")]
+        for (M, N, K, tag) in shapes:
+            a = torch.randn(M, K, device=dev).to(BF16)
+            w = (torch.randn(N, K, device=dev) * 0.05).to(BF16)
+            lin = ops.PackedLinear(w)
+            out = torch.empty(M, N, dtype=BF16, device=dev)
+            o16 = ops.gemm(a, lin, tile=259).float()
+            o32 = ops.gemm(a, lin, tile=258).float()
+            r = {"kind": "mfma", "tag": tag, "M": M, "N": N, "K": K,
+                 "rel_diff_32_vs_16": float((o32 - o16).norm() / o16.norm())}
+            del o16, o32
+            best = {259: 1e9, 258: 1e9}
+            for rep in range(3):                       # interleaved: both arms see the same clocks / thermals
+                for tile in (259, 258):
+                    best[tile] = min(best[tile], timeit(lambda i: ops.gemm(a, lin, out=out, tile=tile), 6, warmup=2))
+            fl = 2.0 * M * N * K
+            r.update(mfma16_ms=best[259], mfma32_ms=best[258], mfma16_tflops=fl / best[259] / 1e9, mfma32_tflops=fl / best[258] / 1e9,
+                     speedup=best[259] / best[258])
+            emit(**r)
     if which == "shortk":   # adapter up-projection (K = 1024) with three residual reads: epilogue-bound; 128x128 vs 256x256 kernel
         M, N, K = 32768, 4096, 1024
         a = torch.randn(M, K, device=dev).to(BF16)
