@@ -88,7 +88,8 @@ typedef struct mg_epilogue {
   const mg_bf16* aux;
   int64_t ldaux;
   int32_t aux_after;  /* apply the aux op after the residual adds */
-  int32_t _pad;
+  int32_t act_n0;     /* `act` applies to columns n >= act_n0 only (0: all) -- two projections sharing one A in one launch:
+                       * [q|k|v | fc_in] with gelu_new on the fc_in columns; multiple of 8 */
   mg_bf16* C2;        /* optional second output (value before `act`), bf16 */
   int64_t ldc2;
 } mg_epilogue;
@@ -215,7 +216,7 @@ int mg_embedding_bf16(const int64_t* ids, int32_t B, int32_t T, const mg_bf16* w
  *   qkv [B*S, 3*H*256];  q_out [B,H,S,256];  kcache/vcache [B,H,Smax,256];
  *   vt (nullable) [B,H,vt_ld/32,256,32] (values transposed in 32-key tiles, vt_ld % 32 == 0);  position of row s = pos0 + s where
  *   pos0 = d_pos ? *d_pos : pos0_host.  sin/cos tables [n_pos, rot_dim/2] f32 */
-int mg_rotary_split_bf16(const mg_bf16* qkv, int32_t B, int32_t S, int32_t H, int32_t rot_dim,
+int mg_rotary_split_bf16(const mg_bf16* qkv, int64_t ld_qkv /* row stride in elements, 0 = 3*H*256 */, int32_t B, int32_t S, int32_t H, int32_t rot_dim,
                          const float* sin_t, const float* cos_t, int32_t pos0_host,
                          const int32_t* d_pos, mg_bf16* q_out, mg_bf16* kcache, mg_bf16* vcache,
                          int32_t Smax, mg_bf16* vt, int32_t vt_ld, void* stream);

@@ -24,7 +24,7 @@ namespace {
 // operands of the backward kernels, which otherwise cost two more passes (mg_head_transpose_bf16) over q and k.
 template <bool QKT>
 __global__ __launch_bounds__(256) void rotary_split_kernel(
-    const mg_bf16* __restrict__ qkv, int B, int S, int H, int rot_dim,
+    const mg_bf16* __restrict__ qkv, int64_t ld_qkv, int B, int S, int H, int rot_dim,
     const float* __restrict__ sin_t, const float* __restrict__ cos_t, int pos0_host,
     const int* __restrict__ d_pos, mg_bf16* __restrict__ q_out, mg_bf16* __restrict__ kcache,
     mg_bf16* __restrict__ vcache, int Smax, mg_bf16* __restrict__ vt, int vt_ld, mg_bf16* __restrict__ qt,
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void rotary_split_kernel(
     const int d0 = c * 8;
     u32x4 vv = (u32x4){0u, 0u, 0u, 0u}, qz = vv, kz = vv;
     if (s < S) {
-      const mg_bf16* base = qkv + (int64_t)(b * S + s) * (3 * dmodel) + h * DH + d0;
+      const mg_bf16* base = qkv + (int64_t)(b * S + s) * ld_qkv + h * DH + d0;
       u32x4 qv = *(const u32x4*)base;
       u32x4 kv = *(const u32x4*)(base + dmodel);
       vv = *(const u32x4*)(base + 2 * dmodel);
@@ -486,12 +486,14 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnDecodeParams
 
 }  // namespace
 
-extern "C" int mg_rotary_split_bf16(const mg_bf16* qkv, int32_t B, int32_t S, int32_t H, int32_t rot_dim,
+extern "C" int mg_rotary_split_bf16(const mg_bf16* qkv, int64_t ld_qkv, int32_t B, int32_t S, int32_t H, int32_t rot_dim,
                                     const float* sin_t, const float* cos_t, int32_t pos0_host,
                                     const int32_t* d_pos, mg_bf16* q_out, mg_bf16* kcache,
                                     mg_bf16* vcache, int32_t Smax, mg_bf16* vt, int32_t vt_ld,
                                     void* stream) {
   if (B <= 0 || S <= 0 || H <= 0) MG_FAIL(MG_ERR_SHAPE, "mg_rotary_split_bf16: B,S,H must be positive");
+  if (ld_qkv == 0) ld_qkv = (int64_t)3 * H * DH;
+  if (ld_qkv < (int64_t)3 * H * DH || (ld_qkv & 7)) MG_FAIL(MG_ERR_SHAPE, "mg_rotary_split_bf16: ld_qkv must be a multiple of 8 and >= 3*H*256");
   if (rot_dim < 0 || rot_dim > DH || (rot_dim & 7)) MG_FAIL(MG_ERR_SHAPE, "mg_rotary_split_bf16: rot_dim must be a multiple of 8 in [0,256]");
   if (!qkv || !q_out || !kcache || !vcache || (rot_dim && (!sin_t || !cos_t))) MG_FAIL(MG_ERR_SHAPE, "mg_rotary_split_bf16: null pointer");
   if (!MG_ALIGNED16(qkv) || !MG_ALIGNED16(q_out) || !MG_ALIGNED16(kcache) || !MG_ALIGNED16(vcache) || !MG_ALIGNED16(vt))
@@ -502,7 +504,7 @@ extern "C" int mg_rotary_split_bf16(const mg_bf16* qkv, int32_t B, int32_t S, in
   }
   if (!d_pos && pos0_host + S > Smax) MG_FAIL(MG_ERR_SHAPE, "mg_rotary_split_bf16: pos0+S exceeds Smax");
   dim3 grid((S + 31) / 32, B * H);
-  hipLaunchKernelGGL(rotary_split_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, qkv, B, S, H, rot_dim, sin_t,
+  hipLaunchKernelGGL(rotary_split_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, qkv, ld_qkv, B, S, H, rot_dim, sin_t,
                      cos_t, pos0_host, d_pos, q_out, kcache, vcache, Smax, vt, vt_ld, nullptr, nullptr);
   MG_CHECK_LAUNCH();
   return MG_OK;
@@ -519,7 +521,7 @@ extern "C" int mg_rotary_split_train_bf16(const mg_bf16* qkv, int32_t B, int32_t
     MG_FAIL(MG_ERR_ALIGN, "mg_rotary_split_train_bf16: pointers must be 16-byte aligned");
   if ((ld_t & 31) || ld_t < ((S + 31) & ~31)) MG_FAIL(MG_ERR_SHAPE, "mg_rotary_split_train_bf16: ld_t must be a multiple of 32 and >= S");
   dim3 grid((S + 31) / 32, B * H);
-  hipLaunchKernelGGL(rotary_split_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, qkv, B, S, H, rot_dim, sin_t,
+  hipLaunchKernelGGL(rotary_split_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, qkv, (int64_t)3 * H * DH, B, S, H, rot_dim, sin_t,
                      cos_t, 0, nullptr, q, k, v, S, vt, ld_t, qt, kt);
   MG_CHECK_LAUNCH();
   return MG_OK;

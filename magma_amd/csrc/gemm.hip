@@ -639,6 +639,7 @@ int check_epilogue(const mg_epilogue& ep, const char* who) {
       !MG_ALIGNED16(ep.res1) || !MG_ALIGNED16(ep.res2))
     MG_FAIL(MG_ERR_ALIGN, "%s: epilogue pointers must be 16-byte aligned", who);
   if (ep.act < 0 || ep.act > 3 || ep.act_after < 0 || ep.act_after > 1) MG_FAIL(MG_ERR_SHAPE, "%s: bad activation code", who);
+  if (ep.act_n0 < 0 || (ep.act_n0 & 7)) MG_FAIL(MG_ERR_SHAPE, "%s: act_n0 must be a non-negative multiple of 8", who);
   if (ep.aux_mode < 0 || ep.aux_mode > 4) MG_FAIL(MG_ERR_SHAPE, "%s: bad aux_mode", who);
   if (ep.aux_mode != MG_AUX_NONE && (!ep.aux || (ep.ldaux & 3) || !MG_ALIGNED16(ep.aux))) MG_FAIL(MG_ERR_ALIGN, "%s: aux operand must be 16-byte aligned with ldaux %% 4 == 0", who);
   if (ep.C2 && ((ep.ldc2 & 3) || !MG_ALIGNED16(ep.C2))) MG_FAIL(MG_ERR_ALIGN, "%s: C2 must be 16-byte aligned with ldc2 %% 4 == 0", who);

@@ -146,8 +146,9 @@ MG_DEV void epilogue_apply_impl(const mg_epilogue& ep, const EpiColsW<W>& c, int
     if (full) store_bf16_row<W, NT>(cp, o);
     else for (int r = 0; r < W; ++r) if (n + r < N) cp[r] = f2bf(o[r]);
   }
+  const int act = n >= ep.act_n0 ? ep.act : MG_ACT_NONE;      // act_n0 % 8 == 0: a lane's W columns are on one side
 #pragma unroll
-  for (int r = 0; r < W; ++r) o[r] = apply_act(o[r], ep.act);
+  for (int r = 0; r < W; ++r) o[r] = apply_act(o[r], act);
   float ax[W];
 #pragma unroll
   for (int r = 0; r < W; ++r) ax[r] = 1.f;

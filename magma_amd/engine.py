@@ -100,7 +100,6 @@ class LMEngine:
                 ly.attn_adapter = (ops.PackedLinear(ad[0].weight, ad[0].bias), ops.PackedLinear(ad[2].weight, ad[2].bias))
                 attn = attn.attn_block
             a = attn.attention
-            ly.qkv = ops.PackedLinear(torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], dim=0))
             ly.out = ops.PackedLinear(a.out_proj.weight)
             mlp = blk.mlp
             ly.mlp_adapter = None
@@ -113,7 +112,14 @@ class LMEngine:
                 ad = mlp[1].adapter
                 ly.mlp_adapter = (ops.PackedLinear(ad[0].weight, ad[0].bias), ops.PackedLinear(ad[2].weight, ad[2].bias))
                 mlp = mlp[0]
-            ly.fc_in = ops.PackedLinear(mlp.c_fc.weight, mlp.c_fc.bias)
+            # qkv and fc_in read the same LayerNorm output: ONE operand [q | k | v | fc_in] (bias: zeros | b_fc) for the fused
+            # prefill GEMM; ly.qkv / ly.fc_in are row ranges of it that share its storage
+            d3 = 3 * self.d
+            fcb = mlp.c_fc.bias.detach().float()
+            ly.in_cat = ops.PackedLinear(torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight, mlp.c_fc.weight], dim=0),
+                                         bias=torch.cat([torch.zeros(d3, dtype=torch.float32, device=dev), fcb]))
+            ly.qkv = ly.in_cat.rows(0, d3)
+            ly.fc_in = ly.in_cat.rows(d3, ly.in_cat.N, bias=fcb.contiguous())
             ly.fc_out = ops.PackedLinear(mlp.c_proj.weight, mlp.c_proj.bias)
             ly.ln_g, ly.ln_b = f32(blk.ln_1.weight), f32(blk.ln_1.bias)
             ly.dec_in = None      # decode-only fused [qkv | fc_in] operand with ln_1 folded in (built lazily)
@@ -148,6 +154,7 @@ class LMEngine:
         # 39.0 us against 28.6 + 13.0 for the two it replaces, but the adapter-down GEMV alone costs 7.2 us (launch floor) and
         # the coherent-load out_proj stream runs on after fc_out has finished (profiles/r03_decode_ctxwait_*).  Opt-in.
         self.ctx_wait = os.environ.get("MAGMA_DECODE_CTXWAIT", "0") == "1"
+        self.fuse_in = os.environ.get("MAGMA_PREFILL_FUSE_IN", "1") == "1"      # [qkv | fc_in] as one prefill GEMM
         self.two_streams = os.environ.get("MAGMA_DECODE_STREAMS", "1") == "2"   # measured slower (3.07 vs 2.94 ms/step): off
 
     def _ensure_decode_packs(self):
@@ -325,7 +332,17 @@ class LMEngine:
         for li, ly in enumerate(self.layers):
             ln = ops.layernorm(x, ly.ln_g, ly.ln_b, self.eps)
             lnq = ops.quantize_rows_fp8(ln) if self.fp8_mode else None      # shared by qkv (and fc_in in "all" mode)
-            qkv = self._linear(ly, "qkv", ly.qkv, ln, lnq)
+            h_fused = None
+            if self.fuse_in and not self.fp8_mode:
+                # qkv and gelu(fc_in) in ONE launch over [q | k | v | fc_in] (gelu_new on the fc_in columns only).  At the
+                # BASELINE prefill (M = 8 x 57 = 456 rows) the 256x256 kernel then covers the 28 672 columns with
+                # 2 x 112 = 224 tiles -- one round of the 256 CUs, no split-K fix-up -- instead of 384 + 512 tiles of 128^2
+                # in two under-filled launches
+                d3 = 3 * self.d
+                qh = ops.gemm(ln, ly.in_cat, act=ops.MG_ACT_GELU_NEW, act_n0=d3, tile=256 if 256 < M <= 512 else 0)
+                qkv, h_fused = qh[:, :d3], qh[:, d3:]
+            else:
+                qkv = self._linear(ly, "qkv", ly.qkv, ln, lnq)
             kc, vc = (cache.k[li], cache.v[li]) if cache is not None else (kscr, vscr)
             ops.rotary_split(qkv, B, S, self.H, self.rot, self.sin_t, self.cos_t, q, kc, vc, pos0=0, vt=vt)
             ops.attn_prefill(q, kc, vt, ctx, B, self.H, S, lse=None if lse_out is None else lse_out[li])
@@ -337,7 +354,7 @@ class LMEngine:
             elif ly.attn_adapter is not None:
                 t = self._linear(ly, "attn_dn", ly.attn_adapter[0], a, act=ops.MG_ACT_RELU)
                 a = self._linear(ly, "attn_up", ly.attn_adapter[1], t, residuals=(a,))
-            h = self._linear(ly, "fc_in", ly.fc_in, ln, lnq, act=ops.MG_ACT_GELU_NEW)
+            h = h_fused if h_fused is not None else self._linear(ly, "fc_in", ly.fc_in, ln, lnq, act=ops.MG_ACT_GELU_NEW)
             if ly.mlp_adapter is not None and ly.mlp_par is not None:        # parallel: adapter reads the MLP INPUT
                 sc, up = self._par_up(ly.mlp_adapter[1], ly.mlp_par)
                 m = self._linear(ly, "fc_out", ly.fc_out, h)

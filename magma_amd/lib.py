@@ -32,7 +32,7 @@ class Epilogue(C.Structure):
         ("C", C.c_void_p), ("ldc", C.c_int64),
         ("out_f32", C.c_int32), ("aux_mode", C.c_int32),
         ("aux", C.c_void_p), ("ldaux", C.c_int64),
-        ("aux_after", C.c_int32), ("_pad", C.c_int32),
+        ("aux_after", C.c_int32), ("act_n0", C.c_int32),
         ("C2", C.c_void_p), ("ldc2", C.c_int64),
     ]
 
@@ -96,7 +96,7 @@ SYMBOLS = {
                                            C.POINTER(SkinnyDesc), C.POINTER(SkinnyDesc), _vp, _vp, _vp]),
     "mg_layernorm_bf16": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp]),
     "mg_embedding_bf16": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _i64, _i32, _vp]),
-    "mg_rotary_split_bf16": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp]),
+    "mg_rotary_split_bf16": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp]),
     "mg_rotary_split_train_bf16": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "mg_attn_prefill_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "mg_attn_decode_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),

@@ -88,6 +88,17 @@ class PackedLinear:
         out[: w.shape[0], : w.shape[1]] = w
         return out
 
+    def rows(self, n0: int, n1: int, bias: Optional[torch.Tensor] = None) -> "PackedLinear":
+        """Output channels [n0, n1) of this weight as a PackedLinear that SHARES its storage (n0 % 16 == 0: whole row tiles of
+        the fragment-tiled layout are contiguous)."""
+        assert n0 % 16 == 0 and 0 <= n0 < n1 <= self.N and (n1 % 16 == 0 or n1 == self.N)
+        v = PackedLinear.__new__(PackedLinear)
+        v.N, v.K, v.Kp, v.device = n1 - n0, self.K, self.Kp, self.device
+        v.ft = None if self.ft is None else self.ft[n0 // 16: (n1 + 15) // 16]
+        v.rm = None if self.rm is None else self.rm[n0:n1]
+        v.bias = bias
+        return v
+
     @staticmethod
     def tile(w: torch.Tensor) -> torch.Tensor:
         n, k = w.shape
@@ -146,8 +157,8 @@ def gemm(a: torch.Tensor, w: PackedLinear, out: Optional[torch.Tensor] = None, *
          residuals: Sequence[torch.Tensor] = (), act_after: int = MG_ACT_NONE, scale=None,
          use_bias: bool = True, out_dtype=BF16, layout: Optional[str] = None,
          conv: Optional[tuple] = None, aux=None, aux_mode: int = MG_AUX_NONE, aux_after: bool = False,
-         out2: Optional[torch.Tensor] = None, tile: int = 0, split_k: int = 0) -> torch.Tensor:
-    """out[M,N] = epilogue(a[M,K] @ w^T).  ``conv=(H, W, Cin)`` switches the A
+         out2: Optional[torch.Tensor] = None, tile: int = 0, split_k: int = 0, act_n0: int = 0) -> torch.Tensor:
+    """out[M,N] = epilogue(a[M,K] @ w^T).  ``act_n0``: ``act`` applies to output columns >= act_n0 only.  ``conv=(H, W, Cin)`` switches the A
     loader to implicit-im2col 3x3 over an NHWC image (a = [B*H*W, Cin]).
     ``split_k``: 0 lets the library cut K when the grid would leave the chip idle, 1 never, n forces n."""
     _need_gpu(a)
@@ -180,6 +191,7 @@ def gemm(a: torch.Tensor, w: PackedLinear, out: Optional[torch.Tensor] = None, *
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     d.ep = _epilogue(out, w.N, w.bias if use_bias else None, scale, act, residuals, act_after, aux, aux_mode,
                      aux_after, out2)
+    d.ep.act_n0 = act_n0
     check(L.load().mg_gemm_bf16(C.byref(d), _stream()), "mg_gemm_bf16")
     return out
 
@@ -352,8 +364,9 @@ def embedding(ids: torch.Tensor, wte: torch.Tensor, out: torch.Tensor, row_off: 
 def rotary_split(qkv, B, S, H, rot_dim, sin_t, cos_t, q_out, kcache, vcache, *, pos0: int = 0,
                  d_pos: Optional[torch.Tensor] = None, vt: Optional[torch.Tensor] = None):
     _need_gpu(qkv)
+    assert qkv.ndim == 2 and qkv.stride(1) == 1          # [B*S, >= 3*H*256]: a column range of a wider GEMM output is fine
     Smax = kcache.shape[2]
-    check(L.load().mg_rotary_split_bf16(qkv.data_ptr(), B, S, H, rot_dim, sin_t.data_ptr(), cos_t.data_ptr(), pos0,
+    check(L.load().mg_rotary_split_bf16(qkv.data_ptr(), qkv.stride(0), B, S, H, rot_dim, sin_t.data_ptr(), cos_t.data_ptr(), pos0,
                                         _p(d_pos), q_out.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), Smax,
                                         _p(vt), 0 if vt is None else vt.shape[2] * 32, _stream()),
           "mg_rotary_split_bf16")

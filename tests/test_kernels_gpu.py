@@ -371,6 +371,27 @@ def test_gemm256_deep_pipeline(dev, layout, M, N, K, tile):
         assert float((out.float() - out128.float()).abs().max()) <= 2e-2 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("tile,M", [(0, 77), (0, 456), (256, 456), (0, 1300)])
+def test_gemm_activation_from_column(dev, tile, M):
+    """ep.act_n0: the activation applies to output columns >= act_n0 only -- [q | k | v | fc_in] of a GPT-J block as ONE
+    GEMM with gelu_new on the fc_in columns (engine._blocks_prefill); 128x128 (+ split-K fix-up), 256x256 kernels."""
+    from magma_amd import ops
+    N, K, n0 = 1536 + 2048, 512, 1536
+    a = rnd(M, K, dev=dev, seed=41).to(BF16)
+    w = rnd(N, K, dev=dev, seed=42, scale=0.05).to(BF16)
+    bias = rnd(N, dev=dev, seed=43)
+    lin = ops.PackedLinear(w, bias=bias)
+    out = ops.gemm(a, lin, act=ops.MG_ACT_GELU_NEW, act_n0=n0, tile=tile)
+    ref = a.float() @ w.float().t() + bias
+    ref[:, n0:] = F.gelu(ref[:, n0:], approximate="tanh")
+    assert_close(out, ref, GEMM_TOL, f"act_n0 tile={tile} M={M}")
+    # the two column ranges as separate GEMMs on row views of the same packed weight: same values
+    qkv = ops.gemm(a, lin.rows(0, n0, bias=bias[:n0].contiguous()))
+    h = ops.gemm(a, lin.rows(n0, N, bias=bias[n0:].contiguous()), act=ops.MG_ACT_GELU_NEW)
+    assert float((out[:, :n0].float() - qkv.float()).abs().max()) <= 2e-2 * float(ref.abs().max())
+    assert float((out[:, n0:].float() - h.float()).abs().max()) <= 2e-2 * float(ref.abs().max())
+
+
 @pytest.mark.parametrize("layout", ["rm", "ft"])
 def test_gemm_split_k(dev, layout):
     """Split-K (fp32 slabs + fixed-order fixup) equals the single-pass kernel up to fp32 summation
