@@ -347,6 +347,18 @@ int mg_im2col_nchw_bf16(const mg_bf16* img, mg_bf16* out, int32_t B, int32_t C, 
 int mg_maxpool3x3s2_nhwc_bf16(const mg_bf16* x, mg_bf16* y, int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
 int mg_subsample2_nhwc_bf16(const mg_bf16* x, mg_bf16* y, int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
 int mg_relu_mean_rows_bf16(const mg_bf16* x, mg_bf16* y, int32_t B, int32_t HW, int32_t C, void* stream);
+/* ... and their backward forms (training the nfresnet50 encoder, reference default freeze_img_encoder: false):
+ *   weight_standardize_bwd  dwhat [cout, ldd] fp32 = gradient wrt the standardised weights in the weight's own (cin,ky,kx) order;
+ *                           dw [cout, fan_in] += r (dn - mean(dn) - n mean(dn n)), dgain [cout] += scale sum(dwhat n),
+ *                           n = (w - mean) r, r = rsqrt(var + eps), dn = dwhat * gain * scale   (fp32 accumulate into the caller's buffers);
+ *   maxpool3x3s2_bwd        dx [B,H,W,C] from dy [B,Ho,Wo,C]: routed to the first maximum of each window (PyTorch's choice), as a gather;
+ *   subsample2_bwd          dx[b,2i,2j,:] = dy[b,i,j,:], zero elsewhere;
+ *   relu_mean_rows_bwd      dx[b,p,c] = x[b,p,c] > 0 ? g[b,c] / HW : 0.                                                                   */
+int mg_weight_standardize_bwd_f32(const mg_bf16* w, const mg_bf16* gain, const float* dwhat, int64_t ldd, float* dw, float* dgain,
+                                  int32_t cout, int32_t fan_in, float scale, float eps, float dmult /* dwhat is read times dmult */, void* stream);
+int mg_maxpool3x3s2_bwd_nhwc_bf16(const mg_bf16* x, const mg_bf16* dy, mg_bf16* dx, int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
+int mg_subsample2_bwd_nhwc_bf16(const mg_bf16* dy, mg_bf16* dx, int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
+int mg_relu_mean_rows_bwd_bf16(const mg_bf16* x, const mg_bf16* g, mg_bf16* dx, int32_t B, int32_t HW, int32_t C, void* stream);
 
 /* Data-parallel exchange step over RCCL / xGMI (csrc/comm.hip): the seam that replaces DeepSpeed's gradient reduction
  * (reference magma/train_loop.py:18-19 model_engine.backward / .step, train.py:103-111 deepspeed.initialize, magma/utils.py:26-34

@@ -153,6 +153,110 @@ __global__ __launch_bounds__(1024) void relu_mean_rows_kernel(const mg_bf16* __r
   }
 }
 
+// ---- backward pieces (training the NF-ResNet encoder) --------------------------------------------------------------------
+// ScaledStdConv2d weight transform, backward: with n = (w - mean) * r, r = rsqrt(var + eps), W_hat = n * gain * scale and
+// dn = dW_hat * gain * scale:   dgain += scale * sum(dW_hat * n),   dw += r * (dn - mean(dn) - n * mean(dn * n))
+// (the LayerNorm backward over the fan-in of one output channel).  One workgroup per output channel; fp32 accumulation
+// into the caller's gradient buffers (grad accumulation across micro-steps).
+__global__ __launch_bounds__(256) void weight_standardize_bwd_kernel(const mg_bf16* __restrict__ w, const mg_bf16* __restrict__ gain,
+                                                                     const float* __restrict__ dwhat, int64_t ldd,
+                                                                     float* __restrict__ dw, float* __restrict__ dgain,
+                                                                     int fan_in, float scale, float eps, float dmult) {
+  __shared__ float red[3][4];
+  const int o = blockIdx.x, tid = threadIdx.x;
+  const mg_bf16* row = w + (int64_t)o * fan_in;
+  const float* drow = dwhat + (int64_t)o * ldd;
+  float s = 0.f;
+  for (int i = tid; i < fan_in; i += 256) s += bf2f(row[i]);
+  s = wave_sum(s);
+  if ((tid & 63) == 0) red[0][tid >> 6] = s;
+  __syncthreads();
+  const float mean = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / (float)fan_in;
+  __syncthreads();
+  float d2 = 0.f;
+  for (int i = tid; i < fan_in; i += 256) { const float v = bf2f(row[i]) - mean; d2 += v * v; }
+  d2 = wave_sum(d2);
+  if ((tid & 63) == 0) red[0][tid >> 6] = d2;
+  __syncthreads();
+  const float r = rsqrtf((red[0][0] + red[0][1] + red[0][2] + red[0][3]) / (float)fan_in + eps);
+  __syncthreads();
+  const float gs = bf2f(gain[o]) * scale;
+  float sdn = 0.f, sdnn = 0.f, sdwn = 0.f;
+  for (int i = tid; i < fan_in; i += 256) {
+    const float n = (bf2f(row[i]) - mean) * r, dh = drow[i] * dmult, dn = dh * gs;
+    sdn += dn; sdnn += dn * n; sdwn += dh * n;
+  }
+  sdn = wave_sum(sdn); sdnn = wave_sum(sdnn); sdwn = wave_sum(sdwn);
+  if ((tid & 63) == 0) { red[0][tid >> 6] = sdn; red[1][tid >> 6] = sdnn; red[2][tid >> 6] = sdwn; }
+  __syncthreads();
+  const float m1 = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / (float)fan_in;
+  const float m2 = (red[1][0] + red[1][1] + red[1][2] + red[1][3]) / (float)fan_in;
+  if (tid == 0) dgain[o] += scale * (red[2][0] + red[2][1] + red[2][2] + red[2][3]);
+  float* orow = dw + (int64_t)o * fan_in;
+  for (int i = tid; i < fan_in; i += 256) {
+    const float n = (bf2f(row[i]) - mean) * r;
+    orow[i] += r * (drow[i] * dmult * gs - m1 - n * m2);
+  }
+}
+
+// MaxPool2d(3, stride 2, padding 1) backward as a gather (deterministic, no atomics): an input pixel receives dy of every
+// window whose FIRST maximum (row-major scan of the window, as PyTorch's max_pool2d picks it) it is.
+__global__ __launch_bounds__(256) void maxpool3x3s2_bwd_kernel(const mg_bf16* __restrict__ x, const mg_bf16* __restrict__ dy,
+                                                               mg_bf16* __restrict__ dx, int B, int H, int W, int C, int Ho, int Wo) {
+  const int64_t total = (int64_t)B * H * W * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    int64_t t = i / C;
+    const int xi = (int)(t % W); t /= W;
+    const int yi = (int)(t % H), b = (int)(t / H);
+    float acc = 0.f;
+    for (int yo = max(0, yi / 2); yo <= min(Ho - 1, (yi + 1) / 2); ++yo)
+      for (int xo = max(0, xi / 2); xo <= min(Wo - 1, (xi + 1) / 2); ++xo) {
+        float best = -INFINITY; int by = -1, bx = -1;
+        for (int ky = 0; ky < 3; ++ky) {
+          const int yy = 2 * yo + ky - 1;
+          if (yy < 0 || yy >= H) continue;
+          for (int kx = 0; kx < 3; ++kx) {
+            const int xx = 2 * xo + kx - 1;
+            if (xx < 0 || xx >= W) continue;
+            const float v = bf2f(x[(((int64_t)b * H + yy) * W + xx) * C + c]);
+            if (v > best) { best = v; by = yy; bx = xx; }
+          }
+        }
+        if (by == yi && bx == xi) acc += bf2f(dy[(((int64_t)b * Ho + yo) * Wo + xo) * C + c]);
+      }
+    dx[i] = f2bf(acc);
+  }
+}
+
+// dx[b, 2i, 2j, :] = dy[b, i, j, :], zero elsewhere (backward of subsample2)
+__global__ __launch_bounds__(256) void subsample2_bwd_kernel(const mg_bf16* __restrict__ dy, mg_bf16* __restrict__ dx, int B, int H,
+                                                             int W, int C, int Ho, int Wo) {
+  const int cv = C >> 3;
+  const int64_t total = (int64_t)B * H * W * cv;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % cv);
+    int64_t t = i / cv;
+    const int xi = (int)(t % W); t /= W;
+    const int yi = (int)(t % H), b = (int)(t / H);
+    u32x4 v = (u32x4){0u, 0u, 0u, 0u};
+    if (!(yi & 1) && !(xi & 1)) v = *(const u32x4*)(dy + (((int64_t)b * Ho + (yi >> 1)) * Wo + (xi >> 1)) * C + c * 8);
+    *(u32x4*)(dx + i * 8) = v;
+  }
+}
+
+// dx[b, p, c] = x[b, p, c] > 0 ? g[b, c] / HW : 0  (backward of relu_mean_rows)
+__global__ __launch_bounds__(256) void relu_mean_rows_bwd_kernel(const mg_bf16* __restrict__ x, const mg_bf16* __restrict__ g,
+                                                                 mg_bf16* __restrict__ dx, int B, int HW, int C) {
+  const int64_t total = (int64_t)B * HW * C;
+  const float inv = 1.0f / (float)HW;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const int b = (int)(i / ((int64_t)HW * C));
+    dx[i] = f2bf(bf2f(x[i]) > 0.f ? bf2f(g[(int64_t)b * C + c]) * inv : 0.f);
+  }
+}
+
 }  // namespace
 
 extern "C" int mg_weight_standardize_bf16(const mg_bf16* w, const mg_bf16* gain, mg_bf16* out, int32_t cout, int32_t cin,
@@ -205,6 +309,39 @@ extern "C" int mg_subsample2_nhwc_bf16(const mg_bf16* x, mg_bf16* y, int32_t B, 
 extern "C" int mg_relu_mean_rows_bf16(const mg_bf16* x, mg_bf16* y, int32_t B, int32_t HW, int32_t C, void* stream) {
   if (!x || !y || B <= 0 || HW <= 0 || C <= 0 || (C & 1)) MG_FAIL(MG_ERR_SHAPE, "mg_relu_mean_rows_bf16: need C even");
   hipLaunchKernelGGL(relu_mean_rows_kernel, dim3((C + 63) / 64, B), dim3(1024), 0, (hipStream_t)stream, x, y, HW, C);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
+extern "C" int mg_weight_standardize_bwd_f32(const mg_bf16* w, const mg_bf16* gain, const float* dwhat, int64_t ldd, float* dw,
+                                             float* dgain, int32_t cout, int32_t fan_in, float scale, float eps, float dmult, void* stream) {
+  if (!w || !gain || !dwhat || !dw || !dgain || cout <= 0 || fan_in <= 0 || ldd < fan_in) MG_FAIL(MG_ERR_SHAPE, "mg_weight_standardize_bwd_f32: bad arguments");
+  hipLaunchKernelGGL(weight_standardize_bwd_kernel, dim3(cout), dim3(256), 0, (hipStream_t)stream, w, gain, dwhat, ldd, dw, dgain, fan_in, scale, eps, dmult);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
+extern "C" int mg_maxpool3x3s2_bwd_nhwc_bf16(const mg_bf16* x, const mg_bf16* dy, mg_bf16* dx, int32_t B, int32_t H, int32_t W,
+                                             int32_t C, void* stream) {
+  if (!x || !dy || !dx || B <= 0 || H <= 0 || W <= 0 || C <= 0) MG_FAIL(MG_ERR_SHAPE, "mg_maxpool3x3s2_bwd_nhwc_bf16: bad arguments");
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3(host_grid((int64_t)B * H * W * C, 256)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, B, H, W, C, Ho, Wo);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
+extern "C" int mg_subsample2_bwd_nhwc_bf16(const mg_bf16* dy, mg_bf16* dx, int32_t B, int32_t H, int32_t W, int32_t C, void* stream) {
+  if (!dy || !dx || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7)) MG_FAIL(MG_ERR_SHAPE, "mg_subsample2_bwd_nhwc_bf16: need C %% 8 == 0");
+  if (!MG_ALIGNED16(dy) || !MG_ALIGNED16(dx)) MG_FAIL(MG_ERR_ALIGN, "mg_subsample2_bwd_nhwc_bf16: pointers must be 16-byte aligned");
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  hipLaunchKernelGGL(subsample2_bwd_kernel, dim3(host_grid((int64_t)B * H * W * (C >> 3), 256)), dim3(256), 0, (hipStream_t)stream, dy, dx, B, H, W, C, Ho, Wo);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
+extern "C" int mg_relu_mean_rows_bwd_bf16(const mg_bf16* x, const mg_bf16* g, mg_bf16* dx, int32_t B, int32_t HW, int32_t C, void* stream) {
+  if (!x || !g || !dx || B <= 0 || HW <= 0 || C <= 0) MG_FAIL(MG_ERR_SHAPE, "mg_relu_mean_rows_bwd_bf16: bad arguments");
+  hipLaunchKernelGGL(relu_mean_rows_bwd_kernel, dim3(host_grid((int64_t)B * HW * C, 256)), dim3(256), 0, (hipStream_t)stream, x, g, dx, B, HW, C);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }

@@ -120,6 +120,10 @@ SYMBOLS = {
     "mg_maxpool3x3s2_nhwc_bf16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mg_subsample2_nhwc_bf16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mg_relu_mean_rows_bf16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
+    "mg_weight_standardize_bwd_f32": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _f32, _f32, _f32, _vp]),
+    "mg_maxpool3x3s2_bwd_nhwc_bf16": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "mg_subsample2_bwd_nhwc_bf16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "mg_relu_mean_rows_bwd_bf16": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "mg_build_labels_i64": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i64, _vp]),
     "mg_ce_rows_f32": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _i32, _vp]),
     "mg_ce_reduce_f32": (C.c_int, [_vp, _vp, _i32, _vp, _vp]),

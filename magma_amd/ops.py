@@ -605,6 +605,46 @@ def relu_mean_rows(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
+def weight_standardize_bwd(w: torch.Tensor, gain: torch.Tensor, dwhat: torch.Tensor, dw: torch.Tensor, dgain: torch.Tensor,
+                           scale: float, eps: float, dmult: float = 1.0):
+    """Backward of weight_standardize: dwhat [cout, >= fan_in] fp32 (weight's own column order) -> dw [cout, fan_in] +=, dgain [cout] +=."""
+    _need_gpu(w, gain, dwhat, dw, dgain)
+    cout = w.shape[0]
+    fan_in = w.numel() // cout
+    assert w.dtype == BF16 and gain.dtype == BF16 and w.is_contiguous() and gain.numel() == cout
+    assert dwhat.dtype == torch.float32 and dwhat.ndim == 2 and dwhat.stride(1) == 1 and dwhat.shape[1] >= fan_in
+    assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.numel() == w.numel() and dgain.dtype == torch.float32 and dgain.numel() == cout
+    check(L.load().mg_weight_standardize_bwd_f32(w.data_ptr(), gain.contiguous().data_ptr(), dwhat.data_ptr(), dwhat.stride(0), dw.data_ptr(),
+                                                 dgain.data_ptr(), cout, fan_in, float(scale), float(eps), float(dmult), _stream()), "mg_weight_standardize_bwd_f32")
+
+
+def maxpool3x3s2_bwd(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    _need_gpu(x, dy)
+    assert x.dtype == BF16 and dy.dtype == BF16 and x.is_contiguous() and dy.is_contiguous() and x.ndim == 4
+    B, H, W, Cc = x.shape
+    dx = torch.empty_like(x)
+    check(L.load().mg_maxpool3x3s2_bwd_nhwc_bf16(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), B, H, W, Cc, _stream()), "mg_maxpool3x3s2_bwd_nhwc_bf16")
+    return dx
+
+
+def subsample2_bwd(dy: torch.Tensor, H: int, W: int) -> torch.Tensor:
+    _need_gpu(dy)
+    assert dy.dtype == BF16 and dy.is_contiguous() and dy.ndim == 4
+    B, _, _, Cc = dy.shape
+    dx = torch.empty(B, H, W, Cc, dtype=BF16, device=dy.device)
+    check(L.load().mg_subsample2_bwd_nhwc_bf16(dy.data_ptr(), dx.data_ptr(), B, H, W, Cc, _stream()), "mg_subsample2_bwd_nhwc_bf16")
+    return dx
+
+
+def relu_mean_rows_bwd(x: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
+    _need_gpu(x, g)
+    assert x.dtype == BF16 and g.dtype == BF16 and x.is_contiguous() and g.is_contiguous() and x.ndim == 3
+    B, HW, Cc = x.shape
+    dx = torch.empty_like(x)
+    check(L.load().mg_relu_mean_rows_bwd_bf16(x.data_ptr(), g.data_ptr(), dx.data_ptr(), B, HW, Cc, _stream()), "mg_relu_mean_rows_bwd_bf16")
+    return dx
+
+
 def build_labels(captions: torch.Tensor, prefix_len: int, eos: int) -> torch.Tensor:
     _need_gpu(captions)
     assert captions.dtype == torch.int64 and captions.ndim == 2 and captions.is_contiguous()

@@ -147,6 +147,7 @@ class MagmaEngine:
         if self.fp8 and self.lm_trainable:
             raise NotImplementedError("MAGMA_TRAIN_FP8 quantises the FROZEN block weights once; with freeze_lm: false they change every step")
         self._fp8_packs = {}
+        self._nf_scales = {}
         self._bn_stats = {}
         # the reference's CLIP tower runs BatchNorm on its frozen statistics until the first eval phase and on
         # BATCH statistics afterwards (train.py:164,182 flips it to train mode).  Default here = frozen (steps 0 ..
@@ -724,14 +725,151 @@ class MagmaEngine:
             return None
         return ops.gemm(g, _t(weight.data.view(weight.shape[0], -1)), layout="rm", use_bias=False, **kw)
 
+    def _pooled_encoder_forward(self, images):
+        from .image_encoders import NFResNet50
+        enc = self.module.image_prefix.enc
+        if not any(self.is_trainable(p) for p in enc.parameters()):
+            return enc(images), None               # frozen encoder: inference path, nothing taped
+        if isinstance(enc, NFResNet50):
+            return self._nf_forward(images)
+        return self._vit_forward(images)
+
+    # ---- timm NF-ResNet-50 (encoder_name "nfresnet50"; reference image_encoders.py:31-45), trained -------------------------
+    def _nf_scale(self, c: int, v: float):
+        key = (c, round(v, 9))
+        t = self._nf_scales.get(key)
+        if t is None:
+            t = self._nf_scales[key] = torch.full((c,), v, dtype=F32, device=self.device)
+        return t
+
+    def _nf_conv_fwd(self, conv, a, mult=1.0, bias_mult=1.0, relu=False, geom=None, residual=None, stem=False):
+        """y = act(mult * (W_hat a) + bias_mult * b) (+ residual) with W_hat = the scaled-standardised LIVE weights; returns
+        (y, record for the backward)."""
+        from .image_encoders import NFResNet50 as NF
+        w = conv.weight.data
+        cout, cin, k, _ = w.shape
+        sc = NF.GAMMA * (cin * k * k) ** -0.5
+        wh = ops.weight_standardize(w.contiguous(), conv.gain.data.reshape(-1).contiguous(), sc, NF.EPS,
+                                    ldo=160 if stem else None)                        # [cout, fan_in] in (cin, ky, kx) order
+        bias = self.master_of(conv.bias) if self.is_trainable(conv.bias) else conv.bias.detach().float()
+        if bias_mult != 1.0:
+            bias = bias * bias_mult
+        convarg = None
+        if stem or k == 1:
+            wop = RawWeight(wh, bias=bias)
+        else:
+            wop = RawWeight(ops.conv_weight_relayout(wh.view(cout, cin, k, k), 0), bias=bias, K=k * k * cin)
+            convarg = (geom[1], geom[2], cin)
+        y = ops.gemm(a, wop, scale=self._nf_scale(cout, mult), act=ops.MG_ACT_RELU if relu else ops.MG_ACT_NONE, conv=convarg,
+                     residuals=() if residual is None else (residual,), layout="rm")
+        return y, {"conv": conv, "a": a, "wh": wh, "sc": sc, "mult": mult, "bias_mult": bias_mult, "geom": geom,
+                   "kind": "stem" if stem else ("1x1" if k == 1 else "3x3")}
+
+    def _nf_conv_bwd(self, rec, g, need_dgrad=True, gate=None, residuals=()):
+        """g = gradient wrt the conv's output y (ReLU already gated by the caller).  Accumulates bias / weight / gain gradients
+        through the weight standardisation; returns dL/da, zeroed where ``gate`` <= 0, plus ``residuals``."""
+        from .image_encoders import NFResNet50 as NF
+        conv, a, wh = rec["conv"], rec["a"], rec["wh"]
+        cout, cin, k, _ = conv.weight.shape
+        if self.is_trainable(conv.bias):
+            if rec["bias_mult"] == 1.0:
+                ops.colsum(g, self.grad_of(conv.bias))
+            else:
+                tmpb = torch.zeros(cout, dtype=F32, device=g.device)
+                ops.colsum(g, tmpb)
+                self.grad_of(conv.bias).add_(tmpb, alpha=rec["bias_mult"])
+        if self.is_trainable(conv.weight):
+            gT = _t(g)
+            if rec["kind"] == "3x3":
+                Bq, hh, ww = rec["geom"]
+                xT = RawWeight(ops.im2col_t(a, Bq, hh, ww, cin))
+            else:
+                xT = _t(a)
+            dwh = ops.gemm(gT.rm, xT, out_dtype=F32, layout="rm", use_bias=False)       # [cout, >= fan_in], weight's own order
+            ops.weight_standardize_bwd(conv.weight.data.contiguous(), conv.gain.data.reshape(-1).contiguous(), dwh,
+                                       self.grad_of(conv.weight).view(cout, -1), self.grad_of(conv.gain).view(-1),
+                                       rec["sc"], NF.EPS, dmult=rec["mult"])
+        if not need_dgrad:
+            return None
+        aux_kw = dict(aux=gate, aux_mode=ops.MG_AUX_RELU_GATE) if gate is not None else {}
+        fan_in = cin * k * k
+        w4 = wh[:, :fan_in].contiguous().view(cout, cin, k, k)
+        wop = RawWeight(ops.conv_weight_relayout(w4, 1, self._nf_scale(cout, rec["mult"])), K=k * k * cout)
+        if rec["kind"] == "3x3":
+            Bq, hh, ww = rec["geom"]
+            return ops.gemm(g, wop, conv=(hh, ww, cout), layout="rm", use_bias=False, residuals=residuals, **aux_kw)
+        return ops.gemm(g, wop, layout="rm", use_bias=False, residuals=residuals, **aux_kw)
+
+    def _nf_forward(self, images):
+        enc = self.module.image_prefix.enc
+        x = images.to(BF16).contiguous()
+        B, _, H, W = x.shape
+        if H % 64 or W % 64:
+            raise ValueError(f"nfresnet50 takes images whose sides are multiples of 64, got {H}x{W}")
+        h, w = H // 2, W // 2
+        cols = ops.im2col_nchw(x, 7, 2, 3, 160)
+        y0, stem = self._nf_conv_fwd(enc.stem_conv, cols, stem=True)                      # [B*h*w, 64], no activation
+        y = ops.maxpool3x3s2(y0.view(B, h, w, -1))
+        tape = {"nf": True, "stem": stem, "y0": y0, "geom0": (B, h, w), "blocks": []}
+        h, w = y.shape[1], y.shape[2]
+        y = y.view(B * h * w, -1)
+        one, zero = self._nf_scale(enc.out_dim, 1.0), self._nf_scale(enc.out_dim, 0.0)
+        for stage in enc.stages:
+            for blk in stage:
+                c = y.shape[1]
+                r = ops.bn_apply(y, one[:c], zero[:c], relu=True)                        # relu(x); beta rides in the epilogues
+                br = {"x": y, "geom": (B, h, w), "stride": blk.stride}
+                shortcut = y
+                if blk.downsample is not None:
+                    s_in = ops.avgpool2(r.view(B, h, w, c)).view(B * (h // 2) * (w // 2), c) if blk.stride > 1 else r
+                    shortcut, br["ud"] = self._nf_conv_fwd(blk.downsample.conv, s_in, mult=blk.beta)
+                o1, br["u1"] = self._nf_conv_fwd(blk.conv1, r, mult=blk.beta, relu=True)
+                o2, br["u2"] = self._nf_conv_fwd(blk.conv2, o1, relu=True, geom=(B, h, w))
+                br["o1"], br["o2"] = o1, o2
+                if blk.stride > 1:
+                    o2 = ops.subsample2(o2.view(B, h, w, -1))
+                    h, w = o2.shape[1], o2.shape[2]
+                    o2 = o2.view(B * h * w, -1)
+                y, br["u3"] = self._nf_conv_fwd(blk.conv3, o2, mult=enc.ALPHA, bias_mult=enc.ALPHA, residual=shortcut)
+                br["out_geom"] = (B, h, w)
+                tape["blocks"].append(br)
+        tape["y_last"] = y.view(B, h * w, -1)
+        return ops.relu_mean_rows(tape["y_last"]), tape
+
+    def _nf_backward(self, tape, d_feats):
+        """d_feats: gradient wrt the pooled (B, 2048) features."""
+        enc = self.module.image_prefix.enc
+        yl = tape["y_last"]
+        B = yl.shape[0]
+        g = ops.relu_mean_rows_bwd(yl, d_feats.contiguous()).view(-1, yl.shape[2])       # dL/dy of the last block
+        blocks = [blk for stage in enc.stages for blk in stage]
+        for blk, br in zip(reversed(blocks), reversed(tape["blocks"])):
+            Bq, h, w = br["geom"]
+            _, ho, wo = br["out_geom"]
+            x = br["x"]
+            # residual branch: y = alpha * conv3(o2s) + shortcut
+            g2 = self._nf_conv_bwd(br["u3"], g)                                           # wrt o2 (sub-sampled), ungated
+            if br["stride"] > 1:
+                g2 = ops.subsample2_bwd(g2.view(Bq, ho, wo, -1), h, w).view(Bq * h * w, -1)
+            g2 = ops.add_gate(g2.contiguous(), gate=br["o2"])                              # ReLU of conv2's output
+            g1 = self._nf_conv_bwd(br["u2"], g2, gate=br["o1"])                           # wrt o1, gated by its ReLU
+            d_r = self._nf_conv_bwd(br["u1"], g1)                                         # wrt r = relu(x)
+            # shortcut branch
+            if "ud" in br:
+                d_s = self._nf_conv_bwd(br["ud"], g)
+                if br["stride"] > 1:
+                    d_s = ops.avgpool2_bwd(d_s.view(Bq, ho, wo, -1), Bq, h, w, d_s.shape[1]).view(Bq * h * w, -1)
+                g = ops.add_gate(d_r, d_s, gate=x)                                        # both paths go through relu(x)
+            else:
+                g = ops.add_gate(ops.add_gate(d_r, gate=x), g)                            # relu path gated, identity path not
+        B0, h0, w0 = tape["geom0"]
+        g0 = ops.maxpool3x3s2_bwd(tape["y0"].view(B0, h0, w0, -1), g.view(B0, (h0 - 1) // 2 + 1, (w0 - 1) // 2 + 1, -1))
+        self._nf_conv_bwd(tape["stem"], g0.view(B0 * h0 * w0, -1), need_dgrad=False)
+        self._reduce_params_async([p for p in enc.parameters() if self.is_trainable(p)])
+
     def _vit_forward(self, images):
         """Taped forward of image_encoders.VisionTransformer.forward (same kernels, live parameters)."""
         enc = self.module.image_prefix.enc
-        if not any(self.is_trainable(p) for p in enc.parameters()):
-            return enc(images), None
-        if not hasattr(enc, "patch_size"):
-            raise NotImplementedError(f"training the {type(enc).__name__} image encoder is not implemented (its inference path "
-                                      "is): set freeze_img_encoder: true to train the prefix and the adapters on top of it")
         Pz, w, Hh = enc.patch_size, enc.width, enc.heads
         x = images.to(BF16).contiguous()
         B = x.shape[0]
@@ -793,7 +931,7 @@ class MagmaEngine:
 
     def _pooled_prefix_forward(self, images, dropout_mask):
         ip = self.module.image_prefix
-        feats, vtape = self._vit_forward(images)                                 # (B, enc_dim)
+        feats, vtape = self._pooled_encoder_forward(images)                      # (B, enc_dim)
         B, s, d = feats.shape[0], ip.out_seq_len, ip.out_dim
         y0 = ops.gemm(feats.contiguous(), self._lin(ip.proj.weight, ip.proj.bias), layout="rm").reshape(B * s, d)
         mask = None
@@ -820,7 +958,10 @@ class MagmaEngine:
         d_feats = self._lin_bwd(ip.proj.weight, ip.proj.bias, g, pt["feats"], want_dx=pt["vit"] is not None)
         self._reduce_params_async([p for n, p in ip.named_parameters() if not n.startswith("enc.")])
         if pt["vit"] is not None:
-            self._vit_backward(pt["vit"], d_feats)
+            if "nf" in pt["vit"]:
+                self._nf_backward(pt["vit"], d_feats)
+            else:
+                self._vit_backward(pt["vit"], d_feats)
 
     # The trunk is executed unit by unit; a unit = conv (+ frozen-statistics BN) (+ ReLU).
     def _bn_vectors(self, bn):

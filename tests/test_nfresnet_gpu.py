@@ -135,3 +135,127 @@ def test_magma_with_nfresnet50_encoder(dev):
     eng.backward(out.loss)
     eng.step()
     assert bool(torch.isfinite(out.loss))
+
+
+def test_nfnet_backward_kernels(dev):
+    """weight_standardize_bwd / maxpool / subsample / relu-mean backward kernels against autograd on the same operands."""
+    import torch.nn.functional as F
+    from magma_amd import ops
+    from oracle.nfnet import RELU_GAMMA, standardized_weight
+    g = torch.Generator().manual_seed(2)
+    for cout, cin, k in [(64, 3, 7), (48, 64, 1), (32, 24, 3)]:
+        w = (torch.randn(cout, cin, k, k, generator=g) + 0.4).to(BF16)
+        gain = (1 + 0.2 * torch.randn(cout, 1, 1, 1, generator=g)).to(BF16)
+        fan_in = cin * k * k
+        ld = (fan_in + 15) // 8 * 8
+        dwh = torch.zeros(cout, ld)
+        dwh[:, :fan_in] = torch.randn(cout, fan_in, generator=g)
+        wf, gf = w.float().requires_grad_(True), gain.float().requires_grad_(True)
+        (standardized_weight(wf, gf, 1e-5).reshape(cout, -1) * dwh[:, :fan_in] * 0.7).sum().backward()
+        dw = torch.zeros(cout, fan_in, device=dev)
+        dg = torch.zeros(cout, device=dev)
+        ops.weight_standardize_bwd(w.cuda(), gain.cuda().reshape(-1), dwh.cuda(), dw, dg, RELU_GAMMA * fan_in ** -0.5, 1e-5, dmult=0.7)
+        assert rel(dw, wf.grad.reshape(cout, -1)) < 2e-4 and rel(dg, gf.grad.reshape(-1)) < 2e-4
+    x = torch.randn(2, 16, 10, 14, generator=g).to(BF16)
+    dy = torch.randn(2, 16, 5, 7, generator=g).to(BF16)
+    xf = x.float().requires_grad_(True)
+    F.max_pool2d(xf, 3, stride=2, padding=1).backward(dy.float())
+    got = ops.maxpool3x3s2_bwd(x.permute(0, 2, 3, 1).contiguous().cuda(), dy.permute(0, 2, 3, 1).contiguous().cuda())
+    assert rel(got.permute(0, 3, 1, 2), xf.grad) < 4e-3          # bf16 rounding of sums of up to 4 window gradients
+    ups = ops.subsample2_bwd(dy.permute(0, 2, 3, 1).contiguous().cuda(), 10, 14).permute(0, 3, 1, 2).cpu()
+    ref = torch.zeros(2, 16, 10, 14, dtype=BF16)
+    ref[:, :, ::2, ::2] = dy
+    assert torch.equal(ups, ref)
+    feats = torch.randn(2, 16, generator=g).to(BF16)
+    xf = x.float().requires_grad_(True)
+    (F.relu(xf).mean(dim=(2, 3)) * feats.float()).sum().backward()
+    got = ops.relu_mean_rows_bwd(x.permute(0, 2, 3, 1).reshape(2, 140, 16).contiguous().cuda(), feats.cuda())
+    assert rel(got.view(2, 10, 14, 16).permute(0, 3, 1, 2), xf.grad) < 4e-3
+
+
+def test_nfresnet50_train_gradients(dev):
+    """Training with encoder_name "nfresnet50" and the encoder UNFROZEN (the reference's default freeze_img_encoder: false):
+    loss and the gradient of every trainable tensor -- all 53 scaled-std convs (weight, bias, gain, through the weight
+    standardisation), the pooled prefix Linear + LayerNorm, the LM adapters -- against autograd through the fp32 oracle
+    (oracle/nfnet.py: parity unpinned to timm, see its header).  Tolerance as tests/test_train_gpu.py."""
+    import torch.nn.functional as F
+    from magma_amd.config import MultimodalConfig
+    from magma_amd.language_model import GPTJConfig
+    from magma_amd.magma import Magma
+    from magma_amd.train_engine import MagmaEngine
+    from oracle.model import OracleConfig, build_labels, init_params as init_lm, lm_forward, pooled_prefix_fwd
+    from oracle.nfnet import NFResNetConfig, encoder_fwd, init_params
+    s_img, d, res = 2, 512, 128
+    mcfg = MultimodalConfig(batch_size=2, train_steps=1, encoder_name="nfresnet50", image_seq_len=s_img, image_size=res,
+                            freeze_img_encoder=False, use_image_embed_layernorm=True, image_embed_dropout_prob=0.1,
+                            adapter_config={"mlp": {"adapter_type": "normal", "downsample_factor": 4}},
+                            image_enc_lr=2.0e-6, lr_decay_iters=1000)
+    lm_cfg = GPTJConfig(vocab_size=1056, hidden_size=d, num_layers=2, num_heads=2, rotary_dim=64, intermediate_size=2048,
+                        max_position_embeddings=128)
+    model = Magma(mcfg, device=dev, lm_config=lm_cfg)
+    cfg, c = OracleConfig.tiny(n_positions=128), NFResNetConfig()
+    params = {k: t for k, t in init_lm(cfg, seed=31).items() if not k.startswith("image_prefix.")}
+    for k in params:
+        if ".adapter." in k:
+            params[k] = params[k] * 20
+    params.update(init_params(c, seed=5))
+    g = torch.Generator().manual_seed(9)
+    params["image_prefix.proj.weight"] = torch.randn(s_img * d, 2048, generator=g) * 2048 ** -0.5
+    params["image_prefix.proj.bias"] = torch.randn(s_img * d, generator=g) * 0.02
+    params["image_prefix.ln.weight"] = 1.0 + torch.randn(d, generator=g) * 0.05
+    params["image_prefix.ln.bias"] = torch.randn(d, generator=g) * 0.02
+    missing, unexpected = model.load_checkpoint_state(params)
+    assert not unexpected and not missing, (missing[:4], unexpected[:4])
+    model.config.gradient_accumulation_steps = 1
+    eng = MagmaEngine(model)
+    eng.train()
+    B, S = 2, model.seq_len
+    images = torch.randn(B, 3, res, res, generator=g).to(BF16).float()
+    caps = torch.full((B, S), cfg.eos_token, dtype=torch.int64)
+    caps[0, :23] = torch.randint(0, 1000, (23,), generator=g)
+    caps[1, :11] = torch.randint(0, 1000, (11,), generator=g)
+    mask = (torch.rand(B, s_img, d, generator=g) < 0.9).float() / 0.9
+    names = [k for k in params if ".adapter." in k or k.startswith("image_prefix.")]
+
+    def oracle(dtype):
+        p = {k: (t.detach().to(dtype).clone() if t.is_floating_point() else t) for k, t in params.items()}
+        for k in names:
+            p[k].requires_grad_(True)
+        prefix = pooled_prefix_fwd(p, d, s_img, encoder_fwd(p, c, images.to(dtype)), dropout_mask=mask.to(dtype))
+        labels = build_labels(s_img, caps, cfg.eos_token)
+        words = F.embedding(caps, p["lm.transformer.wte.weight"]).to(prefix.dtype)
+        out = lm_forward(p, cfg, inputs_embeds=torch.cat((prefix, words[:, : S - s_img, :]), dim=1), labels=labels)
+        out["loss"].backward()
+        return float(out["loss"].detach()), {k: p[k].grad.float() for k in names}
+
+    loss_ref, g_ref = oracle(torch.float32)
+    loss_bf, g_bf = oracle(BF16)
+    out = eng(images.to(dev), caps.to(dev), dropout_mask=mask.to(dev))
+    assert abs(float(out.loss) - loss_ref) <= 2 * abs(loss_bf - loss_ref) + 3e-3 * abs(loss_ref), (float(out.loss), loss_ref, loss_bf)
+    eng.backward(out.loss)
+    name_of = {id(p): n for n, p in model.named_parameters()}
+    seen, bad, worst = set(), [], []
+    dots = n1 = n2 = bd = b1 = 0.0
+    for grp in eng.groups:
+        for p in grp.params:
+            n = name_of[id(p)]
+            n = "lm." + n if n.startswith("transformer.") else n
+            if n in seen or n not in g_ref:
+                continue
+            seen.add(n)
+            got, ref, gb = eng.grad_of(p).float().cpu().reshape(-1), g_ref[n].reshape(-1), g_bf[n].reshape(-1)
+            e_hip, e_bf = rel(got, ref), rel(gb, ref)
+            worst.append((e_hip - 2 * e_bf, n, e_hip, e_bf))
+            if e_hip > 2 * e_bf + 3e-2:
+                bad.append((n, e_hip, e_bf))
+            dots += float((got * ref).sum()); n1 += float((got * got).sum()); n2 += float((ref * ref).sum())
+            bd += float((gb * ref).sum()); b1 += float((gb * gb).sum())
+    worst.sort(reverse=True)
+    print("nf train: loss", float(out.loss), loss_ref, loss_bf, "| worst:", [(n, f"{a:.2e}", f"{b:.2e}") for _, n, a, b in worst[:5]])
+    assert len(seen) == len(g_ref) and len(seen) > 160, (len(seen), len(g_ref), sorted(set(g_ref) - seen)[:5])
+    assert not bad, bad[:8]
+    cos_hip, cos_bf = dots / (n1 ** 0.5 * n2 ** 0.5), bd / (b1 ** 0.5 * n2 ** 0.5)
+    assert 1 - cos_hip <= 2 * (1 - cos_bf) + 1e-3, (cos_hip, cos_bf)
+    eng.step()
+    eng.eval()
+    assert torch.isfinite(eng(images.to(dev), caps.to(dev)).loss)
