@@ -384,13 +384,16 @@ def main():
     args = parse()
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    local = int(os.environ.get("LOCAL_RANK", 0))
+    # one rank per GPU over RCCL.  MAGMA_BENCH_DEVICE / MAGMA_BENCH_BACKEND exist for ONE purpose: rehearsing the multi-rank
+    # control flow (collective order, barriers, rank-0-only sections) with two processes on a single-GPU box (gloo, both
+    # ranks on device 0) -- tools/gpu_bench_2rank_rehearsal.sh; numbers from such a run mean nothing
+    local = int(os.environ.get("MAGMA_BENCH_DEVICE", os.environ.get("LOCAL_RANK", 0)))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(os.environ.get("MAGMA_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
     from magma_amd import Magma
     from magma_amd.language_model import GPTJConfig
 

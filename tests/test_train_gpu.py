@@ -364,3 +364,45 @@ def test_batch_statistics_batchnorm(dev):
             assert rel(params[k], v) > 1e-3 or "running_var" in k            # the statistics did move
     # and the inference path now normalises with the updated statistics
     assert torch.isfinite(eng(images.to(dev), caps).loss)
+
+
+def test_train_step_on_an_on_disk_dataset_with_mixed_image_modes(dev, tmp_path):
+    """reference train.py:34-66 + magma/datasets/dataset.py:92-160 end to end: a dataset directory in the reference's layout with
+    RGB AND greyscale images, read by ImgCptDataset through the model's own transform (device pipeline for RGB, PIL for the rest --
+    both must land on one device or collate_fn's torch.cat fails), split into train / eval by eval_dataset_pct, fed to train_step /
+    eval_step through the engine's loader."""
+    import json
+    import numpy as np
+    import PIL.Image as I
+    from types import SimpleNamespace
+    from magma_amd.datasets import get_pretraining_datasets
+    from magma_amd.testing import build_reduced_magma
+    from magma_amd.train_engine import initialize
+    from magma_amd.train_loop import eval_step, train_step
+    from magma_amd.utils import cycle
+    (tmp_path / "image_data" / "00000").mkdir(parents=True)
+    (tmp_path / "images" / "00000").mkdir(parents=True)
+    rng = np.random.RandomState(0)
+    for i in range(12):
+        arr = (rng.rand(90 + i, 120) * 255).astype("uint8") if i % 3 == 1 else (rng.rand(90 + i, 120, 3) * 255).astype("uint8")
+        I.fromarray(arr).save(tmp_path / "images" / "00000" / f"{i}.png")
+        (tmp_path / "image_data" / "00000" / f"{i}.json").write_text(json.dumps(
+            {"captions": [f"caption number {i}"], "image_path": f"images/00000/{i}.png"}))
+    torch.manual_seed(2)
+    model = build_reduced_magma(dev, n_positions=128)
+    cfg = model.config
+    cfg.gradient_accumulation_steps, cfg.eval_steps, cfg.batch_size = 1, 1, 4
+    dcfg = SimpleNamespace(train_dataset_dir=str(tmp_path), eval_dataset_dir=None, eval_dataset_pct=0.25)
+    train_ds, eval_ds = get_pretraining_datasets(dcfg, model.tokenizer, model.transforms, seq_len=model.seq_len, split_seed=0)
+    assert len(train_ds) == 9 and len(eval_ds) == 3
+    modes = {train_ds[i][0].device.type for i in range(len(train_ds))}
+    assert modes == {"cuda"}, modes
+    engine, _, _, _ = initialize(model, cfg)
+    loader = cycle(engine.deepspeed_io(train_ds, batch_size=4))
+    eloader = cycle(engine.deepspeed_io(eval_ds, batch_size=3))
+    engine.train()
+    l0 = train_step(cfg, loader, engine)
+    l1 = train_step(cfg, loader, engine)
+    engine.eval()
+    ev = eval_step(cfg, eloader, engine)
+    assert all(float(v) > 0 and float(v) == float(v) for v in (l0, l1, ev))
