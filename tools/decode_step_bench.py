@@ -30,3 +30,24 @@ for rep in range(3):
     res.append(e0.elapsed_time(e1) / 40)
 print(json.dumps({"knobs": {k: v for k, v in os.environ.items() if k.startswith("MAGMA_")}, "token_step_ms": min(res), "all": res,
                   "hbm_frac": 12.156e9 / (min(res) * 1e-3) / 8e12}))
+# optional sweep of the fused ln_1+qkv+fc_in GEMV's variant (nt | waves << 4 | kc << 8) inside this process:
+#   DEC_IN_VARIANTS=2177,4225,... python tools/decode_step_bench.py
+for v in [int(x) for x in os.environ.get("DEC_IN_VARIANTS", "").split(",") if x]:
+    eng._dec_in_variant = v
+    cache.decode_state.graphs.clear()
+    cache.pos = int(emb.shape[1]); cache.d_pos.fill_(cache.pos)       # same context length for every variant
+    try:
+        for _ in range(3):
+            eng.decode(tok, cache)
+        best = 1e9
+        for rep in range(3):
+            cache.pos = int(emb.shape[1]); cache.d_pos.fill_(cache.pos)
+            torch.cuda.synchronize(); e0.record()
+            for _ in range(40):
+                eng.decode(tok, cache)
+            e1.record(); torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) / 40)
+        print(json.dumps({"dec_in_variant": {"nt": v & 15, "waves": (v >> 4) & 15, "kc": v >> 8}, "token_step_ms": best}))
+    except Exception as e:  # noqa: BLE001
+        print(json.dumps({"dec_in_variant": v, "error": str(e)[:200]}))
+
