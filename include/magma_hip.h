@@ -136,6 +136,24 @@ int64_t mg_gemm_workspace_bytes(int32_t M, int32_t N, int32_t K);
  * to byte pairs, Kp (ldw) multiple of 128; dense A only; 128x128 tile kernel (split-K as for bf16).  Output
  * bf16 / fp32.                                                                                               */
 int mg_gemm_fp8(const mg_gemm_desc* d, const float* row_scale, void* stream);
+/* OCP MX (microscaling) form -- BASELINE config 5 as SURVEY 8d states it: e4m3 elements with ONE E8M0 scale per 32 consecutive
+ * K-elements of every operand row, multiplied by v_mfma_scale_f32_16x16x128_f8f6f4 with those block scales (no per-row / per-column
+ * scale, fp32 accumulate).
+ *   mg_quantize_mx_fp8  x [M, K] bf16 -> q [M, ldq] e4m3 (ldq % 128 == 0, zero padded) + scales [M, ld_scales] uint32: dword c of
+ *                       a row = the four E8M0 bytes of blocks 4c .. 4c+3 (shared exponent floor(log2 max|x|) - 8, biased by 127;
+ *                       elements saturate at +-448).  Inside every 128-element chunk block b is stored as bytes [16 b, 16 b + 16)
+ *                       and [64 + 16 b, 64 + 16 b + 16) -- the two 16-byte pieces one MFMA lane consumes -- so q is only meaningful
+ *                       to mg_gemm_mx_fp8 (both operands use the same permutation: the dot products are unaffected).
+ *   mg_gemm_mx_fp8      descriptor as for mg_gemm_fp8 (K / lda / ldw count fp8 elements; rows padded to whole 128-element chunks;
+ *                       row-major or fragment-tiled W built from the quantiser's row-major image), a_scales / w_scales from the
+ *                       quantiser.  128x128 tile kernel (split-K as for bf16); the usual epilogue.
+ *   mg_debug_mx_mfma    test probe: ONE wave-level MFMA on caller-supplied operand registers (a, b: [64 lanes][8] dwords) and
+ *                       per-lane scale dwords -> out [64][4]; pins the instruction's lane / block / scale-byte semantics.            */
+int mg_quantize_mx_fp8(const mg_bf16* x, int64_t ldx, int32_t M, int32_t K, uint8_t* q, int64_t ldq, uint32_t* scales,
+                       int64_t ld_scales, void* stream);
+int mg_gemm_mx_fp8(const mg_gemm_desc* d, const uint32_t* a_scales, int64_t ld_a_scales, const uint32_t* w_scales,
+                   int64_t ld_w_scales, void* stream);
+int mg_debug_mx_mfma(const uint32_t* a, const uint32_t* scale_a, const uint32_t* b, const uint32_t* scale_b, float* out, void* stream);
 /* bf16 rows -> e4m3 rows + one fp32 scale per row (x ~= q * scale[m], scale = rowmax|x| / 448, round to
  * nearest even, saturating); q columns [K, ldq) are zero-filled.  K, ldx, ldq multiples of 8.                */
 int mg_quantize_rows_fp8(const mg_bf16* x, int64_t ldx, int32_t M, int32_t K, uint8_t* q, int64_t ldq,

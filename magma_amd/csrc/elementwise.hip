@@ -572,6 +572,93 @@ __global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const mg_bf16* _
 }
 }  // namespace
 
+// ---------------------------------------------------------------------------
+// OCP MX (microscaling) quantiser: bf16 rows -> e4m3 elements with ONE E8M0 scale per 32 consecutive elements
+// (OCP MX v1.0: shared exponent = floor(log2(max|x|)) - emax(e4m3 = 8), element = saturate_e4m3(x * 2^-shared)),
+// the operand format of v_mfma_scale_f32_16x16x128_f8f6f4.  A lane of that MFMA supplies the 32 bytes of ONE block
+// (row = lane & 15, block = lane >> 4 of the 128-wide k-chunk) and its scale byte; the GEMM kernels feed it the two
+// 16-byte pieces [16 b, 16 b + 16) and [64 + 16 b, 64 + 16 b + 16) of the chunk's 128-byte row image, so the quantiser
+// stores block b THERE (first / second half of its 32 elements): the kernels' loaders, LDS images and the fragment tiling
+// of the weights stay what they are.  scales[row][chunk] = one dword, byte b = E8M0 of block b.
+// One workgroup per row, 4 lanes per block.
+// ---------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void quantize_mx_fp8_kernel(const mg_bf16* __restrict__ x, int64_t ldx, int K,
+                                                              uint8_t* __restrict__ q, int64_t ldq,
+                                                              uint32_t* __restrict__ scales, int64_t lds) {
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const mg_bf16* xr = x + (int64_t)row * ldx;
+  uint8_t* qr = q + (int64_t)row * ldq;
+  for (int c = tid * 8; c < (int)ldq; c += 256 * 8) {          // ldq % 128 == 0: whole blocks, whole quads of lanes
+    float f[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = 0.f;
+    if (c < K) {                                                // K % 8 == 0
+      const u32x4 w = *(const u32x4*)(xr + c);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { f[2 * i] = bflo(w[i]); f[2 * i + 1] = bfhi(w[i]); }
+    }
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(f[i]));
+    amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+    amax = fmaxf(amax, __shfl_xor(amax, 2, 64));               // the 4 lanes of a block are consecutive
+    // floor(log2(amax)) from the exponent field (amax is a bf16 value: normal or zero; bf16 subnormals -> exponent field 0)
+    const int ef = (int)((__float_as_uint(amax) >> 23) & 0xff);
+    int e8 = amax > 0.f ? ef - 8 : 127;                          // E8M0 byte = floor(log2 amax) - 8 + 127 = ef - 127 - 8 + 127
+    e8 = max(0, min(254, e8));
+    const float inv = __uint_as_float((uint32_t)(254 - e8) << 23);   // 2^-(e8 - 127)  (e8 in [0, 254] -> exponent field 254 - e8)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = fminf(fmaxf(f[i] * inv, -448.f), 448.f);
+    int lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+    const int chunk = c >> 7, e = c & 127, b = e >> 5, r = e & 31;               // r in {0, 8, 16, 24}
+    const int phys = (chunk << 7) + (r < 16 ? b * 16 + r : 64 + b * 16 + (r - 16));
+    const u32x2 o = {(uint32_t)lo, (uint32_t)hi};
+    *(u32x2*)(qr + phys) = o;
+    if (r == 0) ((uint8_t*)(scales + (int64_t)row * lds + chunk))[b] = (uint8_t)e8;
+  }
+}
+
+// one wave, one v_mfma_scale_f32_16x16x128_f8f6f4: lane l supplies 32 operand bytes + one scale dword per operand.
+// Test-only probe of the instruction's lane / block / scale-byte semantics (tests/test_fp8_gpu.py).
+__global__ __launch_bounds__(64) void mx_mfma_probe_kernel(const uint32_t* __restrict__ a, const uint32_t* __restrict__ sa,
+                                                           const uint32_t* __restrict__ b, const uint32_t* __restrict__ sb,
+                                                           float* __restrict__ out) {
+  typedef __attribute__((ext_vector_type(8))) int i32x8_;
+  const int l = threadIdx.x;
+  i32x8_ av, bv;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { av[i] = (int)a[l * 8 + i]; bv[i] = (int)b[l * 8 + i]; }
+  f32x4 c = {0.f, 0.f, 0.f, 0.f};
+  c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bv, c, 0, 0, 0, (int)sa[l], 0, (int)sb[l]);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) out[l * 4 + r] = c[r];
+}
+}  // namespace
+
+extern "C" int mg_quantize_mx_fp8(const mg_bf16* x, int64_t ldx, int32_t M, int32_t K, uint8_t* q, int64_t ldq,
+                                  uint32_t* scales, int64_t ld_scales, void* stream) {
+  if (!x || !q || !scales) MG_FAIL(MG_ERR_SHAPE, "mg_quantize_mx_fp8: null pointer");
+  if (M <= 0 || K <= 0 || (K & 7) || (ldx & 7) || (ldq & 127) || ldq < K || ldx < K || ld_scales < (ldq >> 7))
+    MG_FAIL(MG_ERR_SHAPE, "mg_quantize_mx_fp8: need K, ldx multiples of 8, ldq a multiple of 128 >= K, ld_scales >= ldq / 128");
+  if (!MG_ALIGNED16(x) || ((uintptr_t)q & 7) || ((uintptr_t)scales & 3)) MG_FAIL(MG_ERR_ALIGN, "mg_quantize_mx_fp8: x 16-byte, q 8-byte, scales 4-byte aligned");
+  hipLaunchKernelGGL(quantize_mx_fp8_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, x, ldx, K, q, ldq, scales, ld_scales);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
+extern "C" int mg_debug_mx_mfma(const uint32_t* a, const uint32_t* scale_a, const uint32_t* b, const uint32_t* scale_b, float* out,
+                                void* stream) {
+  if (!a || !scale_a || !b || !scale_b || !out) MG_FAIL(MG_ERR_SHAPE, "mg_debug_mx_mfma: null pointer");
+  hipLaunchKernelGGL(mx_mfma_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, scale_a, b, scale_b, out);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
 extern "C" int mg_quantize_rows_fp8(const mg_bf16* x, int64_t ldx, int32_t M, int32_t K, uint8_t* q, int64_t ldq,
                                     float* scale, void* stream) {
   if (!x || !q || !scale) MG_FAIL(MG_ERR_SHAPE, "mg_quantize_rows_fp8: null pointer");

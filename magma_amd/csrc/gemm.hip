@@ -81,6 +81,8 @@ struct GemmParams {
   int splits, kt_per;
   int nt;            // non-temporal output stores (large outputs)
   const float* row_scale;   // fp8 path: per-row scale of the A operand (nullptr otherwise)
+  // MX fp8 path (mg_gemm_mx_fp8): E8M0 block scales, one dword per (row, 128-wide k-chunk), byte b = block b; nullptr: unit scales
+  const uint32_t* mx_a; const uint32_t* mx_w; int64_t ld_mxa, ld_mxw;
   float* ws; int64_t ldws;
   mg_epilogue ep;
 };
@@ -220,6 +222,16 @@ __global__ __launch_bounds__(256) void gemm128_kernel(const GemmParams p) {
     if (kt + 1 < kt1) stage(kt + 1, cur ^ 1);
     const char* sb = smem + cur * STAGE_BYTES;
     if constexpr (FP8) {
+      // MX: this K-tile's block scales of the wave's 4 + 4 fragment rows (one dword per row and 128-wide chunk; this lane's
+      // block is byte lq) -- L2-resident, 1/32 of the operand bytes; issued before the fragment reads
+      uint32_t sa[4] = {127u, 127u, 127u, 127u}, sw[4] = {127u, 127u, 127u, 127u};
+      if (p.mx_a) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          sa[t] = p.mx_a[(int64_t)min(m0 + wm * 64 + t * 16 + li, p.M - 1) * p.ld_mxa + kt] >> (lq * 8);
+          sw[t] = p.mx_w[(int64_t)min(n0 + wn * 64 + t * 16 + li, p.N - 1) * p.ld_mxw + kt] >> (lq * 8);
+        }
+      }
       i32x8 af[4], bfr[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t)
@@ -230,7 +242,7 @@ __global__ __launch_bounds__(256) void gemm128_kernel(const GemmParams p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = mfma_fp8_k128(bfr[j], af[i], acc[i][j]);
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma_mx_k128(bfr[j], sw[j], af[i], sa[i], acc[i][j]);
     } else {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -681,7 +693,8 @@ int launch_skinny(const SkinnyParams& sp, hipStream_t s) {
 namespace {
 // Shared by mg_gemm_bf16 and mg_gemm_fp8: validation, tile / split-K policy, launch.  For fp8 the descriptor counts
 // e4m3 elements; the kernels see pairs of them (K/2, lda/2, ldw/2) -- same byte images, see gemm128_kernel.
-int gemm_dispatch(const mg_gemm_desc* d, bool fp8, const float* row_scale, hipStream_t s, const char* who) {
+struct MxScales { const uint32_t* a; int64_t lda; const uint32_t* w; int64_t ldw; };
+int gemm_dispatch(const mg_gemm_desc* d, bool fp8, const float* row_scale, hipStream_t s, const char* who, const MxScales* mx = nullptr) {
   if (!d) MG_FAIL(MG_ERR_SHAPE, "%s: null descriptor", who);
   if (d->M <= 0 || d->N <= 0 || d->K <= 0) MG_FAIL(MG_ERR_SHAPE, "%s: M,N,K must be positive (%d,%d,%d)", who, d->M, d->N, d->K);
   const int epb = fp8 ? 2 : 1;               // descriptor elements per kernel element
@@ -698,6 +711,7 @@ int gemm_dispatch(const mg_gemm_desc* d, bool fp8, const float* row_scale, hipSt
   gp.tiles_m = (d->M + BM - 1) / BM; gp.tiles_n = (d->N + BN - 1) / BN;
   gp.ep = d->ep;
   gp.row_scale = row_scale;
+  gp.mx_a = mx ? mx->a : nullptr; gp.mx_w = mx ? mx->w : nullptr; gp.ld_mxa = mx ? mx->lda : 0; gp.ld_mxw = mx ? mx->ldw : 0;
   // outputs far larger than the caches are streamed out with non-temporal stores (measured -9 % on the
   // 256x256 kernel at K = 4096: the tile no longer evicts the operand panels from L2)
   gp.nt = (int64_t)d->M * d->N * (d->ep.out_f32 ? 4 : 2) >= (int64_t)64 << 20;
@@ -773,6 +787,20 @@ extern "C" int64_t mg_gemm_workspace_bytes(int32_t M, int32_t N, int32_t K) {
 
 extern "C" int mg_gemm_bf16(const mg_gemm_desc* d, void* stream) {
   return gemm_dispatch(d, false, nullptr, (hipStream_t)stream, "mg_gemm_bf16");
+}
+
+// MX (OCP microscaling) form of mg_gemm_fp8: operands and E8M0 block scales from mg_quantize_mx_fp8; no row / column scales.
+extern "C" int mg_gemm_mx_fp8(const mg_gemm_desc* d, const uint32_t* a_scales, int64_t ld_a_scales, const uint32_t* w_scales,
+                              int64_t ld_w_scales, void* stream) {
+  if (!d) MG_FAIL(MG_ERR_SHAPE, "mg_gemm_mx_fp8: null descriptor");
+  const int64_t chunks = ((int64_t)d->K + 127) / 128;
+  if (!a_scales || !w_scales || ld_a_scales < chunks || ld_w_scales < chunks) MG_FAIL(MG_ERR_SHAPE, "mg_gemm_mx_fp8: block scales missing or their row stride < ceil(K / 128)");
+  if (d->lda < chunks * 128 || d->ldw < chunks * 128) MG_FAIL(MG_ERR_SHAPE, "mg_gemm_mx_fp8: operand rows must be padded to whole 128-element chunks (mg_quantize_mx_fp8)");
+  if (d->tile_hint == 256) MG_FAIL(MG_ERR_UNSUPPORTED, "mg_gemm_mx_fp8: block scales are wired into the 128x128 kernel only");
+  const MxScales mx{a_scales, ld_a_scales, w_scales, ld_w_scales};
+  mg_gemm_desc dd = *d;
+  dd.tile_hint = 128;
+  return gemm_dispatch(&dd, true, nullptr, (hipStream_t)stream, "mg_gemm_mx_fp8", &mx);
 }
 
 extern "C" int mg_gemm_fp8(const mg_gemm_desc* d, const float* row_scale, void* stream) {

@@ -991,3 +991,98 @@ def gemm_fp8(aq: torch.Tensor, a_scale: torch.Tensor, w: PackedLinearFP8, out: O
     d.ep = _epilogue(out, w.N, w.bias if use_bias else None, w.scale, act, residuals, act_after, aux, aux_mode, aux_after, out2)
     check(L.load().mg_gemm_fp8(C.byref(d), a_scale.data_ptr(), _stream()), "mg_gemm_fp8")
     return out
+
+
+# ---- OCP MX fp8 (BASELINE config 5 as stated: e4m3 elements + one E8M0 scale per 32 K-elements) ---------------------------------
+def mx_unpermute(q: torch.Tensor) -> torch.Tensor:
+    """Quantiser storage order -> logical K order (uint8 [R, ldq], ldq % 128 == 0): inside every 128-chunk block b lives at bytes
+    [16 b, 16 b + 16) and [64 + 16 b, 64 + 16 b + 16)."""
+    R, ld = q.shape
+    return q.view(R, ld // 128, 2, 4, 16).permute(0, 1, 3, 2, 4).reshape(R, ld)
+
+
+def quantize_mx_fp8(x: torch.Tensor):
+    """bf16 [M, K] -> (uint8 e4m3 [M, ldq] in the MFMA's block order, zero padded to ldq = ceil(K / 128) * 128;
+    int32 [M, ldq / 128] block scales: byte b of dword c = E8M0 exponent of block 4c + b)."""
+    _need_gpu(x)
+    assert x.dtype == BF16 and x.ndim == 2 and x.stride(1) == 1
+    M, K = x.shape
+    ldq = ceil_to(K, 128)
+    q = torch.empty(M, ldq, dtype=torch.uint8, device=x.device)
+    scales = torch.empty(M, ldq // 128, dtype=torch.int32, device=x.device)
+    check(L.load().mg_quantize_mx_fp8(x.data_ptr(), x.stride(0), M, K, q.data_ptr(), ldq, scales.data_ptr(), scales.stride(0), _stream()),
+          "mg_quantize_mx_fp8")
+    return q, scales
+
+
+def mx_dequant(q: torch.Tensor, scales: torch.Tensor, K: int) -> torch.Tensor:
+    """fp32 [R, K] values an MX operand stands for (tests; the fp8 'dequantised oracle')."""
+    R, ld = q.shape
+    e = scales.view(torch.uint8).view(R, ld // 32).float()                         # one byte per 32-block, blocks in order
+    v = mx_unpermute(q).view(torch.float8_e4m3fn).float().view(R, ld // 32, 32) * torch.exp2(e - 127.0)[:, :, None]
+    return v.reshape(R, ld)[:, :K]
+
+
+class PackedLinearMX:
+    """A [N, K] weight as MX fp8: e4m3 bytes in the quantiser's block order (row-major and / or fragment-tiled exactly like
+    PackedLinearFP8 -- the tiling acts on the byte image) + E8M0 block scales [N, Kp / 128] int32."""
+
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, tiled: bool = True, rowmajor: bool = False):
+        _need_gpu(weight)
+        self.N, self.K = weight.shape
+        assert self.K % 16 == 0, "fp8 GEMM needs K % 16 == 0"
+        self.Kp = ceil_to(self.K, 128)
+        n16 = ceil_to(self.N, 16)
+        w = torch.zeros(n16, self.K, dtype=BF16, device=weight.device)
+        w[: self.N] = weight.detach().to(BF16)
+        q, sc = quantize_mx_fp8(w)
+        self._q_rm = q[: self.N] if rowmajor else None
+        self.scales = sc[: self.N].contiguous()
+        self.bias = None if bias is None else bias.detach().to(torch.float32).contiguous()
+        self.rm = q[: self.N].contiguous() if rowmajor else None
+        self.ft = PackedLinear.tile(q.view(torch.int16)).view(torch.uint8) if tiled else None
+        self._n16 = n16
+
+    def dequant(self) -> torch.Tensor:
+        q = self.rm if self.rm is not None else PackedLinear.untile(self.ft.view(torch.int16)).view(torch.uint8)[: self.N]
+        return mx_dequant(q.contiguous(), self.scales, self.K)
+
+
+def gemm_mx_fp8(aq: torch.Tensor, a_scales: torch.Tensor, w: PackedLinearMX, out: Optional[torch.Tensor] = None, *,
+                act: int = MG_ACT_NONE, residuals: Sequence[torch.Tensor] = (), act_after: int = MG_ACT_NONE, use_bias: bool = True,
+                out_dtype=BF16, layout: Optional[str] = None, split_k: int = 0, act_n0: int = 0) -> torch.Tensor:
+    """out[M,N] = epilogue(sum over 32-blocks of 2^(ea + ew) * (qa . qw)) on the block-scaled fp8 MFMA (fp32 accumulate)."""
+    _need_gpu(aq, a_scales)
+    assert aq.dtype == torch.uint8 and aq.ndim == 2 and aq.stride(1) == 1 and aq.shape[1] == w.Kp
+    assert a_scales.dtype == torch.int32 and a_scales.shape == (aq.shape[0], w.Kp // 128)
+    M = aq.shape[0]
+    if out is None:
+        out = torch.empty(M, ceil_to(w.N, 8), dtype=out_dtype, device=aq.device)[:, : w.N]
+    d = GemmDesc()
+    d.A, d.lda = aq.data_ptr(), aq.stride(0)
+    if layout is None:
+        layout = "ft" if w.ft is not None else "rm"
+    if layout == "ft":
+        d.W, d.ldw, d.w_layout = w.ft.data_ptr(), w.Kp, MG_W_FRAGTILED
+    else:
+        d.W, d.ldw, d.w_layout = w.rm.data_ptr(), w.rm.stride(0), MG_W_ROWMAJOR
+    d.M, d.N, d.K = M, w.N, w.Kp
+    d.a_mode = MG_A_DENSE
+    d.zero_page = zero_page(aq.device).data_ptr()
+    d.split_k = split_k
+    if split_k != 1:
+        ws = splitk_workspace(aq.device)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    d.ep = _epilogue(out, w.N, w.bias if use_bias else None, None, act, residuals, act_after)
+    d.ep.act_n0 = act_n0
+    check(L.load().mg_gemm_mx_fp8(C.byref(d), a_scales.data_ptr(), a_scales.stride(0), w.scales.data_ptr(), w.scales.stride(0),
+                                  _stream()), "mg_gemm_mx_fp8")
+    return out
+
+
+def debug_mx_mfma(a: torch.Tensor, sa: torch.Tensor, b: torch.Tensor, sb: torch.Tensor) -> torch.Tensor:
+    """One v_mfma_scale_f32_16x16x128_f8f6f4 on explicit per-lane operands: a, b int32 [64, 8]; sa, sb int32 [64] -> fp32 [64, 4]."""
+    _need_gpu(a, sa, b, sb)
+    out = torch.empty(64, 4, dtype=torch.float32, device=a.device)
+    check(L.load().mg_debug_mx_mfma(a.data_ptr(), sa.data_ptr(), b.data_ptr(), sb.data_ptr(), out.data_ptr(), _stream()), "mg_debug_mx_mfma")
+    return out

@@ -214,3 +214,86 @@ def test_w8a16_generate_tracks_bf16(dev):
     clear = (top2[:, 0] - top2[:, 1]) > 0.2 * logits[False].std(dim=-1)
     assert bool((logits[True].argmax(-1)[clear] == logits[False].argmax(-1)[clear]).all())
     assert not torch.equal(logits[True], logits[False])
+
+
+# ---------------------------------------------------------------------------------------------------- OCP MX block scaling
+def _mx_ref_quant(x):
+    """OCP MX v1.0 restated in torch: per 32 consecutive elements, shared exponent floor(log2 max|x|) - 8 (E8M0, bias 127),
+    elements = saturating e4m3 cast of x * 2^-shared.  Returns (e4m3 values as fp32 [M, Kp], E8M0 bytes [M, Kp/32])."""
+    M, K = x.shape
+    Kp = (K + 127) // 128 * 128
+    xf = torch.zeros(M, Kp, device=x.device)
+    xf[:, :K] = x.float()
+    blk = xf.view(M, Kp // 32, 32)
+    amax = blk.abs().amax(-1)
+    e = torch.where(amax > 0, torch.floor(torch.log2(amax)) - 8 + 127, torch.full_like(amax, 127.0)).clamp(0, 254)
+    q = (blk * torch.exp2(127.0 - e)[:, :, None]).clamp(-448, 448).to(torch.float8_e4m3fn).float()
+    return q.view(M, Kp), e
+
+
+def test_mx_mfma_lane_and_scale_semantics(dev):
+    """Pins what the product relies on: lane l of v_mfma_scale_f32_16x16x128_f8f6f4 supplies row / column l & 15 and the 32
+    elements of k-block l >> 4; byte 0 of its scale dword (opsel 0) multiplies exactly those 32 products by 2^(s - 127);
+    D[i = row of A][j = column of B] sits in lane j + 16 * (i >> 2), register i & 3."""
+    from magma_amd import ops
+    one = 0x38                                    # e4m3 1.0
+    ones = torch.full((64, 8), one * 0x01010101, dtype=torch.int64, device=dev).to(torch.int32)
+    g = torch.Generator(device=dev).manual_seed(0)
+    ea = torch.randint(120, 134, (16, 4), generator=g, device=dev)        # A scale exponents per (row, block)
+    eb = torch.randint(120, 134, (16, 4), generator=g, device=dev)
+    lane = torch.arange(64, device=dev)
+    sa = (ea[lane & 15, lane >> 4] | (0x55 << 8) | (0x33 << 16)).to(torch.int32)      # garbage in the upper bytes must not matter
+    sb = eb[lane & 15, lane >> 4].to(torch.int32)
+    out = ops.debug_mx_mfma(ones, sa, ones, sb)
+    ref = (32.0 * torch.exp2(ea.float() - 127)[:, None, :] * torch.exp2(eb.float() - 127)[None, :, :]).sum(-1)   # [i, j]
+    got = torch.empty(16, 16, device=dev)
+    for r in range(4):
+        got[(lane >> 4) * 4 + r, lane & 15] = out[:, r]
+    assert torch.equal(got, ref), (got - ref).abs().max()
+
+
+@pytest.mark.parametrize("M,K", [(5, 64), (37, 1000), (8, 4096), (3, 16384)])
+def test_quantize_mx(dev, M, K):
+    from magma_amd import ops
+    g = torch.Generator(device=dev).manual_seed(M * K + 1)
+    x = (torch.randn(M, K, device=dev, generator=g) * torch.logspace(-3, 2, M, device=dev)[:, None]).to(BF16)
+    x[0, 1] = 0
+    if K >= 64:
+        x[-1, 32:64] = 0                                       # an all-zero block
+    q, sc = ops.quantize_mx_fp8(x)
+    rq, re = _mx_ref_quant(x)
+    Kp = q.shape[1]
+    assert Kp % 128 == 0 and sc.shape == (M, Kp // 128)
+    assert torch.equal(sc.view(torch.uint8).view(M, Kp // 32).float(), re)
+    got = ops.mx_unpermute(q).view(torch.float8_e4m3fn).float()
+    assert torch.equal(got, rq)                                 # same rounding (nearest even, saturating), same block order
+    assert rel(ops.mx_dequant(q, sc, K), x) < 0.04
+
+
+@pytest.mark.parametrize("layout", ["rm", "ft"])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (300, 200, 192), (77, 1056, 1008), (456, 4096, 4096), (2048, 1024, 4096)])
+def test_gemm_mx_fp8(dev, layout, M, N, K):
+    """mg_gemm_mx_fp8 against the exact restatement: products of the e4m3 values, per-block power-of-two scales, fp32 sum; and
+    the block-scaled quantisation is at least as close to the unquantised product as the per-row scaled one."""
+    from magma_amd import ops
+    g = torch.Generator(device=dev).manual_seed(M + N + K + 7)
+    a = (torch.randn(M, K, device=dev, generator=g) * (1 + 30 * (torch.rand(1, K, device=dev, generator=g) < 0.02))).to(BF16)   # outlier channels
+    w = (torch.randn(N, K, device=dev, generator=g) * 0.05).to(BF16)
+    bias = torch.randn(N, device=dev, generator=g)
+    res = torch.randn(M, ops.ceil_to(N, 8), device=dev, generator=g).to(BF16)
+    lin = ops.PackedLinearMX(w, bias=bias, tiled=True, rowmajor=True)
+    aq, asc = ops.quantize_mx_fp8(a)
+    ad, wd = ops.mx_dequant(aq, asc, K), lin.dequant()
+    ref = F.gelu(ad.double() @ wd.double().t() + bias.double(), approximate="tanh").float() + res[:, :N].float()
+    out = ops.gemm_mx_fp8(aq, asc, lin, layout=layout, act=ops.MG_ACT_GELU_NEW, residuals=(res,), out_dtype=torch.float32)
+    assert rel(out, ref) < 1e-4, rel(out, ref)
+    for sk in (1, 3):
+        o2 = ops.gemm_mx_fp8(aq, asc, lin, layout=layout, act=ops.MG_ACT_GELU_NEW, residuals=(res,), out_dtype=torch.float32, split_k=sk)
+        assert rel(o2, ref) < 1e-4
+    full = a.float() @ w.float().t()
+    plain = ops.gemm_mx_fp8(aq, asc, lin, layout=layout, use_bias=False, out_dtype=torch.float32)
+    q8, s8 = ops.quantize_rows_fp8(a)
+    rowscaled = ops.gemm_fp8(q8, s8, ops.PackedLinearFP8(w), use_bias=False, out_dtype=torch.float32)
+    e_mx, e_row = rel(plain, full), rel(rowscaled, full)
+    print(f"{M}x{N}x{K}: MX block scales {e_mx:.3e}, per-row / per-channel scales {e_row:.3e}")
+    assert e_mx < 0.06 and e_mx <= 1.1 * e_row
