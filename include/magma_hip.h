@@ -139,13 +139,11 @@ int mg_gemm_fp8(const mg_gemm_desc* d, const float* row_scale, void* stream);
 /* OCP MX (microscaling) form -- BASELINE config 5 as SURVEY 8d states it: e4m3 elements with ONE E8M0 scale per 32 consecutive
  * K-elements of every operand row, multiplied by v_mfma_scale_f32_16x16x128_f8f6f4 with those block scales (no per-row / per-column
  * scale, fp32 accumulate).
- *   mg_quantize_mx_fp8  x [M, K] bf16 -> q [M, ldq] e4m3 (ldq % 128 == 0, zero padded) + scales [M, ld_scales] uint32: dword c of
- *                       a row = the four E8M0 bytes of blocks 4c .. 4c+3 (shared exponent floor(log2 max|x|) - 8, biased by 127;
- *                       elements saturate at +-448).  Inside every 128-element chunk block b is stored as bytes [16 b, 16 b + 16)
- *                       and [64 + 16 b, 64 + 16 b + 16) -- the two 16-byte pieces one MFMA lane consumes -- so q is only meaningful
- *                       to mg_gemm_mx_fp8 (both operands use the same permutation: the dot products are unaffected).
+ *   mg_quantize_mx_fp8  x [M, K] bf16 -> q [M, ldq] e4m3 in K order (ldq % 128 == 0, zero padded) + scales [M, ld_scales] uint32:
+ *                       dword c of a row = the four E8M0 bytes of blocks 4c .. 4c+3 (shared exponent floor(log2 max|x|) - 8,
+ *                       biased by 127; elements saturate at +-448) -- the plain OCP MX layout.
  *   mg_gemm_mx_fp8      descriptor as for mg_gemm_fp8 (K / lda / ldw count fp8 elements; rows padded to whole 128-element chunks;
- *                       row-major or fragment-tiled W built from the quantiser's row-major image), a_scales / w_scales from the
+ *                       row-major or fragment-tiled W: the bf16 tiling applied to the byte pairs of the row-major image), a_scales / w_scales from the
  *                       quantiser.  128x128 tile kernel (split-K as for bf16); the usual epilogue.
  *   mg_debug_mx_mfma    test probe: ONE wave-level MFMA on caller-supplied operand registers (a, b: [64 lanes][8] dwords) and
  *                       per-lane scale dwords -> out [64][4]; pins the instruction's lane / block / scale-byte semantics.            */

@@ -575,11 +575,12 @@ __global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const mg_bf16* _
 // ---------------------------------------------------------------------------
 // OCP MX (microscaling) quantiser: bf16 rows -> e4m3 elements with ONE E8M0 scale per 32 consecutive elements
 // (OCP MX v1.0: shared exponent = floor(log2(max|x|)) - emax(e4m3 = 8), element = saturate_e4m3(x * 2^-shared)),
-// the operand format of v_mfma_scale_f32_16x16x128_f8f6f4.  A lane of that MFMA supplies the 32 bytes of ONE block
-// (row = lane & 15, block = lane >> 4 of the 128-wide k-chunk) and its scale byte; the GEMM kernels feed it the two
-// 16-byte pieces [16 b, 16 b + 16) and [64 + 16 b, 64 + 16 b + 16) of the chunk's 128-byte row image, so the quantiser
-// stores block b THERE (first / second half of its 32 elements): the kernels' loaders, LDS images and the fragment tiling
-// of the weights stay what they are.  scales[row][chunk] = one dword, byte b = E8M0 of block b.
+// the operand format of v_mfma_scale_f32_16x16x128_f8f6f4.  Layout = the plain one: elements in K order, scales[row][chunk]
+// = one dword per 128-element chunk whose byte b is the E8M0 of block b.  That IS what the instruction consumes
+// (measured, tests/test_fp8_gpu.py::test_mx_mfma_lane_and_scale_semantics): lane l supplies row l & 15; its registers 0-3
+// are k = 16 (l >> 4) .. + 15 and its registers 4-7 k = 64 + 16 (l >> 4) .. + 15 of the 128-wide chunk -- exactly the two
+// 16-byte pieces the GEMM kernels' loaders already hand it -- and the scale of block b of a row is read from lane
+// row + 16 b (so lane l supplies the scale byte of block l >> 4, although its own elements belong to two other blocks).
 // One workgroup per row, 4 lanes per block.
 // ---------------------------------------------------------------------------
 namespace {
@@ -616,9 +617,8 @@ __global__ __launch_bounds__(256) void quantize_mx_fp8_kernel(const mg_bf16* __r
     hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
     hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
     const int chunk = c >> 7, e = c & 127, b = e >> 5, r = e & 31;               // r in {0, 8, 16, 24}
-    const int phys = (chunk << 7) + (r < 16 ? b * 16 + r : 64 + b * 16 + (r - 16));
     const u32x2 o = {(uint32_t)lo, (uint32_t)hi};
-    *(u32x2*)(qr + phys) = o;
+    *(u32x2*)(qr + c) = o;
     if (r == 0) ((uint8_t*)(scales + (int64_t)row * lds + chunk))[b] = (uint8_t)e8;
   }
 }

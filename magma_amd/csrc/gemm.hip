@@ -222,8 +222,8 @@ __global__ __launch_bounds__(256) void gemm128_kernel(const GemmParams p) {
     if (kt + 1 < kt1) stage(kt + 1, cur ^ 1);
     const char* sb = smem + cur * STAGE_BYTES;
     if constexpr (FP8) {
-      // MX: this K-tile's block scales of the wave's 4 + 4 fragment rows (one dword per row and 128-wide chunk; this lane's
-      // block is byte lq) -- L2-resident, 1/32 of the operand bytes; issued before the fragment reads
+      // MX: this K-tile's block scales of the wave's 4 + 4 fragment rows (one dword per row and 128-wide chunk; this lane
+      // supplies block lq's byte) -- L2-resident, 1/32 of the operand bytes; issued before the fragment reads
       uint32_t sa[4] = {127u, 127u, 127u, 127u}, sw[4] = {127u, 127u, 127u, 127u};
       if (p.mx_a) {
 #pragma unroll

@@ -14,8 +14,9 @@ typedef __attribute__((ext_vector_type(4))) int i32x4;
 MG_DEV f32x4 mfma_fp8_k128(i32x8 a, i32x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0 /*A: e4m3*/, 0 /*B: e4m3*/, 0, 0x7F7F7F7F /*2^0*/, 0, 0x7F7F7F7F);
 }
-// the same with the MX block scales of the two operands: byte 0 of sa / sb = E8M0 scale of the 32 elements THIS lane supplies
-// (block lane >> 4 of row lane & 15 of the 128-wide k-chunk) -- mg_quantize_mx_fp8's layout
+// the same with the MX block scales of the two operands: byte 0 of sa / sb = E8M0 scale of block (lane >> 4) of row (lane & 15)
+// of the 128-wide k-chunk (the hardware reads block b's scale from lane row + 16 b; the lane's own 32 bytes are
+// k = 16 q .. 16 q + 15 and 64 + 16 q .. 64 + 16 q + 15, q = lane >> 4: the chunk's plain byte order)
 MG_DEV f32x4 mfma_mx_k128(i32x8 a, uint32_t sa, i32x8 b, uint32_t sb, f32x4 c) {
   return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, (int)sa, 0, (int)sb);
 }

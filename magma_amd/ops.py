@@ -994,16 +994,9 @@ def gemm_fp8(aq: torch.Tensor, a_scale: torch.Tensor, w: PackedLinearFP8, out: O
 
 
 # ---- OCP MX fp8 (BASELINE config 5 as stated: e4m3 elements + one E8M0 scale per 32 K-elements) ---------------------------------
-def mx_unpermute(q: torch.Tensor) -> torch.Tensor:
-    """Quantiser storage order -> logical K order (uint8 [R, ldq], ldq % 128 == 0): inside every 128-chunk block b lives at bytes
-    [16 b, 16 b + 16) and [64 + 16 b, 64 + 16 b + 16)."""
-    R, ld = q.shape
-    return q.view(R, ld // 128, 2, 4, 16).permute(0, 1, 3, 2, 4).reshape(R, ld)
-
-
 def quantize_mx_fp8(x: torch.Tensor):
-    """bf16 [M, K] -> (uint8 e4m3 [M, ldq] in the MFMA's block order, zero padded to ldq = ceil(K / 128) * 128;
-    int32 [M, ldq / 128] block scales: byte b of dword c = E8M0 exponent of block 4c + b)."""
+    """bf16 [M, K] -> (uint8 e4m3 [M, ldq] in K order, zero padded to ldq = ceil(K / 128) * 128;
+    int32 [M, ldq / 128] block scales: byte b of dword c = E8M0 exponent of block 4c + b) -- the plain OCP MX layout."""
     _need_gpu(x)
     assert x.dtype == BF16 and x.ndim == 2 and x.stride(1) == 1
     M, K = x.shape
@@ -1019,13 +1012,13 @@ def mx_dequant(q: torch.Tensor, scales: torch.Tensor, K: int) -> torch.Tensor:
     """fp32 [R, K] values an MX operand stands for (tests; the fp8 'dequantised oracle')."""
     R, ld = q.shape
     e = scales.view(torch.uint8).view(R, ld // 32).float()                         # one byte per 32-block, blocks in order
-    v = mx_unpermute(q).view(torch.float8_e4m3fn).float().view(R, ld // 32, 32) * torch.exp2(e - 127.0)[:, :, None]
+    v = q.view(torch.float8_e4m3fn).float().view(R, ld // 32, 32) * torch.exp2(e - 127.0)[:, :, None]
     return v.reshape(R, ld)[:, :K]
 
 
 class PackedLinearMX:
-    """A [N, K] weight as MX fp8: e4m3 bytes in the quantiser's block order (row-major and / or fragment-tiled exactly like
-    PackedLinearFP8 -- the tiling acts on the byte image) + E8M0 block scales [N, Kp / 128] int32."""
+    """A [N, K] weight as MX fp8: e4m3 bytes (row-major and / or fragment-tiled exactly like PackedLinearFP8 -- the tiling acts
+    on the byte image) + E8M0 block scales [N, Kp / 128] int32."""
 
     def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, tiled: bool = True, rowmajor: bool = False):
         _need_gpu(weight)
@@ -1036,7 +1029,6 @@ class PackedLinearMX:
         w = torch.zeros(n16, self.K, dtype=BF16, device=weight.device)
         w[: self.N] = weight.detach().to(BF16)
         q, sc = quantize_mx_fp8(w)
-        self._q_rm = q[: self.N] if rowmajor else None
         self.scales = sc[: self.N].contiguous()
         self.bias = None if bias is None else bias.detach().to(torch.float32).contiguous()
         self.rm = q[: self.N].contiguous() if rowmajor else None
