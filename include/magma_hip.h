@@ -139,18 +139,20 @@ int mg_gemm_fp8(const mg_gemm_desc* d, const float* row_scale, void* stream);
 /* OCP MX (microscaling) form -- BASELINE config 5 as SURVEY 8d states it: e4m3 elements with ONE E8M0 scale per 32 consecutive
  * K-elements of every operand row, multiplied by v_mfma_scale_f32_16x16x128_f8f6f4 with those block scales (no per-row / per-column
  * scale, fp32 accumulate).
- *   mg_quantize_mx_fp8  x [M, K] bf16 -> q [M, ldq] e4m3 in K order (ldq % 128 == 0, zero padded) + scales [M, ld_scales] uint32:
- *                       dword c of a row = the four E8M0 bytes of blocks 4c .. 4c+3 (shared exponent floor(log2 max|x|) - 8,
- *                       biased by 127; elements saturate at +-448) -- the plain OCP MX layout.
+ *   mg_quantize_mx_fp8  x [M, K] bf16 -> q [M, ldq] e4m3 in K order (ldq == ceil(K / 128) * 128, zero padded) + the E8M0 block
+ *                       scales (shared exponent floor(log2 max|x|) - 8, biased by 127; elements saturate at +-448) as
+ *                       mg_mx_scale_bytes(M, K) bytes: with R = ceil(M / 64), byte ((((k / 128) * 4 + (k / 32) % 4) * R + m / 64) * 16
+ *                       + m % 16) * 4 + (m % 64) / 16 is the scale of (row m, block k / 32) -- one dword load hands an MFMA lane
+ *                       what it supplies for four 16-row fragments of a 64-row slab (rows >= M of the last slab: unwritten).
  *   mg_gemm_mx_fp8      descriptor as for mg_gemm_fp8 (K / lda / ldw count fp8 elements; rows padded to whole 128-element chunks;
- *                       row-major or fragment-tiled W: the bf16 tiling applied to the byte pairs of the row-major image), a_scales / w_scales from the
- *                       quantiser.  128x128 tile kernel (split-K as for bf16); the usual epilogue.
+ *                       row-major or fragment-tiled W: the bf16 tiling applied to the byte pairs of the row-major image), the scale
+ *                       arrays of the two operands from the quantiser (4-byte aligned).  128x128 tile kernel (split-K as for
+ *                       bf16; the 256x256 fp8 kernel has no register left for the scale operands); the usual epilogue.
  *   mg_debug_mx_mfma    test probe: ONE wave-level MFMA on caller-supplied operand registers (a, b: [64 lanes][8] dwords) and
  *                       per-lane scale dwords -> out [64][4]; pins the instruction's lane / block / scale-byte semantics.            */
-int mg_quantize_mx_fp8(const mg_bf16* x, int64_t ldx, int32_t M, int32_t K, uint8_t* q, int64_t ldq, uint32_t* scales,
-                       int64_t ld_scales, void* stream);
-int mg_gemm_mx_fp8(const mg_gemm_desc* d, const uint32_t* a_scales, int64_t ld_a_scales, const uint32_t* w_scales,
-                   int64_t ld_w_scales, void* stream);
+int64_t mg_mx_scale_bytes(int32_t rows, int32_t K);
+int mg_quantize_mx_fp8(const mg_bf16* x, int64_t ldx, int32_t M, int32_t K, uint8_t* q, int64_t ldq, uint8_t* scales, void* stream);
+int mg_gemm_mx_fp8(const mg_gemm_desc* d, const uint8_t* a_scales, const uint8_t* w_scales, void* stream);
 int mg_debug_mx_mfma(const uint32_t* a, const uint32_t* scale_a, const uint32_t* b, const uint32_t* scale_b, float* out, void* stream);
 /* bf16 rows -> e4m3 rows + one fp32 scale per row (x ~= q * scale[m], scale = rowmax|x| / 448, round to
  * nearest even, saturating); q columns [K, ldq) are zero-filled.  K, ldx, ldq multiples of 8.                */

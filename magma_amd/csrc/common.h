@@ -95,6 +95,13 @@ MG_DEV void glds4a(const void* g, char* lds_wave_base) {
   asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dword %0, off"
                :: "v"(g), "s"(__builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(mg_lptr_t)lds_wave_base)) : "memory");
 }
+// an ordinary dword load issued from assembly (SGPR base + 32-bit per-lane byte offset): like the DMA forms above it is
+// invisible to hipcc's wait-count pass, so a loop that retires its VMEM traffic with hand-counted vmcnt waits can carry it
+// without the compiler draining the ring in front of the first use.  The CALLER guarantees that one of its own waits
+// retires the load before dst is read (dst must not be touched in between).
+MG_DEV void gld32s_async(uint32_t& dst, const void* base_uniform, uint32_t byte_off) {
+  asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(byte_off), "s"(base_uniform) : "memory");
+}
 #define MG_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 // vmcnt(0) through the BUILTIN (gfx9 encoding: vmcnt = 0, expcnt / lgkmcnt untouched): unlike the inline-asm
 // form this one updates hipcc's own scoreboard, so it does not re-wait (vmcnt(0), draining the DMA ring)

@@ -575,18 +575,21 @@ __global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const mg_bf16* _
 // ---------------------------------------------------------------------------
 // OCP MX (microscaling) quantiser: bf16 rows -> e4m3 elements with ONE E8M0 scale per 32 consecutive elements
 // (OCP MX v1.0: shared exponent = floor(log2(max|x|)) - emax(e4m3 = 8), element = saturate_e4m3(x * 2^-shared)),
-// the operand format of v_mfma_scale_f32_16x16x128_f8f6f4.  Layout = the plain one: elements in K order, scales[row][chunk]
-// = one dword per 128-element chunk whose byte b is the E8M0 of block b.  That IS what the instruction consumes
+// the operand format of v_mfma_scale_f32_16x16x128_f8f6f4.  Elements: the plain layout, K order.  That IS what the instruction consumes
 // (measured, tests/test_fp8_gpu.py::test_mx_mfma_lane_and_scale_semantics): lane l supplies row l & 15; its registers 0-3
 // are k = 16 (l >> 4) .. + 15 and its registers 4-7 k = 64 + 16 (l >> 4) .. + 15 of the 128-wide chunk -- exactly the two
 // 16-byte pieces the GEMM kernels' loaders already hand it -- and the scale of block b of a row is read from lane
 // row + 16 b (so lane l supplies the scale byte of block l >> 4, although its own elements belong to two other blocks).
+// Scales: bytes arranged so that ONE dword load gives a lane what it supplies for four 16-row MFMA fragments at once -- the
+// dword index is ((chunk * 4 + block) * ceil(R / 64) + row / 64) * 16 + row % 16 and byte (row % 64) / 16 inside it is the
+// E8M0 of (row, 4 * chunk + block): a wave's 64-row slab of a K-tile costs one load per lane, the MFMA picks the fragment's
+// byte with its op_sel field (mx_scale_index below; ops.mx_scales_rowmajor undoes it for the tests).
 // One workgroup per row, 4 lanes per block.
 // ---------------------------------------------------------------------------
 namespace {
 __global__ __launch_bounds__(256) void quantize_mx_fp8_kernel(const mg_bf16* __restrict__ x, int64_t ldx, int K,
                                                               uint8_t* __restrict__ q, int64_t ldq,
-                                                              uint32_t* __restrict__ scales, int64_t lds) {
+                                                              uint8_t* __restrict__ scales, int rgroups) {
   const int row = blockIdx.x, tid = threadIdx.x;
   const mg_bf16* xr = x + (int64_t)row * ldx;
   uint8_t* qr = q + (int64_t)row * ldq;
@@ -619,7 +622,7 @@ __global__ __launch_bounds__(256) void quantize_mx_fp8_kernel(const mg_bf16* __r
     const int chunk = c >> 7, e = c & 127, b = e >> 5, r = e & 31;               // r in {0, 8, 16, 24}
     const u32x2 o = {(uint32_t)lo, (uint32_t)hi};
     *(u32x2*)(qr + c) = o;
-    if (r == 0) ((uint8_t*)(scales + (int64_t)row * lds + chunk))[b] = (uint8_t)e8;
+    if (r == 0) scales[((((int64_t)chunk * 4 + b) * rgroups + (row >> 6)) * 16 + (row & 15)) * 4 + ((row & 63) >> 4)] = (uint8_t)e8;
   }
 }
 
@@ -640,13 +643,18 @@ __global__ __launch_bounds__(64) void mx_mfma_probe_kernel(const uint32_t* __res
 }
 }  // namespace
 
+extern "C" int64_t mg_mx_scale_bytes(int32_t rows, int32_t K) {
+  if (rows <= 0 || K <= 0) return 0;
+  return (int64_t)((K + 127) / 128) * 4 * ((rows + 63) / 64) * 64;
+}
+
 extern "C" int mg_quantize_mx_fp8(const mg_bf16* x, int64_t ldx, int32_t M, int32_t K, uint8_t* q, int64_t ldq,
-                                  uint32_t* scales, int64_t ld_scales, void* stream) {
+                                  uint8_t* scales, void* stream) {
   if (!x || !q || !scales) MG_FAIL(MG_ERR_SHAPE, "mg_quantize_mx_fp8: null pointer");
-  if (M <= 0 || K <= 0 || (K & 7) || (ldx & 7) || (ldq & 127) || ldq < K || ldx < K || ld_scales < (ldq >> 7))
-    MG_FAIL(MG_ERR_SHAPE, "mg_quantize_mx_fp8: need K, ldx multiples of 8, ldq a multiple of 128 >= K, ld_scales >= ldq / 128");
+  if (M <= 0 || K <= 0 || (K & 7) || (ldx & 7) || (ldq & 127) || ldq < K || ldx < K || ldq != ((K + 127) / 128) * 128)
+    MG_FAIL(MG_ERR_SHAPE, "mg_quantize_mx_fp8: need K, ldx multiples of 8 and ldq == ceil(K / 128) * 128");
   if (!MG_ALIGNED16(x) || ((uintptr_t)q & 7) || ((uintptr_t)scales & 3)) MG_FAIL(MG_ERR_ALIGN, "mg_quantize_mx_fp8: x 16-byte, q 8-byte, scales 4-byte aligned");
-  hipLaunchKernelGGL(quantize_mx_fp8_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, x, ldx, K, q, ldq, scales, ld_scales);
+  hipLaunchKernelGGL(quantize_mx_fp8_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, x, ldx, K, q, ldq, scales, (M + 63) / 64);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }

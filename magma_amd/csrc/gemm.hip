@@ -81,8 +81,9 @@ struct GemmParams {
   int splits, kt_per;
   int nt;            // non-temporal output stores (large outputs)
   const float* row_scale;   // fp8 path: per-row scale of the A operand (nullptr otherwise)
-  // MX fp8 path (mg_gemm_mx_fp8): E8M0 block scales, one dword per (row, 128-wide k-chunk), byte b = block b; nullptr: unit scales
-  const uint32_t* mx_a; const uint32_t* mx_w; int64_t ld_mxa, ld_mxw;
+  // MX fp8 path (mg_gemm_mx_fp8): E8M0 block scales in mg_quantize_mx_fp8's dword layout
+  // [(chunk * 4 + block) * rgroups + row / 64][row % 16] with byte (row % 64) / 16; nullptr: unit scales
+  const uint32_t* mx_a; const uint32_t* mx_w; int rg_a, rg_w;
   float* ws; int64_t ldws;
   mg_epilogue ep;
 };
@@ -214,24 +215,27 @@ __global__ __launch_bounds__(256) void gemm128_kernel(const GemmParams p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // MX block scales (mg_gemm_mx_fp8): per K-tile ONE dword per operand and lane -- byte t = what this lane supplies for fragment
+  // t of the wave's 64-row slab (mg_quantize_mx_fp8's layout; the MFMA's op_sel picks the byte).  Tile kt + 1's pair is loaded
+  // from assembly while tile kt is multiplied (invisible to hipcc's wait counting, retired by the loop's vmcnt(0)).
+  uint32_t mx_sa = 0x7f7f7f7fu, mx_sw = 0x7f7f7f7fu, mx_sa_n = 0x7f7f7f7fu, mx_sw_n = 0x7f7f7f7fu;
+  const bool mx = FP8 && p.mx_a != nullptr;
+  const uint32_t mx_oa = (uint32_t)(((lq * p.rg_a + min((m0 >> 6) + wm, p.rg_a - 1)) * 16 + li) * 4);      // slabs past M / N: rows
+  const uint32_t mx_ow = (uint32_t)(((lq * p.rg_w + min((n0 >> 6) + wn, p.rg_w - 1)) * 16 + li) * 4);      // that are never stored
+  auto mx_load = [&](int kt, uint32_t& a, uint32_t& w) {
+    gld32s_async(a, (const char*)p.mx_a + (int64_t)kt * p.rg_a * 256, mx_oa);
+    gld32s_async(w, (const char*)p.mx_w + (int64_t)kt * p.rg_w * 256, mx_ow);
+  };
+  if (mx) mx_load(kt0, mx_sa, mx_sw);
   stage(kt0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   int cur = 0;
   for (int kt = kt0; kt < kt1; ++kt) {
-    if (kt + 1 < kt1) stage(kt + 1, cur ^ 1);
+    if (kt + 1 < kt1) { stage(kt + 1, cur ^ 1); if (mx) mx_load(kt + 1, mx_sa_n, mx_sw_n); }
     const char* sb = smem + cur * STAGE_BYTES;
     if constexpr (FP8) {
-      // MX: this K-tile's block scales of the wave's 4 + 4 fragment rows (one dword per row and 128-wide chunk; this lane
-      // supplies block lq's byte) -- L2-resident, 1/32 of the operand bytes; issued before the fragment reads
-      uint32_t sa[4] = {127u, 127u, 127u, 127u}, sw[4] = {127u, 127u, 127u, 127u};
-      if (p.mx_a) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          sa[t] = p.mx_a[(int64_t)min(m0 + wm * 64 + t * 16 + li, p.M - 1) * p.ld_mxa + kt] >> (lq * 8);
-          sw[t] = p.mx_w[(int64_t)min(n0 + wn * 64 + t * 16 + li, p.N - 1) * p.ld_mxw + kt] >> (lq * 8);
-        }
-      }
+      // MX block scales of this K-tile: loaded one tile ahead (below), retired by the loop's own vmcnt(0) before the barrier
       i32x8 af[4], bfr[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t)
@@ -242,7 +246,7 @@ __global__ __launch_bounds__(256) void gemm128_kernel(const GemmParams p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = mfma_mx_k128(bfr[j], sw[j], af[i], sa[i], acc[i][j]);
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma_mx_k128(bfr[j], j, mx_sw, af[i], i, mx_sa, acc[i][j]);
     } else {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -260,6 +264,7 @@ __global__ __launch_bounds__(256) void gemm128_kernel(const GemmParams p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tile landed
     __syncthreads();                                   // ... for everyone, and everyone is done reading `cur`
+    if (mx) { asm volatile("" : "+v"(mx_sa_n), "+v"(mx_sw_n)); mx_sa = mx_sa_n; mx_sw = mx_sw_n; }
     cur ^= 1;
   }
 
@@ -693,7 +698,7 @@ int launch_skinny(const SkinnyParams& sp, hipStream_t s) {
 namespace {
 // Shared by mg_gemm_bf16 and mg_gemm_fp8: validation, tile / split-K policy, launch.  For fp8 the descriptor counts
 // e4m3 elements; the kernels see pairs of them (K/2, lda/2, ldw/2) -- same byte images, see gemm128_kernel.
-struct MxScales { const uint32_t* a; int64_t lda; const uint32_t* w; int64_t ldw; };
+struct MxScales { const uint32_t* a; const uint32_t* w; };
 int gemm_dispatch(const mg_gemm_desc* d, bool fp8, const float* row_scale, hipStream_t s, const char* who, const MxScales* mx = nullptr) {
   if (!d) MG_FAIL(MG_ERR_SHAPE, "%s: null descriptor", who);
   if (d->M <= 0 || d->N <= 0 || d->K <= 0) MG_FAIL(MG_ERR_SHAPE, "%s: M,N,K must be positive (%d,%d,%d)", who, d->M, d->N, d->K);
@@ -711,7 +716,7 @@ int gemm_dispatch(const mg_gemm_desc* d, bool fp8, const float* row_scale, hipSt
   gp.tiles_m = (d->M + BM - 1) / BM; gp.tiles_n = (d->N + BN - 1) / BN;
   gp.ep = d->ep;
   gp.row_scale = row_scale;
-  gp.mx_a = mx ? mx->a : nullptr; gp.mx_w = mx ? mx->w : nullptr; gp.ld_mxa = mx ? mx->lda : 0; gp.ld_mxw = mx ? mx->ldw : 0;
+  gp.mx_a = mx ? mx->a : nullptr; gp.mx_w = mx ? mx->w : nullptr; gp.rg_a = (d->M + 63) / 64; gp.rg_w = (d->N + 63) / 64;
   // outputs far larger than the caches are streamed out with non-temporal stores (measured -9 % on the
   // 256x256 kernel at K = 4096: the tile no longer evicts the operand panels from L2)
   gp.nt = (int64_t)d->M * d->N * (d->ep.out_f32 ? 4 : 2) >= (int64_t)64 << 20;
@@ -790,14 +795,16 @@ extern "C" int mg_gemm_bf16(const mg_gemm_desc* d, void* stream) {
 }
 
 // MX (OCP microscaling) form of mg_gemm_fp8: operands and E8M0 block scales from mg_quantize_mx_fp8; no row / column scales.
-extern "C" int mg_gemm_mx_fp8(const mg_gemm_desc* d, const uint32_t* a_scales, int64_t ld_a_scales, const uint32_t* w_scales,
-                              int64_t ld_w_scales, void* stream) {
+extern "C" int mg_gemm_mx_fp8(const mg_gemm_desc* d, const uint8_t* a_scales, const uint8_t* w_scales, void* stream) {
   if (!d) MG_FAIL(MG_ERR_SHAPE, "mg_gemm_mx_fp8: null descriptor");
   const int64_t chunks = ((int64_t)d->K + 127) / 128;
-  if (!a_scales || !w_scales || ld_a_scales < chunks || ld_w_scales < chunks) MG_FAIL(MG_ERR_SHAPE, "mg_gemm_mx_fp8: block scales missing or their row stride < ceil(K / 128)");
+  if (!a_scales || !w_scales || ((uintptr_t)a_scales & 3) || ((uintptr_t)w_scales & 3)) MG_FAIL(MG_ERR_SHAPE, "mg_gemm_mx_fp8: block scales missing or not 4-byte aligned");
   if (d->lda < chunks * 128 || d->ldw < chunks * 128) MG_FAIL(MG_ERR_SHAPE, "mg_gemm_mx_fp8: operand rows must be padded to whole 128-element chunks (mg_quantize_mx_fp8)");
+  // The block scales are wired into the 128x128 kernel.  The 256x256 fp8 kernel has no register left for them: its K loop
+  // lives in exactly 256 VGPRs, and the six scale registers (two A slabs + one W slab, double-buffered) made hipcc spill
+  // accumulators INSIDE the loop (scratch 72 -> 272 bytes per lane) -- measured, removed again.
   if (d->tile_hint == 256) MG_FAIL(MG_ERR_UNSUPPORTED, "mg_gemm_mx_fp8: block scales are wired into the 128x128 kernel only");
-  const MxScales mx{a_scales, ld_a_scales, w_scales, ld_w_scales};
+  const MxScales mx{(const uint32_t*)a_scales, (const uint32_t*)w_scales};
   mg_gemm_desc dd = *d;
   dd.tile_hint = 128;
   return gemm_dispatch(&dd, true, nullptr, (hipStream_t)stream, "mg_gemm_mx_fp8", &mx);

@@ -14,11 +14,25 @@ typedef __attribute__((ext_vector_type(4))) int i32x4;
 MG_DEV f32x4 mfma_fp8_k128(i32x8 a, i32x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0 /*A: e4m3*/, 0 /*B: e4m3*/, 0, 0x7F7F7F7F /*2^0*/, 0, 0x7F7F7F7F);
 }
-// the same with the MX block scales of the two operands: byte 0 of sa / sb = E8M0 scale of block (lane >> 4) of row (lane & 15)
-// of the 128-wide k-chunk (the hardware reads block b's scale from lane row + 16 b; the lane's own 32 bytes are
-// k = 16 q .. 16 q + 15 and 64 + 16 q .. 64 + 16 q + 15, q = lane >> 4: the chunk's plain byte order)
-MG_DEV f32x4 mfma_mx_k128(i32x8 a, uint32_t sa, i32x8 b, uint32_t sb, f32x4 c) {
-  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, (int)sa, 0, (int)sb);
+// the same with the MX block scales of the two operands.  sa / sb: one dword per lane holding the E8M0 bytes this lane supplies
+// for up to four fragments (byte t = fragment t: mg_quantize_mx_fp8's scale layout); OA / OB select the byte (the MFMA's
+// op_sel field, an immediate).  The hardware reads the scale of block b of row r from lane r + 16 b; a lane's own 32 operand
+// bytes are k = 16 q .. + 15 and 64 + 16 q .. + 15 (q = lane >> 4): the chunk's plain byte order under the kernels' loaders.
+template <int OA, int OB>
+MG_DEV f32x4 mfma_mx_k128_sel(i32x8 a, uint32_t sa, i32x8 b, uint32_t sb, f32x4 c) {
+  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, OA, (int)sa, OB, (int)sb);
+}
+MG_DEV f32x4 mfma_mx_k128(i32x8 a, int oa, uint32_t sa, i32x8 b, int ob, uint32_t sb, f32x4 c) {
+  // oa / ob are compile-time constants at every call site (unrolled fragment loops): the switch folds away
+  switch (oa * 4 + ob) {
+#define MG_MX_CASE(A_, B_) case A_ * 4 + B_: return mfma_mx_k128_sel<A_, B_>(a, sa, b, sb, c);
+    MG_MX_CASE(0, 0) MG_MX_CASE(0, 1) MG_MX_CASE(0, 2) MG_MX_CASE(0, 3)
+    MG_MX_CASE(1, 0) MG_MX_CASE(1, 1) MG_MX_CASE(1, 2) MG_MX_CASE(1, 3)
+    MG_MX_CASE(2, 0) MG_MX_CASE(2, 1) MG_MX_CASE(2, 2) MG_MX_CASE(2, 3)
+    MG_MX_CASE(3, 0) MG_MX_CASE(3, 1) MG_MX_CASE(3, 2) MG_MX_CASE(3, 3)
+#undef MG_MX_CASE
+  }
+  return c;
 }
 
 // ---------------------------------------------------------------------------

@@ -137,6 +137,11 @@ class LMEngine:
         # fp8 operands for the prefill / forward GEMMs (BASELINE config 5): None | "attn" (QKV, out_proj, adapters)
         # | "all" (+ fc_in, fc_out).  bf16 stays the default: it is what the parity tests and the headline use.
         self.fp8_mode = os.environ.get("MAGMA_FP8") or None
+        # scaling of the fp8 operands: "row" = one fp32 scale per activation row / weight output channel (any tile kernel), "mx" =
+        # OCP MX, one E8M0 scale per 32 K-elements of both operands, applied by the MFMA itself (128x128 kernel)
+        self.fp8_scaling = os.environ.get("MAGMA_FP8_SCALING", "row")
+        if self.fp8_scaling not in ("row", "mx"):
+            raise ValueError("MAGMA_FP8_SCALING must be 'row' or 'mx'")
         # W8A16 decode: e4m3 weights (per-output-channel scales) widened to bf16 in registers by the weight-streaming
         # GEMVs -> half the bytes per token step.  Changes the numerics (weight quantisation), so it is opt-in.
         self.decode_w8 = os.environ.get("MAGMA_DECODE_W8", "0") == "1"
@@ -254,11 +259,15 @@ class LMEngine:
     def _fp8_weight(self, ly, name: str, lin):
         """e4m3 copy (per-output-channel scales) of a packed bf16 weight, made on first use."""
         packs = ly.__dict__.setdefault("fp8", {})
+        mx = self.fp8_scaling == "mx"
         w8 = packs.get(name)
-        if w8 is None:
+        if w8 is None or isinstance(w8, ops.PackedLinearMX) != mx:
             w = ops.PackedLinear.untile(lin.ft)[: lin.N, : lin.K] if lin.ft is not None else lin.rm[: lin.N, : lin.K]
-            w8 = packs[name] = ops.PackedLinearFP8(w, lin.bias)
+            w8 = packs[name] = (ops.PackedLinearMX if mx else ops.PackedLinearFP8)(w, lin.bias)
         return w8
+
+    def _quantize(self, x):
+        return ops.quantize_mx_fp8(x) if self.fp8_scaling == "mx" else ops.quantize_rows_fp8(x)
 
     def _linear(self, ly, name, lin, x, xq=None, **kw):
         """x @ lin^T through the bf16 tile GEMM, or -- when this projection is in the active fp8 set -- through the
@@ -266,7 +275,9 @@ class LMEngine:
         on = self.fp8_mode == "all" or (self.fp8_mode == "attn" and name not in ("fc_in", "fc_out"))
         if not on or lin.K % 16:
             return ops.gemm(x, lin, **kw)
-        q, sc = xq if xq is not None else ops.quantize_rows_fp8(x)
+        q, sc = xq if xq is not None else self._quantize(x)
+        if self.fp8_scaling == "mx":
+            return ops.gemm_mx_fp8(q, sc, self._fp8_weight(ly, name, lin), **kw)
         return ops.gemm_fp8(q, sc, self._fp8_weight(ly, name, lin), **kw)
 
     # ------------------------------------------------------------------ API
@@ -331,7 +342,7 @@ class LMEngine:
         hs = [x.view(B, S, d)] if want_hidden else None
         for li, ly in enumerate(self.layers):
             ln = ops.layernorm(x, ly.ln_g, ly.ln_b, self.eps)
-            lnq = ops.quantize_rows_fp8(ln) if self.fp8_mode else None      # shared by qkv (and fc_in in "all" mode)
+            lnq = self._quantize(ln) if self.fp8_mode else None             # shared by qkv (and fc_in in "all" mode)
             h_fused = None
             if self.fuse_in and not self.fp8_mode:
                 # qkv and gelu(fc_in) in ONE launch over [q | k | v | fc_in] (gelu_new on the fc_in columns only).  At the

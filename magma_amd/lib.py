@@ -152,8 +152,9 @@ SYMBOLS = {
     "mg_adamw_gbf16_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _vp, _f32, _vp]),
     "mg_gemm_fp8": (C.c_int, [C.POINTER(GemmDesc), _vp, _vp]),
     "mg_quantize_rows_fp8": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp]),
-    "mg_quantize_mx_fp8": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp]),
-    "mg_gemm_mx_fp8": (C.c_int, [C.POINTER(GemmDesc), _vp, _i64, _vp, _i64, _vp]),
+    "mg_mx_scale_bytes": (C.c_int64, [_i32, _i32]),
+    "mg_quantize_mx_fp8": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp]),
+    "mg_gemm_mx_fp8": (C.c_int, [C.POINTER(GemmDesc), _vp, _vp, _vp]),
     "mg_debug_mx_mfma": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "mg_conv_weight_relayout_bf16": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     "mg_bn_fold_f32": (C.c_int, [_vp, _vp, _vp, _vp, _f32, _vp, _vp, _i32, _vp]),

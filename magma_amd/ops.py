@@ -994,16 +994,24 @@ def gemm_fp8(aq: torch.Tensor, a_scale: torch.Tensor, w: PackedLinearFP8, out: O
 
 
 # ---- OCP MX fp8 (BASELINE config 5 as stated: e4m3 elements + one E8M0 scale per 32 K-elements) ---------------------------------
+def mx_scales_rowmajor(scales: torch.Tensor, rows: int, K: int) -> torch.Tensor:
+    """The quantiser's scale bytes (include/magma_hip.h: [chunk][block][row / 64][row % 16][(row % 64) / 16]) as a plain
+    uint8 [rows, ceil(K / 128) * 4] matrix of E8M0 exponents, one per (row, 32-block)."""
+    chunks, rg = (K + 127) // 128, (rows + 63) // 64
+    v = scales.view(chunks, 4, rg, 16, 4).permute(2, 4, 3, 0, 1).reshape(rg * 64, chunks * 4)
+    return v[:rows]
+
+
 def quantize_mx_fp8(x: torch.Tensor):
-    """bf16 [M, K] -> (uint8 e4m3 [M, ldq] in K order, zero padded to ldq = ceil(K / 128) * 128;
-    int32 [M, ldq / 128] block scales: byte b of dword c = E8M0 exponent of block 4c + b) -- the plain OCP MX layout."""
+    """bf16 [M, K] -> (uint8 e4m3 [M, ldq] in K order, zero padded to ldq = ceil(K / 128) * 128; uint8 block scales in the
+    layout of include/magma_hip.h mg_quantize_mx_fp8 -- mx_scales_rowmajor turns them into a [M, ldq / 32] matrix)."""
     _need_gpu(x)
     assert x.dtype == BF16 and x.ndim == 2 and x.stride(1) == 1
     M, K = x.shape
     ldq = ceil_to(K, 128)
     q = torch.empty(M, ldq, dtype=torch.uint8, device=x.device)
-    scales = torch.empty(M, ldq // 128, dtype=torch.int32, device=x.device)
-    check(L.load().mg_quantize_mx_fp8(x.data_ptr(), x.stride(0), M, K, q.data_ptr(), ldq, scales.data_ptr(), scales.stride(0), _stream()),
+    scales = torch.full((int(L.load().mg_mx_scale_bytes(M, K)),), 127, dtype=torch.uint8, device=x.device)
+    check(L.load().mg_quantize_mx_fp8(x.data_ptr(), x.stride(0), M, K, q.data_ptr(), ldq, scales.data_ptr(), _stream()),
           "mg_quantize_mx_fp8")
     return q, scales
 
@@ -1011,7 +1019,7 @@ def quantize_mx_fp8(x: torch.Tensor):
 def mx_dequant(q: torch.Tensor, scales: torch.Tensor, K: int) -> torch.Tensor:
     """fp32 [R, K] values an MX operand stands for (tests; the fp8 'dequantised oracle')."""
     R, ld = q.shape
-    e = scales.view(torch.uint8).view(R, ld // 32).float()                         # one byte per 32-block, blocks in order
+    e = mx_scales_rowmajor(scales, R, ld).float()                                   # [R, ld / 32]
     v = q.view(torch.float8_e4m3fn).float().view(R, ld // 32, 32) * torch.exp2(e - 127.0)[:, :, None]
     return v.reshape(R, ld)[:, :K]
 
@@ -1028,8 +1036,10 @@ class PackedLinearMX:
         n16 = ceil_to(self.N, 16)
         w = torch.zeros(n16, self.K, dtype=BF16, device=weight.device)
         w[: self.N] = weight.detach().to(BF16)
-        q, sc = quantize_mx_fp8(w)
-        self.scales = sc[: self.N].contiguous()
+        q, sc = quantize_mx_fp8(w[: self.N])          # scale slabs are indexed by the weight's own row count
+        if n16 != self.N:
+            q = torch.cat([q, torch.zeros(n16 - self.N, q.shape[1], dtype=torch.uint8, device=q.device)])
+        self.scales = sc
         self.bias = None if bias is None else bias.detach().to(torch.float32).contiguous()
         self.rm = q[: self.N].contiguous() if rowmajor else None
         self.ft = PackedLinear.tile(q.view(torch.int16)).view(torch.uint8) if tiled else None
@@ -1042,12 +1052,12 @@ class PackedLinearMX:
 
 def gemm_mx_fp8(aq: torch.Tensor, a_scales: torch.Tensor, w: PackedLinearMX, out: Optional[torch.Tensor] = None, *,
                 act: int = MG_ACT_NONE, residuals: Sequence[torch.Tensor] = (), act_after: int = MG_ACT_NONE, use_bias: bool = True,
-                out_dtype=BF16, layout: Optional[str] = None, split_k: int = 0, act_n0: int = 0) -> torch.Tensor:
+                out_dtype=BF16, layout: Optional[str] = None, split_k: int = 0, act_n0: int = 0, tile: int = 0) -> torch.Tensor:
     """out[M,N] = epilogue(sum over 32-blocks of 2^(ea + ew) * (qa . qw)) on the block-scaled fp8 MFMA (fp32 accumulate)."""
     _need_gpu(aq, a_scales)
     assert aq.dtype == torch.uint8 and aq.ndim == 2 and aq.stride(1) == 1 and aq.shape[1] == w.Kp
-    assert a_scales.dtype == torch.int32 and a_scales.shape == (aq.shape[0], w.Kp // 128)
     M = aq.shape[0]
+    assert a_scales.dtype == torch.uint8 and a_scales.numel() == int(L.load().mg_mx_scale_bytes(M, w.Kp))
     if out is None:
         out = torch.empty(M, ceil_to(w.N, 8), dtype=out_dtype, device=aq.device)[:, : w.N]
     d = GemmDesc()
@@ -1061,14 +1071,14 @@ def gemm_mx_fp8(aq: torch.Tensor, a_scales: torch.Tensor, w: PackedLinearMX, out
     d.M, d.N, d.K = M, w.N, w.Kp
     d.a_mode = MG_A_DENSE
     d.zero_page = zero_page(aq.device).data_ptr()
+    d.tile_hint = tile
     d.split_k = split_k
     if split_k != 1:
         ws = splitk_workspace(aq.device)
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     d.ep = _epilogue(out, w.N, w.bias if use_bias else None, None, act, residuals, act_after)
     d.ep.act_n0 = act_n0
-    check(L.load().mg_gemm_mx_fp8(C.byref(d), a_scales.data_ptr(), a_scales.stride(0), w.scales.data_ptr(), w.scales.stride(0),
-                                  _stream()), "mg_gemm_mx_fp8")
+    check(L.load().mg_gemm_mx_fp8(C.byref(d), a_scales.data_ptr(), w.scales.data_ptr(), _stream()), "mg_gemm_mx_fp8")
     return out
 
 

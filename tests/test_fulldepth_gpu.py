@@ -285,8 +285,10 @@ def test_w8a16_decode_vs_oracle_on_dequantised_weights(dev):
         eng._cache_pool.clear()
 
 
-def test_fp8_prefill_vs_oracle_on_dequantised_weights(dev):
-    """MAGMA_FP8=all prefill at full width (qkv, out_proj, fc_in, fc_out and the adapter projections on the MX-rate fp8
+@pytest.mark.parametrize("scaling", ["row", "mx"])
+def test_fp8_prefill_vs_oracle_on_dequantised_weights(dev, scaling):
+    """(scaling "mx": OCP MX block scales -- one E8M0 per 32 K-elements of activations and weights, applied by the MFMA.)
+    MAGMA_FP8=all prefill at full width (qkv, out_proj, fc_in, fc_out and the adapter projections on the MX-rate fp8
     MFMA) against the fp32 oracle on the dequantised e4m3 weights.  The oracle keeps fp32 ACTIVATIONS, the kernels quantise
     them per row to e4m3 (3 mantissa bits, the same format as the weights) in front of every projection.  Stated tolerance,
     self-calibrating: the activation quantisation may move the logits by at most 1.5 x what the e4m3 WEIGHT quantisation
@@ -300,10 +302,12 @@ def test_fp8_prefill_vs_oracle_on_dequantised_weights(dev):
     lm = F.lm_only(p)
     emb = F.greedy_inputs(cfg, seed=31, B=8)
     try:
-        eng.fp8_mode = "all"
+        eng.fp8_mode, eng.fp8_scaling = "all", scaling
         with torch.no_grad():
             got = model.lm(inputs_embeds=emb.to(BF16).cuda()).logits.float().cpu()
             packs = eng.layers[0].fp8
+            from magma_amd import ops
+            assert all(isinstance(v, ops.PackedLinearMX) == (scaling == "mx") for v in packs.values())
             assert set(packs) >= {"qkv", "out", "fc_in", "fc_out", "mlp_dn", "mlp_up"}, sorted(packs)
             d = cfg.d_model
             q = dict(lm)
@@ -318,11 +322,11 @@ def test_fp8_prefill_vs_oracle_on_dequantised_weights(dev):
             ref = lm_forward(q, cfg, inputs_embeds=emb)["logits"]
             unq = lm_forward(lm, cfg, inputs_embeds=emb)["logits"]
         e_deq, e_unq = rel(got, ref), rel(got, unq)
-        print(f"fp8 'all' prefill logits: vs dequantised oracle {e_deq:.3e}, vs unquantised oracle {e_unq:.3e}")
+        print(f"fp8 'all' ({scaling} scales) prefill logits: vs dequantised oracle {e_deq:.3e}, vs unquantised oracle {e_unq:.3e}")
         assert torch.isfinite(got).all()
         e_w = rel(ref, unq)
         print(f"e4m3 weight quantisation alone moves the logits by {e_w:.3e}")
         assert e_deq <= 1.5 * e_w, (e_deq, e_w)
         assert e_deq < e_unq
     finally:
-        eng.fp8_mode = None
+        eng.fp8_mode, eng.fp8_scaling = None, "row"
