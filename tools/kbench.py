@@ -172,6 +172,28 @@ def main():
             r.update(mfma16_ms=best[259], mfma32_ms=best[258], mfma16_tflops=fl / best[259] / 1e9, mfma32_tflops=fl / best[258] / 1e9,
                      speedup=best[259] / best[258])
             emit(**r)
+    if which == "mx":   # fp8 GEMM at 5 PF dense peak: MX block-scaled (128x128 kernel) vs per-row scaled (128x128, 256x256) + the quantisers
+        for M in (456, 32768):
+            for (N, K, tag) in [(12288, 4096, "qkv"), (4096, 4096, "out_proj"), (16384, 4096, "fc_in"), (4096, 16384, "fc_out")]:
+                a = torch.randn(M, K, device=dev).to(BF16)
+                w = (torch.randn(N, K, device=dev) * 0.05).to(BF16)
+                lin8, linx = ops.PackedLinearFP8(w), ops.PackedLinearMX(w)
+                out = torch.empty(M, N, dtype=BF16, device=dev)
+                aq, asc = ops.quantize_rows_fp8(a)
+                xq, xsc = ops.quantize_mx_fp8(a)
+                it = 20 if M < 4096 else 5
+                fl = 2.0 * M * N * K
+                r = {"kind": "mx", "tag": tag, "M": M, "N": N, "K": K}
+                for name, fn in (("row_128", lambda i: ops.gemm_fp8(aq, asc, lin8, out=out, tile=128)),
+                                 ("row_256", lambda i: ops.gemm_fp8(aq, asc, lin8, out=out, tile=256 if M >= 256 else 128)),
+                                 ("mx_128", lambda i: ops.gemm_mx_fp8(xq, xsc, linx, out=out)),
+                                 ("quant_row", lambda i: ops.quantize_rows_fp8(a)), ("quant_mx", lambda i: ops.quantize_mx_fp8(a))):
+                    ms = timeit(fn, it)
+                    r[name + "_ms"] = ms
+                    if not name.startswith("quant"):
+                        r[name + "_tflops"] = fl / ms / 1e9
+                        r[name + "_frac_of_5PF"] = fl / ms / 1e9 / 5000.0
+                emit(**r)
     if which == "shortk":   # adapter up-projection (K = 1024) with three residual reads: epilogue-bound; 128x128 vs 256x256 kernel
         M, N, K = 32768, 4096, 1024
         a = torch.randn(M, K, device=dev).to(BF16)
