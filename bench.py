@@ -159,11 +159,13 @@ def decode_gemv_jobs(eng, st):
 
 def pmc_traffic_per_launch(shapes):
     """HBM bytes per launch of the GEMV sweep from the committed rocprofv3 FETCH_SIZE pass over this very sweep
-    (profiles/r02_decode_gemv_fetch_table.json, tools/pmc_decode_sweep.py: per (N, K) shape, counter x 2 for the gfx950
-    wide-read under-count, MI355X_MICROARCH.md HBM).  None when a shape is missing from the table."""
-    path = os.path.join(ROOT, "profiles", "r02_decode_gemv_fetch_table.json")
-    if not os.path.exists(path):
+    (profiles/rNN_decode_gemv_fetch_table.json, newest round; tools/gpu_pmc_decode.sh + tools/pmc_decode_sweep.py: per (N, K)
+    shape, counter x 2 for the gfx950 wide-read under-count, MI355X_MICROARCH.md HBM).  None when a shape is missing."""
+    import glob
+    tabs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_decode_gemv_fetch_table.json")))
+    if not tabs:
         return None, None
+    path = tabs[-1]
     tab = json.load(open(path))["bytes_per_launch"]
     try:
         tot = sum(tab[f"{n}x{k}"] for n, k in shapes)
@@ -311,7 +313,10 @@ def bench_train(model, args, rank, world, dev):
     out["policy"] = "no recompute; bf16; adapters+CLIP trunk+prefix trainable; clip 1.0 + AdamW in the timed region"
     out["per_gpu_batch"], out["seq_len"] = B, S
     n_train = sum(g.n for g in eng.groups)
-    out["data_parallel"] = {"ranks": world, "backend": "RCCL (torch.distributed nccl)" if world > 1 else None,
+    backend = None
+    if world > 1:
+        backend = getattr(eng._exchange, "name", "?") + " / " + torch.distributed.get_backend() + (" = RCCL" if torch.distributed.get_backend() == "nccl" else "")
+    out["data_parallel"] = {"ranks": world, "backend": backend,
                             "rccl_ranks": torch.distributed.get_world_size() if world > 1 else None,
                             "gradient_exchange": ("bf16 buckets" if eng.exchange_bf16 else "fp32") if world > 1 else None,
                             "exchanged_elements": n_train if world > 1 else None,
