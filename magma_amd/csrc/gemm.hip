@@ -90,8 +90,9 @@ struct GemmParams {
 
 // FP8: A and W hold OCP e4m3 bytes and every quantity below counts PAIRS of them (the host passes K/2, lda/2, ldw/2:
 // a 64-"element" K-tile is 128 fp8 values, the byte images in LDS are the same); only the MFMA differs.
-template <int AMODE, int WLAYOUT, bool FP8 = false>
+template <int AMODE, int WLAYOUT, bool FP8 = false, bool MX = false>
 __global__ __launch_bounds__(256) void gemm128_kernel(const GemmParams p) {
+  static_assert(!MX || FP8, "block scales belong to the fp8 path");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(256) void gemm128_kernel(const GemmParams p) {
   // t of the wave's 64-row slab (mg_quantize_mx_fp8's layout; the MFMA's op_sel picks the byte).  Tile kt + 1's pair is loaded
   // from assembly while tile kt is multiplied (invisible to hipcc's wait counting, retired by the loop's vmcnt(0)).
   uint32_t mx_sa = 0x7f7f7f7fu, mx_sw = 0x7f7f7f7fu, mx_sa_n = 0x7f7f7f7fu, mx_sw_n = 0x7f7f7f7fu;
-  const bool mx = FP8 && p.mx_a != nullptr;
+  constexpr bool mx = MX;
   const uint32_t mx_oa = (uint32_t)(((lq * p.rg_a + min((m0 >> 6) + wm, p.rg_a - 1)) * 16 + li) * 4);      // slabs past M / N: rows
   const uint32_t mx_ow = (uint32_t)(((lq * p.rg_w + min((n0 >> 6) + wn, p.rg_w - 1)) * 16 + li) * 4);      // that are never stored
   auto mx_load = [&](int kt, uint32_t& a, uint32_t& w) {
@@ -246,7 +247,10 @@ __global__ __launch_bounds__(256) void gemm128_kernel(const GemmParams p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = mfma_mx_k128(bfr[j], j, mx_sw, af[i], i, mx_sa, acc[i][j]);
+        for (int j = 0; j < 4; ++j) {
+          if constexpr (MX) acc[i][j] = mfma_mx_k128(bfr[j], j, mx_sw, af[i], i, mx_sa, acc[i][j]);
+          else acc[i][j] = mfma_fp8_k128(bfr[j], af[i], acc[i][j]);
+        }
     } else {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -663,10 +667,10 @@ int check_epilogue(const mg_epilogue& ep, const char* who) {
   return MG_OK;
 }
 
-template <int AMODE, int WLAYOUT, bool FP8 = false>
+template <int AMODE, int WLAYOUT, bool FP8 = false, bool MX = false>
 int launch_gemm(const GemmParams& gp, hipStream_t s) {
-  if (int rc = mg_allow_dynamic_lds((const void*)gemm128_kernel<AMODE, WLAYOUT, FP8>, GEMM_LDS, "mg_gemm")) return rc;
-  hipLaunchKernelGGL((gemm128_kernel<AMODE, WLAYOUT, FP8>), dim3(gp.tiles_m * gp.tiles_n * gp.splits), dim3(256), GEMM_LDS, s, gp);
+  if (int rc = mg_allow_dynamic_lds((const void*)gemm128_kernel<AMODE, WLAYOUT, FP8, MX>, GEMM_LDS, "mg_gemm")) return rc;
+  hipLaunchKernelGGL((gemm128_kernel<AMODE, WLAYOUT, FP8, MX>), dim3(gp.tiles_m * gp.tiles_n * gp.splits), dim3(256), GEMM_LDS, s, gp);
   MG_CHECK_LAUNCH();
   if (gp.splits > 1) {
     const int64_t quads = (int64_t)gp.M * ((gp.N + 3) >> 2);
@@ -775,6 +779,7 @@ int gemm_dispatch(const mg_gemm_desc* d, bool fp8, const float* row_scale, hipSt
       if (gp.splits == 1) { gp.ws = nullptr; gp.ldws = 0; }
     }
   }
+  if (fp8 && gp.mx_a) return rm ? launch_gemm<MG_A_DENSE, MG_W_ROWMAJOR, true, true>(gp, s) : launch_gemm<MG_A_DENSE, MG_W_FRAGTILED, true, true>(gp, s);
   if (fp8) return rm ? launch_gemm<MG_A_DENSE, MG_W_ROWMAJOR, true>(gp, s) : launch_gemm<MG_A_DENSE, MG_W_FRAGTILED, true>(gp, s);
   if (d->a_mode == MG_A_DENSE) return rm ? launch_gemm<MG_A_DENSE, MG_W_ROWMAJOR>(gp, s) : launch_gemm<MG_A_DENSE, MG_W_FRAGTILED>(gp, s);
   return rm ? launch_gemm<MG_A_CONV3X3, MG_W_ROWMAJOR>(gp, s) : launch_gemm<MG_A_CONV3X3, MG_W_FRAGTILED>(gp, s);
