@@ -53,12 +53,12 @@ static_assert(GEMM_LDS >= 2 * STAGE_BYTES, "LDS must hold both K-tile stages");
 // (bijective form, guide 5.5 T1); (2) inside the run walk groups of GROUP_M
 // row-tiles x all column-tiles so the A panels of a group stay L2 resident.
 // ---------------------------------------------------------------------------
-MG_DEV void tile_coords(int bid, int tiles_m, int tiles_n, int& tm, int& tn) {
+MG_DEV void tile_coords(int bid, int tiles_m, int tiles_n, int& tm, int& tn, int group_m = 8) {
   const int nwg = tiles_m * tiles_n;
   const int q = nwg >> 3, r = nwg & 7;
   const int xcd = bid & 7, idx = bid >> 3;
   const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  constexpr int GROUP_M = 8;
+  const int GROUP_M = group_m;
   const int per_group = GROUP_M * tiles_n;
   const int group = wg / per_group;
   const int first_m = group * GROUP_M;
@@ -75,6 +75,8 @@ struct GemmParams {
   int H, Wd, Cin;
   const mg_bf16* zero;
   int tiles_m, tiles_n;
+  int group_m;       // 256x256 kernel: row-tiles per group of the tile walk (tile_coords)
+  int64_t a_kt;      // 256x256 kernel: elements between consecutive K-tiles of A (64 = plain row-major rows)
   // split-K (gemm128 only): `splits` workgroups per output tile, each reducing kt_per K-tiles into
   // its own fp32 slab ws[split][M][ldws]; splitk_fixup_kernel adds the slabs in a fixed order and
   // applies the epilogue (deterministic, no atomics).  splits == 1: the epilogue runs in place.
@@ -329,13 +331,29 @@ __global__ __launch_bounds__(256) void splitk_fixup_kernel(const float* __restri
 //     program shifted by ONE barrier, so that while one group is in its MFMA segment
 //     the other is in its read/DMA segment: the matrix pipe of every SIMD always has
 //     a wave to issue from.
-// Phase q of K-tile t (buffer t&1); registers: A 4 m-tiles x 2, W both n-halves:
+// Phase q of K-tile t (buffer t&1); registers: A 4 m-tiles x 2, W both n-halves.
+// bf16 16x16x32 path (EARLY, round 3): the DMA units are cut by the phase of their LAST READ -- A_m = the mh-th 64 rows of both
+// groups, W_n = the nh-th 32 rows of the four wave columns -- and restaged as soon as that read is over, into the buffer that is
+// still being multiplied:
+//   q0: read A(mh0), W(nh0) | DMA A_1(t+1)  (last read: q2 of t-1)   | MFMA (mh0,nh0)
+//   q1: read W(nh1)         | DMA A_0(t+2)  (last read: q0 of t)     | MFMA (mh0,nh1)
+//   q2: read A(mh1)         | DMA W_0(t+2)  (last read: q0 of t)     | MFMA (mh1,nh1)
+//   q3:                     | DMA W_1(t+2)  (last read: q1 of t), vmcnt(6): tile t+1 landed | MFMA (mh1,nh0)
+// Every unit is in flight for 3 to 6 phases before the wait that retires it (the first version, below, cut the units by wave
+// group and issued them at q0..q3 of the tile BEFORE their use: A_hi had ONE phase -- ~350 ns, less than an L2 hit -- so every
+// K-tile waited for memory; an L2-hot ablation ran 3-19 % faster, the K = 16384 shapes most).
+// (32x32x16 path: the same units and schedule; fp8 path: its own unit order, see MG_PHASEQ.)
+// First version of the schedule, kept as tile_hint 266 for A/B runs (units cut by group: W_lo / W_hi = W rows 0-127 / 128-255,
+// A_lo / A_hi = the rows of group 0 / 1):
 //   q0: read A(mh0), W(nh0) | DMA W_hi(t+1) | MFMA (mh0,nh0)
 //   q1: read W(nh1)         | DMA A_lo(t+1) | MFMA (mh0,nh1)
 //   q2: read A(mh1)         | DMA A_hi(t+1) | MFMA (mh1,nh1)
 //   q3:                     | DMA W_lo(t+2) , vmcnt(2): tile t+1 landed | MFMA (mh1,nh0)
-// Hazards (slots = intervals between consecutive barriers; group 1 is one slot late):
-//   WAR  buffer t is last read (lgkmcnt(0) before the barrier) in q2 of group 1; the
+// Hazards (slots = intervals between consecutive barriers; group 1 is one slot late: group 0's read segment of phase q is
+// slot 2q, group 1's is slot 2q+1):
+//   WAR  (EARLY) a unit is restaged in the phase after its last read: the last reader is group 1 (slot 2q+1, its reads retired
+//        by lgkmcnt(0) before the barrier that ends the slot), the first writer group 0 in slot 2q+2.
+//   WAR  (by group) buffer t is last read (lgkmcnt(0) before the barrier) in q2 of group 1; the
 //        first DMA into it is W_lo(t+2) at q3 of group 0, one barrier later.
 //   RAW  every wave retires its own pieces of tile t+1 (vmcnt(2)) in q3 before that
 //        phase's first barrier; the first reader (group 0, q0 of t+1) has passed the
@@ -366,17 +384,24 @@ static_assert(G256_LDS >= 2 * G256_BUF, "LDS must hold two K-tiles");
 // Accumulator map: column m = l & 31, rows n = (reg & 3) + 8 (reg >> 2) + 4 (l >> 5): a register quad is 4 consecutive n,
 // exactly what the LDS-staged epilogue stores.
 typedef __attribute__((ext_vector_type(16))) float f32x16;
-template <int WLAYOUT, bool LATE_LGKM, bool FP8 = false, bool MFMA32 = false>
+// ABL (timing ablations, WRONG results; tile_hint 261..264, tools/kbench.py abl): 1 = every K-tile's DMA reads K-tile (t & 1)
+// (operands always L2-hot: isolates memory latency), 2 = no fragment reads after the first two K-tiles (isolates the LDS read
+// segments), 3 = no MFMA, 4 = no DMA after the prologue.
+template <int WLAYOUT, bool LATE_LGKM, bool FP8 = false, bool MFMA32 = false, int ABL = 0>
 __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   static_assert(!(FP8 && MFMA32), "the 32x32 form is the bf16 path");
+  bool abl_on = true;           // ABL 2 / 4: false once the pipeline is primed
+  // ABL 5 (correct results): each XCD starts its K loop at a different K-tile (rotation by xcd * nkt / 8) -- see KT_SRC
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int tm, tn;
-  tile_coords(blockIdx.x, p.tiles_m, p.tiles_n, tm, tn);
+  tile_coords(blockIdx.x, p.tiles_m, p.tiles_n, tm, tn, p.group_m);
   const int m0 = tm * 256, n0 = tn * 256;
   const int nkt = p.K >> 6;                       // even (K % 128 == 0)
+  const int kt_rot = (ABL == 5) ? (((int)blockIdx.x & 7) * (nkt >> 3)) & ~1 : 0;   // even, so buffer parity follows the loop index
+#define KT_SRC(kt) (ABL == 1 ? ((kt) & 1) : ABL == 5 ? ((kt) + kt_rot >= nkt ? (kt) + kt_rot - nkt : (kt) + kt_rot) : (kt))
   const int wr = wave >> 2, wc = wave & 3;        // wr is also the wave group
   const int li = lane & 15, lq = lane >> 4;
 
@@ -401,21 +426,73 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
 #define MG_DMA_A(kt, h)                                                                                  \
   {                                                                                                      \
     char* dst_ = smem + ((kt) & 1) * G256_BUF + ((h) * 128 + wave * 16) * 128;                           \
-    const mg_bf16* src_ = p.A + (int64_t)(kt) * 64;                                                      \
-    glds16s(src_, (uint32_t)a_off[h][0] * 2u, dst_);                                                     \
-    glds16s(src_, (uint32_t)a_off[h][1] * 2u, dst_ + 1024);                                              \
+    const mg_bf16* src_ = p.A + (int64_t)KT_SRC(kt) * p.a_kt;                            \
+    if (ABL != 4 || abl_on) {                                                                            \
+      glds16s(src_, (uint32_t)a_off[h][0] * 2u, dst_);                                                   \
+      glds16s(src_, (uint32_t)a_off[h][1] * 2u, dst_ + 1024);                                            \
+    }                                                                                                    \
   }
 #define MG_DMA_B(kt, h)                                                                                  \
   {                                                                                                      \
     char* base_ = smem + ((kt) & 1) * G256_BUF + G256_TILE;                                              \
-    if (WLAYOUT == MG_W_ROWMAJOR) {                                                                      \
-      const mg_bf16* src_ = p.W + (int64_t)(kt) * 64;                                                    \
+    if (ABL == 4 && !abl_on) {                                                                           \
+    } else if (WLAYOUT == MG_W_ROWMAJOR) {                                                               \
+      const mg_bf16* src_ = p.W + (int64_t)KT_SRC(kt) * 64;                          \
       glds16s(src_, (uint32_t)b_off[h][0] * 2u, base_ + ((h) * 128 + wave * 16) * 128);                  \
       glds16s(src_, (uint32_t)b_off[h][1] * 2u, base_ + ((h) * 128 + wave * 16 + 8) * 128);              \
     } else {                                                                                             \
-      const mg_bf16* src_ = p.W + (int64_t)(kt) * 1024;                                                  \
+      const mg_bf16* src_ = p.W + (int64_t)KT_SRC(kt) * 1024;                        \
       glds16s(src_, (uint32_t)b_off[h][0] * 2u, base_ + (((h) * 8 + wave) * 2) * 1024);                  \
       glds16s(src_, (uint32_t)b_off[h][1] * 2u, base_ + (((h) * 8 + wave) * 2 + 1) * 1024);              \
+    }                                                                                                    \
+  }
+
+  // ---- DMA units of the EARLY schedule (bf16 16x16x32 path): the 16-KiB units are cut by the PHASE in which their rows are
+  // last read instead of by wave group -- A_m = the mh-th 64 rows of BOTH groups (read in q0 / q2), W_n = the nh-th 32 rows of all
+  // four wave columns (read in q0 / q1) -- so that a unit of the buffer being multiplied can be restaged while the tile is still
+  // in progress and every unit gets at least 3 phases of flight (see the schedule below).  Same LDS image.
+  constexpr bool EARLY = ABL != 6;
+  int a2_off[2][2], b2_off[2][2];
+  if constexpr (EARLY) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int ra = (wave >> 2) * 128 + u * 64 + (wave & 3) * 16 + j * 8 + (lane >> 3);
+        a2_off[u][j] = (int)(min(m0 + ra, p.M - 1) * p.lda + ((lane & 7) ^ ((ra >> 1) & 7)) * 8);
+        if (WLAYOUT == MG_W_ROWMAJOR) {
+          const int rb = (wave >> 1) * 64 + u * 32 + (wave & 1) * 16 + j * 8 + (lane >> 3);
+          b2_off[u][j] = (int)(min(n0 + rb, p.N - 1) * p.ldw + ((lane & 7) ^ ((rb >> 1) & 7)) * 8);
+        } else {
+          const int ntiles = (p.N + 15) >> 4;
+          const int nt = min((n0 >> 4) + (wave >> 1) * 4 + u * 2 + (wave & 1), ntiles - 1);
+          b2_off[u][j] = (int)(((int64_t)nt * (p.ldw >> 5) + j) * 512 + lane * 8);   // j = k-step inside the tile
+        }
+      }
+  }
+#define MG_DMA_A2(kt, u)                                                                                 \
+  {                                                                                                      \
+    char* dst_ = smem + ((kt) & 1) * G256_BUF + ((wave >> 2) * 128 + (u) * 64 + (wave & 3) * 16) * 128;  \
+    const mg_bf16* src_ = p.A + (int64_t)KT_SRC(kt) * p.a_kt;                                            \
+    if (ABL != 4 || abl_on) {                                                                            \
+      glds16s(src_, (uint32_t)a2_off[u][0] * 2u, dst_);                                                  \
+      glds16s(src_, (uint32_t)a2_off[u][1] * 2u, dst_ + 1024);                                           \
+    }                                                                                                    \
+  }
+#define MG_DMA_B2(kt, u)                                                                                 \
+  {                                                                                                      \
+    char* base_ = smem + ((kt) & 1) * G256_BUF + G256_TILE;                                              \
+    if (ABL == 4 && !abl_on) {                                                                           \
+    } else if (WLAYOUT == MG_W_ROWMAJOR) {                                                               \
+      const mg_bf16* src_ = p.W + (int64_t)KT_SRC(kt) * 64;                                              \
+      char* d_ = base_ + ((wave >> 1) * 64 + (u) * 32 + (wave & 1) * 16) * 128;                          \
+      glds16s(src_, (uint32_t)b2_off[u][0] * 2u, d_);                                                    \
+      glds16s(src_, (uint32_t)b2_off[u][1] * 2u, d_ + 1024);                                             \
+    } else {                                                                                             \
+      const mg_bf16* src_ = p.W + (int64_t)KT_SRC(kt) * 1024;                                            \
+      char* d_ = base_ + (((wave >> 1) * 4 + (u) * 2 + (wave & 1)) * 2) * 1024;                          \
+      glds16s(src_, (uint32_t)b2_off[u][0] * 2u, d_);                                                    \
+      glds16s(src_, (uint32_t)b2_off[u][1] * 2u, d_ + 1024);                                             \
     }                                                                                                    \
   }
 
@@ -432,6 +509,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
 #define MG_READ_A(par, mh)                                                                               \
   {                                                                                                      \
     const char* sb_ = smem + (par) * G256_BUF;                                                           \
+    if (ABL != 2 || abl_on)                                                                              \
     _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                     \
       af[i_] = __builtin_shufflevector(*(const i32x4*)(sb_ + a_rd0 + ((mh) * 4 + i_) * 2048),            \
                                        *(const i32x4*)(sb_ + (a_rd0 ^ 64) + ((mh) * 4 + i_) * 2048), 0, 1, 2, 3, 4, 5, 6, 7); \
@@ -439,6 +517,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
 #define MG_READ_B(par, nh)                                                                               \
   {                                                                                                      \
     const char* sb_ = smem + (par) * G256_BUF;                                                           \
+    if (ABL != 2 || abl_on)                                                                              \
     _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                     \
       bw[nh][j_] = __builtin_shufflevector(                                                              \
           *(const i32x4*)(sb_ + b_rd0 + ((nh) * 2 + j_) * B_NT),                                         \
@@ -454,6 +533,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
 #define MG_MMA(mh, nh)                                                                                   \
   {                                                                                                      \
     __builtin_amdgcn_s_setprio(1);                                                                       \
+    if (ABL == 3) {                                                                                      \
+      _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) asm volatile("" ::"v"(af[i_]));                   \
+      _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) asm volatile("" ::"v"(bw[nh][j_]));               \
+    } else                                                                                               \
     _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)                                                     \
       _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                   \
         _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                 \
@@ -524,9 +607,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   }
   // FP8 phases: the 8-register operands leave no room for four A and four W fragments next to 128 accumulators, so a
   // phase is one m-QUARTER (two m-tiles) against all four n-tiles: W is read once per K-tile (q0), A two tiles per phase.
-  // Same DMA schedule; the W regions of a buffer are last read in q0 and the A regions in q3 of the group that owns
-  // them (A_lo = rows of group 0, A_hi = group 1), both before the next DMA into them (W_hi at q0, A_lo / A_hi at q1 / q2
-  // of the NEXT tile of that parity, W_lo at q3 one barrier after the last q0 read).
+  // DMA units as on the bf16 path (A_0 / A_1 = quarters 0,1 / 2,3 of both groups, W_0 / W_1), restaged the phase after their
+  // last read: W (all of it read in q0) at q1 / q2, A_0 (last read q1) at q3, A_1 (last read q3) at q0 of the next tile;
+  // vmcnt(6) at q3 retires tile t+1 (A_1(t+1), issued in q0 of t, is the youngest of it: 3 phases of flight).
 #define MG_READ_AQ(par, mq)                                                                              \
   {                                                                                                      \
     const char* sb_ = smem + (par) * G256_BUF;                                                           \
@@ -554,15 +637,21 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   // K-tile t with buffer parity PAR; NXT: tile t+1 exists, NXT2: tile t+2 exists
 #define MG_G256_TILE(t, PAR, NXT, NXT2)                                                                  \
   if constexpr (FP8) {                                                                                   \
-    MG_PHASEQ({ MG_READ_AQ(PAR, 0); MG_READ_B(PAR, 0); MG_READ_B(PAR, 1); }, { if (NXT) MG_DMA_B((t) + 1, 1); }, 0); \
-    MG_PHASEQ({ MG_READ_AQ(PAR, 1); }, { if (NXT) MG_DMA_A((t) + 1, 0); }, 1);                            \
-    MG_PHASEQ({ MG_READ_AQ(PAR, 2); }, { if (NXT) MG_DMA_A((t) + 1, 1); }, 2);                            \
-    MG_PHASEQ({ MG_READ_AQ(PAR, 3); }, { if (NXT2) { MG_DMA_B((t) + 2, 0); MG_WAIT_VM(2); } else { MG_WAIT_VM(0); } }, 3); \
+    /* all of W is read in q0, the A quarters in q0..q3: A_0 (quarters 0, 1) is free from q2, A_1 from q0 of the next tile */ \
+    MG_PHASEQ({ MG_READ_AQ(PAR, 0); MG_READ_B(PAR, 0); MG_READ_B(PAR, 1); }, { if (NXT) MG_DMA_A2((t) + 1, 1); }, 0); \
+    MG_PHASEQ({ MG_READ_AQ(PAR, 1); }, { if (NXT2) MG_DMA_B2((t) + 2, 0); }, 1);                          \
+    MG_PHASEQ({ MG_READ_AQ(PAR, 2); }, { if (NXT2) MG_DMA_B2((t) + 2, 1); }, 2);                          \
+    MG_PHASEQ({ MG_READ_AQ(PAR, 3); }, { if (NXT2) { MG_DMA_A2((t) + 2, 0); MG_WAIT_VM(6); } else { MG_WAIT_VM(0); } }, 3); \
   } else if constexpr (MFMA32) {                                                                         \
-    MG_PHASE32({ MG_READ_A32(PAR, 0); MG_READ_B32(PAR, 0); }, { if (NXT) MG_DMA_B((t) + 1, 1); }, 0, 0); \
-    MG_PHASE32({ MG_READ_B32(PAR, 1); }, { if (NXT) MG_DMA_A((t) + 1, 0); }, 0, 1);                       \
-    MG_PHASE32({ MG_READ_A32(PAR, 1); }, { if (NXT) MG_DMA_A((t) + 1, 1); }, 1, 1);                       \
-    MG_PHASE32({}, { if (NXT2) { MG_DMA_B((t) + 2, 0); MG_WAIT_VM(2); } else { MG_WAIT_VM(0); } }, 1, 0); \
+    MG_PHASE32({ MG_READ_A32(PAR, 0); MG_READ_B32(PAR, 0); }, { if (NXT) MG_DMA_A2((t) + 1, 1); }, 0, 0); \
+    MG_PHASE32({ MG_READ_B32(PAR, 1); }, { if (NXT2) MG_DMA_A2((t) + 2, 0); }, 0, 1);                     \
+    MG_PHASE32({ MG_READ_A32(PAR, 1); }, { if (NXT2) MG_DMA_B2((t) + 2, 0); }, 1, 1);                     \
+    MG_PHASE32({}, { if (NXT2) { MG_DMA_B2((t) + 2, 1); MG_WAIT_VM(6); } else { MG_WAIT_VM(0); } }, 1, 0); \
+  } else if constexpr (EARLY) {                                                                          \
+    MG_PHASE({ MG_READ_A(PAR, 0); MG_READ_B(PAR, 0); }, { if (NXT) MG_DMA_A2((t) + 1, 1); }, 0, 0);      \
+    MG_PHASE({ MG_READ_B(PAR, 1); }, { if (NXT2) MG_DMA_A2((t) + 2, 0); }, 0, 1);                         \
+    MG_PHASE({ MG_READ_A(PAR, 1); }, { if (NXT2) MG_DMA_B2((t) + 2, 0); }, 1, 1);                         \
+    MG_PHASE({}, { if (NXT2) { MG_DMA_B2((t) + 2, 1); MG_WAIT_VM(6); } else { MG_WAIT_VM(0); } }, 1, 0);  \
   } else {                                                                                               \
     MG_PHASE({ MG_READ_A(PAR, 0); MG_READ_B(PAR, 0); }, { if (NXT) MG_DMA_B((t) + 1, 1); }, 0, 0);       \
     MG_PHASE({ MG_READ_B(PAR, 1); }, { if (NXT) MG_DMA_A((t) + 1, 0); }, 0, 1);                           \
@@ -571,9 +660,15 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   }
 
   // ---- prologue: tile 0 complete, W_lo(1) in flight; group 1 starts one barrier late ----
-  MG_DMA_B(0, 0); MG_DMA_B(0, 1); MG_DMA_A(0, 0); MG_DMA_A(0, 1);
-  MG_DMA_B(1, 0);
-  MG_WAIT_VM(2);
+  if constexpr (EARLY) {     // tile 0 complete; A_0, W_0, W_1 of tile 1 in flight (A_1(1) follows in q0 of tile 0; every path)
+    MG_DMA_B2(0, 0); MG_DMA_B2(0, 1); MG_DMA_A2(0, 0); MG_DMA_A2(0, 1);
+    MG_DMA_A2(1, 0); MG_DMA_B2(1, 0); MG_DMA_B2(1, 1);
+    MG_WAIT_VM(6);
+  } else {
+    MG_DMA_B(0, 0); MG_DMA_B(0, 1); MG_DMA_A(0, 0); MG_DMA_A(0, 1);
+    MG_DMA_B(1, 0);
+    MG_WAIT_VM(2);
+  }
   MG_BAR();
   if (wr == 1) MG_BAR();
 
@@ -581,6 +676,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   for (; t + 2 < nkt; t += 2) {
     MG_G256_TILE(t, 0, true, true)
     MG_G256_TILE(t + 1, 1, true, true)
+    if (ABL == 2 || ABL == 4) abl_on = false;
   }
   MG_G256_TILE(t, 0, true, false)
   MG_G256_TILE(t + 1, 1, false, false)
@@ -600,6 +696,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
 #undef MG_HALF
 #undef MG_DMA_A
 #undef MG_DMA_B
+#undef MG_DMA_A2
+#undef MG_DMA_B2
+#undef KT_SRC
 
   // ---- epilogue: two passes of 128 tile rows (each wave's upper / lower 64) through LDS ----
   const bool wide = epilogue_wide_ok(p.ep);   // 16-byte accesses when every row start allows it
@@ -637,19 +736,19 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   pass(std::integral_constant<int, 1>{});
 }
 
-template <int WAVES, int KC, int NT, bool W8 = false>
+template <int WAVES, int KC, int NT, bool W8 = false, bool PIPE = false>
 __global__ __launch_bounds__(WAVES * 64) void skinny_kernel(const SkinnyParams p) {
   __shared__ __attribute__((aligned(16))) char lds[skinny_lds_bytes<WAVES, NT>()];
-  skinny_body<WAVES, KC, NT, W8>(p, blockIdx.x, lds);
+  skinny_body<WAVES, KC, NT, W8, false, NoWait, PIPE>(p, blockIdx.x, lds);
 }
 
 // two independent GEMVs (same variant) in ONE launch: blocks [0, g0) work on p0, the rest on p1.
 // Decode uses it for out_proj || adapter-down: the 64-workgroup adapter GEMV hides under the other.
-template <int WAVES, int KC, int NT, bool W8 = false>
+template <int WAVES, int KC, int NT, bool W8 = false, bool PIPE = false>
 __global__ __launch_bounds__(WAVES * 64) void skinny2_kernel(const SkinnyParams p0, const SkinnyParams p1, int g0) {
   __shared__ __attribute__((aligned(16))) char lds[skinny_lds_bytes<WAVES, NT>()];
-  if ((int)blockIdx.x < g0) skinny_body<WAVES, KC, NT, W8>(p0, blockIdx.x, lds);
-  else skinny_body<WAVES, KC, NT, W8>(p1, blockIdx.x - g0, lds);
+  if ((int)blockIdx.x < g0) skinny_body<WAVES, KC, NT, W8, false, NoWait, PIPE>(p0, blockIdx.x, lds);
+  else skinny_body<WAVES, KC, NT, W8, false, NoWait, PIPE>(p1, blockIdx.x - g0, lds);
 }
 
 int check_epilogue(const mg_epilogue& ep, const char* who) {
@@ -680,19 +779,36 @@ int launch_gemm(const GemmParams& gp, hipStream_t s) {
   return MG_OK;
 }
 
-template <int WLAYOUT, bool LATE_LGKM, bool FP8 = false, bool MFMA32 = false>
+// Row-tiles per group of the 256x256 kernel's tile walk.  An XCD runs 32 consecutive tiles of the walk at a time, i.e. a block
+// of group_m row-tiles x 32 / group_m column-tiles whose A and W panels its L2 shares.  MAGMA_G256_GROUP_M overrides (tuning).
+int group_m_256(int tiles_m, int tiles_n, int K) {
+  const char* e = getenv("MAGMA_G256_GROUP_M");
+  if (e && atoi(e) > 0) return atoi(e);
+  // measured (tools/kbench.py group, profiles/r03_kbench_gemm256_*): 4 x 8 blocks are at or above every other shape for
+  // K <= 8192; with a long K and few column tiles, 2 row-tiles x ALL column tiles stream A exactly once (1 GB at the fc_out
+  // shape, more than the 256 MiB Infinity Cache can hand from one column block to the next): +8 % there
+  if (K >= 8192 && tiles_n <= 16) return 32 / tiles_n > 0 ? 32 / tiles_n : 1;
+  return 4;
+}
+
+template <int WLAYOUT, bool LATE_LGKM, bool FP8 = false, bool MFMA32 = false, int ABL = 0>
 int launch_gemm256(GemmParams gp, hipStream_t s) {
-  if (int rc = mg_allow_dynamic_lds((const void*)gemm256_kernel<WLAYOUT, LATE_LGKM, FP8, MFMA32>, G256_LDS, "mg_gemm")) return rc;
+  if (int rc = mg_allow_dynamic_lds((const void*)gemm256_kernel<WLAYOUT, LATE_LGKM, FP8, MFMA32, ABL>, G256_LDS, "mg_gemm")) return rc;
   gp.tiles_m = (gp.M + 255) / 256; gp.tiles_n = (gp.N + 255) / 256;
-  hipLaunchKernelGGL((gemm256_kernel<WLAYOUT, LATE_LGKM, FP8, MFMA32>), dim3(gp.tiles_m * gp.tiles_n), dim3(512), G256_LDS, s, gp);
+  gp.group_m = group_m_256(gp.tiles_m, gp.tiles_n, gp.K);
+  gp.a_kt = 64;
+  if (const char* e = getenv("MAGMA_G256_A_BLOCKED"); e && atoi(e) == 1 && !FP8) {   // EXPERIMENT: A stored [K/64][M][64]
+    gp.lda = 64; gp.a_kt = (int64_t)gp.M * 64;
+  }
+  hipLaunchKernelGGL((gemm256_kernel<WLAYOUT, LATE_LGKM, FP8, MFMA32, ABL>), dim3(gp.tiles_m * gp.tiles_n), dim3(512), G256_LDS, s, gp);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }
 
-template <int WAVES, int KC, int NT, bool W8 = false>
+template <int WAVES, int KC, int NT, bool W8 = false, bool PIPE = false>
 int launch_skinny(const SkinnyParams& sp, hipStream_t s) {
   const int grid = (sp.ntiles + NT - 1) / NT;
-  hipLaunchKernelGGL((skinny_kernel<WAVES, KC, NT, W8>), dim3(grid), dim3(WAVES * 64), 0, s, sp);
+  hipLaunchKernelGGL((skinny_kernel<WAVES, KC, NT, W8, PIPE>), dim3(grid), dim3(WAVES * 64), 0, s, sp);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }
@@ -744,12 +860,23 @@ int gemm_dispatch(const mg_gemm_desc* d, bool fp8, const float* row_scale, hipSt
   // large dense shapes go to the deep-pipelined 256x256 kernel (tile_hint: 0 auto, 128 / 256 force)
   const int64_t wgs256 = (int64_t)((d->M + 255) / 256) * ((d->N + 255) / 256);
   const bool can256 = d->a_mode == MG_A_DENSE && (gp.K % 128) == 0;           // gp.K counts PAIRS of fp8 values on the fp8 path
-  const bool want256 = d->tile_hint == 256 || d->tile_hint == 257 || d->tile_hint == 258 || d->tile_hint == 259 ||
+  const bool want256 = (d->tile_hint >= 256 && d->tile_hint <= 266) ||
                        (d->tile_hint == 0 && wgs256 >= 192 && d->M >= 1024 && d->N >= 512);
   // bf16: 32x32x16 MFMA (tile_hint 258) or 16x16x32 (259); 0 / 256 follow MAGMA_GEMM256_MFMA (default below)
   static const int mfma_env = [] { const char* e = getenv("MAGMA_GEMM256_MFMA"); return e ? atoi(e) : MG_GEMM256_MFMA_DEFAULT; }();
   const bool mfma32 = !fp8 && (d->tile_hint == 258 || (d->tile_hint != 259 && d->tile_hint != 257 && mfma_env == 32));
   if (can256 && want256) {
+    if (d->tile_hint == 265 && !fp8 && !rm) return launch_gemm256<MG_W_FRAGTILED, false, false, false, 5>(gp, s);   // per-XCD K rotation
+    if (d->tile_hint == 266 && !fp8 && !rm) return launch_gemm256<MG_W_FRAGTILED, false, false, false, 6>(gp, s);   // first DMA schedule (A/B)
+    if (d->tile_hint >= 261 && d->tile_hint <= 264) {      // timing ablations of the bf16 kernel (WRONG results; tools/kbench.py abl)
+      if (fp8 || rm) MG_FAIL(MG_ERR_UNSUPPORTED, "%s: ablation builds exist for bf16 fragment-tiled weights only", who);
+      switch (d->tile_hint) {
+        case 261: return launch_gemm256<MG_W_FRAGTILED, false, false, false, 1>(gp, s);
+        case 262: return launch_gemm256<MG_W_FRAGTILED, false, false, false, 2>(gp, s);
+        case 263: return launch_gemm256<MG_W_FRAGTILED, false, false, false, 3>(gp, s);
+        default: return launch_gemm256<MG_W_FRAGTILED, false, false, false, 4>(gp, s);
+      }
+    }
     if (mfma32) return rm ? launch_gemm256<MG_W_ROWMAJOR, false, false, true>(gp, s) : launch_gemm256<MG_W_FRAGTILED, false, false, true>(gp, s);
     if (d->tile_hint == 257 && !fp8)   // experiment: LDS-read wait after the barrier
       return rm ? launch_gemm256<MG_W_ROWMAJOR, true>(gp, s) : launch_gemm256<MG_W_FRAGTILED, true>(gp, s);
@@ -848,12 +975,12 @@ int fill_skinny(const mg_skinny_desc* d, SkinnyParams& sp, const char* who) {
 // decode attention workgroups and the workgroups of one weight-streaming GEMV in ONE launch: the
 // attention part (B*H workgroups, latency-bound, a few hundred KB of KV) runs underneath the GEMV's
 // HBM stream instead of leaving most of the chip idle for ~10 us per layer.
-template <int KC, bool W8 = false>
+template <int KC, bool W8 = false, bool PIPE = false>
 __global__ __launch_bounds__(256) void decode_attn_gemv_kernel(const AttnDecodeParams ap, int n_attn, const SkinnyParams sp) {
   constexpr int LDS = ATTN_DEC_LDS > skinny_lds_bytes<4, 1>() ? ATTN_DEC_LDS : skinny_lds_bytes<4, 1>();
   __shared__ __attribute__((aligned(16))) char lds[LDS];
   if ((int)blockIdx.x < n_attn) attn_decode_body<true>(ap, blockIdx.x, lds);
-  else skinny_body<4, KC, 1, W8>(sp, blockIdx.x - n_attn, lds);
+  else skinny_body<4, KC, 1, W8, false, NoWait, PIPE>(sp, blockIdx.x - n_attn, lds);
 }
 
 // The same launch with a SECOND GEMV that consumes the attention output (out_proj of the block): its workgroups start
@@ -866,6 +993,7 @@ __global__ __launch_bounds__(256) void decode_attn_gemv_kernel(const AttnDecodeP
 // under-filled launch.  Deadlock freedom: the waiters need the attention workgroups to RUN, nothing else; the host entry
 // refuses grids that are not co-resident at 3 workgroups per CU (then every workgroup of the launch is resident at once
 // and dispatch order is irrelevant), and every spin is bounded: on time-out *err is set and the workgroup runs on.
+constexpr int MG_DECODE_PIPE_DEFAULT = 0;
 constexpr int CTX_SHARDS = 8, CTX_SHARD_STRIDE = 16;      // ints: one 64-byte line per shard
 constexpr int CTX_SPIN_LIMIT = 1 << 20;
 struct CtxWait {
@@ -1007,6 +1135,14 @@ extern "C" int mg_gemm_skinny_bf16(const mg_skinny_desc* d, void* stream) {
   // workgroup).  nt_hint == 0 -> tuned default for the shape; otherwise
   // nt_hint = nt | waves<<4 | kc<<8 (bench/tuning sweeps use this).
   int nt = d->nt_hint & 15, waves = (d->nt_hint >> 4) & 15, kc = (d->nt_hint >> 8) & 255;
+  const bool pipe = (d->nt_hint >> 16) & 1;        // double-buffered weight bursts (skinny_body<..., PIPE>)
+  if (pipe) {
+    if (sp.w_scale || nt != 1 || sp.ksteps % (waves * kc) != 0) MG_FAIL(MG_ERR_UNSUPPORTED, "mg_gemm_skinny_bf16: pipelined variants are bf16, one n-tile");
+#define MG_SKP(W_, K_) if (waves == W_ && kc == K_) return launch_skinny<W_, K_, 1, false, true>(sp, s)
+    MG_SKP(4, 16); MG_SKP(4, 8); MG_SKP(8, 8); MG_SKP(8, 4); MG_SKP(4, 4);
+#undef MG_SKP
+    MG_FAIL(MG_ERR_UNSUPPORTED, "mg_gemm_skinny_bf16: pipelined variant (waves=%d,kc=%d) not instantiated", waves, kc);
+  }
   if (d->nt_hint == 0) {
     // measured on MI355X (tools/kbench.py, profiles/r01_kbench_*.jsonl): many
     // waves with short load bursts beat few waves with deep ones.
@@ -1048,6 +1184,8 @@ extern "C" int mg_gemm_skinny2_bf16(const mg_skinny_desc* a, const mg_skinny_des
   if (int rc = fill_skinny(b, pb, "mg_gemm_skinny2_bf16(b)")) return rc;
   hipStream_t s = (hipStream_t)stream;
   const int grid = pa.ntiles + pb.ntiles;
+  // (burst shapes other than 8 waves x 4 k-steps -- one burst of 16, two of 8 issued up front, double-buffered 4 x 16 and
+  //  8 x 4 -- were measured inside the decode graph in rounds 2 and 3: all slower, 2.55-2.60 ms per token against 2.54)
   if ((pa.w_scale != nullptr) != (pb.w_scale != nullptr)) MG_FAIL(MG_ERR_UNSUPPORTED, "mg_gemm_skinny2_bf16: both problems must use the same weight type");
   if (pa.w_scale && pa.ksteps % 64 == 0 && pb.ksteps % 64 == 0) {
     hipLaunchKernelGGL((skinny2_kernel<8, 8, 1, true>), dim3(grid), dim3(512), 0, s, pa, pb, pa.ntiles);
@@ -1080,7 +1218,11 @@ extern "C" int mg_decode_attn_gemv_bf16(const mg_bf16* qkv, mg_bf16* kcache, mg_
   hipStream_t s = (hipStream_t)stream;
   const int n_attn = B * H, grid = n_attn + sp.ntiles;
   if (sp.w_scale && sp.ksteps % 64 != 0) MG_FAIL(MG_ERR_UNSUPPORTED, "mg_decode_attn_gemv_bf16: fp8 weights need K %% 2048 == 0 here");
+  // MAGMA_DECODE_PIPE: 0 = burst-and-drain, 16 / 8 = double-buffered bursts of that many k-steps (bf16 weights)
+  const int pipe = [] { const char* e = getenv("MAGMA_DECODE_PIPE"); return e ? atoi(e) : MG_DECODE_PIPE_DEFAULT; }();   // read per call (graph capture)
   if (sp.w_scale) hipLaunchKernelGGL((decode_attn_gemv_kernel<16, true>), dim3(grid), dim3(256), 0, s, ap, n_attn, sp);
+  else if (pipe == 16 && sp.ksteps % 64 == 0) hipLaunchKernelGGL((decode_attn_gemv_kernel<16, false, true>), dim3(grid), dim3(256), 0, s, ap, n_attn, sp);
+  else if (pipe == 8 && sp.ksteps % 32 == 0) hipLaunchKernelGGL((decode_attn_gemv_kernel<8, false, true>), dim3(grid), dim3(256), 0, s, ap, n_attn, sp);
   else if (sp.ksteps % 64 == 0) hipLaunchKernelGGL((decode_attn_gemv_kernel<16>), dim3(grid), dim3(256), 0, s, ap, n_attn, sp);
   else if (sp.ksteps % 16 == 0) hipLaunchKernelGGL((decode_attn_gemv_kernel<4>), dim3(grid), dim3(256), 0, s, ap, n_attn, sp);
   else if (sp.ksteps % 4 == 0) hipLaunchKernelGGL((decode_attn_gemv_kernel<1>), dim3(grid), dim3(256), 0, s, ap, n_attn, sp);

@@ -376,9 +376,14 @@ struct NoWait { MG_DEV void operator()() const {} };
 // COH: activations in / out go through the coherent 8-byte accessors (persistent decode step); `wait` is called once,
 // AFTER the first chunk's weight loads have been issued and BEFORE the first activation load: inside the persistent
 // launch it blocks on the producer's completion counter while the weights are already streaming in.
-template <int WAVES, int KC, int NT, bool W8 = false, bool COH = false, class Wait = NoWait>
+// PIPE: the weight bursts are double-buffered in registers -- burst c+1 is issued BEFORE the MFMAs of burst c, so a wave
+// always has KC..2*KC weight loads in flight instead of draining its queue at every burst boundary.  That matters where
+// occupancy cannot hide the drain: fc_out (N = 4096 -> 256 workgroups of 4 waves, ONE wave per SIMD, 8 bursts of 16 loads
+// each).  Same MFMA order per accumulator, hence bit-identical results.
+template <int WAVES, int KC, int NT, bool W8 = false, bool COH = false, class Wait = NoWait, bool PIPE = false>
 MG_DEV void skinny_body(const SkinnyParams& p, int block, char* lds, Wait wait = Wait()) {
   static_assert(!W8 || KC % 2 == 0, "fp8 weights are stored in k-step pairs");
+  static_assert(!PIPE || (!COH && __is_same(Wait, NoWait)), "the pipelined stream has no dependency wait / coherent loads");
   float* red = (float*)lds;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -408,6 +413,66 @@ MG_DEV void skinny_body(const SkinnyParams& p, int block, char* lds, Wait wait =
   };
   constexpr bool AHEAD = !__is_same(Wait, NoWait);     // persistent step: first weight burst before the dependency wait
   if constexpr (AHEAD) { load_w(0); wait(); }
+  if constexpr (PIPE) {
+    u32x4 wg[NT][WL];                                    // second register buffer (wf is the first)
+    auto load_into = [&](u32x4 (&dst)[NT][WL], int kc) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int nt = min(nt0 + t, p.ntiles - 1);
+        const u32x4* wp = W8 ? (const u32x4*)p.W + ((int64_t)nt * (p.ksteps >> 1) + ((ks0 + kc) >> 1)) * 64 + lane
+                             : (const u32x4*)p.W + ((int64_t)nt * p.ksteps + ks0 + kc) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < WL; ++i) dst[t][i] = __builtin_nontemporal_load(wp + i * 64);
+      }
+    };
+    // one burst: x fragments of burst kc (L2 hits), THEN the weights of the following burst, then the MFMAs of burst kc --
+    // vmcnt counts in order, so the wait for x leaves exactly the following burst's weight loads outstanding
+    // (has_next is a compile-time fact of the call site: behind a run-time branch hipcc has to assume at the join that
+    //  the following burst was NOT issued and waits for vmcnt(0) -- which drains the very loads this is about)
+    auto burst = [&](u32x4 (&cur)[NT][WL], u32x4 (&nxt)[NT][WL], int kc, auto has_next) {
+      bf16x8 xf[KC];
+#pragma unroll
+      for (int i = 0; i < KC; ++i) {
+        u32x4 raw = *(const u32x4*)(xrow + (int64_t)(ks0 + kc + i) * 32);
+        if (!xok) raw = (u32x4){0u, 0u, 0u, 0u};
+        xf[i] = __builtin_bit_cast(bf16x8, raw);
+      }
+      if constexpr (decltype(has_next)::value) load_into(nxt, kc + KC);
+      __builtin_amdgcn_sched_barrier(0);
+      if (p.ln_colsum && !(p.dbg & 1)) {
+#pragma unroll
+        for (int i = 0; i < KC; ++i) {
+          const u32x4 raw = __builtin_bit_cast(u32x4, xf[i]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float a = bflo(raw[j]), b = bfhi(raw[j]);
+            xs += a + b;
+            xss += a * a + b * b;
+          }
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < KC; ++i) {
+          bf16x8 w;
+          if constexpr (W8) w = fp8x8_to_bf16(cur[t][i >> 1][(i & 1) * 2], cur[t][i >> 1][(i & 1) * 2 + 1]);
+          else w = __builtin_bit_cast(bf16x8, cur[t][i]);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, xf[i], acc[t], 0, 0, 0);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    constexpr std::integral_constant<bool, true> more{};
+    constexpr std::integral_constant<bool, false> last{};
+    load_into(wf, 0);
+    int kc = 0;
+    for (; kc + 2 * KC < per_wave; kc += 2 * KC) {       // both bursts of the pair have a successor
+      burst(wf, wg, kc, more);
+      burst(wg, wf, kc + KC, more);
+    }
+    if (kc + KC < per_wave) { burst(wf, wg, kc, more); burst(wg, wf, kc + KC, last); }
+    else burst(wf, wg, kc, last);
+  } else
   for (int kc = 0; kc < per_wave; kc += KC) {
     // Issue the whole chunk's loads before the first MFMA (GEMV recipe: loads
     // straight to VGPRs, deep queue, late wait): weights first (HBM, non-temporal

@@ -132,6 +132,27 @@ def test_gemm_skinny(dev, M, N, K, variant):
     assert_close(out32, F.relu(x.float() @ w.float().t() + bias), 1e-4, "skinny relu f32")
 
 
+@pytest.mark.parametrize("N,K,base", [(4096, 16384, 1 | 4 << 4 | 16 << 8), (4096, 8192, 1 | 4 << 4 | 16 << 8), (4096, 4096, 1 | 8 << 4 | 8 << 8),
+                                      (1024, 4096, 1 | 8 << 4 | 4 << 8), (4096, 1024, 1 | 8 << 4 | 4 << 8), (4096, 2048, 1 | 4 << 4 | 16 << 8)])
+def test_gemm_skinny_pipelined_bursts_are_bit_identical(dev, N, K, base):
+    """skinny_body<..., PIPE>: double-buffered weight bursts, same MFMA order per accumulator -> the same bits as the drained
+    variant, LayerNorm fold included (odd burst counts exercise the peeled tail: K = 2048 -> one burst per wave)."""
+    from magma_amd import ops
+    M = 8
+    x = rnd(M, K, dev=dev, seed=31).to(BF16)
+    w = rnd(N, K, dev=dev, seed=32, scale=0.05).to(BF16)
+    lin = ops.PackedLinear(w, bias=rnd(N, dev=dev, seed=33))
+    a = ops.gemm_skinny(x, lin, out_dtype=torch.float32, variant=base)
+    b = ops.gemm_skinny(x, lin, out_dtype=torch.float32, variant=base | 1 << 16)
+    assert torch.equal(a, b)
+    assert_close(a, x.float() @ w.float().t() + lin.bias, 1e-4 * (K / 1024) ** 0.5 + 1e-4, "skinny f32")
+    colsum = w.float().sum(1).contiguous()
+    fold = (colsum, K, 1e-5)
+    a = ops.gemm_skinny(x, lin, out_dtype=torch.float32, variant=base, ln_fold=fold)
+    b = ops.gemm_skinny(x, lin, out_dtype=torch.float32, variant=base | 1 << 16, ln_fold=fold)
+    assert torch.equal(a, b)
+
+
 def test_tile_roundtrip(dev):
     from magma_amd import ops
     w = rnd(48, 128, dev=dev, seed=31).to(BF16)
@@ -255,6 +276,41 @@ def test_decode_attention(dev, ctx):
     ops.attn_decode_fused(qkv, kc2, vc2, out2, B, H, d_pos, 64, sin_t, cos_t)
     assert torch.equal(kc2, kc) and torch.equal(vc2, vc), "fused append must write the same cache rows"
     assert_close(out2, ref, 3e-3, "fused decode attention")
+
+
+def test_decode_colaunch_burst_variants_are_bit_identical(dev, monkeypatch):
+    """MAGMA_DECODE_PIPE (attention || fc_out with double-buffered weight bursts) changes the load schedule only: outputs equal
+    the default launch bit for bit."""
+    from magma_amd import ops
+    from oracle.model import rotary_tables
+    B, H, Smax, ctx = 8, 2, 128, 61
+    d = H * 256
+    kc0 = rnd(B, H, Smax, 256, dev=dev, seed=81, scale=0.5).to(BF16)
+    vc0 = rnd(B, H, Smax, 256, dev=dev, seed=82).to(BF16)
+    qkv = rnd(B, 3 * d, dev=dev, seed=83, scale=0.5).to(BF16)
+    sin_t, cos_t = rotary_tables(64, Smax)
+    sin_t, cos_t = sin_t.to(dev).contiguous(), cos_t.to(dev).contiguous()
+    d_pos = torch.tensor([ctx - 1], dtype=torch.int32, device=dev)
+    x = rnd(B, 16384, dev=dev, seed=84).to(BF16)
+    w = rnd(4096, 16384, dev=dev, seed=85, scale=0.05).to(BF16)
+    lin = ops.PackedLinear(w, bias=rnd(4096, dev=dev, seed=86))
+
+    def co(pipe):
+        if pipe:
+            monkeypatch.setenv("MAGMA_DECODE_PIPE", str(pipe))
+        else:
+            monkeypatch.delenv("MAGMA_DECODE_PIPE", raising=False)
+        kc, vc = kc0.clone(), vc0.clone()
+        att = torch.empty(B, d, dtype=BF16, device=dev)
+        y = torch.empty(B, 4096, dtype=torch.float32, device=dev)
+        ops.decode_attn_gemv(qkv, kc, vc, att, B, H, d_pos, 64, sin_t, cos_t, (x, lin, y, {"out_dtype": torch.float32}))
+        return att, y, kc, vc
+    ref = co(0)
+    assert_close(ref[1], x.float() @ w.float().t() + lin.bias, 1e-3, "fc_out")
+    for pipe in (16, 8):
+        got = co(pipe)
+        assert all(torch.equal(a, b) for a, b in zip(ref, got)), pipe
+    monkeypatch.delenv("MAGMA_DECODE_PIPE", raising=False)
 
 
 def test_argmax_and_pos(dev):

@@ -51,3 +51,30 @@ for v in [int(x) for x in os.environ.get("DEC_IN_VARIANTS", "").split(",") if x]
     except Exception as e:  # noqa: BLE001
         print(json.dumps({"dec_in_variant": v, "error": str(e)[:200]}))
 
+
+# in-process sweep of environment knobs the library reads per call (MAGMA_DECODE_PIPE, ...):
+#   DEC_ENV_SWEEP="MAGMA_DECODE_PIPE=16;MAGMA_DECODE_PIPE=8,DEC_IN=66689;-" python tools/decode_step_bench.py
+for setting in [x for x in os.environ.get("DEC_ENV_SWEEP", "").split(";") if x]:
+    kv = dict(item.split("=") for item in setting.split(",")) if setting != "-" else {}
+    eng._dec_in_variant = int(kv.pop("DEC_IN", 0))      # nt | waves << 4 | kc << 8 | pipelined << 16 of the ln_1+qkv+fc_in GEMV
+    kv_env = dict(kv)
+    for k, v in kv_env.items():
+        os.environ[k] = v
+    cache.decode_state.graphs.clear()
+    best = 1e9
+    try:
+        cache.pos = int(emb.shape[1]); cache.d_pos.fill_(cache.pos)
+        for _ in range(3):
+            eng.decode(tok, cache)
+        for rep in range(4):
+            cache.pos = int(emb.shape[1]); cache.d_pos.fill_(cache.pos)
+            torch.cuda.synchronize(); e0.record()
+            for _ in range(40):
+                eng.decode(tok, cache)
+            e1.record(); torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) / 40)
+        print(json.dumps({"env": kv_env, "dec_in": eng._dec_in_variant, "token_step_ms": best}))
+    except Exception as e:  # noqa: BLE001
+        print(json.dumps({"env": kv_env, "dec_in": eng._dec_in_variant, "error": str(e)[:200]}))
+    for k in kv_env:
+        os.environ.pop(k, None)

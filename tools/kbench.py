@@ -194,6 +194,121 @@ def main():
                         r[name + "_tflops"] = fl / ms / 1e9
                         r[name + "_frac_of_5PF"] = fl / ms / 1e9 / 5000.0
                 emit(**r)
+    if which == "lib":   # calibration: the vendor libraries on the same shapes (torch.matmul -> hipBLASLt / rocBLAS, SDPA)
+        for (M, N, K, tag) in [(32768, 12288, 4096, "qkv"), (32768, 4096, 4096, "out_proj"), (32768, 16384, 4096, "fc_in"),
+                               (32768, 4096, 16384, "fc_out"), (8192, 8192, 8192, "square8k"), (456, 28672, 4096, "prefill_qkv_fc_in")]:
+            a = torch.randn(M, K, device=dev).to(BF16)
+            w = (torch.randn(N, K, device=dev) * 0.05).to(BF16)
+            lin = ops.PackedLinear(w)
+            out = torch.empty(M, N, dtype=BF16, device=dev)
+            wt = w.t()
+            fl = 2.0 * M * N * K
+            r = {"kind": "lib_gemm", "tag": tag, "M": M, "N": N, "K": K}
+            for name, fn in (("mine", lambda i: ops.gemm(a, lin, out=out, tile=256 if M <= 512 else 0)),
+                             ("torch_nt", lambda i: torch.matmul(a, wt, out=out)),
+                             ("mine_again", lambda i: ops.gemm(a, lin, out=out, tile=256 if M <= 512 else 0)),
+                             ("torch_nt_again", lambda i: torch.matmul(a, wt, out=out))):
+                ms = timeit(fn, 10)
+                r[name + "_ms"] = ms
+                r[name + "_tflops"] = fl / ms / 1e9
+            emit(**r)
+        import torch.nn.functional as Fn
+        B, H, S = 16, 16, 2048
+        q = (torch.randn(B, H, S, 256, device=dev) * 0.5).to(BF16)
+        k = (torch.randn(B, H, S, 256, device=dev) * 0.5).to(BF16)
+        v = torch.randn(B, H, S, 256, device=dev).to(BF16)
+        fl = B * H * 4.0 * S * S * 256 / 2
+        r = {"kind": "lib_attention", "B": B, "H": H, "S": S, "dh": 256}
+        try:
+            ms = timeit(lambda i: Fn.scaled_dot_product_attention(q, k, v, is_causal=True, scale=1.0 / 16), 5)
+            r["sdpa_fwd_ms"] = ms
+            r["sdpa_fwd_tflops_causal"] = fl / ms / 1e9
+            qg, kg, vg = (t.clone().requires_grad_(True) for t in (q, k, v))
+            o = Fn.scaled_dot_product_attention(qg, kg, vg, is_causal=True, scale=1.0 / 16)
+            do = torch.randn_like(o)
+            ms = timeit(lambda i: torch.autograd.grad(o, (qg, kg, vg), do, retain_graph=True), 5)
+            r["sdpa_bwd_ms"] = ms
+        except Exception as e:  # noqa: BLE001
+            r["sdpa_error"] = str(e)[:300]
+        hs = H * S * 256
+        vt = ops.head_transpose(v, B, H, S, sb=hs, ss=256, sh=S * 256)
+        out = torch.empty(B * S, H * 256, dtype=BF16, device=dev)
+        lse = torch.empty(B, H, S, dtype=torch.float32, device=dev)
+        ms = timeit(lambda i: ops.attn_prefill(q, k, vt, out, B, H, S, lse=lse), 5)
+        r["mine_fwd_ms"] = ms
+        r["mine_fwd_tflops_causal"] = fl / ms / 1e9
+        qt = ops.head_transpose(q, B, H, S, sb=hs, ss=256, sh=S * 256)
+        kt = ops.head_transpose(k, B, H, S, sb=hs, ss=256, sh=S * 256)
+        dO = torch.randn(B * S, H * 256, device=dev).to(BF16)
+        dOt = ops.head_transpose(dO, B, H, S, sb=S * H * 256, ss=H * 256, sh=256)
+        ms = timeit(lambda i: ops.attn_bwd(q, k, v, qt, kt, dO, dOt, out, lse, B, H, S), 5)
+        r["mine_bwd_ms"] = ms
+        emit(**r)
+    if which == "abl":   # timing ablations of the 256x256 bf16 kernel (results of 261..264 are WRONG by construction)
+        for (M, N, K, tag) in [(32768, 16384, 4096, "fc_in"), (32768, 4096, 16384, "fc_out"), (32768, 4096, 4096, "out_proj"), (32768, 12288, 4096, "qkv"),
+                               (8192, 8192, 8192, "square8k")]:
+            a = torch.randn(M, K, device=dev).to(BF16)
+            lin = ops.PackedLinear((torch.randn(N, K, device=dev) * 0.05).to(BF16))
+            out = torch.empty(M, N, dtype=BF16, device=dev)
+            fl = 2.0 * M * N * K
+            ref = ops.gemm(a, lin, tile=256).float()
+            rot = ops.gemm(a, lin, tile=265).float()
+            old = ops.gemm(a, lin, tile=266)
+            r = {"kind": "abl", "k_rot_rel_vs_full": float((rot - ref).norm() / ref.norm()), "equal_to_first_schedule": bool(torch.equal(old.float(), ref)), "tag": tag, "M": M, "N": N, "K": K}
+            for rep in range(2):
+                for name, tile in (("full", 256), ("l2hot_dma", 261), ("no_ds_read", 262), ("no_mfma", 263), ("no_dma", 264), ("k_rot", 265), ("first_dma_schedule", 266)):
+                    ms = timeit(lambda i: ops.gemm(a, lin, out=out, tile=tile), 8)
+                    r[f"{name}_ms_{rep}"] = round(ms, 4)
+                    r[f"{name}_tf_{rep}"] = round(fl / ms / 1e9, 1)
+            emit(**r)
+    if which == "pad":   # does a power-of-two row stride of A cost bandwidth (L2 / HBM channel aliasing)?  lda = K + pad elements
+        for (M, N, K, tag) in [(32768, 4096, 16384, "fc_out"), (32768, 4096, 4096, "out_proj"), (32768, 16384, 4096, "fc_in"), (8192, 8192, 8192, "square8k")]:
+            lin = ops.PackedLinear((torch.randn(N, K, device=dev) * 0.05).to(BF16))
+            out = torch.empty(M, N, dtype=BF16, device=dev)
+            fl = 2.0 * M * N * K
+            r = {"kind": "pad", "tag": tag, "M": M, "N": N, "K": K}
+            for rep in range(2):
+                for pad in (0, 64, 128, 256, 576):
+                    a = torch.randn(M, K + pad, device=dev).to(BF16)[:, :K]
+                    ms = timeit(lambda i: ops.gemm(a, lin, out=out, tile=256), 8)
+                    r[f"pad{pad}_tf_{rep}"] = round(fl / ms / 1e9, 1)
+                    del a
+            emit(**r)
+    if which == "group":   # tile-walk block shape of the 256x256 kernel: group_m row-tiles x 32/group_m column-tiles per XCD at a time
+        for (M, N, K, tag) in [(32768, 4096, 16384, "fc_out"), (32768, 4096, 4096, "out_proj"), (32768, 16384, 4096, "fc_in"), (32768, 12288, 4096, "qkv"),
+                               (8192, 8192, 8192, "square8k"), (4096, 16384, 32768, "wgrad_fc_in")]:
+            a = torch.randn(M, K, device=dev).to(BF16)
+            lin = ops.PackedLinear((torch.randn(N, K, device=dev) * 0.05).to(BF16))
+            out = torch.empty(M, N, dtype=BF16, device=dev)
+            fl = 2.0 * M * N * K
+            r = {"kind": "group", "tag": tag, "M": M, "N": N, "K": K}
+            for rep in range(2):
+                for gm in (8, 1, 2, 4, 16, 32):
+                    os.environ["MAGMA_G256_GROUP_M"] = str(gm)
+                    ms = timeit(lambda i: ops.gemm(a, lin, out=out, tile=256), 8)
+                    r[f"gm{gm}_tf_{rep}"] = round(fl / ms / 1e9, 1)
+            os.environ.pop("MAGMA_G256_GROUP_M", None)
+            emit(**r)
+    if which == "ablocked":   # A stored K-tile-major [K/64][M][64] (a K-tile of 256 rows = 32 KiB contiguous) vs row-major
+        for (M, N, K, tag) in [(32768, 4096, 16384, "fc_out"), (32768, 4096, 4096, "out_proj"), (32768, 16384, 4096, "fc_in"), (8192, 8192, 8192, "square8k")]:
+            a = torch.randn(M, K, device=dev).to(BF16)
+            ab = a.view(M, K // 64, 64).permute(1, 0, 2).contiguous()
+            lin = ops.PackedLinear((torch.randn(N, K, device=dev) * 0.05).to(BF16))
+            out = torch.empty(M, N, dtype=BF16, device=dev)
+            fl = 2.0 * M * N * K
+            ref = ops.gemm(a, lin, tile=256).float()
+            os.environ["MAGMA_G256_A_BLOCKED"] = "1"
+            got = ops.gemm(ab.view(M, K), lin, tile=256).float()
+            os.environ.pop("MAGMA_G256_A_BLOCKED")
+            r = {"kind": "ablocked", "tag": tag, "M": M, "N": N, "K": K, "rel": float((got - ref).norm() / ref.norm())}
+            for rep in range(2):
+                ms = timeit(lambda i: ops.gemm(a, lin, out=out, tile=256), 8)
+                r[f"rowmajor_tf_{rep}"] = round(fl / ms / 1e9, 1)
+                os.environ["MAGMA_G256_A_BLOCKED"] = "1"
+                ms = timeit(lambda i: ops.gemm(ab.view(M, K), lin, out=out, tile=256), 8)
+                os.environ.pop("MAGMA_G256_A_BLOCKED")
+                r[f"blocked_tf_{rep}"] = round(fl / ms / 1e9, 1)
+            emit(**r)
     if which == "shortk":   # adapter up-projection (K = 1024) with three residual reads: epilogue-bound; 128x128 vs 256x256 kernel
         M, N, K = 32768, 4096, 1024
         a = torch.randn(M, K, device=dev).to(BF16)
