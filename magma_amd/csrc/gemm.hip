@@ -384,14 +384,14 @@ static_assert(G256_LDS >= 2 * G256_BUF, "LDS must hold two K-tiles");
 // Accumulator map: column m = l & 31, rows n = (reg & 3) + 8 (reg >> 2) + 4 (l >> 5): a register quad is 4 consecutive n,
 // exactly what the LDS-staged epilogue stores.
 typedef __attribute__((ext_vector_type(16))) float f32x16;
-// ABL (timing ablations, WRONG results; tile_hint 261..264, tools/kbench.py abl): 1 = every K-tile's DMA reads K-tile (t & 1)
-// (operands always L2-hot: isolates memory latency), 2 = no fragment reads after the first two K-tiles (isolates the LDS read
-// segments), 3 = no MFMA, 4 = no DMA after the prologue.
+// ABL (timing ablations, WRONG results unless noted; tile_hint 261.., tools/kbench.py abl / ksweep; compiled with `make ABL=1`):
+// 1 = every K-tile's DMA reads K-tile (t & 1) (operands always L2-hot: isolates memory latency), 2 = no fragment reads after
+// the first two K-tiles (isolates the LDS read segments), 3 = no MFMA, 4 = no DMA after the prologue, 6 = the first DMA
+// schedule (correct results), 7 = no epilogue, 8 = epilogue staging only, 10 = every tile stores to tile (0, 0).
 template <int WLAYOUT, bool LATE_LGKM, bool FP8 = false, bool MFMA32 = false, int ABL = 0>
 __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   static_assert(!(FP8 && MFMA32), "the 32x32 form is the bf16 path");
   bool abl_on = true;           // ABL 2 / 4: false once the pipeline is primed
-  // ABL 5 (correct results): each XCD starts its K loop at a different K-tile (rotation by xcd * nkt / 8) -- see KT_SRC
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -400,8 +400,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   tile_coords(blockIdx.x, p.tiles_m, p.tiles_n, tm, tn, p.group_m);
   const int m0 = tm * 256, n0 = tn * 256;
   const int nkt = p.K >> 6;                       // even (K % 128 == 0)
-  const int kt_rot = (ABL == 5) ? (((int)blockIdx.x & 7) * (nkt >> 3)) & ~1 : 0;   // even, so buffer parity follows the loop index
-#define KT_SRC(kt) (ABL == 1 ? ((kt) & 1) : ABL == 5 ? ((kt) + kt_rot >= nkt ? (kt) + kt_rot - nkt : (kt) + kt_rot) : (kt))
+#define KT_SRC(kt) (ABL == 1 ? ((kt) & 1) : (kt))
   const int wr = wave >> 2, wc = wave & 3;        // wr is also the wave group
   const int li = lane & 15, lq = lane >> 4;
 
@@ -700,6 +699,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
 #undef MG_DMA_B2
 #undef KT_SRC
 
+  if constexpr (ABL == 7) {      // timing ablation: no epilogue (nothing is stored)
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+    return;
+  }
   // ---- epilogue: two passes of 128 tile rows (each wave's upper / lower 64) through LDS ----
   const bool wide = epilogue_wide_ok(p.ep);   // 16-byte accesses when every row start allows it
   __syncthreads();
@@ -727,10 +733,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
         *(f32x4*)(smem + (wr * 64 + i * 16 + li) * EPI256_ROWB + (wc * 64 + j * 16 + lq * 4) * 4) = acc[h * 4 + i][j];
     }
     __syncthreads();
-    const int mb = m0 + h * 64;
-    if (!wide) epilogue_rows<256, EPI256_ROWB, 4, false>(p.ep, smem, 128, 8, wave, lane, mb, 128, n0, p.M, p.N, p.row_scale);
-    else if (p.nt) epilogue_rows<256, EPI256_ROWB, 8, true>(p.ep, smem, 128, 8, wave, lane, mb, 128, n0, p.M, p.N, p.row_scale);
-    else epilogue_rows<256, EPI256_ROWB, 8, false>(p.ep, smem, 128, 8, wave, lane, mb, 128, n0, p.M, p.N, p.row_scale);
+    // (timing ablations: 8 = LDS staging only, no row walk; 10 = every tile stores to the rows / columns of tile (0, 0))
+    const int mb = (ABL == 10 ? 0 : m0) + h * 64, nb = ABL == 10 ? 0 : n0, mlim = ABL == 8 ? 0 : p.M;
+    if (!wide) epilogue_rows<256, EPI256_ROWB, 4, false>(p.ep, smem, 128, 8, wave, lane, mb, 128, nb, mlim, p.N, p.row_scale);
+    else if (p.nt) epilogue_rows<256, EPI256_ROWB, 8, true>(p.ep, smem, 128, 8, wave, lane, mb, 128, nb, mlim, p.N, p.row_scale);
+    else epilogue_rows<256, EPI256_ROWB, 8, false>(p.ep, smem, 128, 8, wave, lane, mb, 128, nb, mlim, p.N, p.row_scale);
   };
   pass(std::integral_constant<int, 0>{});
   pass(std::integral_constant<int, 1>{});
@@ -797,9 +804,6 @@ int launch_gemm256(GemmParams gp, hipStream_t s) {
   gp.tiles_m = (gp.M + 255) / 256; gp.tiles_n = (gp.N + 255) / 256;
   gp.group_m = group_m_256(gp.tiles_m, gp.tiles_n, gp.K);
   gp.a_kt = 64;
-  if (const char* e = getenv("MAGMA_G256_A_BLOCKED"); e && atoi(e) == 1 && !FP8) {   // EXPERIMENT: A stored [K/64][M][64]
-    gp.lda = 64; gp.a_kt = (int64_t)gp.M * 64;
-  }
   hipLaunchKernelGGL((gemm256_kernel<WLAYOUT, LATE_LGKM, FP8, MFMA32, ABL>), dim3(gp.tiles_m * gp.tiles_n), dim3(512), G256_LDS, s, gp);
   MG_CHECK_LAUNCH();
   return MG_OK;
@@ -860,22 +864,29 @@ int gemm_dispatch(const mg_gemm_desc* d, bool fp8, const float* row_scale, hipSt
   // large dense shapes go to the deep-pipelined 256x256 kernel (tile_hint: 0 auto, 128 / 256 force)
   const int64_t wgs256 = (int64_t)((d->M + 255) / 256) * ((d->N + 255) / 256);
   const bool can256 = d->a_mode == MG_A_DENSE && (gp.K % 128) == 0;           // gp.K counts PAIRS of fp8 values on the fp8 path
-  const bool want256 = (d->tile_hint >= 256 && d->tile_hint <= 266) ||
+  const bool want256 = (d->tile_hint >= 256 && d->tile_hint <= 270) ||
                        (d->tile_hint == 0 && wgs256 >= 192 && d->M >= 1024 && d->N >= 512);
   // bf16: 32x32x16 MFMA (tile_hint 258) or 16x16x32 (259); 0 / 256 follow MAGMA_GEMM256_MFMA (default below)
   static const int mfma_env = [] { const char* e = getenv("MAGMA_GEMM256_MFMA"); return e ? atoi(e) : MG_GEMM256_MFMA_DEFAULT; }();
   const bool mfma32 = !fp8 && (d->tile_hint == 258 || (d->tile_hint != 259 && d->tile_hint != 257 && mfma_env == 32));
   if (can256 && want256) {
-    if (d->tile_hint == 265 && !fp8 && !rm) return launch_gemm256<MG_W_FRAGTILED, false, false, false, 5>(gp, s);   // per-XCD K rotation
-    if (d->tile_hint == 266 && !fp8 && !rm) return launch_gemm256<MG_W_FRAGTILED, false, false, false, 6>(gp, s);   // first DMA schedule (A/B)
-    if (d->tile_hint >= 261 && d->tile_hint <= 264) {      // timing ablations of the bf16 kernel (WRONG results; tools/kbench.py abl)
+    if (d->tile_hint >= 261) {      // timing ablations / A-B variants of the bf16 kernel (tools/kbench.py abl, ksweep)
+#ifdef MG_GEMM_ABLATIONS            // `make ABL=1`: each one is another copy of the kernel and its epilogue (minutes of compile time)
       if (fp8 || rm) MG_FAIL(MG_ERR_UNSUPPORTED, "%s: ablation builds exist for bf16 fragment-tiled weights only", who);
       switch (d->tile_hint) {
-        case 261: return launch_gemm256<MG_W_FRAGTILED, false, false, false, 1>(gp, s);
-        case 262: return launch_gemm256<MG_W_FRAGTILED, false, false, false, 2>(gp, s);
-        case 263: return launch_gemm256<MG_W_FRAGTILED, false, false, false, 3>(gp, s);
-        default: return launch_gemm256<MG_W_FRAGTILED, false, false, false, 4>(gp, s);
+        case 261: return launch_gemm256<MG_W_FRAGTILED, false, false, false, 1>(gp, s);    // DMA always reads K-tiles 0 / 1 (L2-hot)
+        case 262: return launch_gemm256<MG_W_FRAGTILED, false, false, false, 2>(gp, s);    // no fragment reads
+        case 263: return launch_gemm256<MG_W_FRAGTILED, false, false, false, 3>(gp, s);    // no MFMA
+        case 264: return launch_gemm256<MG_W_FRAGTILED, false, false, false, 4>(gp, s);    // no DMA after the prologue
+        case 266: return launch_gemm256<MG_W_FRAGTILED, false, false, false, 6>(gp, s);    // first DMA schedule (correct results)
+        case 267: return launch_gemm256<MG_W_FRAGTILED, false, false, false, 7>(gp, s);    // no epilogue
+        case 268: return launch_gemm256<MG_W_FRAGTILED, false, false, false, 8>(gp, s);    // epilogue: LDS staging only
+        case 270: return launch_gemm256<MG_W_FRAGTILED, false, false, false, 10>(gp, s);   // epilogue: all tiles store to tile (0,0)
+        default: MG_FAIL(MG_ERR_UNSUPPORTED, "%s: no such ablation (tile_hint %d)", who, d->tile_hint);
       }
+#else
+      MG_FAIL(MG_ERR_UNSUPPORTED, "%s: tile_hint %d is a timing ablation; build the library with `make ABL=1`", who, d->tile_hint);
+#endif
     }
     if (mfma32) return rm ? launch_gemm256<MG_W_ROWMAJOR, false, false, true>(gp, s) : launch_gemm256<MG_W_FRAGTILED, false, false, true>(gp, s);
     if (d->tile_hint == 257 && !fp8)   // experiment: LDS-read wait after the barrier

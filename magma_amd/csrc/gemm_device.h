@@ -246,6 +246,45 @@ MG_DEV void epilogue_apply_impl(const mg_epilogue& ep, const EpiColsW<W>& c, int
   }
 }
 
+// The same arithmetic for an epilogue WITHOUT aux / residual operands (scale, bias, activation, optional pre-activation copy,
+// trailing ReLU): no global load anywhere in it.  epilogue_rows uses it for such epilogues in a loop of its own -- in the
+// general loop hipcc cannot count the conditional loads and guards every LDS read with s_waitcnt vmcnt(0), which on this
+// chip also waits for the STORES of the previous row to be acknowledged (vmcnt counts stores): ~0.75 us per row pair, 12 us
+// of the 14 us a 256x256 tile spent in its epilogue.
+template <int W, bool NT>
+MG_DEV void epilogue_apply_plain(const mg_epilogue& ep, const EpiColsW<W>& c, int m, int n, const float* v, int N) {
+  const bool full = (n + W - 1 < N);
+  float o[W];
+#pragma unroll
+  for (int r = 0; r < W; ++r) o[r] = v[r] * c.sc[r] + c.bi[r];
+  if (ep.C2) {
+    mg_bf16* cp = ep.C2 + (int64_t)m * ep.ldc2 + n;
+    if (full) store_bf16_row<W, NT>(cp, o);
+    else for (int r = 0; r < W; ++r) if (n + r < N) cp[r] = f2bf(o[r]);
+  }
+  const int act = n >= ep.act_n0 ? ep.act : MG_ACT_NONE;
+#pragma unroll
+  for (int r = 0; r < W; ++r) o[r] = apply_act(o[r], act);
+  if (ep.act_after == MG_ACT_RELU) {
+#pragma unroll
+    for (int r = 0; r < W; ++r) o[r] = o[r] > 0.f ? o[r] : 0.f;
+  }
+  if (ep.out_f32) {
+    float* cp = (float*)ep.C + (int64_t)m * ep.ldc + n;
+    if (full) {
+#pragma unroll
+      for (int g = 0; g < W; g += 4) {
+        const f32x4 w = {o[g], o[g + 1], o[g + 2], o[g + 3]};
+        if (NT) __builtin_nontemporal_store(w, (f32x4*)(cp + g)); else *(f32x4*)(cp + g) = w;
+      }
+    } else for (int r = 0; r < W; ++r) if (n + r < N) cp[r] = o[r];
+  } else {
+    mg_bf16* cp = (mg_bf16*)ep.C + (int64_t)m * ep.ldc + n;
+    if (full) store_bf16_row<W, NT>(cp, o);
+    else for (int r = 0; r < W; ++r) if (n + r < N) cp[r] = f2bf(o[r]);
+  }
+}
+
 template <int W, bool NT, bool COH = false>
 MG_DEV void epilogue_apply(const mg_epilogue& ep, const EpiColsW<W>& c, int m, int n, const float* v, int N) {
   const EpiPre<W> none{};
@@ -298,6 +337,34 @@ MG_DEV void epilogue_rows(const mg_epilogue& ep, const char* lds, int rows, int 
   const int step = nwaves * RPI;
   int r = wave * RPI + lane / LPR;
   const bool extra = ep.aux_mode != MG_AUX_NONE || ep.res0 || ep.res1 || ep.res2;
+  if (!extra && !row_scale) {     // no operand to load: LDS reads of four rows, then their arithmetic and stores; no vmcnt wait
+    auto lds_row = [&](int rr, float (&v)[W]) {
+#pragma unroll
+      for (int g = 0; g < W; g += 4) {
+        const f32x4 t = *(const f32x4*)(lds + rr * ROWB + (cl * W + g) * 4);
+        v[g] = t[0]; v[g + 1] = t[1]; v[g + 2] = t[2]; v[g + 3] = t[3];
+      }
+    };
+    auto row_of = [&](int rr) { return m_base + (rr >> 6) * hi_stride + (rr & 63); };
+    for (; r + 3 * step < rows; r += 4 * step) {
+      float v0[W], v1[W], v2[W], v3[W];
+      lds_row(r, v0); lds_row(r + step, v1); lds_row(r + 2 * step, v2); lds_row(r + 3 * step, v3);
+      const int ma = row_of(r), mb = row_of(r + step), mc = row_of(r + 2 * step), md = row_of(r + 3 * step);
+      if (ma < M) epilogue_apply_plain<W, NT>(ep, c, ma, n, v0, N);
+      if (mb < M) epilogue_apply_plain<W, NT>(ep, c, mb, n, v1, N);
+      if (mc < M) epilogue_apply_plain<W, NT>(ep, c, mc, n, v2, N);
+      if (md < M) epilogue_apply_plain<W, NT>(ep, c, md, n, v3, N);
+    }
+    for (; r < rows; r += step) {
+      const int m = row_of(r);
+      if (m < M) {
+        float v[W];
+        lds_row(r, v);
+        epilogue_apply_plain<W, NT>(ep, c, m, n, v, N);
+      }
+    }
+    return;
+  }
   if (extra && n + W - 1 < N) {
     // rows in batches of 4: all aux / residual loads of the batch first, then the arithmetic and the stores
     // (four named structs, not an array: an indexed array of them ends up in scratch)
