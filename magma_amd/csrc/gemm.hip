@@ -392,6 +392,7 @@ template <int WLAYOUT, bool LATE_LGKM, bool FP8 = false, bool MFMA32 = false, in
 __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   static_assert(!(FP8 && MFMA32), "the 32x32 form is the bf16 path");
   bool abl_on = true;           // ABL 2 / 4: false once the pipeline is primed
+  const unsigned long long t_start = ABL == 11 ? __builtin_amdgcn_s_memrealtime() : 0ull;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -707,13 +708,21 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
     return;
   }
   // ---- epilogue: two passes of 128 tile rows (each wave's upper / lower 64) through LDS ----
+  // Barriers here are RAW s_barrier + lgkmcnt(0): the hazards are LDS-only (staging writes vs row reads), and __syncthreads()
+  // would add s_waitcnt vmcnt(0) -- with the stores of pass 0 outstanding that is a full store drain in the middle of the
+  // epilogue (vmcnt counts stores on this chip).  For the same reason the per-column vectors are loaded once, before pass 0.
   const bool wide = epilogue_wide_ok(p.ep);   // 16-byte accesses when every row start allows it
-  __syncthreads();
+  // ABL 11: 100-MHz time stamps of wave 0 into p.ws[blockIdx.x * 8 ..] (start, K loop done, staged 0, walked 0, staged 1, walked 1, drained)
+  unsigned long long* stamps = (unsigned long long*)p.ws + (size_t)blockIdx.x * 8;
+#define MG_STAMP(i) if (ABL == 11 && tid == 0) stamps[i] = __builtin_amdgcn_s_memrealtime()
+  if (ABL == 11 && tid == 0) stamps[0] = t_start;
+  MG_STAMP(1);
+  MG_WAIT_LGKM0();
+  MG_BAR();                                   // every wave has read its last fragments: the K-tile buffers are free
   // (a generic lambda called with two compile-time halves: a `for (h)` loop around this much code is not unrolled by
   //  hipcc any more, and acc[h * 4 + i] with a run-time h puts the 128 accumulators in scratch)
-  auto pass = [&](auto hc) {
+  auto stage = [&](auto hc) {
     constexpr int h = decltype(hc)::value;
-    if (h) __syncthreads();   // pass 0 has been read
     if constexpr (MFMA32) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -727,20 +736,46 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
           }
     } else {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        *(f32x4*)(smem + (wr * 64 + i * 16 + li) * EPI256_ROWB + (wc * 64 + j * 16 + lq * 4) * 4) = acc[h * 4 + i][j];
+        for (int j = 0; j < 4; ++j)
+          *(f32x4*)(smem + (wr * 64 + i * 16 + li) * EPI256_ROWB + (wc * 64 + j * 16 + lq * 4) * 4) = acc[h * 4 + i][j];
     }
-    __syncthreads();
-    // (timing ablations: 8 = LDS staging only, no row walk; 10 = every tile stores to the rows / columns of tile (0, 0))
-    const int mb = (ABL == 10 ? 0 : m0) + h * 64, nb = ABL == 10 ? 0 : n0, mlim = ABL == 8 ? 0 : p.M;
-    if (!wide) epilogue_rows<256, EPI256_ROWB, 4, false>(p.ep, smem, 128, 8, wave, lane, mb, 128, nb, mlim, p.N, p.row_scale);
-    else if (p.nt) epilogue_rows<256, EPI256_ROWB, 8, true>(p.ep, smem, 128, 8, wave, lane, mb, 128, nb, mlim, p.N, p.row_scale);
-    else epilogue_rows<256, EPI256_ROWB, 8, false>(p.ep, smem, 128, 8, wave, lane, mb, 128, nb, mlim, p.N, p.row_scale);
+    MG_WAIT_LGKM0();
+    MG_BAR();
   };
-  pass(std::integral_constant<int, 0>{});
-  pass(std::integral_constant<int, 1>{});
+  // (timing ablations: 8 = LDS staging only, no row walk; 10 = every tile stores to the rows / columns of tile (0, 0))
+  const int mb0 = (ABL == 10 ? 0 : m0), nb = ABL == 10 ? 0 : n0, mlim = ABL == 8 ? 0 : p.M;
+  auto both = [&](auto wc_, auto ntc_, auto fullc_) {
+    constexpr int W = decltype(wc_)::value;
+    constexpr bool NT = decltype(ntc_)::value;
+    constexpr bool FULL = decltype(fullc_)::value;      // interior column tile: no per-element tail code
+    EpiColsW<W> c;
+    const int n = nb + (lane % (256 / W)) * W;
+    if (n < p.N) epilogue_cols<W>(p.ep, n, p.N, c);
+    stage(std::integral_constant<int, 0>{});
+    MG_STAMP(2);
+    epilogue_rows_c<256, EPI256_ROWB, W, NT, FULL>(p.ep, c, smem, 128, 8, wave, lane, mb0, 128, nb, mlim, p.N, p.row_scale);
+    MG_WAIT_LGKM0();
+    MG_BAR();                                 // pass 0 has been read
+    MG_STAMP(3);
+    stage(std::integral_constant<int, 1>{});
+    MG_STAMP(4);
+    epilogue_rows_c<256, EPI256_ROWB, W, NT, FULL>(p.ep, c, smem, 128, 8, wave, lane, mb0 + 64, 128, nb, mlim, p.N, p.row_scale);
+    MG_STAMP(5);
+    if (ABL == 11) {
+      MG_WAIT_VM(0);
+      MG_STAMP(6);
+      if (tid == 0) stamps[7] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4);   // XCC_ID, HW_ID
+    }
+  };
+  const bool interior = nb + 256 <= p.N;
+  if (!wide) both(std::integral_constant<int, 4>{}, std::false_type{}, std::false_type{});
+  else if (p.nt && interior) both(std::integral_constant<int, 8>{}, std::true_type{}, std::true_type{});
+  else if (interior) both(std::integral_constant<int, 8>{}, std::false_type{}, std::true_type{});
+  else if (p.nt) both(std::integral_constant<int, 8>{}, std::true_type{}, std::false_type{});
+  else both(std::integral_constant<int, 8>{}, std::false_type{}, std::false_type{});
+#undef MG_STAMP
 }
 
 template <int WAVES, int KC, int NT, bool W8 = false, bool PIPE = false>
@@ -864,7 +899,7 @@ int gemm_dispatch(const mg_gemm_desc* d, bool fp8, const float* row_scale, hipSt
   // large dense shapes go to the deep-pipelined 256x256 kernel (tile_hint: 0 auto, 128 / 256 force)
   const int64_t wgs256 = (int64_t)((d->M + 255) / 256) * ((d->N + 255) / 256);
   const bool can256 = d->a_mode == MG_A_DENSE && (gp.K % 128) == 0;           // gp.K counts PAIRS of fp8 values on the fp8 path
-  const bool want256 = (d->tile_hint >= 256 && d->tile_hint <= 270) ||
+  const bool want256 = (d->tile_hint >= 256 && d->tile_hint <= 271) ||
                        (d->tile_hint == 0 && wgs256 >= 192 && d->M >= 1024 && d->N >= 512);
   // bf16: 32x32x16 MFMA (tile_hint 258) or 16x16x32 (259); 0 / 256 follow MAGMA_GEMM256_MFMA (default below)
   static const int mfma_env = [] { const char* e = getenv("MAGMA_GEMM256_MFMA"); return e ? atoi(e) : MG_GEMM256_MFMA_DEFAULT; }();
@@ -882,6 +917,10 @@ int gemm_dispatch(const mg_gemm_desc* d, bool fp8, const float* row_scale, hipSt
         case 267: return launch_gemm256<MG_W_FRAGTILED, false, false, false, 7>(gp, s);    // no epilogue
         case 268: return launch_gemm256<MG_W_FRAGTILED, false, false, false, 8>(gp, s);    // epilogue: LDS staging only
         case 270: return launch_gemm256<MG_W_FRAGTILED, false, false, false, 10>(gp, s);   // epilogue: all tiles store to tile (0,0)
+        case 271:                                                                          // time stamps into the workspace (8 x uint64 per workgroup)
+          if (!d->workspace || d->workspace_bytes < (int64_t)wgs256 * 64) MG_FAIL(MG_ERR_SHAPE, "%s: the stamp build needs 64 bytes of workspace per tile", who);
+          gp.ws = d->workspace;
+          return launch_gemm256<MG_W_FRAGTILED, false, false, false, 11>(gp, s);
         default: MG_FAIL(MG_ERR_UNSUPPORTED, "%s: no such ablation (tile_hint %d)", who, d->tile_hint);
       }
 #else

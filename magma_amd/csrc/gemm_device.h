@@ -154,10 +154,12 @@ MG_DEV void epilogue_prefetch(const mg_epilogue& ep, int m, int n, EpiPre<W>& p)
 
 // v[W] = accumulators of columns n .. n+W-1 of row m.  NT: non-temporal output stores (large outputs
 // that nobody re-reads soon: keeps the L2 for the operand panels and streams the tile out).
-template <int W, bool NT, bool COH, bool PRE>
+// FULL: the caller guarantees n + W <= N (interior column tile): the per-element tail paths are not even compiled -- they are
+// most of the instructions of an epilogue, and a tile's epilogue runs once per ~100 us, from a cold instruction cache.
+template <int W, bool NT, bool COH, bool PRE, bool FULL = false>
 MG_DEV void epilogue_apply_impl(const mg_epilogue& ep, const EpiColsW<W>& c, int m, int n, const float* v, int N,
                                 const EpiPre<W>& pre) {
-  const bool full = (n + W - 1 < N);
+  const bool full = FULL || (n + W - 1 < N);
   float o[W];
 #pragma unroll
   for (int r = 0; r < W; ++r) o[r] = v[r] * c.sc[r] + c.bi[r];
@@ -246,49 +248,10 @@ MG_DEV void epilogue_apply_impl(const mg_epilogue& ep, const EpiColsW<W>& c, int
   }
 }
 
-// The same arithmetic for an epilogue WITHOUT aux / residual operands (scale, bias, activation, optional pre-activation copy,
-// trailing ReLU): no global load anywhere in it.  epilogue_rows uses it for such epilogues in a loop of its own -- in the
-// general loop hipcc cannot count the conditional loads and guards every LDS read with s_waitcnt vmcnt(0), which on this
-// chip also waits for the STORES of the previous row to be acknowledged (vmcnt counts stores): ~0.75 us per row pair, 12 us
-// of the 14 us a 256x256 tile spent in its epilogue.
-template <int W, bool NT>
-MG_DEV void epilogue_apply_plain(const mg_epilogue& ep, const EpiColsW<W>& c, int m, int n, const float* v, int N) {
-  const bool full = (n + W - 1 < N);
-  float o[W];
-#pragma unroll
-  for (int r = 0; r < W; ++r) o[r] = v[r] * c.sc[r] + c.bi[r];
-  if (ep.C2) {
-    mg_bf16* cp = ep.C2 + (int64_t)m * ep.ldc2 + n;
-    if (full) store_bf16_row<W, NT>(cp, o);
-    else for (int r = 0; r < W; ++r) if (n + r < N) cp[r] = f2bf(o[r]);
-  }
-  const int act = n >= ep.act_n0 ? ep.act : MG_ACT_NONE;
-#pragma unroll
-  for (int r = 0; r < W; ++r) o[r] = apply_act(o[r], act);
-  if (ep.act_after == MG_ACT_RELU) {
-#pragma unroll
-    for (int r = 0; r < W; ++r) o[r] = o[r] > 0.f ? o[r] : 0.f;
-  }
-  if (ep.out_f32) {
-    float* cp = (float*)ep.C + (int64_t)m * ep.ldc + n;
-    if (full) {
-#pragma unroll
-      for (int g = 0; g < W; g += 4) {
-        const f32x4 w = {o[g], o[g + 1], o[g + 2], o[g + 3]};
-        if (NT) __builtin_nontemporal_store(w, (f32x4*)(cp + g)); else *(f32x4*)(cp + g) = w;
-      }
-    } else for (int r = 0; r < W; ++r) if (n + r < N) cp[r] = o[r];
-  } else {
-    mg_bf16* cp = (mg_bf16*)ep.C + (int64_t)m * ep.ldc + n;
-    if (full) store_bf16_row<W, NT>(cp, o);
-    else for (int r = 0; r < W; ++r) if (n + r < N) cp[r] = f2bf(o[r]);
-  }
-}
-
-template <int W, bool NT, bool COH = false>
+template <int W, bool NT, bool COH = false, bool FULL = false>
 MG_DEV void epilogue_apply(const mg_epilogue& ep, const EpiColsW<W>& c, int m, int n, const float* v, int N) {
   const EpiPre<W> none{};
-  epilogue_apply_impl<W, NT, COH, false>(ep, c, m, n, v, N, none);
+  epilogue_apply_impl<W, NT, COH, false, FULL>(ep, c, m, n, v, N, none);
 }
 
 template <bool COH = false>
@@ -313,91 +276,178 @@ MG_DEV bool epilogue_wide_ok(const mg_epilogue& ep) {
 // stores are full contiguous lines (8 or 16 bytes per lane), and the code is one small rolled loop instead of one inlined epilogue
 // per accumulator (which made the GEMM kernels > 20k instructions, mostly instruction-cache misses).
 // Tile row r is global row  m_base + (r >> 6) * hi_stride + (r & 63).
-template <int NCOLS, int ROWB, int W, bool NT>
-MG_DEV void epilogue_rows(const mg_epilogue& ep, const char* lds, int rows, int nwaves, int wave, int lane,
-                          int m_base, int hi_stride, int n0, int M, int N, const float* row_scale = nullptr) {
+// epilogue_rows_c: the per-column vectors `c` (epilogue_cols of this lane's W columns) come from the caller, so that a tile
+// walked in several passes loads them ONCE -- a global load inside a later pass makes hipcc wait for vmcnt(0), and on this
+// chip that also waits for the acknowledgement of every store of the pass before.
+template <int NCOLS, int ROWB, int W, bool NT, bool FULL = false>
+MG_DEV void epilogue_rows_c(const mg_epilogue& ep, const EpiColsW<W>& c, const char* lds, int rows, int nwaves, int wave, int lane,
+                            int m_base, int hi_stride, int n0, int M, int N, const float* row_scale = nullptr) {
   constexpr int LPR = NCOLS / W, RPI = 64 / LPR;     // lanes per row, rows per wave-iteration
   const int cl = lane % LPR;
   const int n = n0 + cl * W;
   if (n >= N) return;
-  EpiColsW<W> c;
-  epilogue_cols<W>(ep, n, N, c);
-  auto acc_row = [&](int r, float (&v)[W], int m) {
-#pragma unroll
-    for (int g = 0; g < W; g += 4) {
-      const f32x4 t = *(const f32x4*)(lds + r * ROWB + (cl * W + g) * 4);
-      v[g] = t[0]; v[g + 1] = t[1]; v[g + 2] = t[2]; v[g + 3] = t[3];
-    }
-    if (row_scale) {   // fp8 operands: per-row activation scale (the per-column weight scale is ep.scale)
-      const float rs = row_scale[m];
-#pragma unroll
-      for (int g = 0; g < W; ++g) v[g] *= rs;
-    }
-  };
   const int step = nwaves * RPI;
   int r = wave * RPI + lane / LPR;
-  const bool extra = ep.aux_mode != MG_AUX_NONE || ep.res0 || ep.res1 || ep.res2;
-  if (!extra && !row_scale) {     // no operand to load: LDS reads of four rows, then their arithmetic and stores; no vmcnt wait
-    auto lds_row = [&](int rr, float (&v)[W]) {
+  auto row_m = [&](int rr) { return m_base + (rr >> 6) * hi_stride + (rr & 63); };
+  auto lds_row = [&](int rr, float (&v)[W]) {
 #pragma unroll
-      for (int g = 0; g < W; g += 4) {
-        const f32x4 t = *(const f32x4*)(lds + rr * ROWB + (cl * W + g) * 4);
-        v[g] = t[0]; v[g + 1] = t[1]; v[g + 2] = t[2]; v[g + 3] = t[3];
-      }
-    };
-    auto row_of = [&](int rr) { return m_base + (rr >> 6) * hi_stride + (rr & 63); };
-    for (; r + 3 * step < rows; r += 4 * step) {
-      float v0[W], v1[W], v2[W], v3[W];
-      lds_row(r, v0); lds_row(r + step, v1); lds_row(r + 2 * step, v2); lds_row(r + 3 * step, v3);
-      const int ma = row_of(r), mb = row_of(r + step), mc = row_of(r + 2 * step), md = row_of(r + 3 * step);
-      if (ma < M) epilogue_apply_plain<W, NT>(ep, c, ma, n, v0, N);
-      if (mb < M) epilogue_apply_plain<W, NT>(ep, c, mb, n, v1, N);
-      if (mc < M) epilogue_apply_plain<W, NT>(ep, c, mc, n, v2, N);
-      if (md < M) epilogue_apply_plain<W, NT>(ep, c, md, n, v3, N);
+    for (int g = 0; g < W; g += 4) {
+      const f32x4 t = *(const f32x4*)(lds + rr * ROWB + (cl * W + g) * 4);
+      v[g] = t[0]; v[g + 1] = t[1]; v[g + 2] = t[2]; v[g + 3] = t[3];
     }
-    for (; r < rows; r += step) {
-      const int m = row_of(r);
-      if (m < M) {
-        float v[W];
-        lds_row(r, v);
-        epilogue_apply_plain<W, NT>(ep, c, m, n, v, N);
+  };
+  if (FULL || n + W - 1 < N) {
+    // Lanes whose W columns are all inside the matrix (every lane of an interior tile): TWO rows per iteration, and the
+    // epilogue's run-time options are branched on once per iteration -- uniform branches around straight-line code for all
+    // two rows -- not once per row and element.  (The per-row form of this loop was ~2 300 instructions of divergent
+    // control flow per iteration and took 5 us per 128-row pass of a 256x256 tile; in-kernel stamps, tools/kbench.py stamps.)
+    // Order of the arithmetic as in epilogue_apply_impl: (acc * row_scale) * scale + bias -> [C2] -> act -> aux (before) ->
+    // residuals 0, 1, 2 -> aux (after) -> trailing ReLU -> store.
+    constexpr int R = 2, H = W / 2;      // (four rows: 195 registers in the loop alone -- spills next to the live accumulator half)
+    const bool act_on = n >= ep.act_n0;              // act_n0 % 8 == 0: a lane's W columns are on one side
+    for (; r < rows; r += R * step) {
+      int m[R], mc[R], rr[R];
+      bool ok[R];
+#pragma unroll
+      for (int k = 0; k < R; ++k) {
+        const int q = r + k * step;
+        rr[k] = min(q, rows - 1);
+        m[k] = row_m(rr[k]);
+        ok[k] = q < rows && m[k] < M;
+        mc[k] = min(m[k], M - 1);
+      }
+      uint32_t ax[R][H], rs0[R][H], rs1[R][H], rs2[R][H];
+      float rsc[R];
+      if (ep.aux_mode != MG_AUX_NONE) {
+#pragma unroll
+        for (int k = 0; k < R; ++k) epi_raw_load<W>(ep.aux + (int64_t)mc[k] * ep.ldaux + n, ax[k]);
+      }
+      if (ep.res0) {
+#pragma unroll
+        for (int k = 0; k < R; ++k) epi_raw_load<W>(ep.res0 + (int64_t)mc[k] * ep.ldr + n, rs0[k]);
+      }
+      if (ep.res1) {
+#pragma unroll
+        for (int k = 0; k < R; ++k) epi_raw_load<W>(ep.res1 + (int64_t)mc[k] * ep.ldr + n, rs1[k]);
+      }
+      if (ep.res2) {
+#pragma unroll
+        for (int k = 0; k < R; ++k) epi_raw_load<W>(ep.res2 + (int64_t)mc[k] * ep.ldr + n, rs2[k]);
+      }
+      if (row_scale) {
+#pragma unroll
+        for (int k = 0; k < R; ++k) rsc[k] = row_scale[mc[k]];
+      }
+      float o[R][W];
+#pragma unroll
+      for (int k = 0; k < R; ++k) lds_row(rr[k], o[k]);
+      if (row_scale) {   // fp8 operands: per-row activation scale (the per-column weight scale is ep.scale)
+#pragma unroll
+        for (int k = 0; k < R; ++k)
+#pragma unroll
+          for (int g = 0; g < W; ++g) o[k][g] *= rsc[k];
+      }
+#pragma unroll
+      for (int k = 0; k < R; ++k)
+#pragma unroll
+        for (int g = 0; g < W; ++g) o[k][g] = o[k][g] * c.sc[g] + c.bi[g];
+      if (ep.C2) {       // pre-activation copy for the backward pass
+#pragma unroll
+        for (int k = 0; k < R; ++k)
+          if (ok[k]) store_bf16_row<W, NT>(ep.C2 + (int64_t)m[k] * ep.ldc2 + n, o[k]);
+      }
+      if (ep.act == MG_ACT_RELU) {
+#pragma unroll
+        for (int k = 0; k < R; ++k)
+#pragma unroll
+          for (int g = 0; g < W; ++g) o[k][g] = act_on ? (o[k][g] > 0.f ? o[k][g] : 0.f) : o[k][g];
+      } else if (ep.act == MG_ACT_GELU_NEW) {
+#pragma unroll
+        for (int k = 0; k < R; ++k)
+#pragma unroll
+          for (int g = 0; g < W; ++g) { const float t = gelu_new_f(o[k][g]); o[k][g] = act_on ? t : o[k][g]; }
+      } else if (ep.act == MG_ACT_QUICK_GELU) {
+#pragma unroll
+        for (int k = 0; k < R; ++k)
+#pragma unroll
+          for (int g = 0; g < W; ++g) { const float t = apply_act(o[k][g], MG_ACT_QUICK_GELU); o[k][g] = act_on ? t : o[k][g]; }
+      }
+      auto aux_mul = [&]() {
+        // o *= f(aux): the mode is uniform, one straight-line block per mode
+#define MG_AUX_BLOCK(F_)                                                                  \
+        _Pragma("unroll") for (int k = 0; k < R; ++k)                                     \
+          _Pragma("unroll") for (int h = 0; h < H; ++h) {                                 \
+            const float a0 = bflo(ax[k][h]), a1 = bfhi(ax[k][h]);                         \
+            o[k][2 * h] *= F_(a0); o[k][2 * h + 1] *= F_(a1);                             \
+          }
+#define MG_F_GATE(a_) ((a_) > 0.f ? 1.f : 0.f)
+#define MG_F_ID(a_) (a_)
+        if (ep.aux_mode == MG_AUX_RELU_GATE) { MG_AUX_BLOCK(MG_F_GATE) }
+        else if (ep.aux_mode == MG_AUX_GELU_GRAD) { MG_AUX_BLOCK(gelu_new_grad_f) }
+        else if (ep.aux_mode == MG_AUX_QUICK_GELU_GRAD) { MG_AUX_BLOCK(quick_gelu_grad_f) }
+        else { MG_AUX_BLOCK(MG_F_ID) }
+#undef MG_F_ID
+#undef MG_F_GATE
+#undef MG_AUX_BLOCK
+      };
+      if (ep.aux_mode != MG_AUX_NONE && !ep.aux_after) aux_mul();
+#define MG_RES_ADD(RS_)                                                                   \
+      _Pragma("unroll") for (int k = 0; k < R; ++k)                                       \
+        _Pragma("unroll") for (int h = 0; h < H; ++h) { o[k][2 * h] += bflo(RS_[k][h]); o[k][2 * h + 1] += bfhi(RS_[k][h]); }
+      if (ep.res0) { MG_RES_ADD(rs0) }
+      if (ep.res1) { MG_RES_ADD(rs1) }
+      if (ep.res2) { MG_RES_ADD(rs2) }
+#undef MG_RES_ADD
+      if (ep.aux_mode != MG_AUX_NONE && ep.aux_after) aux_mul();
+      if (ep.act_after == MG_ACT_RELU) {
+#pragma unroll
+        for (int k = 0; k < R; ++k)
+#pragma unroll
+          for (int g = 0; g < W; ++g) o[k][g] = o[k][g] > 0.f ? o[k][g] : 0.f;
+      }
+      if (ep.out_f32) {
+#pragma unroll
+        for (int k = 0; k < R; ++k)
+          if (ok[k]) {
+            float* cp = (float*)ep.C + (int64_t)m[k] * ep.ldc + n;
+#pragma unroll
+            for (int g = 0; g < W; g += 4) {
+              const f32x4 w = {o[k][g], o[k][g + 1], o[k][g + 2], o[k][g + 3]};
+              if (NT) __builtin_nontemporal_store(w, (f32x4*)(cp + g)); else *(f32x4*)(cp + g) = w;
+            }
+          }
+      } else {
+#pragma unroll
+        for (int k = 0; k < R; ++k)
+          if (ok[k]) store_bf16_row<W, NT>((mg_bf16*)ep.C + (int64_t)m[k] * ep.ldc + n, o[k]);
       }
     }
     return;
   }
-  if (extra && n + W - 1 < N) {
-    // rows in batches of 4: all aux / residual loads of the batch first, then the arithmetic and the stores
-    // (four named structs, not an array: an indexed array of them ends up in scratch)
-    auto row_m = [&](int rr) { return m_base + (rr >> 6) * hi_stride + (rr & 63); };
-    auto finish = [&](int rr, int m, const EpiPre<W>& pre) {
-      if (m < M) {
-        float v[W];
-        acc_row(rr, v, m);
-        epilogue_apply_impl<W, NT, false, true>(ep, c, m, n, v, N, pre);
-      }
-    };
-    for (; r + 3 * step < rows; r += 4 * step) {
-      const int m0 = row_m(r), m1 = row_m(r + step), m2 = row_m(r + 2 * step), m3 = row_m(r + 3 * step);
-      EpiPre<W> p0, p1, p2, p3;
-      epilogue_prefetch<W>(ep, min(m0, M - 1), n, p0);
-      epilogue_prefetch<W>(ep, min(m1, M - 1), n, p1);
-      epilogue_prefetch<W>(ep, min(m2, M - 1), n, p2);
-      epilogue_prefetch<W>(ep, min(m3, M - 1), n, p3);
-      finish(r, m0, p0);
-      finish(r + step, m1, p1);
-      finish(r + 2 * step, m2, p2);
-      finish(r + 3 * step, m3, p3);
-    }
-  }
-#pragma unroll 2
+  // lanes on a partial group of columns (last column tile of a matrix whose N is not a multiple of W): one row at a time
   for (; r < rows; r += step) {
-    const int m = m_base + (r >> 6) * hi_stride + (r & 63);
+    const int m = row_m(r);
     if (m < M) {
       float v[W];
-      acc_row(r, v, m);
+      lds_row(r, v);
+      if (row_scale) {
+        const float rs = row_scale[m];
+#pragma unroll
+        for (int g = 0; g < W; ++g) v[g] *= rs;
+      }
       epilogue_apply<W, NT>(ep, c, m, n, v, N);
     }
   }
+}
+
+template <int NCOLS, int ROWB, int W, bool NT>
+MG_DEV void epilogue_rows(const mg_epilogue& ep, const char* lds, int rows, int nwaves, int wave, int lane,
+                          int m_base, int hi_stride, int n0, int M, int N, const float* row_scale = nullptr) {
+  const int n = n0 + (lane % (NCOLS / W)) * W;
+  if (n >= N) return;
+  EpiColsW<W> c;
+  epilogue_cols<W>(ep, n, N, c);
+  epilogue_rows_c<NCOLS, ROWB, W, NT>(ep, c, lds, rows, nwaves, wave, lane, m_base, hi_stride, n0, M, N, row_scale);
 }
 
 

@@ -288,6 +288,64 @@ def main():
                     r[f"gm{gm}_tf_{rep}"] = round(fl / ms / 1e9, 1)
             os.environ.pop("MAGMA_G256_GROUP_M", None)
             emit(**r)
+    if which == "tilecost":   # per-tile overhead a and per-K-tile cost b of the 256x256 kernel (T_tile = a + b * K/64) for three epilogues
+        M = N = 8192
+        r1 = torch.randn(M, N, device=dev).to(BF16)
+        aux = torch.randn(M, N, device=dev).to(BF16)
+        out = torch.empty(M, N, dtype=BF16, device=dev)
+        for name, kw in (("plain", {}), ("bias_gelu", {"act": ops.MG_ACT_GELU_NEW}), ("one_residual", {"residuals": (r1,)}),
+                         ("gelu_grad_aux", {"aux": aux, "aux_mode": ops.MG_AUX_GELU_GRAD})):
+            pts = {}
+            for K in (1024, 4096, 16384):
+                a = torch.randn(M, K, device=dev).to(BF16)
+                lin = ops.PackedLinear((torch.randn(N, K, device=dev) * 0.05).to(BF16), bias=torch.randn(N, device=dev))
+                try:
+                    ms = min(timeit(lambda i: ops.gemm(a, lin, out=out, tile=256, **kw), 8) for _ in range(2))
+                except TypeError as e:
+                    pts = {"error": str(e)[:100]}
+                    break
+                pts[K] = ms * 1e3 / 4          # us per tile (1024 tiles on 256 CUs)
+            if "error" not in pts:
+                b = (pts[16384] - pts[4096]) / 192
+                emit(kind="tilecost", epilogue=name, us_per_tile=pts, b_us_per_ktile=b, a_us_per_tile=pts[4096] - 64 * b,
+                     a_from_1024=pts[1024] - 16 * b)
+            else:
+                emit(kind="tilecost", epilogue=name, **pts)
+    if which == "stamps":   # (make ABL=1) in-kernel 100-MHz time stamps of the 256x256 kernel: where does a tile's time go?
+        for (M, N, K, tag) in [(8192, 8192, 4096, "square_k4096"), (32768, 4096, 4096, "out_proj"), (8192, 8192, 1024, "square_k1024")]:
+            a = torch.randn(M, K, device=dev).to(BF16)
+            lin = ops.PackedLinear((torch.randn(N, K, device=dev) * 0.05).to(BF16))
+            out = torch.empty(M, N, dtype=BF16, device=dev)
+            nt = (M // 256) * (N // 256)
+            ws = ops.splitk_workspace(dev)
+            for _ in range(3):
+                ops.gemm(a, lin, out=out, tile=271)
+            torch.cuda.synchronize()
+            st = ws[: nt * 16].view(torch.int64).view(nt, 8).cpu()
+            t = st[:, :7].double() / 100.0                       # us
+            seg = (t[:, 1:] - t[:, :-1])
+            names = ["k_loop(+prologue)", "stage0", "walk0", "stage1", "walk1", "drain"]
+            r = {"kind": "stamps", "tag": tag, "M": M, "N": N, "K": K, "tiles": nt,
+                 "mean_us": {n: round(float(seg[:, i].mean()), 2) for i, n in enumerate(names)},
+                 "p90_us": {n: round(float(seg[:, i].quantile(0.9)), 2) for i, n in enumerate(names)},
+                 "launch_span_us": round(float(t[:, 6].max() - t[:, 0].min()), 1)}
+            # per CU: gap between one workgroup's drain and the next workgroup's start
+            hw = st[:, 7]
+            key = ((hw >> 32) & 0xf) * 4096 + (hw & 0xffff & ~0x3f)    # XCC id, SE / SH / CU bits of HW_ID (wave / simd ids dropped)
+            gaps, firsts = [], []
+            for k in key.unique():
+                idx = (key == k).nonzero().flatten()
+                ts = t[idx]
+                order = ts[:, 0].argsort()
+                ts = ts[order]
+                firsts.append(float(ts[0, 0]))
+                for j in range(1, ts.shape[0]):
+                    gaps.append(float(ts[j, 0] - ts[j - 1, 6]))
+            g = torch.tensor(gaps) if gaps else torch.zeros(1)
+            r["cus_seen"] = int(key.unique().numel())
+            r["gap_between_workgroups_us"] = {"mean": round(float(g.mean()), 2), "p10": round(float(g.quantile(0.1)), 2), "p90": round(float(g.quantile(0.9)), 2)}
+            r["first_wave_start_spread_us"] = round(max(firsts) - min(firsts), 2)
+            emit(**r)
     if which == "shortk":   # adapter up-projection (K = 1024) with three residual reads: epilogue-bound; 128x128 vs 256x256 kernel
         M, N, K = 32768, 4096, 1024
         a = torch.randn(M, K, device=dev).to(BF16)
