@@ -257,6 +257,49 @@ MG_DEV void epilogue_apply(const mg_epilogue& ep, const EpiColsW<W>& c, int m, i
 template <bool COH = false>
 MG_DEV void epilogue_store4(const mg_epilogue& ep, int m, int n, f32x4 v, int N) {
   if (n >= N) return;
+  if constexpr (!COH) {
+    // The common decode / split-K fix-up case -- four columns inside the matrix, no aux operand, no pre-activation copy -- as
+    // one short straight-line block (same arithmetic and order as epilogue_apply_impl).  A weight-streaming GEMV runs its
+    // epilogue ONCE per workgroup, from a cold instruction cache: what counts is how few cache lines the taken path touches.
+    if (n + 3 < N && ep.aux_mode == MG_AUX_NONE && !ep.C2) {
+      f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
+      if (ep.scale) sc = *(const f32x4*)(ep.scale + n);
+      if (ep.bias) bi = *(const f32x4*)(ep.bias + n);
+      u32x2 r0 = {0u, 0u}, r1 = {0u, 0u}, r2 = {0u, 0u};
+      if (ep.res0) r0 = *(const u32x2*)(ep.res0 + (int64_t)m * ep.ldr + n);
+      if (ep.res1) r1 = *(const u32x2*)(ep.res1 + (int64_t)m * ep.ldr + n);
+      if (ep.res2) r2 = *(const u32x2*)(ep.res2 + (int64_t)m * ep.ldr + n);
+      float o[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = v[r] * sc[r] + bi[r];
+      if (n >= ep.act_n0 && ep.act != MG_ACT_NONE) {
+        if (ep.act == MG_ACT_RELU) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = o[r] > 0.f ? o[r] : 0.f;
+        } else if (ep.act == MG_ACT_GELU_NEW) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = gelu_new_f(o[r]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = apply_act(o[r], ep.act);
+        }
+      }
+      if (ep.res0) { o[0] += bflo(r0[0]); o[1] += bfhi(r0[0]); o[2] += bflo(r0[1]); o[3] += bfhi(r0[1]); }
+      if (ep.res1) { o[0] += bflo(r1[0]); o[1] += bfhi(r1[0]); o[2] += bflo(r1[1]); o[3] += bfhi(r1[1]); }
+      if (ep.res2) { o[0] += bflo(r2[0]); o[1] += bfhi(r2[0]); o[2] += bflo(r2[1]); o[3] += bfhi(r2[1]); }
+      if (ep.act_after == MG_ACT_RELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = o[r] > 0.f ? o[r] : 0.f;
+      }
+      if (ep.out_f32) {
+        *(f32x4*)((float*)ep.C + (int64_t)m * ep.ldc + n) = (f32x4){o[0], o[1], o[2], o[3]};
+      } else {
+        u32x2 w; w[0] = pack2bf(o[0], o[1]); w[1] = pack2bf(o[2], o[3]);
+        *(u32x2*)((mg_bf16*)ep.C + (int64_t)m * ep.ldc + n) = w;
+      }
+      return;
+    }
+  }
   EpiCols c;
   epilogue_cols<4>(ep, n, N, c);
   const float vv[4] = {v[0], v[1], v[2], v[3]};

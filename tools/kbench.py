@@ -107,7 +107,7 @@ def main():
             a = torch.randn(8192, K, device=dev).to(BF16)
             lin = ops.PackedLinear((torch.randn(8192, K, device=dev) * 0.05).to(BF16))
             out = torch.empty(8192, 8192, dtype=BF16, device=dev)
-            for tile in (256, 267, 268, 270):      # (library built with `make ABL=1`) 267: no epilogue; 268: LDS staging only; 270: all tiles store to tile (0,0)
+            for tile in (256, 267, 268, 270):      # (MAGMA_HIP_LIB=magma_amd/libmagma_hip_abl.so, built with `make ABL=1`) 267: no epilogue; 268: LDS staging only; 270: all tiles store to tile (0,0)
                 ms = timeit(lambda i: ops.gemm(a, lin, out=out, tile=tile, split_k=1), 10)
                 emit(kind="ksweep", M=8192, N=8192, K=K, tile=tile, ms=ms, tflops=2.0 * 8192 * 8192 * K / ms / 1e9)
         a = torch.randn(32768, 4096, device=dev).to(BF16)
@@ -329,22 +329,16 @@ def main():
                  "mean_us": {n: round(float(seg[:, i].mean()), 2) for i, n in enumerate(names)},
                  "p90_us": {n: round(float(seg[:, i].quantile(0.9)), 2) for i, n in enumerate(names)},
                  "launch_span_us": round(float(t[:, 6].max() - t[:, 0].min()), 1)}
-            # per CU: gap between one workgroup's drain and the next workgroup's start
-            hw = st[:, 7]
-            key = ((hw >> 32) & 0xf) * 4096 + (hw & 0xffff & ~0x3f)    # XCC id, SE / SH / CU bits of HW_ID (wave / simd ids dropped)
-            gaps, firsts = [], []
-            for k in key.unique():
-                idx = (key == k).nonzero().flatten()
-                ts = t[idx]
-                order = ts[:, 0].argsort()
-                ts = ts[order]
-                firsts.append(float(ts[0, 0]))
-                for j in range(1, ts.shape[0]):
-                    gaps.append(float(ts[j, 0] - ts[j - 1, 6]))
-            g = torch.tensor(gaps) if gaps else torch.zeros(1)
-            r["cus_seen"] = int(key.unique().numel())
-            r["gap_between_workgroups_us"] = {"mean": round(float(g.mean()), 2), "p10": round(float(g.quantile(0.1)), 2), "p90": round(float(g.quantile(0.9)), 2)}
-            r["first_wave_start_spread_us"] = round(max(firsts) - min(firsts), 2)
+            # turnaround of a CU slot: workgroup j (by start time, beyond the first wave) starts when the (j - first_wave)-th
+            # workgroup to finish has freed its CU; first_wave = workgroups that started within 20 us of the launch
+            order = t[:, 0].argsort()
+            starts = t[order, 0]
+            ends = t[:, 6].sort().values
+            first_wave = int((starts < starts[0] + 20.0).sum())
+            gaps = (starts[first_wave:] - ends[: nt - first_wave]) if nt > first_wave else torch.zeros(1, dtype=torch.float64)
+            r["first_wave"] = first_wave
+            r["slot_turnaround_us"] = {"mean": round(float(gaps.mean()), 2), "p10": round(float(gaps.quantile(0.1)), 2), "p50": round(float(gaps.quantile(0.5)), 2), "p90": round(float(gaps.quantile(0.9)), 2)}
+            r["first_wave_start_spread_us"] = round(float(starts[first_wave - 1] - starts[0]), 2)
             emit(**r)
     if which == "shortk":   # adapter up-projection (K = 1024) with three residual reads: epilogue-bound; 128x128 vs 256x256 kernel
         M, N, K = 32768, 4096, 1024
