@@ -452,6 +452,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   // four wave columns (read in q0 / q1) -- so that a unit of the buffer being multiplied can be restaged while the tile is still
   // in progress and every unit gets at least 3 phases of flight (see the schedule below).  Same LDS image.
   constexpr bool EARLY = ABL != 6;
+  constexpr bool BALANCED = EARLY && !FP8 && !MFMA32 && !LATE_LGKM && ABL == 12;     // ABL 12 only: measured neutral (+-1 %), see the schedule
   int a2_off[2][2], b2_off[2][2];
   if constexpr (EARLY) {
 #pragma unroll
@@ -523,6 +524,17 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
           *(const i32x4*)(sb_ + b_rd0 + ((nh) * 2 + j_) * B_NT),                                         \
           *(const i32x4*)(sb_ + ((WLAYOUT == MG_W_ROWMAJOR) ? (b_rd0 ^ 64) : (b_rd0 + B_KS)) + ((nh) * 2 + j_) * B_NT), 0, 1, 2, 3, 4, 5, 6, 7); \
   }
+  // the same read into an explicit register slot: the balanced bf16 schedule keeps n-half 0 of EVEN tiles in bw[0] and of ODD
+  // tiles in bw[1] (it is read one phase before the tile starts, while the other slot is still in use)
+#define MG_READ_BS(par, nh, slot)                                                                        \
+  {                                                                                                      \
+    const char* sb_ = smem + (par) * G256_BUF;                                                           \
+    if (ABL != 2 || abl_on)                                                                              \
+    _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                     \
+      bw[slot][j_] = __builtin_shufflevector(                                                            \
+          *(const i32x4*)(sb_ + b_rd0 + ((nh) * 2 + j_) * B_NT),                                         \
+          *(const i32x4*)(sb_ + ((WLAYOUT == MG_W_ROWMAJOR) ? (b_rd0 ^ 64) : (b_rd0 + B_KS)) + ((nh) * 2 + j_) * B_NT), 0, 1, 2, 3, 4, 5, 6, 7); \
+  }
 #define MG_HALF(v, s_) __builtin_bit_cast(bf16x8, (s_) ? __builtin_shufflevector(v, v, 4, 5, 6, 7) : __builtin_shufflevector(v, v, 0, 1, 2, 3))
 
   f32x4 acc[8][4];
@@ -542,6 +554,20 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
         _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                 \
           acc[(mh) * 4 + i_][(nh) * 2 + j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                   \
               MG_HALF(bw[nh][j_], s_), MG_HALF(af[i_], s_), acc[(mh) * 4 + i_][(nh) * 2 + j_], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                       \
+  }
+#define MG_MMAS(mh, nh, slot)                                                                            \
+  {                                                                                                      \
+    __builtin_amdgcn_s_setprio(1);                                                                       \
+    if (ABL == 3) {                                                                                      \
+      _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) asm volatile("" ::"v"(af[i_]));                   \
+      _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) asm volatile("" ::"v"(bw[slot][j_]));             \
+    } else                                                                                               \
+    _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)                                                     \
+      _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                   \
+        _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                 \
+          acc[(mh) * 4 + i_][(nh) * 2 + j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                   \
+              MG_HALF(bw[slot][j_], s_), MG_HALF(af[i_], s_), acc[(mh) * 4 + i_][(nh) * 2 + j_], 0, 0, 0); \
     __builtin_amdgcn_s_setprio(0);                                                                       \
   }
   // ---- 32x32x16 variant: fragments [tile][k-substep], same regions per phase as the 16x16 readers above ----
@@ -605,6 +631,15 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
     MG_MMA(MH, NH);                                                                                      \
     MG_BAR();                                                                                            \
   }
+#define MG_PHASES(READS, DMA, MH, NH, SLOT)                                                              \
+  {                                                                                                      \
+    READS;                                                                                               \
+    DMA;                                                                                                 \
+    MG_WAIT_LGKM0();                                                                                     \
+    MG_BAR();                                                                                            \
+    MG_MMAS(MH, NH, SLOT);                                                                               \
+    MG_BAR();                                                                                            \
+  }
   // FP8 phases: the 8-register operands leave no room for four A and four W fragments next to 128 accumulators, so a
   // phase is one m-QUARTER (two m-tiles) against all four n-tiles: W is read once per K-tile (q0), A two tiles per phase.
   // DMA units as on the bf16 path (A_0 / A_1 = quarters 0,1 / 2,3 of both groups, W_0 / W_1), restaged the phase after their
@@ -647,6 +682,15 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
     MG_PHASE32({ MG_READ_B32(PAR, 1); }, { if (NXT2) MG_DMA_A2((t) + 2, 0); }, 0, 1);                     \
     MG_PHASE32({ MG_READ_A32(PAR, 1); }, { if (NXT2) MG_DMA_B2((t) + 2, 0); }, 1, 1);                     \
     MG_PHASE32({}, { if (NXT2) { MG_DMA_B2((t) + 2, 1); MG_WAIT_VM(6); } else { MG_WAIT_VM(0); } }, 1, 0); \
+  } else if constexpr (BALANCED) {                                                                       \
+    /* fragment reads 8 / 4 / 8 / 4 per phase instead of 12 / 4 / 8 / 0: W(nh0) of tile t+1 is read in q3 of tile t, into   \
+       the register slot W(nh1) of tile t has just left (slots swap roles every tile: PAR = slot of nh0).  Its DMA unit     \
+       W_0(t+1), issued in q2 of t-1, is retired one phase earlier for that: vmcnt(8) in q2 leaves the four younger units    \
+       in flight (W_1(t+1), A_1(t+1), A_0(t+2), W_0(t+2)).                                                                    */ \
+    MG_PHASES({ MG_READ_A(PAR, 0); }, { if (NXT) MG_DMA_A2((t) + 1, 1); }, 0, 0, PAR);                    \
+    MG_PHASES({ MG_READ_BS(PAR, 1, 1 - (PAR)); }, { if (NXT2) MG_DMA_A2((t) + 2, 0); }, 0, 1, 1 - (PAR)); \
+    MG_PHASES({ MG_READ_A(PAR, 1); }, { if (NXT2) { MG_DMA_B2((t) + 2, 0); MG_WAIT_VM(8); } else if (NXT) { MG_WAIT_VM(4); } }, 1, 1, 1 - (PAR)); \
+    MG_PHASES({ if (NXT) MG_READ_BS(1 - (PAR), 0, 1 - (PAR)); }, { if (NXT2) { MG_DMA_B2((t) + 2, 1); MG_WAIT_VM(6); } else { MG_WAIT_VM(0); } }, 1, 0, PAR); \
   } else if constexpr (EARLY) {                                                                          \
     MG_PHASE({ MG_READ_A(PAR, 0); MG_READ_B(PAR, 0); }, { if (NXT) MG_DMA_A2((t) + 1, 1); }, 0, 0);      \
     MG_PHASE({ MG_READ_B(PAR, 1); }, { if (NXT2) MG_DMA_A2((t) + 2, 0); }, 0, 1);                         \
@@ -671,6 +715,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   }
   MG_BAR();
   if (wr == 1) MG_BAR();
+  if constexpr (BALANCED) { MG_READ_BS(0, 0, 0); }      // W(nh0) of tile 0: later tiles get theirs in q3 of the tile before
 
   int t = 0;
   for (; t + 2 < nkt; t += 2) {
@@ -683,6 +728,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   if (wr == 0) MG_BAR();
 #undef MG_G256_TILE
 #undef MG_PHASE32
+#undef MG_PHASES
+#undef MG_MMAS
+#undef MG_READ_BS
 #undef MG_MMA32
 #undef MG_READ_A32
 #undef MG_READ_B32
@@ -899,7 +947,7 @@ int gemm_dispatch(const mg_gemm_desc* d, bool fp8, const float* row_scale, hipSt
   // large dense shapes go to the deep-pipelined 256x256 kernel (tile_hint: 0 auto, 128 / 256 force)
   const int64_t wgs256 = (int64_t)((d->M + 255) / 256) * ((d->N + 255) / 256);
   const bool can256 = d->a_mode == MG_A_DENSE && (gp.K % 128) == 0;           // gp.K counts PAIRS of fp8 values on the fp8 path
-  const bool want256 = (d->tile_hint >= 256 && d->tile_hint <= 271) ||
+  const bool want256 = (d->tile_hint >= 256 && d->tile_hint <= 272) ||
                        (d->tile_hint == 0 && wgs256 >= 192 && d->M >= 1024 && d->N >= 512);
   // bf16: 32x32x16 MFMA (tile_hint 258) or 16x16x32 (259); 0 / 256 follow MAGMA_GEMM256_MFMA (default below)
   static const int mfma_env = [] { const char* e = getenv("MAGMA_GEMM256_MFMA"); return e ? atoi(e) : MG_GEMM256_MFMA_DEFAULT; }();
@@ -917,6 +965,7 @@ int gemm_dispatch(const mg_gemm_desc* d, bool fp8, const float* row_scale, hipSt
         case 267: return launch_gemm256<MG_W_FRAGTILED, false, false, false, 7>(gp, s);    // no epilogue
         case 268: return launch_gemm256<MG_W_FRAGTILED, false, false, false, 8>(gp, s);    // epilogue: LDS staging only
         case 270: return launch_gemm256<MG_W_FRAGTILED, false, false, false, 10>(gp, s);   // epilogue: all tiles store to tile (0,0)
+        case 272: return launch_gemm256<MG_W_FRAGTILED, false, false, false, 12>(gp, s);   // fragment reads 8 / 4 / 8 / 4 per phase instead of 12 / 4 / 8 / 0 (correct results)
         case 271:                                                                          // time stamps into the workspace (8 x uint64 per workgroup)
           if (!d->workspace || d->workspace_bytes < (int64_t)wgs256 * 64) MG_FAIL(MG_ERR_SHAPE, "%s: the stamp build needs 64 bytes of workspace per tile", who);
           gp.ws = d->workspace;

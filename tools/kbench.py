@@ -255,7 +255,7 @@ def main():
             old = ops.gemm(a, lin, tile=266)
             r = {"kind": "abl", "equal_to_first_schedule": bool(torch.equal(old.float(), ref)), "tag": tag, "M": M, "N": N, "K": K}
             for rep in range(2):
-                for name, tile in (("full", 256), ("l2hot_dma", 261), ("no_ds_read", 262), ("no_mfma", 263), ("no_dma", 264), ("first_dma_schedule", 266)):
+                for name, tile in (("full", 256), ("l2hot_dma", 261), ("no_ds_read", 262), ("no_mfma", 263), ("no_dma", 264), ("first_dma_schedule", 266), ("balanced_fragment_reads", 272)):
                     ms = timeit(lambda i: ops.gemm(a, lin, out=out, tile=tile), 8)
                     r[f"{name}_ms_{rep}"] = round(ms, 4)
                     r[f"{name}_tf_{rep}"] = round(fl / ms / 1e9, 1)
