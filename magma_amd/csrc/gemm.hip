@@ -801,15 +801,20 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
     EpiColsW<W> c;
     const int n = nb + (lane % (256 / W)) * W;
     if (n < p.N) epilogue_cols<W>(p.ep, n, p.N, c);
+    // an epilogue without aux / residual operands walks its rows in a build of the loop that contains no global load
+    // (interior bf16-output tiles only: W == 8 and FULL): nothing in it waits for the stores of the rows before
+    const bool loads = p.ep.aux_mode != MG_AUX_NONE || p.ep.res0 || p.ep.res1 || p.ep.res2;
     stage(std::integral_constant<int, 0>{});
     MG_STAMP(2);
-    epilogue_rows_c<256, EPI256_ROWB, W, NT, FULL>(p.ep, c, smem, 128, 8, wave, lane, mb0, 128, nb, mlim, p.N, p.row_scale);
+    if (FULL && W == 8 && !loads) epilogue_rows_c<256, EPI256_ROWB, W, NT, FULL, false>(p.ep, c, smem, 128, 8, wave, lane, mb0, 128, nb, mlim, p.N, p.row_scale);
+    else epilogue_rows_c<256, EPI256_ROWB, W, NT, FULL>(p.ep, c, smem, 128, 8, wave, lane, mb0, 128, nb, mlim, p.N, p.row_scale);
     MG_WAIT_LGKM0();
     MG_BAR();                                 // pass 0 has been read
     MG_STAMP(3);
     stage(std::integral_constant<int, 1>{});
     MG_STAMP(4);
-    epilogue_rows_c<256, EPI256_ROWB, W, NT, FULL>(p.ep, c, smem, 128, 8, wave, lane, mb0 + 64, 128, nb, mlim, p.N, p.row_scale);
+    if (FULL && W == 8 && !loads) epilogue_rows_c<256, EPI256_ROWB, W, NT, FULL, false>(p.ep, c, smem, 128, 8, wave, lane, mb0 + 64, 128, nb, mlim, p.N, p.row_scale);
+    else epilogue_rows_c<256, EPI256_ROWB, W, NT, FULL>(p.ep, c, smem, 128, 8, wave, lane, mb0 + 64, 128, nb, mlim, p.N, p.row_scale);
     MG_STAMP(5);
     if (ABL == 11) {
       MG_WAIT_VM(0);

@@ -322,7 +322,9 @@ MG_DEV bool epilogue_wide_ok(const mg_epilogue& ep) {
 // epilogue_rows_c: the per-column vectors `c` (epilogue_cols of this lane's W columns) come from the caller, so that a tile
 // walked in several passes loads them ONCE -- a global load inside a later pass makes hipcc wait for vmcnt(0), and on this
 // chip that also waits for the acknowledgement of every store of the pass before.
-template <int NCOLS, int ROWB, int W, bool NT, bool FULL = false>
+// LOADS = false (caller's promise: no aux operand, no residual, and rows <= 8 * step): the walk is compiled without a single
+// global load -- see `iteration` below.
+template <int NCOLS, int ROWB, int W, bool NT, bool FULL = false, bool LOADS = true>
 MG_DEV void epilogue_rows_c(const mg_epilogue& ep, const EpiColsW<W>& c, const char* lds, int rows, int nwaves, int wave, int lane,
                             int m_base, int hi_stride, int n0, int M, int N, const float* row_scale = nullptr) {
   constexpr int LPR = NCOLS / W, RPI = 64 / LPR;     // lanes per row, rows per wave-iteration
@@ -348,7 +350,10 @@ MG_DEV void epilogue_rows_c(const mg_epilogue& ep, const EpiColsW<W>& c, const c
     // residuals 0, 1, 2 -> aux (after) -> trailing ReLU -> store.
     constexpr int R = 2, H = W / 2;      // (four rows: 195 registers in the loop alone -- spills next to the live accumulator half)
     const bool act_on = n >= ep.act_n0;              // act_n0 % 8 == 0: a lane's W columns are on one side
-    for (; r < rows; r += R * step) {
+    // LOADS = false: the iteration contains no global load at all (no aux, no residual; the row scales come in as values).
+    // That matters beyond the loads themselves: with a load anywhere in the loop hipcc guards the first use with
+    // s_waitcnt vmcnt(0), which on this chip also waits for the acknowledgement of the PREVIOUS iteration's stores.
+    auto iteration = [&](int r, const float* rsc_in) {
       int m[R], mc[R], rr[R];
       bool ok[R];
 #pragma unroll
@@ -361,25 +366,27 @@ MG_DEV void epilogue_rows_c(const mg_epilogue& ep, const EpiColsW<W>& c, const c
       }
       uint32_t ax[R][H], rs0[R][H], rs1[R][H], rs2[R][H];
       float rsc[R];
-      if (ep.aux_mode != MG_AUX_NONE) {
+      const bool has_aux = LOADS && ep.aux_mode != MG_AUX_NONE;
+      const bool has_r0 = LOADS && ep.res0, has_r1 = LOADS && ep.res1, has_r2 = LOADS && ep.res2;
+      if (has_aux) {
 #pragma unroll
         for (int k = 0; k < R; ++k) epi_raw_load<W>(ep.aux + (int64_t)mc[k] * ep.ldaux + n, ax[k]);
       }
-      if (ep.res0) {
+      if (has_r0) {
 #pragma unroll
         for (int k = 0; k < R; ++k) epi_raw_load<W>(ep.res0 + (int64_t)mc[k] * ep.ldr + n, rs0[k]);
       }
-      if (ep.res1) {
+      if (has_r1) {
 #pragma unroll
         for (int k = 0; k < R; ++k) epi_raw_load<W>(ep.res1 + (int64_t)mc[k] * ep.ldr + n, rs1[k]);
       }
-      if (ep.res2) {
+      if (has_r2) {
 #pragma unroll
         for (int k = 0; k < R; ++k) epi_raw_load<W>(ep.res2 + (int64_t)mc[k] * ep.ldr + n, rs2[k]);
       }
       if (row_scale) {
 #pragma unroll
-        for (int k = 0; k < R; ++k) rsc[k] = row_scale[mc[k]];
+        for (int k = 0; k < R; ++k) rsc[k] = LOADS ? row_scale[mc[k]] : rsc_in[k];
       }
       float o[R][W];
 #pragma unroll
@@ -433,15 +440,15 @@ MG_DEV void epilogue_rows_c(const mg_epilogue& ep, const EpiColsW<W>& c, const c
 #undef MG_F_GATE
 #undef MG_AUX_BLOCK
       };
-      if (ep.aux_mode != MG_AUX_NONE && !ep.aux_after) aux_mul();
+      if (has_aux && !ep.aux_after) aux_mul();
 #define MG_RES_ADD(RS_)                                                                   \
       _Pragma("unroll") for (int k = 0; k < R; ++k)                                       \
         _Pragma("unroll") for (int h = 0; h < H; ++h) { o[k][2 * h] += bflo(RS_[k][h]); o[k][2 * h + 1] += bfhi(RS_[k][h]); }
-      if (ep.res0) { MG_RES_ADD(rs0) }
-      if (ep.res1) { MG_RES_ADD(rs1) }
-      if (ep.res2) { MG_RES_ADD(rs2) }
+      if (has_r0) { MG_RES_ADD(rs0) }
+      if (has_r1) { MG_RES_ADD(rs1) }
+      if (has_r2) { MG_RES_ADD(rs2) }
 #undef MG_RES_ADD
-      if (ep.aux_mode != MG_AUX_NONE && ep.aux_after) aux_mul();
+      if (has_aux && ep.aux_after) aux_mul();
       if (ep.act_after == MG_ACT_RELU) {
 #pragma unroll
         for (int k = 0; k < R; ++k)
@@ -464,6 +471,22 @@ MG_DEV void epilogue_rows_c(const mg_epilogue& ep, const EpiColsW<W>& c, const c
         for (int k = 0; k < R; ++k)
           if (ok[k]) store_bf16_row<W, NT>((mg_bf16*)ep.C + (int64_t)m[k] * ep.ldc + n, o[k]);
       }
+    };
+    constexpr int MAXIT = 4;
+    if constexpr (!LOADS) {
+      // up to four iterations, unrolled; the row scales of all of them are loaded up front (one wait, before any store)
+      float rsc_all[MAXIT][R];
+      if (row_scale) {
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it)
+#pragma unroll
+          for (int k = 0; k < R; ++k) rsc_all[it][k] = row_scale[min(row_m(min(r + (it * R + k) * step, rows - 1)), M - 1)];
+      }
+#pragma unroll
+      for (int it = 0; it < MAXIT; ++it)
+        if (r + it * R * step < rows) iteration(r + it * R * step, rsc_all[it]);
+    } else {
+      for (; r < rows; r += R * step) iteration(r, nullptr);
     }
     return;
   }
