@@ -513,7 +513,12 @@ MG_DEV void epilogue_rows(const mg_epilogue& ep, const char* lds, int rows, int 
   if (n >= N) return;
   EpiColsW<W> c;
   epilogue_cols<W>(ep, n, N, c);
-  epilogue_rows_c<NCOLS, ROWB, W, NT>(ep, c, lds, rows, nwaves, wave, lane, m_base, hi_stride, n0, M, N, row_scale);
+  // no aux / residual operand and at most four iterations per lane: the build of the walk without global loads
+  const bool loads = ep.aux_mode != MG_AUX_NONE || ep.res0 || ep.res1 || ep.res2;
+  if (!loads && rows <= 8 * nwaves * (64 / (NCOLS / W)))
+    epilogue_rows_c<NCOLS, ROWB, W, NT, false, false>(ep, c, lds, rows, nwaves, wave, lane, m_base, hi_stride, n0, M, N, row_scale);
+  else
+    epilogue_rows_c<NCOLS, ROWB, W, NT>(ep, c, lds, rows, nwaves, wave, lane, m_base, hi_stride, n0, M, N, row_scale);
 }
 
 
