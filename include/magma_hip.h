@@ -110,7 +110,9 @@ typedef struct mg_gemm_desc {
   int32_t H, Wd, Cin; /* conv3x3 only: A is [B,H,Wd,Cin], M = B*H*Wd, K=9*Cin */
   const mg_bf16* zero_page; /* >= 16 zero bytes, 16-B aligned (K/halo padding) */
   mg_epilogue ep;
-  int32_t tile_hint; /* 0 = auto; 128 / 256 force the workgroup-tile kernel        */
+  int32_t tile_hint; /* 0 = auto; 128 / 256 force the workgroup-tile kernel; 258 / 259: the 256x256 bf16 kernel on the
+                      * 32x32x16 / 16x16x32 MFMA (bit-identical, A/B runs); 261..272: timing ablations that exist only in the
+                      * ablation build of the library (magma_amd/csrc/Makefile, ABL=1; MG_ERR_UNSUPPORTED otherwise)          */
   int32_t split_k;   /* 0 = auto (only when a workspace is given); 1 = never; n = n-way */
   /* Split-K scratch (optional): small-M GEMMs with a long K (prefill at a few hundred rows,
    * the late CLIP stages) launch fewer tiles than the chip has CUs; with a workspace the
