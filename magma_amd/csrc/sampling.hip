@@ -17,7 +17,11 @@
 //                iff it is not the first maximum and the probability mass of the strictly larger logits is < 1 - threshold,
 //                and that mass is monotone in the logit -- so the set is {x >= t*} minus the maximum, with t* the smallest
 //                logit whose strictly-larger mass is below the bound.  t* comes from the same radix descent with MASS
-//                histograms.  Masses are 2^-40 fixed point in 64-bit integers: integer atomics are associative, so the
+//                histograms, preceded (round 3) by one level of 256 LINEAR value bins over [max(min, max - 32), max]: the
+//                key's top byte puts nearly all 50 258 logits into two or three buckets -- one LDS atomic queue -- and a
+//                monotone partition of any shape keeps the descent's invariant; the 256 buckets of a level are scanned by
+//                one wave (suffix sums by shuffles, the monotone predicate by ballot) instead of one thread.  172 -> ~120 us
+//                per step for 8 rows.  Masses are 2^-40 fixed point in 64-bit integers: integer atomics are associative, so the
 //                result does not depend on the order in which the lanes arrive (fp32 atomics would make a sampled token
 //                depend on scheduling).  Ties at t* are dropped one by one in index order, as a stable sort would.
 //   multinomial  inverse-CDF draw in index order over the same fixed-point weights exp((x - max) / temperature):
@@ -101,6 +105,34 @@ __global__ __launch_bounds__(ST) void sample_kernel(const SampleParams p) {
   const int tid = threadIdx.x, V = p.V;
   const float* x = p.logits + (int64_t)blockIdx.x * p.ld;
 
+  // One wave scans the 256 buckets of a top-p level (it used to be one thread walking them: ~8 us per level): the lowest
+  // non-empty bucket whose strictly-larger mass -- `start` plus the buckets above it -- is below `limit`.  That mass only grows
+  // downwards, so the predicate is monotone: suffix sums by shuffles, the lowest qualifying bucket by ballot.
+  auto scan_mass = [&](unsigned long long start, unsigned long long limit) {
+    if (tid < 64) {
+      unsigned long long m[4]; uint32_t c[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { m[j] = hist64[4 * tid + j]; c[j] = hist32[4 * tid + j]; }
+      const unsigned long long lane_sum = m[0] + m[1] + m[2] + m[3];
+      unsigned long long incl = lane_sum;                   // sum over lanes >= this one
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long t = __shfl_down(incl, o, 64);
+        if (tid + o < 64) incl += t;
+      }
+      const unsigned long long s3 = start + (incl - lane_sum);    // mass strictly above bucket 4 * tid + 3
+      const unsigned long long s2 = s3 + m[3], s1 = s2 + m[2], s0 = s1 + m[1];
+      int j = -1; unsigned long long sj = 0;
+      if (c[0] && s0 < limit) { j = 0; sj = s0; }
+      else if (c[1] && s1 < limit) { j = 1; sj = s1; }
+      else if (c[2] && s2 < limit) { j = 2; sj = s2; }
+      else if (c[3] && s3 < limit) { j = 3; sj = s3; }
+      const unsigned long long has = __ballot(j >= 0);
+      if (has == 0ull) { if (tid == 0) { bc[0] = 0u; bc[1] = 0u; bc64[0] = start; bc64[1] = 0ull; } }
+      else if (tid == (int)__builtin_ctzll(has)) { bc[0] = (uint32_t)(4 * tid + j); bc[1] = c[j]; bc64[0] = sj; bc64[1] = m[j]; }
+    }
+  };
+
   // ---------------- top-k: key of the k-th largest logit ----------------
   uint32_t tk = 0;                                  // alive(i) = key > tk || (key == tk && i < k_cut): exactly k survive
   int k_cut = 0x7fffffff;
@@ -142,9 +174,10 @@ __global__ __launch_bounds__(ST) void sample_kernel(const SampleParams p) {
   auto alive = [&](int i, uint32_t k) -> bool { return k > tk || (k == tk && i < k_cut); };
 
   // ---------------- first maximum (rank 0 of the reference's sort; never dropped) ----------------
-  float mx = -INFINITY;
-  for (int i = tid; i < V; i += ST) mx = fmaxf(mx, x[i]);
+  float mx = -INFINITY, mn = INFINITY;      // mn: smallest finite logit (only spans the top-p level-0 bins)
+  for (int i = tid; i < V; i += ST) { const float v = x[i]; mx = fmaxf(mx, v); if (v > -INFINITY) mn = fminf(mn, v); }
   mx = blk_max(mx, shf);
+  mn = -blk_max(-mn, shf);
   int imax = 0x7fffffff;
   for (int i = tid; i < V; i += ST) if (x[i] == mx) { imax = min(imax, i); }
   imax = blk_min_i(imax, shi);
@@ -161,35 +194,41 @@ __global__ __launch_bounds__(ST) void sample_kernel(const SampleParams p) {
     z = blk_sum(z, shf);
     const float rz = 1.0f / z;
     const unsigned long long cfix = (unsigned long long)(bound * FIX);
+    // Level 0: 256 LINEAR value bins over [max(min, max - 32), max] (below max - 32 the fixed-point mass is 0), then the four 8-bit levels of
+    // the order-preserving key inside the chosen bin.  Any monotone partition keeps the descent's invariant (`above` = mass
+    // strictly above the current range), so t* is what four key levels alone would find -- but the key's top byte (sign + high
+    // exponent bits) puts nearly all of the 50 000 logits into two or three buckets, i.e. one LDS atomic queue; linear bins
+    // spread them.
+    const float lo = fmaxf(mn, mx - 32.0f);
+    const float bscale = mx > lo ? 255.99f / (mx - lo) : 0.f;
+    auto bin0 = [&](float v) -> int { const int b = (int)((v - lo) * bscale); return v > lo ? min(b, 255) : 0; };
     uint32_t prefix = 0, mask = 0;
-    unsigned long long above = 0;     // mass of the alive keys strictly above the current key range
+    unsigned long long above = 0;     // mass of the alive keys strictly above the current range
     uint32_t n_eq = 0;
-    for (int shift = 24; shift >= 0; shift -= 8) {
+    int b0 = 0;
+    for (int level = 0; level < 5; ++level) {
+      const int shift = 24 - 8 * (level - 1);            // levels 1..4: key bytes, most significant first
       if (tid < 256) { hist64[tid] = 0; hist32[tid] = 0; }
       __syncthreads();
       for (int i = tid; i < V; i += ST) {
-        const uint32_t k = fkey(x[i]);
-        if (alive(i, k) && (k & mask) == prefix) {
-          const unsigned long long q = (unsigned long long)((double)(__expf(x[i] - mx) * rz) * FIX + 0.5);
-          atomicAdd(&hist64[(k >> shift) & 255], q);
-          atomicAdd(&hist32[(k >> shift) & 255], 1u);
+        const float v = x[i];
+        const uint32_t k = fkey(v);
+        if (alive(i, k)) {
+          const int vb = bin0(v);
+          if (level == 0 || (vb == b0 && (k & mask) == prefix)) {
+            const int bucket = level == 0 ? vb : (int)((k >> shift) & 255);
+            const unsigned long long q = (unsigned long long)((double)(__expf(v - mx) * rz) * FIX + 0.5);
+            atomicAdd(&hist64[bucket], q);
+            atomicAdd(&hist32[bucket], 1u);
+          }
         }
       }
       __syncthreads();
-      if (tid == 0) {
-        // lowest non-empty bucket whose strictly-larger mass is still below the bound (it exists: the highest one has mass
-        // `above` < bound by induction, 0 at the top level)
-        unsigned long long s = above, cand_s = above; int cand = -1;
-        for (int b = 255; b >= 0; --b) {
-          if (hist32[b] == 0) continue;
-          if (s < cfix) { cand = b; cand_s = s; } else break;
-          s += hist64[b];
-        }
-        bc[0] = (uint32_t)(cand < 0 ? 0 : cand); bc[1] = cand < 0 ? 0u : hist32[cand];
-        bc64[0] = cand_s; bc64[1] = cand < 0 ? 0ull : hist64[cand];
-      }
+      scan_mass(above, cfix);
       __syncthreads();
-      prefix |= bc[0] << shift; mask |= 255u << shift; above = bc64[0]; n_eq = bc[1];
+      if (level == 0) b0 = (int)bc[0];
+      else { prefix |= bc[0] << shift; mask |= 255u << shift; n_eq = bc[1]; }
+      above = bc64[0];
       __syncthreads();
     }
     tstar = prefix;
@@ -225,24 +264,25 @@ __global__ __launch_bounds__(ST) void sample_kernel(const SampleParams p) {
   if (!p.out) return;
 
   // ---------------- multinomial draw: inverse CDF over fixed-point weights, index order ----------------
-  // thread t owns the contiguous index range [t*C, (t+1)*C)
-  const int C = (V + ST - 1) / ST;
-  const int i0 = tid * C, i1 = min(V, i0 + C);
+  // Wave w owns the contiguous index range [w * RW * 64, (w + 1) * RW * 64) as RW rows of 64: lane l reads index
+  // seg0 + j * 64 + l, so every load is one coalesced 256-byte row (a contiguous range PER THREAD made each load instruction
+  // touch 64 cache lines).  Index order inside the range is (row, lane): the wave that holds the target walks its rows with a
+  // lane scan per row.  Same integers, same order of the CDF: the same token as before.
+  const int lane = tid & 63, wave = tid >> 6;
+  const int RW = (V + ST - 1) / ST;
+  const int seg0 = wave * RW * 64;
   const float rt = 1.0f / p.temperature;
-  unsigned long long mine = 0;
-  for (int i = i0; i < i1; ++i) {
+  auto weight = [&](int i) -> unsigned long long {
+    if (i >= V) return 0ull;
     const float v = x[i];
-    if (kept(i, v)) mine += (unsigned long long)((double)__expf((v - mx) * rt) * 4294967296.0 + 0.5);
-  }
-  // exclusive scan over the 1024 partial sums: wave scan + serial scan of the 16 wave totals
-  unsigned long long incl = mine;
+    return kept(i, v) ? (unsigned long long)((double)__expf((v - mx) * rt) * 4294967296.0 + 0.5) : 0ull;
+  };
+  unsigned long long wsum = 0;
+  for (int j = 0; j < RW; ++j) wsum += weight(seg0 + j * 64 + lane);
 #pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const unsigned long long t = __shfl_up(incl, o, 64);
-    if ((tid & 63) >= o) incl += t;
-  }
+  for (int o = 32; o > 0; o >>= 1) wsum += __shfl_xor(wsum, o, 64);          // total of this wave's range, in every lane
   __syncthreads();
-  if ((tid & 63) == 63) shu[tid >> 6] = incl;
+  if (lane == 0) shu[wave] = wsum;
   __syncthreads();
   if (tid == 0) {
     unsigned long long run = 0;
@@ -250,23 +290,30 @@ __global__ __launch_bounds__(ST) void sample_kernel(const SampleParams p) {
     shu[ST / 64] = run;
   }
   __syncthreads();
-  const unsigned long long excl = shu[tid >> 6] + incl - mine, total = shu[ST / 64];
+  const unsigned long long excl = shu[wave], total = shu[ST / 64];
   uint32_t c[4] = {(uint32_t)p.state[0], blockIdx.x, 0u, 0u};
   const unsigned long long seed = p.seed ? *p.seed : 0ull;
   philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
   const unsigned long long r = ((unsigned long long)c[0] << 32) | c[1];
   const unsigned long long target = __umul64hi(r, total);           // uniform in [0, total)
-  if (mine > 0 && target >= excl && target < excl + mine) {         // exactly one thread
+  if (wsum > 0 && target >= excl && target < excl + wsum) {         // exactly one wave (the condition is wave-uniform)
     unsigned long long run = excl;
-    int tok = i0;
-    for (int i = i0; i < i1; ++i) {
-      const float v = x[i];
-      if (!kept(i, v)) continue;
-      run += (unsigned long long)((double)__expf((v - mx) * rt) * 4294967296.0 + 0.5);
-      tok = i;
-      if (run > target) break;
+    for (int j = 0; j < RW; ++j) {
+      const int i = seg0 + j * 64 + lane;
+      unsigned long long incl = weight(i);
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+      }
+      const unsigned long long row_total = __shfl(incl, 63, 64);
+      if (run + row_total > target) {                               // the token is in this row
+        const unsigned long long hit = __ballot(run + incl > target);
+        if (lane == 0) p.out[blockIdx.x] = seg0 + j * 64 + (int)__builtin_ctzll(hit);     // first index whose inclusive CDF exceeds the target
+        break;
+      }
+      run += row_total;
     }
-    p.out[blockIdx.x] = tok;
   }
   if (total == 0 && tid == 0) p.out[blockIdx.x] = imax == 0x7fffffff ? 0 : imax;   // nothing representable: the maximum
 }
