@@ -427,6 +427,26 @@ def test_gemm256_deep_pipeline(dev, layout, M, N, K, tile):
         assert float((out.float() - out128.float()).abs().max()) <= 2e-2 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("group_m", [1, 2, 3, 5, 8, 32])
+def test_gemm256_tile_walk_group_sizes(dev, monkeypatch, group_m):
+    """MAGMA_G256_GROUP_M: the tile walk of the 256x256 kernel (group_m row-tiles x 32 / group_m column-tiles per XCD at a time) is
+    a bijection onto the tiles for every group size, ragged last group included: same bits as the default walk, plain and with a
+    residual + GELU epilogue (the two row-walk builds)."""
+    from magma_amd import ops
+    M, N, K = 1800, 1300, 256                     # 8 x 6 tiles, both edges ragged
+    a = rnd(M, K, dev=dev, seed=401).to(BF16)
+    w = rnd(N, K, dev=dev, seed=402, scale=0.05).to(BF16)
+    res = rnd(M, 1304, dev=dev, seed=403).to(BF16)[:, :N]
+    lin = ops.PackedLinear(w, bias=rnd(N, dev=dev, seed=404))
+    monkeypatch.delenv("MAGMA_G256_GROUP_M", raising=False)
+    ref_plain = ops.gemm(a, lin, tile=256, out_dtype=torch.float32)
+    ref_res = ops.gemm(a, lin, tile=256, act=ops.MG_ACT_GELU_NEW, residuals=(res,))
+    assert_close(ref_plain, a.float() @ w.float().t() + lin.bias, GEMM_TOL, "default walk")
+    monkeypatch.setenv("MAGMA_G256_GROUP_M", str(group_m))
+    assert torch.equal(ops.gemm(a, lin, tile=256, out_dtype=torch.float32), ref_plain)
+    assert torch.equal(ops.gemm(a, lin, tile=256, act=ops.MG_ACT_GELU_NEW, residuals=(res,)), ref_res)
+
+
 @pytest.mark.parametrize("tile,M", [(0, 77), (0, 456), (256, 456), (0, 1300)])
 def test_gemm_activation_from_column(dev, tile, M):
     """ep.act_n0: the activation applies to output columns >= act_n0 only -- [q | k | v | fc_in] of a GPT-J block as ONE
