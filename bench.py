@@ -45,7 +45,8 @@ def parse():
     ap.add_argument("--config", default="MAGMA_v1")
     ap.add_argument("--layers", type=int, default=None, help="debug: fewer LM layers (result is then NOT the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--train-steps", type=int, default=2, help="timed training steps for the extra 'train' object (0 = skip)")
+    ap.add_argument("--train-steps", type=int, default=5, help="timed training steps for the extra 'train' object (0 = skip)")
+    ap.add_argument("--train-warmup", type=int, default=2, help="untimed training steps in front of the timed ones")
     ap.add_argument("--train-batch", type=int, default=16, help="per-GPU micro-batch of the training step (BASELINE config[2])")
     ap.add_argument("--train-truncate", action=argparse.BooleanOptionalAction, default=True,
                     help="also time the exact-truncation variant (SURVEY Q3: identical loss and gradients, the sequence is cut "
@@ -55,6 +56,10 @@ def parse():
                     help="also time BASELINE config[4]: fp8 (e4m3) MFMA for QKV/out_proj/adapter GEMMs ('attn') or every "
                          "block GEMM ('all'), W8A16 decode and the fp8 training step; reported in extra objects "
                          "('generate_fp8', 'train.forward_only_fp8', 'train.full_S2048_fp8'), never in 'value'")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="launch check: N ranks are started exactly as for a real run (self-launch or torch.distributed.run), join "
+                         "the process group, run the bench's barrier / MAX-over-ranks collectives and rank 0 prints a line with "
+                         "n_gpus = N and value = null; no model, no GPU needed with MAGMA_BENCH_BACKEND=gloo")
     ap.add_argument("--variants", action=argparse.BooleanOptionalAction, default=True,
                     help="N = 1 only: also time BASELINE config[3] (MAGMA_v2: attention + MLP adapters) and the model-native 384^2 "
                          "images as extra objects ('magma_v2', 'generate_res384'); never in 'value'")
@@ -210,6 +215,25 @@ def _forward_fp8(model, images, caps, mode, sync, dtf, f_fwd):
         lm_eng.fp8_mode = None
 
 
+def timed_steps(step, n, warmup, sync):
+    """`warmup` untimed steps, then n steps bracketed by sync() (the mean, as before) with one HIP event between steps on the
+    launch stream: (mean seconds, {"min_ms", "median_ms", "max_ms"}, last return value)."""
+    for _ in range(warmup):
+        step()
+    sync()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+    t0 = time.perf_counter()
+    ev[0].record()
+    for i in range(n):
+        ret = step()
+        ev[i + 1].record()
+    sync()
+    dt = (time.perf_counter() - t0) / n
+    per = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(n))
+    return dt, {"min_ms": per[0], "median_ms": per[len(per) // 2] if n % 2 else 0.5 * (per[n // 2 - 1] + per[n // 2]),
+                "max_ms": per[-1], "timed_steps": n, "warmup_steps": warmup}, ret
+
+
 def bench_train(model, args, rank, world, dev):
     """Config[2]: MAGMA_v1 training step, synthetic img-caption pairs, per-GPU batch 16,
     S = 2048, trainable = adapters + CLIP trunk + prefix; no recompute; AdamW + clip inside
@@ -260,15 +284,12 @@ def bench_train(model, args, rank, world, dev):
     exposed_comm_ms = overlapped = None
     for trunc in ([False, True] if args.train_truncate else [False]):
         eng.truncate = trunc
-        step()
+        for _ in range(args.train_warmup):
+            step()
         sync()
         eng.time_comm = not trunc
         eng.exposed_comm_ms()
-        t0 = time.perf_counter()
-        for _ in range(args.train_steps):
-            loss = step()
-        sync()
-        dt = (time.perf_counter() - t0) / args.train_steps
+        dt, spread, loss = timed_steps(step, args.train_steps, 0, sync)
         if not trunc:
             exposed_comm_ms, overlapped = eng.exposed_comm_ms(), getattr(eng, "last_overlapped_elems", None)
         eng.time_comm = False
@@ -282,7 +303,7 @@ def bench_train(model, args, rank, world, dev):
         out[key] = {"images_per_s": world * B / dt, "ms_per_step": dt * 1e3, "loss": float(loss),
                     "algorithmic_tflops_per_gpu": None if trunc else fl / dt / 1e12,
                     "mfma_frac_of_2.5PF": None if trunc else fl / dt / 2.5e15,
-                    "mfma_frac_executed": None if trunc else fl_exec / dt / 2.5e15}
+                    "mfma_frac_executed": None if trunc else fl_exec / dt / 2.5e15, "spread": spread}
         if trunc:
             out[key]["note"] = ("NOT the BASELINE config: the sequence is cut after the longest caption (+ prefix); with causal "
                                 "attention and the masked loss this leaves loss and gradients mathematically unchanged (same values up "
@@ -292,18 +313,12 @@ def bench_train(model, args, rank, world, dev):
     if args.fp8:   # BASELINE config[4], training side: frozen-weight block GEMMs (forward + dgrad) on the fp8 MFMA
         eng.fp8, eng.truncate = True, False
         try:
-            step()
-            sync()
-            t0 = time.perf_counter()
-            for _ in range(args.train_steps):
-                loss8 = step()
-            sync()
-            dt8 = (time.perf_counter() - t0) / args.train_steps
+            dt8, spread8, loss8 = timed_steps(step, args.train_steps, args.train_warmup, sync)
             if world > 1:
                 t = torch.tensor([dt8], device=dev, dtype=torch.float64)
                 torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
                 dt8 = float(t)
-            out["full_S2048_fp8"] = {"images_per_s": world * B / dt8, "ms_per_step": dt8 * 1e3, "loss": float(loss8),
+            out["full_S2048_fp8"] = {"images_per_s": world * B / dt8, "ms_per_step": dt8 * 1e3, "loss": float(loss8), "spread": spread8,
                                      "note": "qkv / out_proj / fc_in / fc_out forward and dgrad GEMMs in e4m3 (per-row / per-channel "
                                              "scales, fp32 accumulate); adapters, attention, wgrads, trunk stay bf16",
                                      "loss_note": "this leg runs AFTER the optimizer steps of the bf16 legs (same model, same batch), so its "
@@ -374,24 +389,85 @@ def variant_v2(args, dev):
             eng.backward(o.loss)
             eng.step()
             return o.loss
-        step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.train_steps):
-            loss = step()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / args.train_steps
+        dt, spread, loss = timed_steps(step, args.train_steps, args.train_warmup, torch.cuda.synchronize)
         fl = train_flops_per_image(model, args.res, S) * B
-        out["train_full_S2048"] = {"images_per_s": B / dt, "ms_per_step": dt * 1e3, "loss": float(loss),
+        out["train_full_S2048"] = {"images_per_s": B / dt, "ms_per_step": dt * 1e3, "loss": float(loss), "spread": spread,
                                    "mfma_frac_of_2.5PF": fl / dt / 2.5e15,
                                    "mfma_frac_executed": train_flops_per_image(model, args.res, S, c=0.5) * B / dt / 2.5e15}
     return out
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves, the way the reference is
+    started (one process per GPU: reference README.md:121 `deepspeed train.py`, train.py:76,103-111) -- re-exec this script
+    under torch.distributed.run on 127.0.0.1 with the same flags.  Returns the launcher's exit code."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    return subprocess.call(cmd, env=env)
+
+
+def check_launch(args, world):
+    """A mis-launched run must not pass for an N-GPU run: --gpus has to equal the number of ranks, and (outside the one-GPU
+    rehearsal mode, MAGMA_BENCH_DEVICE) every rank needs its own visible GPU."""
+    if args.gpus != world:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
+                 f"(or run `python bench.py --gpus {args.gpus}` without a launcher: it starts the ranks itself)")
+    if args.rendezvous_only or "MAGMA_BENCH_DEVICE" in os.environ:
+        return
+    n_dev = torch.cuda.device_count()
+    if n_dev < world:
+        sys.exit(f"bench.py: --gpus {world} but only {n_dev} GPU(s) visible; refusing to label a {n_dev}-GPU run n_gpus={world}")
+
+
+def rendezvous_only(args, rank, world):
+    """The multi-rank control flow of main() without the model: process group, barrier, MAX over ranks, rank-0 line."""
+    import torch.distributed as dist
+    t0 = time.perf_counter()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+        ranks = torch.zeros(world, dtype=torch.int64)
+        ranks[rank] = 1
+        dist.all_reduce(ranks)
+        assert int(ranks.sum()) == world
+    if rank == 0:
+        print(json.dumps({"metric": "launch check (no model)", "value": None, "unit": "tokens/s", "n_gpus": world, "steps": 0,
+                          "warmup": 0, "ms_per_step": dt * 1e3, "rendezvous_only": True,
+                          "backend": dist.get_backend() if world > 1 else None,
+                          "launched_by": os.environ.get("MAGMA_BENCH_LAUNCHER", "external")}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        os.environ["MAGMA_BENCH_LAUNCHER"] = "self"
+        sys.exit(self_launch(args))
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    check_launch(args, world)
+    if args.rendezvous_only:
+        if world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(os.environ.get("MAGMA_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
+        return rendezvous_only(args, rank, world)
     # one rank per GPU over RCCL.  MAGMA_BENCH_DEVICE / MAGMA_BENCH_BACKEND exist for ONE purpose: rehearsing the multi-rank
     # control flow (collective order, barriers, rank-0-only sections) with two processes on a single-GPU box (gloo, both
     # ranks on device 0) -- tools/gpu_bench_2rank_rehearsal.sh; numbers from such a run mean nothing

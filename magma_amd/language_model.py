@@ -23,7 +23,10 @@ import torch.nn as nn
 
 @dataclass
 class GPTJConfig:
-    vocab_size: int = 50400
+    vocab_size: int = 50400            # rows of wte (the INPUT vocabulary)
+    vocab_out: Optional[int] = None    # rows of lm_head; None = vocab_size.  SURVEY Q1: the reference resizes the token
+                                       # embeddings to len(tokenizer) = 50258 (magma.py:50) while whether the untied 50400-row
+                                       # head follows is decided inside the un-vendored fork -- both sizes are independent here
     hidden_size: int = 4096
     num_layers: int = 28
     num_heads: int = 16
@@ -41,6 +44,10 @@ class GPTJConfig:
     @property
     def head_dim(self):
         return self.hidden_size // self.num_heads
+
+    @property
+    def head_rows(self) -> int:
+        return self.vocab_size if self.vocab_out is None else self.vocab_out
 
 
 def gptj_config(**overrides) -> GPTJConfig:
@@ -107,7 +114,7 @@ class GPTJForCausalLM(nn.Module):
         with torch.no_grad():
             _skip = nn.init  # noqa: F841  (torch inits run on-device; cheap on a GPU)
             self.transformer = Transformer(config, **kw)
-            self.lm_head = nn.Linear(config.hidden_size, config.vocab_size, bias=True, **kw)
+            self.lm_head = nn.Linear(config.hidden_size, config.head_rows, bias=True, **kw)
         if init:
             self.init_weights()
         self._engine = None
@@ -128,28 +135,37 @@ class GPTJForCausalLM(nn.Module):
                 m.weight.fill_(1.0)
                 m.bias.zero_()
 
-    def resize_token_embeddings(self, new_num_tokens: int):
-        """the reference resizes to len(tokenizer) = 50258; we resize
-        wte AND lm_head (untied, bias kept) and keep the leading rows."""
-        old = self.config.vocab_size
-        if new_num_tokens == old:
-            return self.transformer.wte
+    def resize_token_embeddings(self, new_num_tokens: Optional[int] = None, resize_head: bool = True,
+                                new_head_rows: Optional[int] = None):
+        """the reference resizes to len(tokenizer) = 50258 (magma.py:50).  ``resize_head=True`` (HF's rule for an
+        untied output embedding) gives lm_head the same row count; ``resize_head=False`` keeps the head (a checkpoint whose
+        fork left the 50400-row head alone); ``new_head_rows`` sets the head on its own.  Leading rows are kept."""
         wte, head = self.transformer.wte, self.lm_head
         kw = dict(device=wte.weight.device, dtype=wte.weight.dtype)
-        n = min(old, new_num_tokens)
-        new_wte = nn.Embedding(new_num_tokens, self.config.hidden_size, **kw)
-        new_head = nn.Linear(self.config.hidden_size, new_num_tokens, bias=True, **kw)
-        with torch.no_grad():
-            new_wte.weight.normal_(0.0, self.config.init_std)
-            new_head.weight.normal_(0.0, self.config.init_std)
-            new_head.bias.zero_()
-            new_wte.weight[:n] = wte.weight[:n]
-            new_head.weight[:n] = head.weight[:n]
-            new_head.bias[:n] = head.bias[:n]
-        self.transformer.wte, self.lm_head = new_wte, new_head
-        self.config.vocab_size = new_num_tokens
-        self.invalidate_packed()
-        return new_wte
+        old_in, old_out = wte.weight.shape[0], head.weight.shape[0]
+        new_in = old_in if new_num_tokens is None else int(new_num_tokens)
+        new_out = int(new_head_rows) if new_head_rows is not None else (new_in if resize_head else old_out)
+        if new_in != old_in:
+            n = min(old_in, new_in)
+            new_wte = nn.Embedding(new_in, self.config.hidden_size, **kw)
+            with torch.no_grad():
+                new_wte.weight.normal_(0.0, self.config.init_std)
+                new_wte.weight[:n] = wte.weight[:n]
+            self.transformer.wte = new_wte
+        if new_out != old_out:
+            n = min(old_out, new_out)
+            new_head = nn.Linear(self.config.hidden_size, new_out, bias=True, **kw)
+            with torch.no_grad():
+                new_head.weight.normal_(0.0, self.config.init_std)
+                new_head.bias.zero_()
+                new_head.weight[:n] = head.weight[:n]
+                new_head.bias[:n] = head.bias[:n]
+            self.lm_head = new_head
+        self.config.vocab_size = new_in
+        self.config.vocab_out = None if new_out == new_in else new_out
+        if new_in != old_in or new_out != old_out:
+            self.invalidate_packed()
+        return self.transformer.wte
 
     device_token_selection = True      # forward(..., sampling=, eos_token=, seed=) picks the next token in the HIP engine
 

@@ -59,9 +59,10 @@ class Magma(nn.Module):
         self.eos_token = self.tokenizer.eos_token_id
         if lm_config is None:   # full-size model: len(tokenizer) = 50258
             self.lm.resize_token_embeddings(len(self.tokenizer))
-        elif self.lm.config.vocab_size < len(self.tokenizer):
-            # reduced test vocabularies: keep the special ids in range (eos = V-2, image = V-1)
-            self.eos_token, self.image_token = self.lm.config.vocab_size - 2, self.lm.config.vocab_size - 1
+        elif min(self.lm.config.vocab_size, self.lm.config.head_rows) < len(self.tokenizer):
+            # reduced test vocabularies: keep the special ids in range of BOTH tables (eos = V-2, image = V-1)
+            v = min(self.lm.config.vocab_size, self.lm.config.head_rows)
+            self.eos_token, self.image_token = v - 2, v - 1
         self.lm.config.pad_token_id = self.tokenizer.eos_token_id
         self.word_embedding = self.lm.transformer.wte
         self.transformer = self.lm.transformer.h
@@ -260,11 +261,15 @@ class Magma(nn.Module):
             elif k == "word_embedding.weight":
                 k = "lm.transformer.wte.weight"
             fixed[k] = v
-        for name in ("lm.transformer.wte.weight", "lm.lm_head.weight"):
-            if name in fixed and name in own and fixed[name].shape[0] != own[name].shape[0]:
-                self.lm.resize_token_embeddings(fixed[name].shape[0])
-                self.word_embedding = self.lm.transformer.wte
-                own = self.state_dict()
+        # Q1: the input and the output vocabulary are sniffed independently (a checkpoint may carry a 50258-row wte next
+        # to a 50400-row lm_head, or the reverse of neither)
+        v_in = fixed["lm.transformer.wte.weight"].shape[0] if "lm.transformer.wte.weight" in fixed else None
+        v_out = fixed["lm.lm_head.weight"].shape[0] if "lm.lm_head.weight" in fixed else None
+        cur_in, cur_out = own["lm.transformer.wte.weight"].shape[0], own["lm.lm_head.weight"].shape[0]
+        if (v_in is not None and v_in != cur_in) or (v_out is not None and v_out != cur_out):
+            self.lm.resize_token_embeddings(v_in if v_in is not None else cur_in, new_head_rows=v_out if v_out is not None else cur_out)
+            self.word_embedding = self.lm.transformer.wte
+            own = self.state_dict()
         missing, unexpected = [], []
         bad = [f"{k}: checkpoint {tuple(v.shape)} vs model {tuple(own[k].shape)}" for k, v in fixed.items()
                if k in own and own[k].shape != v.shape]

@@ -128,3 +128,29 @@ def test_two_rank_engine_step(dev):
         assert torch.equal(a, b)
         big = g.abs() > 1e-2 * g.abs().max()
         assert float((a[big] - ref[big]).norm() / (ref[big].norm() + 1e-30)) < 1e-3
+
+
+def test_bench_two_ranks_self_launched(dev):
+    """`python bench.py --gpus 2 ...` -- no launcher around it -- is a 2-rank run: bench.py starts the ranks itself (one-GPU
+    rehearsal mode: both on device 0, gloo instead of RCCL, which refuses two ranks per device), every rank issues the same
+    collectives in the same order, rank 0 prints ONE line with n_gpus = 2 and the data-parallel fields of the training leg.
+    The numbers of such a run mean nothing; the control flow is what N real GPUs execute."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MAGMA_BENCH_BACKEND="gloo", MAGMA_BENCH_DEVICE="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--layers", "1",
+                        "--train-steps", "1", "--train-warmup", "1", "--train-batch", "2", "--no-cpu-baseline", "--fp8", "off",
+                        "--no-train-truncate"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["train_ranks"] == 2 and line["value"] > 0
+    dp = line["train"]["data_parallel"]
+    assert dp["ranks"] == 2 and dp["rccl_ranks"] == 2 and dp["global_batch"] == 4
+    assert dp["exposed_comm_ms_per_step"] is not None and dp["elements_handed_over_during_backward"] > 0
+    assert line["train_images_per_s"] > 0

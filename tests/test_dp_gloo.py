@@ -2,6 +2,8 @@
 all-reduce and the loss reduction give every rank the same mean, and averaging
 the gradients of two half batches equals the full-batch gradient."""
 import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 import socket
 
 import torch
@@ -68,3 +70,32 @@ def test_lr_schedule_shape():
     for _ in range(450):
         s.step()
     assert abs(s.get_lr()[0] - 4e-4) < 1e-9          # half way down the linear decay
+
+
+def _run_bench(args, env_extra, timeout=180):
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r.returncode, (json.loads(lines[-1]) if lines else None), r.stderr
+
+
+def test_bench_gpus_n_launches_n_ranks_by_itself():
+    """`python bench.py --gpus 2` with no launcher around it starts 2 ranks (torch.distributed.run on 127.0.0.1), which join
+    one process group and run the bench's barrier / MAX-over-ranks collectives; rank 0 prints ONE line with n_gpus = 2.
+    (--rendezvous-only: the launch path without the model -- the model needs a GPU; the same path with the model is
+    tests/test_dp_engine_gpu.py::test_bench_two_ranks_self_launched.)"""
+    rc, line, err = _run_bench(["--gpus", "2", "--rendezvous-only"], {"MAGMA_BENCH_BACKEND": "gloo"})
+    assert rc == 0, err[-2000:]
+    assert line["n_gpus"] == 2 and line["launched_by"] == "self" and line["backend"] == "gloo"
+
+
+def test_bench_refuses_a_mislabelled_launch():
+    """--gpus must equal the number of ranks: a 1-rank run asked for 2 GPUs exits non-zero instead of printing n_gpus = 1."""
+    rc, line, err = _run_bench(["--gpus", "2", "--rendezvous-only"], {"WORLD_SIZE": "1", "RANK": "0"})
+    assert rc != 0 and line is None and "--gpus 2 but WORLD_SIZE=1" in err
