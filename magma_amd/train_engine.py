@@ -432,7 +432,8 @@ class MagmaEngine:
             tape["caption_ids"] = captions
         loss = self._lm_forward(emb, labels[:, :S].contiguous(), tape)
         self._tape = tape
-        return LMOutput(loss=loss, logits=None, labels=labels)
+        # rows are b * S + position within the (possibly truncated) sequence of this step
+        return LMOutput(loss=loss, logits=None, labels=labels, target_rows=tape["rows"], target_logits=tape.pop("target_logits"))
 
     def _lm_forward(self, emb, labels, tape):
         eng = self.module.lm.engine
@@ -505,6 +506,7 @@ class MagmaEngine:
         _, head_t = self._lm_packs()
         loss, dlogits = ops.cross_entropy_fwd_bwd(logits[:, : eng.V], tgt, head_t.K)
         tape.update(xr=xr, dlogits=dlogits, M=M)
+        tape["target_logits"] = logits[:, : eng.V]         # fp32, rows that carry a target (reference magma.py:270-276 .logits, those rows)
         if self.lm_trainable:
             tape["xl"] = xl
         return loss

@@ -56,15 +56,21 @@ def margin_safe(ref_logits):
 
 
 # ------------------------------------------------------------------------------------------------ (a) 28 blocks
-def test_magma_v1_at_28_blocks(dev):
-    """The headline model, every block of it: error accumulation through 28 parallel-residual blocks, the 28-layer KV cache,
-    the captured 115-launch token step."""
-    from oracle.model import lm_forward
+@pytest.fixture(scope="module")
+def v1_28(dev):
+    """MAGMA_v1 at all 28 blocks (5.9 B values drawn once for both 28-block tests)."""
     cfg = F.full_width_config(n_layer=28, **TINY_TRUNK)
     params = F.full_depth_params(cfg)
     model = build(dev, cfg, params)
+    return cfg, params, model
+
+
+def test_magma_v1_at_28_blocks(v1_28):
+    """The headline model, every block of it: error accumulation through 28 parallel-residual blocks, the 28-layer KV cache,
+    the captured 115-launch token step."""
+    from oracle.model import lm_forward
+    cfg, params, model = v1_28
     lm = F.lm_only(params)
-    del params
     emb = F.greedy_inputs(cfg, F.FULLDEPTH_INPUT_SEED)
     steps, S0 = F.FULLDEPTH_STEPS, F.PREFILL_LEN
     with torch.no_grad():
@@ -92,6 +98,53 @@ def test_magma_v1_at_28_blocks(dev):
         toks = model.generate(emb.to(BF16).cuda(), max_steps=steps, temperature=0.0, decode=False, stop_on_eos=False).cpu()
     assert toks.shape == ref_toks.shape == (F.GREEDY_B, S0 + steps)
     assert torch.equal(toks, ref_toks), (toks[:, S0:], ref_toks[:, S0:], margins)
+
+
+def test_training_engine_loss_at_28_blocks_s2048(v1_28, dev):
+    """The TRAINING engine's forward (taped activations, the 256x256 GEMMs at M = 2048 rows, flash attention at S = 2048 with the
+    LSE written for the backward, rotary split that also emits q^T / k^T, the loss head on the target rows) through all 28 blocks
+    at the sequence length of BASELINE config[2], against the fp32 oracle forward (reference magma.py:238-276): the loss and the
+    fp32 logits of every row that carries a target, under the 2 x eager-bf16 criterion.  B = 1 keeps the CPU oracle at ~30 TF."""
+    from magma_amd.train_engine import MagmaEngine
+    from oracle.model import magma_forward
+    cfg, params, model = v1_28
+    model.config.gradient_accumulation_steps = 1
+    eng = MagmaEngine(model)
+    eng.train()
+    B, S = 1, 2048
+    P = (64 // 32) ** 2
+    g = torch.Generator().manual_seed(29)
+    images = torch.randn(B, 3, 64, 64, generator=g).to(BF16).float()
+    caps = torch.full((B, S), cfg.eos_token, dtype=torch.int64)
+    n_tok = 96
+    caps[0, :n_tok] = torch.randint(0, 50256, (n_tok,), generator=g)
+    mask = (torch.rand(B, P, cfg.d_model, generator=g) < 0.9).float() / 0.9
+    with torch.no_grad():
+        ref = magma_forward(params, cfg, images, caps, dropout_mask=mask)
+        pb = bf16_params(params)
+        rb = magma_forward(pb, cfg, images.to(BF16), caps, dropout_mask=mask.to(BF16))
+        del pb
+    labels = ref["labels"]
+    rows = (labels[0, 1:] != -100).nonzero().squeeze(1)           # positions whose NEXT token carries a label
+    assert rows.numel() == n_tok + 1                               # the caption tokens + the first eos (reference utils.py:334-364)
+    ref_lg, bf_lg = ref["logits"][0, rows].float(), rb["logits"][0, rows].float()
+    loss_ref, loss_bf = float(ref["loss"]), float(rb["loss"])
+    del ref, rb
+    out = eng(images.to(dev), caps.to(dev), dropout_mask=mask.to(dev))
+    assert torch.equal(out.target_rows.cpu(), rows)
+    e_hip, e_bf = rel(out.target_logits, ref_lg), rel(bf_lg, ref_lg)
+    print(f"28-block training forward: loss HIP {float(out.loss):.5f} oracle {loss_ref:.5f} eager-bf16 {loss_bf:.5f}; "
+          f"target-row logits HIP {e_hip:.3e} eager-bf16 {e_bf:.3e}")
+    assert abs(float(out.loss) - loss_ref) <= 2 * abs(loss_bf - loss_ref) + 3e-3 * abs(loss_ref), (float(out.loss), loss_ref, loss_bf)
+    check(e_hip, e_bf, "28 blocks, S = 2048: target-row logits of the training forward", floor=3e-3)
+    # the backward runs on this tape (28 blocks of saved activations) and leaves finite, non-zero adapter gradients
+    eng.backward(out.loss)
+    ad = model.lm.transformer.h[0].mlp[1].adapter[0].weight
+    gn = float(eng.grad_of(ad).float().norm())
+    assert gn > 0 and gn == gn
+    model.zero_grad(set_to_none=True)
+    for grp in eng.groups:
+        grp.grad.zero_()
 
 
 # ------------------------------------------------------------------------------------------------ (b) MAGMA_v2
