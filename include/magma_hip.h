@@ -61,6 +61,14 @@ extern "C" {
 typedef uint16_t mg_bf16;
 
 const char* mg_version(void);
+/* Binary interface revision.  A binder built against another revision must not call into the library: arguments moved.
+ *   1  rounds 1-3.  Within it (before this counter existed) three signatures changed: mg_epilogue._pad became act_n0;
+ *      mg_rotary_split_bf16 gained ld_qkv as its 2nd argument; mg_sample_f32's top_p went from float to double.
+ *   2  round 4: mg_decode_attn_gemv_bf16 gained ld_attn_out (5th argument); removed: mg_decode_attn_2gemv_bf16,
+ *      mg_decode_ctx_counter_ints, the persistent decode step's four entry points mg_decode_plan_* / mg_decode_step_* (in-launch hand-off
+ *      experiments, measured slower than the launch chain: DESIGN.md 8).                                                        */
+#define MG_ABI_VERSION 2
+int32_t mg_abi_version(void);
 const char* mg_last_error(void);
 
 /* Fused epilogue shared by both GEMM kernels:
@@ -200,23 +208,12 @@ int mg_gemm_skinny2_bf16(const mg_skinny_desc* a, const mg_skinny_desc* b, void*
 /* mg_attn_decode_fused_bf16 co-launched with one GEMV that does not depend on it (fc_out of
  * the parallel block): attention workgroups first, GEMV workgroups behind them, one grid.  */
 int mg_decode_attn_gemv_bf16(const mg_bf16* qkv, mg_bf16* kcache, mg_bf16* vcache, mg_bf16* attn_out,
+                             int64_t ld_attn_out /* row stride of attn_out in elements; 0 = H*256.  ABI 2: a wider row lets the
+                                                  * context land beside another activation, [ctx | t], the input of one K-concatenated
+                                                  * GEMV [W_out | W_up] */,
                              int32_t B, int32_t H, int32_t Smax, const int32_t* d_pos, int32_t rot_dim,
                              const float* sin_t, const float* cos_t, const mg_skinny_desc* gemv,
                              void* stream);
-
-/* The same co-launch plus a SECOND weight-streaming GEMV that READS the attention output (out_proj, reference GPT-J block:
- * attn_outputs = out_proj(context)): its workgroups start with the launch, issue their first weight loads and wait -- off
- * the critical path, while gemv_indep keeps the HBM stream busy -- for the B*H attention workgroups of this launch
- * (coherent stores + sharded arrival counter).  gemv_ctx->X must be attn_out, K % 1024 == 0, no LayerNorm fold / split.
- *   counter  mg_decode_ctx_counter_ints() int32, 64-byte aligned, ZERO on entry (re-armed by mg_sample_finish's `clear`);
- *   err      int32, set to 1 if a (bounded) wait timed out -- the step's results are invalid then.
- * Refuses grids whose workgroups cannot all be resident at once (MG_ERR_UNSUPPORTED): the caller falls back to
- * mg_decode_attn_gemv_bf16 + mg_gemm_skinny2_bf16.                                                                        */
-int32_t mg_decode_ctx_counter_ints(void);
-int mg_decode_attn_2gemv_bf16(const mg_bf16* qkv, mg_bf16* kcache, mg_bf16* vcache, mg_bf16* attn_out, int32_t B, int32_t H,
-                              int32_t Smax, const int32_t* d_pos, int32_t rot_dim, const float* sin_t, const float* cos_t,
-                              const mg_skinny_desc* gemv_indep, const mg_skinny_desc* gemv_ctx, int32_t* counter,
-                              int32_t* err, void* stream);
 
 /* K8/K17 + ImagePrefix LN: y = (x-mean)/sqrt(var+eps)*gamma+beta, fp32 stats.  Replaces nn.LayerNorm at reference
  * magma/image_prefix.py:58-60,106-107 and ln_1 / ln_f of the GPT-J blocks built at magma/language_model.py:12-45
@@ -268,33 +265,6 @@ int mg_attn_decode_fused_bf16(const mg_bf16* qkv, mg_bf16* kcache, mg_bf16* vcac
                               int32_t H, int32_t Smax, const int32_t* d_pos, int32_t rot_dim,
                               const float* sin_t, const float* cos_t, void* stream);
 
-/* ---- persistent decode step -------------------------------------------------------------------------------------------
- * One launch for a whole cached token step (reference magma/sampling.py:86-93: model.lm(input_ids=..., past_key_values=...)):
- * the step is described ONCE as a list of ops -- weight-streaming GEMVs (kind 0: mg_skinny_desc, bf16 weights, K % 1024 == 0,
- * M <= 16) and fused decode attentions (kind 1: the arguments of mg_attn_decode_fused_bf16) -- in execution order.  Every op
- * owns a completion counter (in the caller's int32 `counters` array of mg_decode_counter_ints(n_ops), bumped once per work item = one
- * 16-column tile or one (batch, head)) and may wait for up to two earlier ops to complete.  The ops' workgroups
- * all live in one persistent grid: a consumer first issues its weight loads, then waits for its producers, so the HBM
- * weight stream does not drain between ops as it does between launches.  Activations that cross ops MUST NOT be read or
- * written by anything else while the step runs; `counters` must be zero at launch (mg_sample_finish can clear it) and
- * `err` (one int32, 0) becomes 1 if a wait timed out.
- *   mg_decode_plan_bytes / mg_decode_plan_build: translate the host op list into the device table (one synchronous copy,
- *   not capturable -- do it once); mg_decode_step_bf16: enqueue the step (capturable).                                     */
-typedef struct mg_decode_op {
-  int32_t kind;                 /* 0 = GEMV, 1 = decode attention */
-  int32_t dep0, dep1;           /* indices of EARLIER ops of the list this op reads from (-1 = none) */
-  int32_t _pad;
-  mg_skinny_desc gemv;          /* kind 0 */
-  const mg_bf16* qkv; mg_bf16* kcache; mg_bf16* vcache; mg_bf16* attn_out;   /* kind 1 */
-  int32_t B, H, Smax, rot_dim;
-  const int32_t* d_pos; const float* sin_t; const float* cos_t;
-} mg_decode_op;
-int64_t mg_decode_plan_bytes(int32_t n_ops);
-int32_t mg_decode_counter_ints(int32_t n_ops);   /* length of the int32 `counters` array (sharded, one cache line per shard) */
-int mg_decode_plan_build(const mg_decode_op* ops, int32_t n_ops, void* plan_device, int32_t* total_items_out);
-int mg_decode_step_bf16(const void* plan_device, int32_t n_ops, int32_t total_items, int32_t* counters, int32_t* err,
-                        void* stream);
-
 /* K24 greedy (reference magma/sampling.py:96-97, temperature == 0.0): token[b] = argmax_v logits[b, v] (first maximum), int64 out;
  * optionally appends to out_tokens[b*out_ld + *d_pos_out] and bumps *d_pos.  */
 int mg_argmax_f32(const float* logits, int64_t ld, int32_t B, int32_t V, int64_t* token,
@@ -313,8 +283,8 @@ int mg_advance_pos(int32_t* d_pos, int32_t delta, void* stream);
  * (token == eos).all() (reference sampling.py:109, read by the host every few steps instead of a sync per token), advances
  * the step counter, bumps the KV-cache write position *d_pos by delta (NULL: untouched) and appends the tokens to
  * history[b * ld_history + step] (NULL: off; the host copies the history once when generate() ends); `clear` (NULL: off) =
- * n_clear int32 at clear[i * clear_stride] set to zero for the next step (the sharded completion counters of
- * mg_decode_step_bf16: one word per 64-byte line).                                                                         */
+ * n_clear int32 at clear[i * clear_stride] set to zero for the next step (device-side counters a caller wants re-armed
+ * inside the captured step).                                                                                             */
 int mg_sample_f32(const float* logits, int64_t ld, int32_t B, int32_t V, float temperature, int32_t top_k, double top_p,
                   const uint64_t* seed, const int32_t* state, int64_t* token, float* filtered, int64_t ld_filtered,
                   void* stream);

@@ -246,237 +246,7 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(
   }
 }
 
-// ---------------------------------------------------------------------------
-// flash attention forward, second structure: 32 queries per wave on v_mfma_f32_32x32x16_bf16.
-//
-// Why: in attn_prefill_kernel every wave owns 16 queries and reads the whole K tile and the whole V^T tile from LDS
-// per 32 MFMAs -- per CU and 32-key step that is 256 KiB of ds_read_b128 (1 024 LDS cycles) beside 1 024 cycles of
-// MFMA per SIMD, and the PMC shows the two (plus ~800 cycles of softmax VALU) running one after the other.  Here a
-// workgroup is 4 waves (ONE per SIMD, the whole 512-register file each) x 32 queries: the same 32 fragment reads now
-// feed twice the MFMA work (128 KiB = 512 LDS cycles per step and CU), and a lane owns 16 scores of ONE query, so the
-// softmax is the same VALU work per query with half the cross-lane traffic.
-//
-//   S^T[key][q] = K . Q^T    16 x mfma_32x32x16 (k = 256 / 16), one accumulate chain  (A = K rows, B = Q^T)
-//   O^T[d][q]  += V^T . P^T   8 d-blocks of 32 x 2 k-steps of 16 keys = 16 MFMAs      (A = V^T, B = P^T)
-// MFMA row m of the S^T tile is key  swap_bits_2_3(m)  (the K fragment read picks that LDS row): accumulator register i
-// of lane (q = lane & 31, hh = lane >> 5) then holds key  16 (i >> 3) + 8 hh + (i & 7), i.e. registers 8s .. 8s+7 ARE
-// the eight consecutive k-indices lane hh must supply as the P^T operand of PV k-step s, and the V^T fragment of that
-// step is the 16-byte chunk 2s + hh of a V^T row: no cross-lane movement, no key permutation in memory.
-// Tile images, swizzles and the LDS-DMA ring are those of attn_tile_device.h (conflict-free for this read pattern too:
-// the four 16-lane groups of ds_read_b128 see (m >> 2) in {0,3,5,6} / {1,2,4,7}, on which both swizzles are injective).
-// ---------------------------------------------------------------------------
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-constexpr int FA2_EPI_ROWB = DH * 2 + 16;          // bf16 output row in LDS (+16 B bank skew)
-constexpr float FA2_DEFER = 8.0f;                   // log2 units: rescale only when the running max grows by more than 256x
-
-MG_DEV int swap_bits_2_3(int m) { return (m & ~12) | ((m & 4) << 1) | ((m & 8) >> 1); }
-
-template <bool HINT>
-__global__ __launch_bounds__(256, 1) void attn_prefill32_kernel(
-    const mg_bf16* __restrict__ q, const mg_bf16* __restrict__ kcache,
-    const mg_bf16* __restrict__ vt, mg_bf16* __restrict__ out, float* __restrict__ lse,
-    int B, int H, int S, int Smax, int vt_ld) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, hh = lane >> 5;
-  const int nblk = (S + 127) >> 7;
-  const int wg = xcd_contiguous_index(blockIdx.x, gridDim.x);
-  const int bh = wg / nblk, b = bh / H, h = bh - b * H;
-  const int qt0 = (nblk - 1 - (wg - bh * nblk)) * 128;   // longest blocks first
-  const int qrow = qt0 + wave * 32 + l31;
-  const int qrow_c = min(qrow, S - 1);
-  const mg_bf16* kbase = kcache + (int64_t)bh * Smax * DH;
-  const mg_bf16* vbase = vt + (int64_t)bh * DH * vt_ld;
-  const int kv_end = min(S, qt0 + 128);
-  const int ntiles = (kv_end + 31) >> 5;
-
-  // LDS-DMA: a tile = 16 blocks of 1 KiB per operand, wave w moves blocks 4w .. 4w+3 of each
-  auto issue = [&](int t, int buf) {
-    const int c0 = min(t, ntiles - 1) * 32;
-    char* st = smem + buf * FA_STAGE;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int blk = wave * 4 + i;
-      const int row = blk * 2 + (lane >> 5);
-      const int c = (lane & 31) ^ row_swz(row);
-      glds16a(kbase + (int64_t)min(c0 + row, S - 1) * DH + c * 8, st + blk * 1024);
-    }
-    const mg_bf16* src = vbase + (int64_t)(c0 >> 5) * (DH * 32);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int blk = wave * 4 + i;
-      const int row = blk * 16 + (lane >> 2);
-      const int c = (lane & 3) ^ t_swz(row);
-      glds16a(src + row * 32 + c * 8, st + ROW_TILE + blk * 1024);
-    }
-  };
-#pragma unroll
-  for (int i = 0; i < FA_STAGES - 1; ++i) issue(i, i);
-
-  // Q^T fragments (B operand): Q[q][16 ks + 8 hh .. +7]
-  bf16x8 qf[16];
-  {
-    const mg_bf16* qp = q + ((int64_t)bh * S + qrow_c) * DH + hh * 8;
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
-  }
-  f32x16 o[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
-  float m2 = -1e30f, lsum = 0.f;
-  const float sc2 = 0.0625f * 1.4426950408889634f;  // 1/sqrt(256) * log2(e)
-  const int q_first = qt0 + wave * 32, my_last = q_first + 31;
-  const int krow = swap_bits_2_3(l31);
-  const int ksw = row_swz(krow);
-  const int koff = krow * 512;
-  const int toff = ROW_TILE + l31 * 64;
-  const int tsw = t_swz(l31);
-
-  // one 32-key step: scores of tile in `st` -> P (bf16 fragments pf[2]), updating m2 / lsum; returns alpha
-  auto scores = [&](const char* st, f32x16& sacc) {
-    bf16x8 kf[16];
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) kf[ks] = *(const bf16x8*)(st + koff + (((ks * 2 + hh) ^ ksw) << 4));
-#pragma unroll
-    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], sacc, 0, 0, 0);
-    if constexpr (HINT) {   // keep six fragment reads in flight ahead of the accumulate chain (guide T19)
-      __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-#pragma unroll
-      for (int i = 0; i < 10; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      }
-      __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
-    }
-  };
-  auto softmax = [&](f32x16& sacc, int kv0, bf16x8 (&pf)[2]) -> float {
-    if (kv0 + 31 > q_first || kv0 + 32 > S) {     // diagonal tiles of this wave / ragged last tile
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int key = kv0 + 16 * (i >> 3) + 8 * hh + (i & 7);
-        sacc[i] = (key > qrow || key >= S) ? -1e30f : sacc[i];
-      }
-    }
-    float tmax = sacc[0];
-#pragma unroll
-    for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, sacc[i]);
-    {   // the other 16 keys of this query live in lane ^ 32
-      const uint32_t u = __float_as_uint(tmax);
-      const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-      tmax = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-    }
-    // deferred running max (guide T13): the reference point of the exponentials only moves when a tile's maximum exceeds
-    // it by more than 2^FA2_DEFER -- then (and in the first tile) O and l are rescaled, otherwise alpha == 1 exactly and
-    // P is bounded by 2^FA2_DEFER instead of 1 (bf16 P / fp32 accumulate keep their relative precision).  With O in the
-    // accumulator file a rescale costs 128 register moves each way, so it must be the rare path.
-    const float cand = tmax * sc2;
-    const float mnew = (cand > m2 + FA2_DEFER) ? cand : m2;
-    const float alpha = __builtin_amdgcn_exp2f(m2 - mnew);
-    m2 = mnew;
-    float p[16], psum = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      p[i] = __builtin_amdgcn_exp2f(fmaf(sacc[i], sc2, -mnew));
-      psum += p[i];
-    }
-    lsum = lsum * alpha + psum;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      u32x4 pw;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) pw[j] = pack2bf(p[8 * s + 2 * j], p[8 * s + 2 * j + 1]);
-      pf[s] = __builtin_bit_cast(bf16x8, pw);
-    }
-    return alpha;
-  };
-  auto pv = [&](const char* st, const bf16x8 (&pf)[2], float alpha) {
-    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
-#pragma unroll
-      for (int db = 0; db < 8; ++db)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
-    }
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      bf16x8 vf[4][2];
-#pragma unroll
-      for (int d4 = 0; d4 < 4; ++d4)
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-          vf[d4][s] = *(const bf16x8*)(st + toff + (half * 4 + d4) * 2048 + (((2 * s + hh) ^ tsw) << 4));
-#pragma unroll
-      for (int d4 = 0; d4 < 4; ++d4)
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-          o[half * 4 + d4] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[d4][s], pf[s], o[half * 4 + d4], 0, 0, 0);
-      if constexpr (HINT) {
-        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-      }
-    }
-  };
-
-  int sc = 0;
-  MG_USE8(qf); MG_USE8(qf + 8);       // see attn_prefill_kernel
-  {
-    for (int t = 0; t < ntiles; ++t) {
-      MG_WAIT_VMCNT(16);               // tile t landed (this wave's pieces); tiles t+1, t+2 (8 pieces each) may be in flight
-      MG_BARRIER_KEEP_DMA();
-      issue(t + FA_STAGES - 1, sc == 0 ? FA_STAGES - 1 : sc - 1);
-      const int kv0 = t * 32;
-      if (kv0 <= my_last) {
-        const char* st = smem + sc * FA_STAGE;
-        f32x16 sacc;
-        bf16x8 pf[2];
-        scores(st, sacc);
-        const float alpha = softmax(sacc, kv0, pf);
-        pv(st, pf, alpha);
-      }
-      sc = sc == FA_STAGES - 1 ? 0 : sc + 1;
-    }
-  }
-  MG_WAIT_VMCNT(0);                    // drain the ring's trailing loads
-  // ---- epilogue: O^T / l -> bf16, staged through LDS so that global stores are whole 512-byte rows ----
-  {
-    const uint32_t u = __float_as_uint(lsum);
-    const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    lsum = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-  }
-  const float inv = 1.0f / lsum;
-  __syncthreads();                     // every wave is done with the ring
-  char* my = smem + wave * (32 * FA2_EPI_ROWB);
-#pragma unroll
-  for (int db = 0; db < 8; ++db)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {      // registers 4g .. 4g+3 = d = 32 db + 8 g + 4 hh + (0..3) of query l31
-      u32x2 w;
-      w[0] = pack2bf(o[db][4 * g] * inv, o[db][4 * g + 1] * inv);
-      w[1] = pack2bf(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
-      *(u32x2*)(my + l31 * FA2_EPI_ROWB + (db * 32 + g * 8 + hh * 4) * 2) = w;
-    }
-  if (lse && hh == 0 && qrow < S) lse[(int64_t)bh * S + qrow] = (m2 + log2f(lsum)) * 0.6931471805599453f;
-  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes are visible to itself below
-  __builtin_amdgcn_wave_barrier();
-#pragma unroll
-  for (int it = 0; it < 16; ++it) {    // 32 rows x 32 chunks of 16 B; 64 lanes take 2 rows per iteration
-    const int r = it * 2 + (lane >> 5), c = lane & 31;
-    const int qr = q_first + r;
-    if (qr < S) {
-      const u32x4 v = *(const u32x4*)(my + r * FA2_EPI_ROWB + c * 16);
-      *(u32x4*)(out + (int64_t)(b * S + qr) * (H * DH) + h * DH + c * 8) = v;
-    }
-  }
-}
+constexpr float FA2_DEFER = 8.0f;                   // log2 units: rescale only when the running max grows by more than 256x (guide T13)
 
 template <bool FUSED>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnDecodeParams P) {
@@ -534,25 +304,15 @@ extern "C" int mg_attn_prefill_bf16(const mg_bf16* q, const mg_bf16* kcache, con
   if ((vt_ld & 31) || vt_ld < ((S + 31) & ~31)) MG_FAIL(MG_ERR_SHAPE, "mg_attn_prefill_bf16: vt_ld must be a multiple of 32 and >= S");
   if (!q || !kcache || !vt || !out) MG_FAIL(MG_ERR_SHAPE, "mg_attn_prefill_bf16: null pointer");
   if (!MG_ALIGNED16(q) || !MG_ALIGNED16(kcache) || !MG_ALIGNED16(vt) || !MG_ALIGNED16(out)) MG_FAIL(MG_ERR_ALIGN, "mg_attn_prefill_bf16: pointers must be 16-byte aligned");
-  // kernel structure (MAGMA_ATTN_FWD overrides; measured at B=16, S=2048, profiles/r02_attention_variants.txt):
-  //   3 (default)  16-query waves x 8 (two per SIMD), deferred running max          0.95 ms
-  //   0            the same with the plain running max (round 1)                     1.00 ms
-  //   2 / 1        32-query waves x 4 (one per SIMD) on the 32x32x16 MFMA, with / without scheduling hints: half the LDS
-  //                fragment traffic per MFMA, but a single wave per SIMD exposes every LDS / barrier / VALU latency that
-  //                the second wave used to cover                                      1.10 / 1.13 ms  (kept for reference)
+  // 16-query waves x 8 (two per SIMD), deferred running max: 0.90 ms per layer at B = 16, S = 2048.  MAGMA_ATTN_FWD=0 keeps the
+  // plain running max (1.00 ms).  The 32-query-wave structure on the 32x32x16 MFMA measured slower (1.10 ms,
+  // profiles/r02_attention_variants.txt) and is gone from the library (git history: attn_prefill32_kernel).
   static const int variant = [] { const char* e = getenv("MAGMA_ATTN_FWD"); return e ? atoi(e) : 3; }();
   const int lds = FA_STAGES * FA_STAGE;
-  const void* fn = (variant == 0 || variant == 3) ? (const void*)attn_prefill_kernel
-                 : variant == 1 ? (const void*)attn_prefill32_kernel<false> : (const void*)attn_prefill32_kernel<true>;
-  if (int rc = mg_allow_dynamic_lds(fn, lds, "mg_attn_prefill_bf16")) return rc;
+  if (int rc = mg_allow_dynamic_lds((const void*)attn_prefill_kernel, lds, "mg_attn_prefill_bf16")) return rc;
   dim3 grid((unsigned)(((S + 127) / 128) * B * H));
-  if (variant == 0 || variant == 3)
-    hipLaunchKernelGGL(attn_prefill_kernel, grid, dim3(512), lds, (hipStream_t)stream, q, kcache, vt, out, lse, B, H, S, Smax, vt_ld,
-                       variant == 3 ? FA2_DEFER : 0.0f);
-  else if (variant == 1)
-    hipLaunchKernelGGL(attn_prefill32_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, q, kcache, vt, out, lse, B, H, S, Smax, vt_ld);
-  else
-    hipLaunchKernelGGL(attn_prefill32_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, q, kcache, vt, out, lse, B, H, S, Smax, vt_ld);
+  hipLaunchKernelGGL(attn_prefill_kernel, grid, dim3(512), lds, (hipStream_t)stream, q, kcache, vt, out, lse, B, H, S, Smax, vt_ld,
+                     variant == 0 ? 0.0f : FA2_DEFER);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }

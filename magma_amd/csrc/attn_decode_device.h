@@ -22,6 +22,7 @@ constexpr int ATTN_DEC_LDS = DEC_MAX_CTX * 4 + 4 * 256 * 4 + 8 * 4 + 256 * 2 + 3
 struct AttnDecodeParams {
   const mg_bf16* qin; mg_bf16* kcache; mg_bf16* vcache; mg_bf16* out;
   int H, Smax; const int* d_pos; int rot_dim; const float* sin_t; const float* cos_t;
+  int64_t ld_out = 0;      // row stride of `out` in elements (0 = H * 256)
 };
 
 // Device body: `bh` = (batch, head) index, `lds` = ATTN_DEC_LDS bytes of scratch (16-byte aligned).
@@ -46,6 +47,7 @@ MG_DEV void attn_decode_body(const AttnDecodeParams& P, int bh, char* lds) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lq = lane >> 4;
   const int b = bh / H, h = bh - b * H;
+  const int64_t out_off = P.ld_out ? (int64_t)b * P.ld_out + (int64_t)h * DH : (int64_t)bh * DH;
   const int pos = *d_pos;
   const int ctx = min(pos + 1, min(Smax, DEC_MAX_CTX));
   mg_bf16* kb = kcache + (int64_t)bh * Smax * DH;
@@ -143,10 +145,10 @@ MG_DEV void attn_decode_body(const AttnDecodeParams& P, int bh, char* lds) {
     __syncthreads();
     if (tid < 64) {
       u32x2 w; w[0] = pack2bf(red[tid * 4], red[tid * 4 + 1]); w[1] = pack2bf(red[tid * 4 + 2], red[tid * 4 + 3]);
-      st8_coh(out + (int64_t)bh * DH + tid * 4, w);
+      st8_coh(out + out_off + tid * 4, w);
     }
   } else {
-    out[(int64_t)bh * DH + tid] = f2bf(v);
+    out[out_off + tid] = f2bf(v);
   }
 }
 

@@ -14,7 +14,8 @@ void mg_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-extern "C" const char* mg_version(void) { return "magma_hip 0.1 (gfx950)"; }
+extern "C" const char* mg_version(void) { return "magma_hip 0.2 (gfx950)"; }
+extern "C" int32_t mg_abi_version(void) { return MG_ABI_VERSION; }
 extern "C" const char* mg_last_error(void) { return g_err; }
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device).  The launchers used to keep a process-wide

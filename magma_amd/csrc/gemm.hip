@@ -981,9 +981,16 @@ int gemm_dispatch(const mg_gemm_desc* d, bool fp8, const float* row_scale, hipSt
       MG_FAIL(MG_ERR_UNSUPPORTED, "%s: tile_hint %d is a timing ablation; build the library with `make ABL=1`", who, d->tile_hint);
 #endif
     }
+    // A/B variants that measured slower (32x32x16 MFMA: -5..10 %, profiles/r03_kbench_gemm256_mfma32_vs_16.jsonl; LDS-read wait
+    // after the barrier): ablation library only (`make ABL=1`), not in the product .so
+#ifdef MG_GEMM_ABLATIONS
     if (mfma32) return rm ? launch_gemm256<MG_W_ROWMAJOR, false, false, true>(gp, s) : launch_gemm256<MG_W_FRAGTILED, false, false, true>(gp, s);
     if (d->tile_hint == 257 && !fp8)   // experiment: LDS-read wait after the barrier
       return rm ? launch_gemm256<MG_W_ROWMAJOR, true>(gp, s) : launch_gemm256<MG_W_FRAGTILED, true>(gp, s);
+#else
+    if (mfma32 || (d->tile_hint == 257 && !fp8))
+      MG_FAIL(MG_ERR_UNSUPPORTED, "%s: tile_hint %d / MAGMA_GEMM256_MFMA=32 select an A/B variant of the 256x256 kernel that exists only in the ablation library (`make ABL=1`)", who, d->tile_hint);
+#endif
     if (fp8) return rm ? launch_gemm256<MG_W_ROWMAJOR, false, true>(gp, s) : launch_gemm256<MG_W_FRAGTILED, false, true>(gp, s);
     return rm ? launch_gemm256<MG_W_ROWMAJOR, false>(gp, s) : launch_gemm256<MG_W_FRAGTILED, false>(gp, s);
   }
@@ -1087,149 +1094,8 @@ __global__ __launch_bounds__(256) void decode_attn_gemv_kernel(const AttnDecodeP
   else skinny_body<4, KC, 1, W8, false, NoWait, PIPE>(sp, blockIdx.x - n_attn, lds);
 }
 
-// The same launch with a SECOND GEMV that consumes the attention output (out_proj of the block): its workgroups start
-// together with everything else, issue their first burst of weight loads, and only then wait -- off the critical path --
-// for the B*H attention workgroups of this launch to publish the context rows (coherent 8-byte stores, drained, then one
-// relaxed agent-scope increment of a sharded arrival counter; the readers use sc1 loads, so no L1 / cross-XCD L2 line can
-// be stale).  While they wait the independent GEMV (fc_out, 134 MB) keeps the HBM stream saturated, so the hand-off
-// latency that sank the persistent token step (negative result 1: ~14 us per DEPENDENCY LEVEL on the critical
-// path) is hidden here: the launch ends when both streams are done, and the block loses one launch boundary and one
-// under-filled launch.  Deadlock freedom: the waiters need the attention workgroups to RUN, nothing else; the host entry
-// refuses grids that are not co-resident at 3 workgroups per CU (then every workgroup of the launch is resident at once
-// and dispatch order is irrelevant), and every spin is bounded: on time-out *err is set and the workgroup runs on.
 constexpr int MG_DECODE_PIPE_DEFAULT = 0;
-constexpr int CTX_SHARDS = 8, CTX_SHARD_STRIDE = 16;      // ints: one 64-byte line per shard
-constexpr int CTX_SPIN_LIMIT = 1 << 20;
-struct CtxWait {
-  const int* counter; int n_attn; int* err;
-  MG_DEV void operator()() const {
-    if (threadIdx.x < CTX_SHARDS) {
-      const int sh = threadIdx.x;
-      const int target = n_attn / CTX_SHARDS + (sh < (n_attn % CTX_SHARDS) ? 1 : 0);    // arrivals with bid % 8 == sh
-      const int* c = counter + sh * CTX_SHARD_STRIDE;
-      int spins = 0;
-      while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-        __builtin_amdgcn_s_sleep(8);
-        if (++spins > CTX_SPIN_LIMIT) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-      }
-    }
-    __syncthreads();
-  }
-};
-template <int KC>
-__global__ __launch_bounds__(256) void decode_attn_2gemv_kernel(const AttnDecodeParams ap, int n_attn, const SkinnyParams spa,
-                                                                int ga, const SkinnyParams spb, int* __restrict__ counter,
-                                                                int* __restrict__ err) {
-  constexpr int LDS = ATTN_DEC_LDS > skinny_lds_bytes<4, 1>() ? ATTN_DEC_LDS : skinny_lds_bytes<4, 1>();
-  __shared__ __attribute__((aligned(16))) char lds[LDS];
-  const int bid = blockIdx.x;
-  if (bid < n_attn) {
-    attn_decode_body<true, true>(ap, bid, lds);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the coherent context stores have left before the counter moves
-    __syncthreads();
-    if (threadIdx.x == 0)
-      __hip_atomic_fetch_add(counter + (bid % CTX_SHARDS) * CTX_SHARD_STRIDE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  } else if (bid < n_attn + ga) {
-    skinny_body<4, KC, 1>(spa, bid - n_attn, lds);
-  } else {
-    skinny_body<4, 8, 1, false, true, CtxWait>(spb, bid - n_attn - ga, lds, CtxWait{counter, n_attn, err});
-  }
-}
 }  // namespace
-
-// ---------------------------------------------------------------------------
-// decode_mega_kernel: ONE persistent launch for a whole token step.
-//
-// A decode step is a chain of ~115 small weight-streaming launches; each boundary costs a drain + ramp of the HBM stream
-// (the same weight-streaming kernel runs at 6.1 TB/s on the 412 MB head but at 3.2 / 1.5 TB/s on the 42 / 8 MB launches of
-// a block -- profiles/r02_decode_trace_by_grid.txt).  Here the step is a list of OPS (fused ln_1+qkv+fc_in GEMV, decode
-// attention, fc_out, out_proj, adapter-down, adapter-up ... head), each cut into work items (one 16-column tile / one
-// (batch, head)); item i belongs to workgroup i mod gridDim.x, which walks its items in increasing order.  An op's items
-// wait on the completion counters of the ops they read from -- AFTER having issued their first burst of weight loads, so
-// the weight stream keeps flowing while a dependency resolves (weights never depend on activations).
-//   * deadlock freedom: every workgroup of the grid is resident (grid = min(4, occupancy query) x CUs, set by the host
-//     entry) and never blocks behind a LATER item, so by induction over the op order every counter reaches its
-//     target.  No assumption on dispatch order or XCD placement.  Every spin is bounded: on time-out the workgroup sets
-//     *err and runs on (the host raises).
-//   * hand-offs: activations cross workgroups through 8-byte agent-scope atomics on both sides (gemm_device.h ld8_coh /
-//     st8_coh); a producer's stores are drained (s_waitcnt vmcnt(0)) before its relaxed counter increment.
-// ---------------------------------------------------------------------------
-// Completion counters are SHARDED eight ways (one 64-byte line per shard): item i bumps shard i % 8 of its op, so the
-// ~2 000 arrivals of a large op spread over eight lines instead of queueing on one word (~12 ns per device-scope atomic),
-// and a waiter checks the shards one after the other against their exact per-shard targets.
-constexpr int MEGA_SHARDS = 8, MEGA_SHARD_STRIDE = 16;      // ints
-struct MegaOp {
-  int kind;            // 0 = GEMV (skinny_body<4, 8, 1>), 1 = decode attention
-  int counter;         // incremented once per finished item
-  int dep[2];          // ops to wait for (-1 = none); their item ranges (below) give the per-shard targets
-  int dep_item0[2], dep_items[2];
-  int item0, n_items;
-  SkinnyParams sp;
-  AttnDecodeParams ap;
-};
-constexpr int MEGA_SPIN_LIMIT = 1 << 20;    // ~1 s of polling; after the first time-out every later wait returns at once
-
-// Dependency wait of one item.  Lanes 0..7 of wave 0 poll one shard each (one L2 round trip when the producer is already
-// done, instead of eight in a row); `verified` (LDS, one flag per op) remembers completed producers, so the second item of
-// a workgroup that reads from the same op does not touch the counters again.
-struct MegaWait {
-  const MegaOp* op; int* counters; int* err; unsigned char* verified; int dbg;
-  MG_DEV void operator()() const {
-    if (dbg & 1) return;      // tuning experiment: no waits (wrong results)
-    if (threadIdx.x < MEGA_SHARDS) {
-      const int sh = threadIdx.x;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int d = op->dep[j];
-        if (d < 0 || verified[d]) continue;
-        const int i0 = op->dep_item0[j], n = op->dep_items[j];
-        const int first = i0 + ((sh - i0) & 7);                       // items i0 .. i0+n-1 with i % 8 == sh
-        const int target = first < i0 + n ? (i0 + n - 1 - first) / 8 + 1 : 0;
-        const int* c = counters + (d * MEGA_SHARDS + sh) * MEGA_SHARD_STRIDE;
-        int spins = 0;
-        while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-          __builtin_amdgcn_s_sleep(16);
-          if ((++spins & 255) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-          if (spins > MEGA_SPIN_LIMIT) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-        }
-      }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      if (op->dep[0] >= 0) verified[op->dep[0]] = 1;
-      if (op->dep[1] >= 0) verified[op->dep[1]] = 1;
-    }
-  }
-};
-constexpr int MEGA_MAX_OPS = 1024;
-
-__global__ __launch_bounds__(256, 4) void decode_mega_kernel(const MegaOp* __restrict__ ops, int n_ops, int total_items,
-                                                             int* __restrict__ counters, int* __restrict__ err, int dbg) {
-  constexpr int LDS = ATTN_DEC_LDS > skinny_lds_bytes<4, 1>() ? ATTN_DEC_LDS : skinny_lds_bytes<4, 1>();
-  __shared__ __attribute__((aligned(16))) char lds[LDS];
-  __shared__ unsigned char verified[MEGA_MAX_OPS];
-  for (int i = threadIdx.x; i < n_ops; i += 256) verified[i] = 0;
-  __syncthreads();
-  int cur = 0;
-  for (int item = blockIdx.x; item < total_items; item += gridDim.x) {
-    while (cur + 1 < n_ops && item >= ops[cur].item0 + ops[cur].n_items) ++cur;
-    const MegaOp* op = ops + cur;
-    const int local = item - op->item0;
-    const MegaWait wait{op, counters, err, verified, dbg};
-    if (op->kind == 0) {
-      skinny_body<4, 8, 1, false, true, MegaWait>(op->sp, local, lds, wait);
-    } else {
-      wait();
-      attn_decode_body<true, true>(op->ap, local, lds);
-    }
-    // publish: this item's coherent stores are drained, then the counter moves
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0 && !(dbg & 2))
-      __hip_atomic_fetch_add(counters + (op->counter * MEGA_SHARDS + (item & 7)) * MEGA_SHARD_STRIDE, 1, __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
 
 extern "C" int mg_gemm_skinny_bf16(const mg_skinny_desc* d, void* stream) {
   SkinnyParams sp;
@@ -1308,7 +1174,7 @@ extern "C" int mg_gemm_skinny2_bf16(const mg_skinny_desc* a, const mg_skinny_des
 
 // Decode attention (rotary + KV append + attention, see mg_attn_decode_fused_bf16) co-launched with
 // one weight-streaming GEMV that does not depend on it (fc_out of the parallel GPT-J block).
-extern "C" int mg_decode_attn_gemv_bf16(const mg_bf16* qkv, mg_bf16* kcache, mg_bf16* vcache, mg_bf16* attn_out,
+extern "C" int mg_decode_attn_gemv_bf16(const mg_bf16* qkv, mg_bf16* kcache, mg_bf16* vcache, mg_bf16* attn_out, int64_t ld_attn_out,
                                         int32_t B, int32_t H, int32_t Smax, const int32_t* d_pos, int32_t rot_dim,
                                         const float* sin_t, const float* cos_t, const mg_skinny_desc* gemv,
                                         void* stream) {
@@ -1318,7 +1184,8 @@ extern "C" int mg_decode_attn_gemv_bf16(const mg_bf16* qkv, mg_bf16* kcache, mg_
   if (!MG_ALIGNED16(qkv) || !MG_ALIGNED16(kcache) || !MG_ALIGNED16(vcache) || !MG_ALIGNED16(attn_out)) MG_FAIL(MG_ERR_ALIGN, "mg_decode_attn_gemv_bf16: pointers must be 16-byte aligned");
   SkinnyParams sp;
   if (int rc = fill_skinny(gemv, sp, "mg_decode_attn_gemv_bf16(gemv)")) return rc;
-  AttnDecodeParams ap{qkv, kcache, vcache, attn_out, H, Smax, d_pos, rot_dim, sin_t, cos_t};
+  if (ld_attn_out != 0 && (ld_attn_out < (int64_t)H * 256 || (ld_attn_out & 7))) MG_FAIL(MG_ERR_SHAPE, "mg_decode_attn_gemv_bf16: ld_attn_out must be 0 or a multiple of 8 >= H*256");
+  AttnDecodeParams ap{qkv, kcache, vcache, attn_out, H, Smax, d_pos, rot_dim, sin_t, cos_t, ld_attn_out};
   hipStream_t s = (hipStream_t)stream;
   const int n_attn = B * H, grid = n_attn + sp.ntiles;
   if (sp.w_scale && sp.ksteps % 64 != 0) MG_FAIL(MG_ERR_UNSUPPORTED, "mg_decode_attn_gemv_bf16: fp8 weights need K %% 2048 == 0 here");
@@ -1331,114 +1198,6 @@ extern "C" int mg_decode_attn_gemv_bf16(const mg_bf16* qkv, mg_bf16* kcache, mg_
   else if (sp.ksteps % 16 == 0) hipLaunchKernelGGL((decode_attn_gemv_kernel<4>), dim3(grid), dim3(256), 0, s, ap, n_attn, sp);
   else if (sp.ksteps % 4 == 0) hipLaunchKernelGGL((decode_attn_gemv_kernel<1>), dim3(grid), dim3(256), 0, s, ap, n_attn, sp);
   else MG_FAIL(MG_ERR_UNSUPPORTED, "mg_decode_attn_gemv_bf16: K of the GEMV must be a multiple of 128");
-  MG_CHECK_LAUNCH();
-  return MG_OK;
-}
-
-// The same co-launch plus a second GEMV that READS the attention output (out_proj): see decode_attn_2gemv_kernel.
-// counter: CTX_SHARDS x 16 int32 (one 64-byte line per shard), ZERO on entry (mg_sample_finish's `clear` re-arms it at the
-// end of the token step); err: int32 set to 1 if a bounded wait timed out (results of the step are then invalid).
-extern "C" int32_t mg_decode_ctx_counter_ints(void) { return CTX_SHARDS * CTX_SHARD_STRIDE; }
-extern "C" int mg_decode_attn_2gemv_bf16(const mg_bf16* qkv, mg_bf16* kcache, mg_bf16* vcache, mg_bf16* attn_out, int32_t B,
-                                         int32_t H, int32_t Smax, const int32_t* d_pos, int32_t rot_dim, const float* sin_t,
-                                         const float* cos_t, const mg_skinny_desc* gemv_indep, const mg_skinny_desc* gemv_ctx,
-                                         int32_t* counter, int32_t* err, void* stream) {
-  const char* who = "mg_decode_attn_2gemv_bf16";
-  if (B <= 0 || H <= 0 || Smax <= 0 || Smax > DEC_MAX_CTX) MG_FAIL(MG_ERR_SHAPE, "%s: need 0 < Smax <= %d", who, DEC_MAX_CTX);
-  if (rot_dim < 0 || rot_dim > 256 || (rot_dim & 7)) MG_FAIL(MG_ERR_SHAPE, "%s: rot_dim must be a multiple of 8 in [0,256]", who);
-  if (!qkv || !kcache || !vcache || !attn_out || !d_pos || !counter || !err || (rot_dim && (!sin_t || !cos_t))) MG_FAIL(MG_ERR_SHAPE, "%s: null pointer", who);
-  if (!MG_ALIGNED16(qkv) || !MG_ALIGNED16(kcache) || !MG_ALIGNED16(vcache) || !MG_ALIGNED16(attn_out) || ((uintptr_t)counter & 63)) MG_FAIL(MG_ERR_ALIGN, "%s: pointers must be 16-byte aligned (counter: 64-byte)", who);
-  SkinnyParams spa, spb;
-  if (int rc = fill_skinny(gemv_indep, spa, who)) return rc;
-  if (int rc = fill_skinny(gemv_ctx, spb, who)) return rc;
-  if (spa.w_scale || spb.w_scale) MG_FAIL(MG_ERR_UNSUPPORTED, "%s: bf16 weights only", who);
-  if (spb.X != attn_out) MG_FAIL(MG_ERR_SHAPE, "%s: the dependent GEMV must read the attention output", who);
-  if (spb.ksteps % 32 != 0) MG_FAIL(MG_ERR_UNSUPPORTED, "%s: K of the dependent GEMV must be a multiple of 1024", who);
-  if (spb.ln_colsum || spb.split_n) MG_FAIL(MG_ERR_UNSUPPORTED, "%s: the dependent GEMV takes neither a LayerNorm fold nor a split output", who);
-  const int n_attn = B * H, grid = n_attn + spa.ntiles + spb.ntiles;
-  // every workgroup of the launch must be resident at once (a waiter must never keep an attention workgroup from starting)
-  int dev = 0, cus = 0;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-    MG_FAIL(MG_ERR_HIP, "%s: cannot query the CU count", who);
-  hipStream_t s = (hipStream_t)stream;
-#define MG_L2(KC_)                                                                                                     \
-  {                                                                                                                    \
-    static int per_cu = -1;      /* occupancy of this instantiation, queried once */                                   \
-    if (per_cu < 0 && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_attn_2gemv_kernel<KC_>, 256, 0) != hipSuccess) per_cu = 0; \
-    /* the occupancy query can be one block high when SGPRs are the binding limit (MI355X_MICROARCH.md, residency); this   \
-       kernel is bound by VGPRs / LDS (102 SGPRs admit 6 blocks of 256 threads), so the answer is trusted up to 5 */      \
-    if ((int64_t)(per_cu > 5 ? 5 : per_cu) * cus < grid)                                                                \
-      MG_FAIL(MG_ERR_UNSUPPORTED, "%s: %d workgroups are not co-resident (%d per CU x %d CUs)", who, grid, per_cu, cus); \
-    hipLaunchKernelGGL((decode_attn_2gemv_kernel<KC_>), dim3(grid), dim3(256), 0, s, ap, n_attn, spa, spa.ntiles, spb, counter, err); \
-  }
-  AttnDecodeParams ap{qkv, kcache, vcache, attn_out, H, Smax, d_pos, rot_dim, sin_t, cos_t};
-  if (spa.ksteps % 64 == 0) MG_L2(16)
-  else if (spa.ksteps % 16 == 0) MG_L2(4)
-  else if (spa.ksteps % 4 == 0) MG_L2(1)
-  else MG_FAIL(MG_ERR_UNSUPPORTED, "%s: K of the independent GEMV must be a multiple of 128", who);
-#undef MG_L2
-  MG_CHECK_LAUNCH();
-  return MG_OK;
-}
-
-// ---- persistent decode step: plan (host op list -> device table) and launch -----------------------------------------
-extern "C" int64_t mg_decode_plan_bytes(int32_t n_ops) { return (int64_t)n_ops * (int64_t)sizeof(MegaOp); }
-extern "C" int32_t mg_decode_counter_ints(int32_t n_ops) { return n_ops * MEGA_SHARDS * MEGA_SHARD_STRIDE; }
-
-extern "C" int mg_decode_plan_build(const mg_decode_op* ops, int32_t n_ops, void* plan_device, int32_t* total_items_out) {
-  if (!ops || n_ops <= 0 || n_ops > MEGA_MAX_OPS || !plan_device || !total_items_out) MG_FAIL(MG_ERR_SHAPE, "mg_decode_plan_build: need 0 < n_ops <= %d", MEGA_MAX_OPS);
-  std::vector<MegaOp> tab((size_t)n_ops);
-  int item0 = 0;
-  for (int i = 0; i < n_ops; ++i) {
-    const mg_decode_op& o = ops[i];
-    MegaOp& m = tab[(size_t)i];
-    memset(&m, 0, sizeof(m));
-    m.kind = o.kind; m.counter = i;
-    m.dep[0] = o.dep0; m.dep[1] = o.dep1;
-    for (int j = 0; j < 2; ++j) {
-      if (m.dep[j] >= i) MG_FAIL(MG_ERR_SHAPE, "mg_decode_plan_build: op %d waits for op %d, which is not earlier in the list", i, m.dep[j]);
-      if (m.dep[j] >= 0) { m.dep_item0[j] = tab[(size_t)m.dep[j]].item0; m.dep_items[j] = tab[(size_t)m.dep[j]].n_items; }
-    }
-    if (o.kind == 0) {
-      if (int rc = fill_skinny(&o.gemv, m.sp, "mg_decode_plan_build")) return rc;
-      if (m.sp.w_scale) MG_FAIL(MG_ERR_UNSUPPORTED, "mg_decode_plan_build: fp8 weights are not supported in the persistent step");
-      if (m.sp.ksteps % 32 != 0) MG_FAIL(MG_ERR_UNSUPPORTED, "mg_decode_plan_build: op %d needs K %% 1024 == 0 (4 waves x 8 k-steps)", i);
-      m.n_items = m.sp.ntiles;
-    } else if (o.kind == 1) {
-      if (o.B <= 0 || o.H <= 0 || o.Smax <= 0 || o.Smax > DEC_MAX_CTX || !o.qkv || !o.kcache || !o.vcache || !o.attn_out || !o.d_pos)
-        MG_FAIL(MG_ERR_SHAPE, "mg_decode_plan_build: bad attention op %d", i);
-      m.ap = AttnDecodeParams{o.qkv, o.kcache, o.vcache, o.attn_out, o.H, o.Smax, o.d_pos, o.rot_dim, o.sin_t, o.cos_t};
-      m.n_items = o.B * o.H;
-    } else MG_FAIL(MG_ERR_SHAPE, "mg_decode_plan_build: bad op kind %d", o.kind);
-    m.item0 = item0;
-    item0 += m.n_items;
-  }
-  hipError_t e = hipMemcpy(plan_device, tab.data(), tab.size() * sizeof(MegaOp), hipMemcpyHostToDevice);
-  if (e != hipSuccess) MG_FAIL(MG_ERR_HIP, "mg_decode_plan_build: hipMemcpy: %s", hipGetErrorString(e));
-  *total_items_out = item0;
-  return MG_OK;
-}
-
-extern "C" int mg_decode_step_bf16(const void* plan_device, int32_t n_ops, int32_t total_items, int32_t* counters, int32_t* err,
-                                   void* stream) {
-  if (!plan_device || n_ops <= 0 || total_items <= 0 || !counters || !err) MG_FAIL(MG_ERR_SHAPE, "mg_decode_step_bf16: bad arguments");
-  // grid = 4 workgroups per CU, all of which must be resident: the hand-rolled waits assume it (MI355X_MICROARCH.md,
-  // residency and cooperative launch -- one block of margin against the occupancy API over-reporting)
-  static int grid = 0;
-  if (grid == 0) {
-    int dev = 0, cus = 0, per_cu = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)decode_mega_kernel, 256, 0);
-    if (e != hipSuccess || cus <= 0) MG_FAIL(MG_ERR_HIP, "mg_decode_step_bf16: occupancy query failed");
-    // 114 VGPRs / 66 SGPRs: register-limited to exactly 4 workgroups (16 waves) per CU -- below the SGPR thresholds at
-    // which the API over-reports.  Should a workgroup not be resident after all, the bounded waits time out and *err is set.
-    if (per_cu < 2) MG_FAIL(MG_ERR_UNSUPPORTED, "mg_decode_step_bf16: only %d workgroup(s) per CU fit", per_cu);
-    grid = (per_cu < 4 ? per_cu : 4) * cus;
-  }
-  static const int dbg = [] { const char* e = getenv("MAGMA_MEGA_DBG"); return e ? atoi(e) : 0; }();
-  hipLaunchKernelGGL(decode_mega_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const MegaOp*)plan_device, n_ops,
-                     total_items, counters, err, dbg);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }

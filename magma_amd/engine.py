@@ -146,19 +146,16 @@ class LMEngine:
         # GEMVs -> half the bytes per token step.  Changes the numerics (weight quantisation), so it is opt-in.
         self.decode_w8 = os.environ.get("MAGMA_DECODE_W8", "0") == "1"
         self._dec_in_variant = int(os.environ.get("MAGMA_DEC_IN_VARIANT", "0"))   # tuning knob: nt | waves<<4 | kc<<8
-        # persistent decode step (one launch per token instead of ~115 -- csrc/gemm.hip decode_mega_kernel).  Parity-green at
-        # full width but SLOWER than the launch chain on this chip (3.93 vs 2.55 ms per token at B = 8: every dependency level
-        # exposes a ~14 us hand-off chain -- drained stores, counter, poll, L2-served activations -- where a launch boundary
-        # costs ~3 us; without the waits the same structure streams at 2.27 ms).  Opt-in: MAGMA_DECODE_MEGA=1.
-        self.mega = os.environ.get("MAGMA_DECODE_MEGA", "0") == "1"
         self._side_stream = torch.cuda.Stream(device=dev)
         self.group_launches = os.environ.get("MAGMA_DECODE_GROUPED", "1") == "1"
-        # MAGMA_DECODE_CTXWAIT=1: out_proj inside the attention || fc_out launch (its workgroups wait in-kernel for the
-        # attention workgroups, off the critical path), adapter-down alone in the third launch.  Parity-green at full width
-        # (tests/test_fullwidth_gpu.py) and SLOWER on this chip: 2.66 vs 2.56 ms per token at B = 8 -- the merged launch takes
-        # 39.0 us against 28.6 + 13.0 for the two it replaces, but the adapter-down GEMV alone costs 7.2 us (launch floor) and
-        # the coherent-load out_proj stream runs on after fc_out has finished (profiles/r03_decode_ctxwait_*).  Opt-in.
-        self.ctx_wait = os.environ.get("MAGMA_DECODE_CTXWAIT", "0") == "1"
+        # MAGMA_DECODE_FOLD (default 1): three dependent launches per MAGMA_v1 block instead of four.  The adapter's
+        # down-projection reads the MLP output m = W_fc h + b_fc, so t = relu(W_dn m + b_dn) = relu((W_dn W_fc) h + (W_dn b_fc +
+        # b_dn)): with W_dn W_fc multiplied out ONCE per weight set (fp32, rounded to bf16; +25 MB per block) the bottleneck
+        # comes out of the fc_out launch as a second output segment, and the up-projection shares a launch with out_proj as ONE
+        # GEMV over the concatenated input [ctx | t] against [W_out | W_up]  (x' = that + b_up + m + x: the same sum the
+        # reference forms, reference adapters.py:38-39, in another association order -- the 2 x eager-bf16 criterion and the
+        # exact-greedy-id tests hold, tests/test_fullwidth_gpu.py, test_fulldepth_gpu.py).  0 = the four-launch block.
+        self.fold_dn = os.environ.get("MAGMA_DECODE_FOLD", "1") == "1"
         self.fuse_in = os.environ.get("MAGMA_PREFILL_FUSE_IN", "1") == "1"      # [qkv | fc_in] as one prefill GEMM
         self.two_streams = os.environ.get("MAGMA_DECODE_STREAMS", "1") == "2"   # measured slower (3.07 vs 2.94 ms/step): off
 
@@ -179,9 +176,29 @@ class LMEngine:
             lin.bias_b, lin.colsum = b2[d3:].contiguous(), cs
             ly.dec_in = lin
             del w, w2
+            self._fold_adapter_down(ly)
         w2, b2, cs = ops.fold_layernorm(self._lm_head.weight, self._lm_head.bias, self.lnf_g, self.lnf_b)
         self.head_dec = ops.PackedLinear(w2, bias=b2)
         self.head_dec.colsum = cs
+
+    def _fold_adapter_down(self, ly):
+        """Decode-only operands of the three-launch block (self.fold_dn), or None where a block does not have the MAGMA_v1
+        shape (mlp adapter of the 'normal' type only, K % 128 == 0):
+          ly.fc_dn  = [W_fc_out ; W_dn W_fc_out]   (d + r rows over K = ff;  bias b_fc | W_dn b_fc + b_dn)
+          ly.out_up = [W_out | W_up]               (d rows over K = d + r;   bias b_up)"""
+        ly.fc_dn = ly.out_up = None
+        if not self.fold_dn or ly.mlp_adapter is None or ly.attn_adapter is not None or ly.mlp_par is not None:
+            return
+        dn, up = ly.mlp_adapter
+        a, mlp = ly._src
+        if dn.N % 16 or (self.d + dn.N) % 128 or ly.fc_out.Kp % 128 or dn.K != self.d or up.K != dn.N or up.Kp != up.K:
+            return
+        w_fc, b_fc = mlp.c_proj.weight.detach().float(), mlp.c_proj.bias.detach().float()
+        w_dn = ops.PackedLinear.untile(dn.ft)[: dn.N, : dn.K].float()
+        w_up = ops.PackedLinear.untile(up.ft)[: up.N, : up.K]
+        ly.fc_dn = ops.PackedLinear(torch.cat([mlp.c_proj.weight.detach().to(BF16), (w_dn @ w_fc).to(BF16)], dim=0), bias=b_fc)
+        ly.fc_dn.bias_b = (w_dn @ b_fc + dn.bias).contiguous()
+        ly.out_up = ops.PackedLinear(torch.cat([a.out_proj.weight.detach().to(BF16), w_up], dim=1), bias=up.bias)
 
     def _ensure_decode_packs_w8(self):
         """e4m3 copies of every decode operand (same LayerNorm folds; the fold's column sums are taken from the
@@ -226,6 +243,8 @@ class LMEngine:
                     ly.mlp_par = torch.full((self.d,), blk.mlp.scale_value(), dtype=torch.float32, device=ly.mlp_par.device)
             ly.fp8 = {}
             ly.__dict__.pop("up_cat", None)
+            if self.head_dec is not None:          # decode operands exist: the folded ones contain the adapter weights
+                self._fold_adapter_down(ly)
 
     @staticmethod
     def _par_up(up, par):
@@ -401,8 +420,6 @@ class LMEngine:
         x, hs = self._blocks_prefill(embeds, cache, want_hidden)
         cache.pos = S
         cache.d_pos.fill_(S)
-        if cache.decode_state is not None:       # a token step that raised mid-way may have left arrivals behind
-            cache.decode_state.ctx_counters.zero_()
         last = x.view(B, S, self.d)[:, S - 1, :]                 # strided rows, no copy
         xl = ops.layernorm(last, self.lnf_g, self.lnf_b, self.eps)
         logits = self._head(xl)
@@ -438,59 +455,13 @@ class LMEngine:
         r_att = max([ly.attn_adapter[0].N for ly in self.layers if ly.attn_adapter] + [8])
         st.t, st.ta = e(B, r_mlp), e(B, r_att)
         st.tcat = e(B, r_mlp + r_att)      # [mlp bottleneck | attention bottleneck] side by side (fused up-projection)
+        st.ctx_t = e(B, d + r_mlp)         # [attention context | mlp bottleneck]: input of the [W_out | W_up] GEMV (fold_dn)
         st.lnf = e(B, d)
         st.logits = e(B, self.Vp, dt=torch.float32)
         st.token = torch.zeros(B, dtype=torch.int64, device=dev)
-        # arrival counters of the in-launch attention -> out_proj hand-off (one set of 64-byte lines per layer, re-armed by
-        # the bookkeeping launch at the end of every token step) and the time-out flag of its bounded waits
-        n_ctx = ops.decode_ctx_counter_ints()
-        st.ctx_counters = torch.zeros(len(self.layers) * n_ctx, dtype=torch.int32, device=dev)
-        st.ctx_err = torch.zeros(1, dtype=torch.int32, device=dev)
-        st.ctx_wait = self.ctx_wait and not self.decode_w8 and B <= 16
         st.graphs = {}             # token-selection mode (None = greedy | (temperature, top_k, top_p)) -> captured hipGraph
         st.steps = 0
-        st.plan = self._build_decode_plan(cache, st) if self.mega and not self.decode_w8 and B <= 16 else None
         return st
-
-    def _build_decode_plan(self, cache: KVCache, st):
-        """Op list of the persistent token step (csrc/gemm.hip decode_mega_kernel) for the MAGMA_v1 block shape: per layer
-        [ln_1+qkv+gelu(fc_in)] -> {attention, fc_out} -> {out_proj, adapter-down} -> adapter-up(+3 residuals), then
-        [ln_f+lm_head].  Returns None when a block does not have that shape (v2 / parallel adapters, K % 1024 != 0): the
-        launch chain is used then.  The activation buffers are shared by all layers; every reuse is ordered by the
-        dependency chain (a layer's first op waits for the previous layer's last one)."""
-        B, d3 = cache.B, 3 * self.d
-        plan_ops = []
-        x, xn = st.xa, st.xb
-        for li, ly in enumerate(self.layers):
-            ok = (ly.mlp_adapter is not None and ly.attn_adapter is None and ly.mlp_par is None
-                  and all(p.Kp % 1024 == 0 for p in (ly.dec_in, ly.fc_out, ly.out, ly.mlp_adapter[0], ly.mlp_adapter[1])))
-            if not ok:
-                return None
-            t = st.t[:, : ly.mlp_adapter[0].N]
-            plan_ops += [
-                {"name": f"in{li}", "deps": [f"up{li - 1}"] if li else [],
-                 "gemv": (x, ly.dec_in, st.qkv, dict(ln_fold=(ly.dec_in.colsum, self.d, self.eps),
-                                                     split=(d3, st.h, ops.MG_ACT_GELU_NEW, ly.dec_in.bias_b)))},
-                {"name": f"attn{li}", "deps": [f"in{li}"],
-                 "attn": (st.qkv, cache.k[li], cache.v[li], st.ctx, B, self.H, cache.d_pos, self.rot, self.sin_t, self.cos_t)},
-                {"name": f"fco{li}", "deps": [f"in{li}"], "gemv": (st.h, ly.fc_out, st.m, {})},
-                {"name": f"out{li}", "deps": [f"attn{li}"], "gemv": (st.ctx, ly.out, st.a, {})},
-                {"name": f"dn{li}", "deps": [f"fco{li}"], "gemv": (st.m, ly.mlp_adapter[0], t, dict(act=ops.MG_ACT_RELU))},
-                {"name": f"up{li}", "deps": [f"dn{li}", f"out{li}"],
-                 "gemv": (t, ly.mlp_adapter[1], xn, dict(residuals=(st.m, st.a, x)))},
-            ]
-            x, xn = xn, x
-        if self.head_dec.Kp % 1024:
-            return None
-        plan_ops.append({"name": "head", "deps": [f"up{len(self.layers) - 1}"],
-                         "gemv": (x, self.head_dec, st.logits, dict(ln_fold=(self.head_dec.colsum, self.d, self.eps)))})
-        try:
-            return ops.DecodePlan(plan_ops, self.device)
-        except ops.L.MagmaHipError as e:       # shape the persistent kernel does not take: fall back to the launch chain
-            if os.environ.get("MAGMA_DECODE_MEGA_STRICT") == "1":
-                raise
-            self._mega_refused = str(e)
-            return None
 
     def select_token(self, logits: torch.Tensor, cache: KVCache, mode, out: Optional[torch.Tensor] = None,
                      advance: bool = False, clear: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -507,16 +478,8 @@ class LMEngine:
         return tok
 
     def check_decode(self, cache: KVCache):
-        """Raise if a wait of the persistent decode step timed out (one device read; generate() calls it once at the end)."""
-        st = cache.decode_state
-        if st is not None and st.ctx_wait and int(st.ctx_err) != 0:
-            st.ctx_err.zero_()
-            st.ctx_counters.zero_()
-            raise ops.L.MagmaHipError("decode step: the in-launch wait for the attention workgroups timed out (results of this "
-                                      "call are invalid); set MAGMA_DECODE_CTXWAIT=0 to use separate launches")
-        if st is not None and st.plan is not None and int(st.plan.err) != 0:
-            raise ops.L.MagmaHipError("persistent decode step: a dependency wait timed out (results of this call are invalid); "
-                                      "set MAGMA_DECODE_MEGA=0 to use the launch chain")
+        """Kept for callers of earlier revisions (the in-launch hand-off experiments had a time-out flag to read here)."""
+        return None
 
     def _decode_step(self, cache: KVCache, st, mode=None, feed_back: bool = False):
         """Enqueue one token step for all B sequences (graph-capturable: no
@@ -525,10 +488,6 @@ class LMEngine:
         reference's loop feeds exactly those back (sampling.py:88-90) -- instead of ids copied in from the caller."""
         B = cache.B
         ops.embedding(st.token.view(B, 1) if feed_back else st.ids, self.wte, st.xa.view(B, 1, self.d))
-        if st.plan is not None:      # the whole step as ONE persistent launch, then token selection + bookkeeping
-            st.plan.launch()
-            self.select_token(st.logits[:, : self.V], cache, mode, out=st.token, advance=True, clear=st.plan.counters)   # stride 16
-            return
         x, xn = st.xa, st.xb
         d3 = 3 * self.d
         main = torch.cuda.current_stream()
@@ -556,16 +515,15 @@ class LMEngine:
             par = ly.mlp_par is not None or ly.attn_par is not None
             grouped = (not wide and self.group_launches and not par and ly.mlp_adapter is not None and ly.attn_adapter is None
                        and ly.fc_out.Kp % 128 == 0 and ly.out.Kp % 128 == 0 and ly.mlp_adapter[0].Kp % 128 == 0)
-            if grouped and st.ctx_wait and ly.out.Kp % 1024 == 0:
-                # launch 2: attention || fc_out || out_proj (the out_proj workgroups wait in-kernel for the context rows)
-                n_ctx = st.ctx_counters.numel() // len(self.layers)
-                ops.decode_attn_2gemv(st.qkv, cache.k[li], cache.v[li], st.ctx, B, self.H, cache.d_pos, self.rot, self.sin_t,
-                                      self.cos_t, (st.h, ly.fc_out, st.m, {}), (st.ctx, ly.out, st.a, {}),
-                                      st.ctx_counters[li * n_ctx: (li + 1) * n_ctx], st.ctx_err)
-                # launch 3: adapter-down alone; launch 4: adapter-up + the block's three residuals
-                t = st.t[:, : ly.mlp_adapter[0].N]
-                ops.gemm_skinny(st.m, ly.mlp_adapter[0], out=t, act=ops.MG_ACT_RELU)
-                ops.gemm_skinny(t, ly.mlp_adapter[1], out=xn, residuals=(st.m, st.a, x))
+            if grouped and not w8_on and ly.fc_dn is not None:
+                # three launches (fold_dn).  launch 2: attention || [fc_out ; W_dn W_fc_out]: m and the adapter bottleneck t
+                # from ONE pass over h; the context row lands beside t in st.ctx_t
+                r = ly.mlp_adapter[0].N
+                ctx, t = st.ctx_t[:, : self.d], st.ctx_t[:, self.d: self.d + r]
+                ops.decode_attn_gemv(st.qkv, cache.k[li], cache.v[li], ctx, B, self.H, cache.d_pos, self.rot, self.sin_t, self.cos_t,
+                                     (st.h, ly.fc_dn, st.m, {"split": (self.d, t, ops.MG_ACT_RELU, ly.fc_dn.bias_b)}))
+                # launch 3: x' = [W_out | W_up] [ctx ; t] + b_up + m + x
+                ops.gemm_skinny(st.ctx_t[:, : self.d + r], ly.out_up, out=xn, residuals=(st.m, x))
                 x, xn = xn, x
                 continue
             if grouped:
@@ -637,8 +595,7 @@ class LMEngine:
         else:
             head = self.head_w8 if w8_on else self.head_dec
             ops.gemm_skinny(x, head, out=st.logits, ln_fold=(head.colsum, self.d, self.eps))
-        self.select_token(st.logits[:, : self.V], cache, mode, out=st.token, advance=True,
-                          clear=st.ctx_counters if st.ctx_wait else None)
+        self.select_token(st.logits[:, : self.V], cache, mode, out=st.token, advance=True)
 
     def _ensure_decode_state(self, cache: KVCache):
         st = cache.decode_state

@@ -19,6 +19,9 @@ MG_A_DENSE, MG_A_CONV3X3 = 0, 1
 MG_AUX_NONE, MG_AUX_RELU_GATE, MG_AUX_GELU_GRAD, MG_AUX_MUL, MG_AUX_QUICK_GELU_GRAD = 0, 1, 2, 3, 4
 
 
+ABI_VERSION = 2      # include/magma_hip.h MG_ABI_VERSION
+
+
 class MagmaHipError(RuntimeError):
     pass
 
@@ -64,36 +67,23 @@ class SkinnyDesc(C.Structure):
     ]
 
 
-class DecodeOp(C.Structure):
-    """mg_decode_op: one op of the persistent decode step."""
-    _fields_ = [
-        ("kind", C.c_int32), ("dep0", C.c_int32), ("dep1", C.c_int32), ("_pad", C.c_int32),
-        ("gemv", SkinnyDesc),
-        ("qkv", C.c_void_p), ("kcache", C.c_void_p), ("vcache", C.c_void_p), ("attn_out", C.c_void_p),
-        ("B", C.c_int32), ("H", C.c_int32), ("Smax", C.c_int32), ("rot_dim", C.c_int32),
-        ("d_pos", C.c_void_p), ("sin_t", C.c_void_p), ("cos_t", C.c_void_p),
-    ]
-
-
 # every symbol include/magma_hip.h declares: (name, restype, argtypes)
 _i32, _i64, _f32, _vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 SYMBOLS = {
     "mg_version": (C.c_char_p, []),
     "mg_last_error": (C.c_char_p, []),
+    "mg_abi_version": (C.c_int32, []),
     "mg_gemm_bf16": (C.c_int, [C.POINTER(GemmDesc), _vp]),
     "mg_gemm_workspace_bytes": (C.c_int64, [_i32, _i32, _i32]),
     "mg_gemm_skinny_bf16": (C.c_int, [C.POINTER(SkinnyDesc), _vp]),
     "mg_gemm_skinny2_bf16": (C.c_int, [C.POINTER(SkinnyDesc), C.POINTER(SkinnyDesc), _vp]),
-    "mg_decode_attn_gemv_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp,
+    "mg_decode_attn_gemv_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _i32, _vp, _vp,
                                           C.POINTER(SkinnyDesc), _vp]),
     "mg_comm_unique_id": (C.c_int, [_vp]),
     "mg_comm_init": (C.c_int, [C.POINTER(C.c_void_p), _vp, _i32, _i32]),
     "mg_comm_allreduce_sum": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
     "mg_comm_broadcast": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
     "mg_comm_destroy": (C.c_int, [_vp]),
-    "mg_decode_ctx_counter_ints": (C.c_int32, []),
-    "mg_decode_attn_2gemv_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp,
-                                           C.POINTER(SkinnyDesc), C.POINTER(SkinnyDesc), _vp, _vp, _vp]),
     "mg_layernorm_bf16": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp]),
     "mg_embedding_bf16": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _i64, _i32, _vp]),
     "mg_rotary_split_bf16": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp]),
@@ -105,10 +95,6 @@ SYMBOLS = {
     "mg_advance_pos": (C.c_int, [_vp, _i32, _vp]),
     "mg_sample_f32": (C.c_int, [_vp, _i64, _i32, _i32, _f32, _i32, C.c_double, _vp, _vp, _vp, _vp, _i64, _vp]),
     "mg_sample_finish": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _i32, _vp, _i64, _i32, _vp, _i32, _i32, _vp]),
-    "mg_decode_plan_bytes": (C.c_int64, [_i32]),
-    "mg_decode_counter_ints": (C.c_int32, [_i32]),
-    "mg_decode_plan_build": (C.c_int, [C.POINTER(DecodeOp), _i32, _vp, C.POINTER(C.c_int32)]),
-    "mg_decode_step_bf16": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp]),
     "mg_patchify_bf16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mg_vit_embed_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "mg_attn_small_bf16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
@@ -178,6 +164,14 @@ def load() -> C.CDLL:
             "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or "
             "`make -C magma_amd/csrc`.")
     lib = C.CDLL(str(path))
+    try:
+        lib.mg_abi_version.restype = C.c_int32
+        abi = int(lib.mg_abi_version())
+    except AttributeError:
+        abi = 1
+    if abi != ABI_VERSION:
+        raise MagmaHipError(f"{path} speaks C-ABI revision {abi}, this package binds revision {ABI_VERSION} "
+                            "(include/magma_hip.h MG_ABI_VERSION): rebuild with `make -C magma_amd/csrc`")
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res

@@ -298,30 +298,11 @@ def decode_attn_gemv(qkv, kcache, vcache, attn_out, B, H, d_pos, rot_dim, sin_t,
     gemv = (x, w, out, kwargs)."""
     _need_gpu(qkv)
     d, og = skinny_desc(gemv[0], gemv[1], gemv[2], **gemv[3])
+    assert attn_out.ndim == 2 and attn_out.stride(1) == 1 and attn_out.shape[1] == H * 256   # a column range of a wider row is fine
     check(L.load().mg_decode_attn_gemv_bf16(qkv.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), attn_out.data_ptr(),
-                                            B, H, kcache.shape[2], d_pos.data_ptr(), rot_dim, sin_t.data_ptr(),
+                                            attn_out.stride(0), B, H, kcache.shape[2], d_pos.data_ptr(), rot_dim, sin_t.data_ptr(),
                                             cos_t.data_ptr(), C.byref(d), _stream()), "mg_decode_attn_gemv_bf16")
     return attn_out, og
-
-
-def decode_ctx_counter_ints() -> int:
-    return int(L.load().mg_decode_ctx_counter_ints())
-
-
-def decode_attn_2gemv(qkv, kcache, vcache, attn_out, B, H, d_pos, rot_dim, sin_t, cos_t, gemv_indep: tuple, gemv_ctx: tuple,
-                      counter: torch.Tensor, err: torch.Tensor):
-    """Decode attention co-launched with an independent GEMV (fc_out) AND a GEMV that reads the attention output (out_proj,
-    x must be ``attn_out``): one launch, the dependent workgroups wait in-kernel for the attention workgroups.  ``counter``
-    (decode_ctx_counter_ints() int32, zero) and ``err`` (int32[1]) as in include/magma_hip.h."""
-    _need_gpu(qkv, counter, err)
-    assert counter.dtype == torch.int32 and err.dtype == torch.int32 and gemv_ctx[0].data_ptr() == attn_out.data_ptr()
-    da, oa = skinny_desc(gemv_indep[0], gemv_indep[1], gemv_indep[2], **gemv_indep[3])
-    db, ob = skinny_desc(gemv_ctx[0], gemv_ctx[1], gemv_ctx[2], **gemv_ctx[3])
-    check(L.load().mg_decode_attn_2gemv_bf16(qkv.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), attn_out.data_ptr(),
-                                             B, H, kcache.shape[2], d_pos.data_ptr(), rot_dim, sin_t.data_ptr(),
-                                             cos_t.data_ptr(), C.byref(da), C.byref(db), counter.data_ptr(), err.data_ptr(),
-                                             _stream()), "mg_decode_attn_2gemv_bf16")
-    return attn_out, oa, ob
 
 
 def fold_layernorm(weight: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor):
@@ -446,46 +427,6 @@ def sample_finish(token: torch.Tensor, eos: int, state: torch.Tensor, d_pos: Opt
                                     0 if history is None else history.stride(0), 0 if history is None else history.shape[1],
                                     _p(clear), 0 if clear is None else clear.numel() // clear_stride, clear_stride, _stream()),
           "mg_sample_finish")
-
-
-class DecodePlan:
-    """Device table of a persistent decode step (mg_decode_plan_build) + its completion counters and error flag.
-    ``ops`` = list of dicts: {"gemv": (x, w, out, kwargs)} or {"attn": (qkv, kcache, vcache, out, B, H, d_pos, rot, sin, cos)},
-    each with "name", and "deps": names of the ops it reads from."""
-
-    def __init__(self, ops_list, device):
-        n = len(ops_list)
-        arr = (L.DecodeOp * n)()
-        index = {o["name"]: i for i, o in enumerate(ops_list)}
-        for i, o in enumerate(ops_list):
-            d = arr[i]
-            if "gemv" in o:
-                x, w, out, kw = o["gemv"]
-                sd, _ = skinny_desc(x, w, out, **kw)
-                d.kind, d.gemv = 0, sd
-            else:
-                qkv, kc, vc, out, B, H, d_pos, rot, sin_t, cos_t = o["attn"]
-                d.kind = 1
-                d.qkv, d.kcache, d.vcache, d.attn_out = qkv.data_ptr(), kc.data_ptr(), vc.data_ptr(), out.data_ptr()
-                d.B, d.H, d.Smax, d.rot_dim = B, H, kc.shape[2], rot
-                d.d_pos, d.sin_t, d.cos_t = d_pos.data_ptr(), sin_t.data_ptr(), cos_t.data_ptr()
-            deps = [index[nm] for nm in o.get("deps", ())]
-            assert len(deps) <= 2 and all(j < i for j in deps), "an op waits for at most two EARLIER ops"
-            d.dep0 = deps[0] if len(deps) > 0 else -1
-            d.dep1 = deps[1] if len(deps) > 1 else -1
-        lib = L.load()
-        self.n_ops = n
-        self.table = torch.empty(int(lib.mg_decode_plan_bytes(n)), dtype=torch.uint8, device=device)
-        self.counters = torch.zeros(int(lib.mg_decode_counter_ints(n)), dtype=torch.int32, device=device)
-        self.err = torch.zeros(1, dtype=torch.int32, device=device)
-        total = C.c_int32(0)
-        torch.cuda.synchronize(device)
-        check(lib.mg_decode_plan_build(arr, n, self.table.data_ptr(), C.byref(total)), "mg_decode_plan_build")
-        self.total_items = int(total.value)
-
-    def launch(self):
-        check(L.load().mg_decode_step_bf16(self.table.data_ptr(), self.n_ops, self.total_items, self.counters.data_ptr(),
-                                           self.err.data_ptr(), _stream()), "mg_decode_step_bf16")
 
 
 def advance_pos(d_pos: torch.Tensor, delta: int = 1):

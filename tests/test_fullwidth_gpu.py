@@ -156,59 +156,50 @@ def test_greedy_ids_batch8_margin_rule(full):
     assert n_safe >= 0.75 * 8 * steps, n_safe
 
 
-def test_persistent_decode_step_equals_launch_chain(full):
-    """csrc/gemm.hip decode_mega_kernel (MAGMA_DECODE_MEGA=1: one persistent launch per token step, cross-workgroup hand-offs
-    through agent-scope accesses and sharded completion counters) against the default chain of launches: same tokens, same
-    logits up to the summation order of the K split (4 waves x 8 k-steps there, 8 x 4 here), no wait timed out."""
+@pytest.mark.parametrize("B", [2, 8, 16])
+def test_folded_three_launch_block_vs_four_launch_block_and_oracle(full, B):
+    """MAGMA_DECODE_FOLD (default): the cached MAGMA_v1 block as THREE dependent launches -- the adapter's down-projection
+    multiplied through fc_out offline ([W_fc ; W_dn W_fc], bottleneck t as a second output segment of the fc_out launch) and the
+    up-projection K-concatenated with out_proj ([W_out | W_up] over [ctx | t]) -- against the four-launch block (the
+    reference's association order, reference adapters.py:38-39) AND against the fp32 oracle: a re-association of the same
+    sum, so the logits differ by rounding only and both sit inside the 2 x eager-bf16 criterion; free-running tokens equal the
+    four-launch block's except at near-ties."""
+    from oracle.model import lm_forward
     cfg, p, model = full
     from magma_amd.engine import LMEngine
-    emb = F.greedy_inputs(cfg, F.GREEDY_INPUT_SEED, B=8).to(torch.bfloat16).cuda()
+    emb32 = F.greedy_inputs(cfg, F.GREEDY_INPUT_SEED, B=B)
+    emb = emb32.to(torch.bfloat16).cuda()
+    steps = 8
 
-    def run(mega):
+    def run(fold):
         eng = LMEngine(model.lm)
-        eng.mega = mega
-        out = eng.forward(inputs_embeds=emb, use_cache=True, cache_hint=8, eos_token=cfg.eos_token)
-        cache, toks = out.past_key_values, [out.next_token.clone()]
-        assert (cache.decode_state.plan is not None) == mega, getattr(eng, "_mega_refused", "")
-        for _ in range(7):            # eager step, graph capture, graph replays
-            _, tk = eng.decode(None, cache)
+        eng.fold_dn = fold
+        out = eng.forward(inputs_embeds=emb, use_cache=True, cache_hint=steps + 4, eos_token=cfg.eos_token)
+        cache, toks, lgs = out.past_key_values, [out.next_token.clone()], []
+        for _ in range(steps - 1):            # eager step, graph capture, graph replays
+            lg, tk = eng.decode(None, cache)
             toks.append(tk.clone())
-        eng.check_decode(cache)
-        return torch.stack(toks, 1).cpu(), cache.decode_state.logits[:, :50258].float().cpu()
+            lgs.append(lg.float().cpu().clone())
+        assert (eng.layers[0].fc_dn is not None) == fold
+        return torch.stack(toks, 1).cpu(), lgs
 
-    t0, l0 = run(False)
-    t1, l1 = run(True)
-    assert rel(l1, l0) < 2e-3
-    same = (t0 == t1).all(1)
-    assert int(same.sum()) >= 6, (t0, t1)         # rows may only part ways at a near-tie of the two summation orders
+    t4, l4 = run(False)
+    t3, l3 = run(True)
+    e43 = max(rel(a, b) for a, b in zip(l3[:2], l4[:2]))       # the first steps (same inputs: tokens can only part ways later)
+    print(f"three-launch vs four-launch block, B = {B}: logits differ by {e43:.3e}")
+    assert e43 < 6e-3
+    same = (t3 == t4).all(1)
+    assert int(same.sum()) >= B - max(1, B // 8), (t3, t4)
+    # against the oracle, teacher-forced on the three-launch block's own tokens: step 1 of the cached decode
+    lm, lmb = F.lm_only(p), {k: (v.to(torch.bfloat16) if v.is_floating_point() else v) for k, v in F.lm_only(p).items()}
+    with torch.no_grad():
+        r = lm_forward(lm, cfg, inputs_embeds=emb32)
+        rb = lm_forward(lmb, cfg, inputs_embeds=emb32.to(torch.bfloat16))
+        tok = t3[:, :1]
+        r1 = lm_forward(lm, cfg, input_ids=tok, past=r["past_key_values"])["logits"][:, -1]
+        rb1 = lm_forward(lmb, cfg, input_ids=tok, past=rb["past_key_values"])["logits"][:, -1]
+    e_hip, e_bf = rel(l3[0], r1), rel(rb1, r1)
+    print(f"three-launch block vs oracle: {e_hip:.3e} (four-launch {rel(l4[0], r1):.3e}, eager bf16 {e_bf:.3e})")
+    assert e_hip <= 2 * e_bf + 2e-3
 
 
-@pytest.mark.parametrize("B", [8, 16])
-def test_ctx_wait_block_equals_separate_launches(full, B):
-    """MAGMA_DECODE_CTXWAIT=1 runs out_proj INSIDE the attention || fc_out launch (csrc/gemm.hip decode_attn_2gemv_kernel: its
-    workgroups wait in-kernel for the attention workgroups' context rows; opt-in, measured slower -- engine.py).  Against
-    the default block (attention || fc_out, then out_proj || adapter-down): the same arithmetic, identical tokens and
-    logits equal up to the summation order of the K split; no wait timed out; the counters re-arm inside the graph.
-    B = 16 is the largest batch of the launch (768 workgroups = 3 per CU, the kernel's residency)."""
-    cfg, p, model = full
-    from magma_amd.engine import LMEngine
-    emb = F.greedy_inputs(cfg, F.GREEDY_INPUT_SEED, B=B).to(torch.bfloat16).cuda()
-
-    def run(ctx_wait):
-        eng = LMEngine(model.lm)
-        eng.ctx_wait = ctx_wait
-        out = eng.forward(inputs_embeds=emb, use_cache=True, cache_hint=12, eos_token=cfg.eos_token)
-        cache, toks = out.past_key_values, [out.next_token.clone()]
-        assert cache.decode_state.ctx_wait == ctx_wait
-        for _ in range(9):            # eager step, graph capture, graph replays (the counters re-arm inside the graph)
-            _, tk = eng.decode(None, cache)
-            toks.append(tk.clone())
-        eng.check_decode(cache)
-        assert int(cache.decode_state.ctx_counters.abs().sum()) == 0      # re-armed by the bookkeeping launch
-        return torch.stack(toks, 1).cpu(), cache.decode_state.logits[:, :50258].float().cpu()
-
-    t0, l0 = run(False)
-    t1, l1 = run(True)
-    assert rel(l1, l0) < 1e-3, rel(l1, l0)
-    same = (t0 == t1).all(1)
-    assert int(same.sum()) >= B - 1, (t0, t1)         # rows may only part ways at a near-tie

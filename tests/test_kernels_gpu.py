@@ -406,13 +406,13 @@ def test_skinny_layernorm_fold_and_split(dev):
     assert_close(o32, ref, 1e-2, "ln-fold fp32")
 
 
-@pytest.mark.parametrize("tile", [256, 258, 259])
+@pytest.mark.parametrize("tile", [256])
 @pytest.mark.parametrize("layout", ["rm", "ft"])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (1000, 520, 256), (512, 1056, 1024), (2048, 4096, 4096)])
 def test_gemm256_deep_pipeline(dev, layout, M, N, K, tile):
     """The 256x256 staggered / counted-vmcnt kernel against fp32 and against the 128x128 kernel;
-    repeated launches on fresh data to screen for LDS-DMA races.  tile 258 / 259 force its 32x32x16 / 16x16x32 MFMA
-    forms (256 = the library's default form)."""
+    repeated launches on fresh data to screen for LDS-DMA races.  (The 32x32x16-MFMA form of the kernel, tile 258, measured
+    5-10 % slower and lives in the ablation library only: `make ABL=1`.)"""
     from magma_amd import ops
     for rep in range(3):
         a = rnd(M, K, dev=dev, seed=300 + rep).to(BF16)

@@ -17,6 +17,9 @@ tab = {f"{n}x{k}": sum(v) / len(v) for (n, k), v in agg.items()}
 algo = {f"{n}x{k}": n * k * 2 for (n, k) in agg}
 res = {"source": "rocprofv3 --pmc FETCH_SIZE over tools/pmc_decode_sweep.py (x2 gfx950 wide-read correction)",
        "bytes_per_launch": tab, "algorithmic_bytes": algo, "ratio": {k: tab[k] / algo[k] for k in tab},
-       "sweep_total_ratio": sum(tab[f"{n}x{k}"] for n, k in shapes) / sum(n * k * 2 for n, k in shapes)}
+       "sweep_total_ratio": sum(tab[f"{n}x{k}"] for n, k in shapes) / sum(n * k * 2 for n, k in shapes),
+       # the launches may stream more than the algorithm needs (folded adapter-down: [W_fc ; W_dn W_fc]); against the
+       # reference model's weights once (meta["wbytes"]) the sweep's traffic is:
+       "sweep_total_vs_algorithmic": sum(tab[f"{n}x{k}"] for n, k in shapes) / meta["wbytes"]}
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res["ratio"]), res["sweep_total_ratio"])
