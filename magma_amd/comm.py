@@ -44,13 +44,13 @@ class RcclExchange:
         from . import lib as L
         self._L, self._C = L, C
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        torch.cuda.set_device(device)          # before ANY collective: the id broadcast below may itself use the GPU (nccl backend)
         ident = [None]
         if self.rank == 0:
             buf = (C.c_uint8 * 128)()
             L.check(L.load().mg_comm_unique_id(buf), "mg_comm_unique_id")
             ident[0] = bytes(buf)
         dist.broadcast_object_list(ident, src=0)
-        torch.cuda.set_device(device)
         h = C.c_void_p()
         idbuf = (C.c_uint8 * 128).from_buffer_copy(ident[0])
         L.check(L.load().mg_comm_init(C.byref(h), idbuf, self.rank, self.world), "mg_comm_init")
@@ -71,14 +71,23 @@ class RcclExchange:
         return None                                   # ordered by the stream it was enqueued on
 
     def broadcast(self, t: torch.Tensor, src: int = 0):
-        assert t.is_cuda and t.is_contiguous()
-        self._L.check(self._L.load().mg_comm_broadcast(self._h, t.data_ptr(), t.numel() * t.element_size(), 2, src,
+        assert t.is_cuda
+        buf = t if t.is_contiguous() else t.contiguous()      # a strided (e.g. transposed-view) parameter goes through a staging copy
+        self._L.check(self._L.load().mg_comm_broadcast(self._h, buf.data_ptr(), buf.numel() * buf.element_size(), 2, src,
                                                        torch.cuda.current_stream().cuda_stream), "mg_comm_broadcast")
+        if buf is not t:
+            t.copy_(buf)
 
     def close(self):
-        if self._h:
+        if getattr(self, "_h", None):
             self._L.load().mg_comm_destroy(self._h)
             self._h = None
+
+    def __del__(self):       # the engine calls close(); this is the net under an engine that is dropped without it
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
 
 
 def make_exchange(device):

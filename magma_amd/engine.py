@@ -615,6 +615,13 @@ class LMEngine:
             raise ValueError(f"KV cache full (Smax={cache.Smax}); pass a larger cache_hint / max_steps")
         if cache.B > 16:
             use_graph = False       # the tile-GEMM step of large batches is launched eagerly (split-K scratch is per stream)
+            if not getattr(self, "_warned_wide", False):
+                self._warned_wide = True
+                import warnings
+                warnings.warn(f"decode batch {cache.B} > 16: the token step runs every projection through the tile GEMM, launched "
+                              "eagerly with a separate LayerNorm (correct, tested) -- the weight-streaming GEMVs, the fused "
+                              "launches and the captured hipGraph of the B <= 16 step do not apply, and W8A16 decode is refused",
+                              RuntimeWarning, stacklevel=2)
         st = self._ensure_decode_state(cache)
         feed_back = input_ids is None
         if not feed_back:
@@ -657,6 +664,8 @@ class LMEngine:
         logits = torch.empty(xl.shape[0], self.Vp, dtype=torch.float32, device=self.device)
         ops.gemm(xl, self.head, out=logits)
         loss, _ = ops.cross_entropy(logits[:, : self.V], tgt[keep].contiguous())
-        full = self._full_logits(x, B * S).view(B, S, self.V) if want_logits else None   # reference magma.py:270-276 .logits
+        # reference magma.py:270-276 .logits: (B, S, V) over every position -- on request now, otherwise on first access
+        full = (self._full_logits(x, B * S).view(B, S, self.V) if want_logits
+                else LMOutput.lazy(lambda: self._full_logits(x, B * S).view(B, S, self.V)))
         return LMOutput(loss=loss, logits=full, hidden_states=hs, past_key_values=None,
                         target_rows=rows[keep], target_logits=logits[:, : self.V])

@@ -368,8 +368,8 @@ class NFResNet50(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         pk = self._ensure_packed()
-        if x.ndim != 4 or x.shape[1] != 3 or x.shape[2] % 64 or x.shape[3] % 64:
-            raise ValueError(f"expected (B,3,H,W) with H,W multiples of 64 (even maps at every stage), got {tuple(x.shape)}")
+        if x.ndim != 4 or x.shape[1] != 3 or x.shape[2] % 32 or x.shape[3] % 32:
+            raise ValueError(f"expected (B,3,H,W) with H,W multiples of 32 (the inputs of the three stride-2 stages must be even: 224 -> 112, 56, 28, 14, 7), got {tuple(x.shape)}")
         x = x.to(torch.bfloat16).contiguous()
         B, _, H, W = x.shape
         h, w = H // 2, W // 2

@@ -55,7 +55,31 @@ def gptj_config(**overrides) -> GPTJConfig:
 
 
 class LMOutput(dict):
-    """Minimal ModelOutput: attribute + key access (.loss, .logits, .past_key_values, .hidden_states)."""
+    """Minimal ModelOutput: attribute + key access (.loss, .logits, .past_key_values, .hidden_states).
+
+    A value may be LAZY (``LMOutput.lazy(fn)``): it is computed on first access and then stored.  The training-form forward
+    uses it for ``.logits``: the reference materialises (B, 2048, V) logits on every call (magma.py:270-276); here the loss
+    head runs on the rows that carry a target and the full tensor is produced only if a caller actually reads it."""
+
+    class lazy:
+        def __init__(self, fn):
+            self.fn = fn
+
+    def __getitem__(self, k):
+        v = dict.__getitem__(self, k)
+        if isinstance(v, LMOutput.lazy):
+            v = v.fn()
+            dict.__setitem__(self, k, v)
+        return v
+
+    def get(self, k, default=None):
+        return self[k] if k in self else default
+
+    def values(self):
+        return [self[k] for k in self.keys()]
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
 
     def __getattr__(self, k):
         try:

@@ -196,9 +196,9 @@ class Magma(nn.Module):
     # ------------------------------------------------------------- forward
     def forward(self, images=None, captions=None, output_hidden_states: bool = False, input_embeddings=None,
                 dropout_mask=None, return_logits: bool = False) -> LMOutput:
-        """reference magma.py:238-276.  ``.loss`` always; ``.logits`` (B, seq_len, V) bf16 only with
-        ``return_logits=True`` -- the reference materialises them on every call (2048 x 50258 per sample), this
-        path evaluates lm_head on the rows that carry a target unless the caller asks for the full tensor."""
+        """reference magma.py:238-276.  ``.loss`` and ``.logits`` (B, seq_len, V) bf16 as in the reference; the loss head runs
+        on the rows that carry a target and the full logits tensor (2048 x 50258 per sample) is computed when a caller first
+        reads ``.logits`` (or at once with ``return_logits=True``)."""
         torch.cuda.set_device(self.device)
         assert captions is not None, "Must provide captions in training"
         assert (images is None) != (input_embeddings is None), "Pass in either images, or input embeddings, not both."

@@ -287,6 +287,18 @@ class MagmaEngine:
         torch.cuda.current_stream().wait_stream(self._comm_stream)
 
     # ---- helpers -------------------------------------------------------------
+    def close(self):
+        """Release what the engine owns outside PyTorch's allocator: the RCCL communicator of the mg_comm_* exchange."""
+        ex = getattr(self, "_exchange", None)
+        if ex is not None:
+            ex.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
     def grad_of(self, p: torch.nn.Parameter) -> torch.Tensor:
         gi, _ = self._where[id(p)]
         return self.groups[gi].view(self.groups[gi].grad, p)
@@ -433,7 +445,9 @@ class MagmaEngine:
         loss = self._lm_forward(emb, labels[:, :S].contiguous(), tape)
         self._tape = tape
         # rows are b * S + position within the (possibly truncated) sequence of this step
-        return LMOutput(loss=loss, logits=None, labels=labels, target_rows=tape["rows"], target_logits=tape.pop("target_logits"))
+        xf = tape.pop("x_final")
+        return LMOutput(loss=loss, labels=labels, target_rows=tape["rows"], target_logits=tape.pop("target_logits"),
+                        logits=LMOutput.lazy(lambda: eng._full_logits(xf, xf.shape[0]).view(B, S, eng.V)))
 
     def _lm_forward(self, emb, labels, tape):
         eng = self.module.lm.engine
@@ -507,6 +521,7 @@ class MagmaEngine:
         loss, dlogits = ops.cross_entropy_fwd_bwd(logits[:, : eng.V], tgt, head_t.K)
         tape.update(xr=xr, dlogits=dlogits, M=M)
         tape["target_logits"] = logits[:, : eng.V]         # fp32, rows that carry a target (reference magma.py:270-276 .logits, those rows)
+        tape["x_final"] = x                                # [B*S, d]: .logits over every position is computed from it on first access
         if self.lm_trainable:
             tape["xl"] = xl
         return loss
@@ -806,8 +821,8 @@ class MagmaEngine:
         enc = self.module.image_prefix.enc
         x = images.to(BF16).contiguous()
         B, _, H, W = x.shape
-        if H % 64 or W % 64:
-            raise ValueError(f"nfresnet50 takes images whose sides are multiples of 64, got {H}x{W}")
+        if H % 32 or W % 32:
+            raise ValueError(f"nfresnet50 takes images whose sides are multiples of 32, got {H}x{W}")
         h, w = H // 2, W // 2
         cols = ops.im2col_nchw(x, 7, 2, 3, 160)
         y0, stem = self._nf_conv_fwd(enc.stem_conv, cols, stem=True)                      # [B*h*w, 64], no activation

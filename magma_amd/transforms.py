@@ -98,17 +98,26 @@ def _device_pipeline(image, n_px, device):
 def clip_preprocess(n_px, use_pad=False, device=None):
     """``device``: a GPU -> RGB images are resized / cropped / normalised on it (same bits as the host path);
     other modes (palette, alpha, grey) and ``device=None`` use PIL on the host like the reference."""
-    if use_pad:
-        raise NotImplementedError("pad mode is not used by any shipped config")
     mean = torch.tensor(CLIP_MEAN).view(3, 1, 1)
     std = torch.tensor(CLIP_STD).view(3, 1, 1)
 
     on_gpu = device is not None and torch.device(device).type == "cuda"
 
+    def pad_img(im):
+        """reference transforms.py:87-108: long side -> n_px (LANCZOS, PIL's old ANTIALIAS), pasted centred on black."""
+        old = im.size
+        ratio = float(n_px) / max(old)
+        new = tuple(int(x * ratio) for x in old)
+        im = im.resize(new, PilImage.LANCZOS)
+        canvas = PilImage.new("RGB", (n_px, n_px))
+        canvas.paste(im, ((n_px - new[0]) // 2, (n_px - new[1]) // 2))
+        return canvas
+
     def fn(image):
-        if on_gpu and image.mode == "RGB" and min(image.size) >= 2:
+        if on_gpu and not use_pad and image.mode == "RGB" and min(image.size) >= 2:
             return _device_pipeline(image, n_px, device)
-        image = _center_crop(_resize_short_side(image, n_px), n_px).convert("RGB")
+        image = _resize_short_side(image, n_px)
+        image = (pad_img(image) if use_pad else _center_crop(image, n_px)).convert("RGB")
         t = torch.from_numpy(np.asarray(image, dtype=np.uint8).copy()).permute(2, 0, 1).float() / 255.0
         out = maybe_add_batch_dim((t - mean) / std)
         # one transform -> one device: grey / palette / alpha images take the PIL branch but must land where the RGB
@@ -167,10 +176,50 @@ class RandCropResize:
         return _random_crop(img, self.target_size)
 
 
+class ColorJitter:
+    """torchvision T.ColorJitter(brightness, contrast, saturation, hue) on a PIL image (reference transforms.py:78-80 uses
+    (0.1, 0.1, 0.1, 0.05)), restated from torchvision's published algorithm (un-vendored, absent here): the four operations in
+    a random order (torch.randperm), factors uniform in [max(0, 1 - v), 1 + v] / [-hue, hue] (torch's RNG, as torchvision
+    draws them); brightness / contrast / saturation through PIL.ImageEnhance (what torchvision's PIL backend calls), hue as a
+    cyclic shift of the H channel of the HSV image by uint8(hue * 255)."""
+
+    def __init__(self, brightness=0.0, contrast=0.0, saturation=0.0, hue=0.0):
+        self.b = (max(0.0, 1 - brightness), 1 + brightness) if brightness else None
+        self.c = (max(0.0, 1 - contrast), 1 + contrast) if contrast else None
+        self.s = (max(0.0, 1 - saturation), 1 + saturation) if saturation else None
+        self.h = (-hue, hue) if hue else None
+
+    @staticmethod
+    def _adjust_hue(img, f):
+        if img.mode in ("L", "1", "I", "F"):
+            return img
+        h, s, v = img.convert("HSV").split()
+        nh = np.asarray(h, dtype=np.uint8)
+        with np.errstate(over="ignore"):
+            nh = nh + np.uint8(int(f * 255) % 256)           # uint8 wrap-around = cyclic shift of the hue
+        return PilImage.merge("HSV", (PilImage.fromarray(nh, "L"), s, v)).convert(img.mode)
+
+    def __call__(self, img):
+        from PIL import ImageEnhance
+        order = torch.randperm(4)
+        draw = lambda r: None if r is None else float(torch.empty(1).uniform_(r[0], r[1]))  # noqa: E731
+        fb, fc, fs, fh = draw(self.b), draw(self.c), draw(self.s), draw(self.h)
+        for k in order.tolist():
+            if k == 0 and fb is not None:
+                img = ImageEnhance.Brightness(img).enhance(fb)
+            elif k == 1 and fc is not None:
+                img = ImageEnhance.Contrast(img).enhance(fc)
+            elif k == 2 and fs is not None:
+                img = ImageEnhance.Color(img).enhance(fs)
+            elif k == 3 and fh is not None:
+                img = self._adjust_hue(img, fh)
+        return img
+
+
 def base_transforms(image_size, use_extra_transforms=False, device=None):
-    """reference transforms.py:71-84: RGB -> RandCropResize -> RandomHorizontalFlip(0.5) -> ToTensor -> batch dim."""
-    if use_extra_transforms:
-        raise NotImplementedError("use_extra_transforms (torchvision ColorJitter) is not reproduced; no shipped config sets it")
+    """reference transforms.py:71-84: RGB -> RandCropResize -> RandomHorizontalFlip(0.5) [-> ColorJitter(0.1, 0.1, 0.1, 0.05)
+    with use_extra_transforms] -> ToTensor -> batch dim."""
+    jitter = ColorJitter(0.1, 0.1, 0.1, 0.05) if use_extra_transforms else None
     crop = RandCropResize(image_size)
     on_gpu = device is not None and torch.device(device).type == "cuda"
 
@@ -179,6 +228,8 @@ def base_transforms(image_size, use_extra_transforms=False, device=None):
         img = crop(img)
         if float(torch.rand(1)) < 0.5:
             img = img.transpose(PilImage.FLIP_LEFT_RIGHT)
+        if jitter is not None:
+            img = jitter(img)
         t = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).float() / 255.0
         t = maybe_add_batch_dim(t)
         return t.to(device) if on_gpu else t

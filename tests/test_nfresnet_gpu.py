@@ -54,7 +54,7 @@ def test_pool_and_im2col_kernels(dev):
     assert torch.equal(cols[:, :147], ref) and bool((cols[:, 147:] == 0).all())
 
 
-@pytest.mark.parametrize("res", [128, 256])
+@pytest.mark.parametrize("res", [96, 128, 224, 256])      # 96, 224: multiples of 32 that are not multiples of 64 (odd final map)
 def test_nfresnet50_encoder_and_pooled_prefix(dev, res):
     """The full architecture (53 scaled-std convs, 23.5 M parameters) at two resolutions, then the pooled prefix on top."""
     from magma_amd.image_encoders import NFResNet50

@@ -229,7 +229,11 @@ def test_from_checkpoint_classmethod_and_logits(dev, tmp_path, monkeypatch):
     out = model(images.cuda(), caps.cuda(), return_logits=True)
     assert abs(float(out.loss) - float(ref["loss"])) < 1e-2 * abs(float(ref["loss"]))
     assert out.logits.shape == ref["logits"].shape and rel(out.logits, ref["logits"]) < 2e-2
-    assert model(images.cuda(), caps.cuda()).logits is None           # default: the (B, 2048, V) tensor is not materialised
+    # default call, as the reference's (magma.py:238-276): .logits is there -- materialised on first access, not before
+    from magma_amd.language_model import LMOutput
+    o2 = model(images.cuda(), caps.cuda())
+    assert isinstance(dict.__getitem__(o2, "logits"), LMOutput.lazy)
+    assert o2.logits.shape == ref["logits"].shape and torch.equal(o2.logits, out.logits) and o2["logits"] is o2.logits
     # a checkpoint whose tensor shapes disagree with the model is an error, as load_state_dict(strict=False) makes it
     bad = dict(sd)
     bad["image_prefix.proj.weight"] = torch.zeros(7, 5)
