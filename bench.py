@@ -101,6 +101,10 @@ def cpu_baseline(args, budget_s):
 
     L = 28
     legs = {}
+    # thread counts: 32 (PyTorch's CPU GEMMs at these sizes -- 456 x 4096 x 16384 and 8 x 4096 x 16384 per call -- stop scaling
+    # around one CCD group of the box's two sockets; more threads add NUMA traffic and barrier time) AND every hardware thread,
+    # as far as the time budget goes: the faster (dtype, threads) leg is `value`, every leg is reported with its thread count
+    plans = [(torch.float32, nthr), (torch.bfloat16, nthr)] + ([(torch.bfloat16, cores)] if cores > nthr else [])
     with torch.no_grad():
         # image encoder + prefix projection: the full RN50x16 trunk on ONE image in fp32, scaled by the batch
         enc_p = {k: v for k, v in O.init_params(O.OracleConfig(n_layer=0, vocab_in=8, vocab_out=8), seed=0).items()
@@ -110,9 +114,10 @@ def cpu_baseline(args, budget_s):
         O.image_prefix_fwd(enc_p, ecfg, img)
         t0 = time.time(); O.image_prefix_fwd(enc_p, ecfg, img); t_enc = (time.time() - t0) * B
         del enc_p
-        for dtype in (torch.float32, torch.bfloat16):
+        for dtype, thr in plans:
             if legs and time.time() - t_used > budget_s * 0.6:
                 break
+            torch.set_num_threads(thr)
             p, mk = build(dtype)
             x = mk(B, S0, d) * 50
             O.block_fwd(p, cfg, 0, x, None, 0)
@@ -126,16 +131,16 @@ def cpu_baseline(args, budget_s):
             head_w, head_b = mk(cfg.vocab_out, d), mk(cfg.vocab_out)
             t0 = time.time(); torch.nn.functional.linear(x1[:, 0], head_w, head_b); th = time.time() - t0
             total = t_enc + L * tp + args.gen * (L * td + th)
-            legs[str(dtype).split(".")[-1]] = {"tokens_per_s": B * args.gen / total, "prefill_layer_ms": tp * 1e3,
-                                               "decode_layer_ms": td * 1e3, "lm_head_ms": th * 1e3}
+            legs[f"{str(dtype).split('.')[-1]}@{thr}"] = {"tokens_per_s": B * args.gen / total, "threads": thr, "prefill_layer_ms": tp * 1e3,
+                                                        "decode_layer_ms": td * 1e3, "lm_head_ms": th * 1e3}
             del p, head_w, head_b, past
+    torch.set_num_threads(nthr)
     best = max(legs, key=lambda k: legs[k]["tokens_per_s"])
-    return {"value": legs[best]["tokens_per_s"], "unit": "tokens/s", "cores": nthr, "kind": "port", "dtype": best,
-            "legs": legs, "encoder_ms_per_batch": t_enc * 1e3,
-            "sample": f"oracle (PyTorch CPU, {nthr} threads of {cores}): CLIP RN50x16 trunk + prefix on 1 image x{B} "
-                      f"({t_enc*1e3:.0f} ms, fp32) + one full-size GPT-J block+adapter timed at prefill B={B},S={S0} and at the "
-                      f"cached decode shape, x{L} layers + lm_head x {args.gen} steps, in fp32 and bf16 (faster leg = value: {best}); "
-                      f"measured in {time.time()-t_used:.0f} s"}
+    return {"value": legs[best]["tokens_per_s"], "unit": "tokens/s", "cores": legs[best]["threads"], "kind": "port", "dtype": best.split("@")[0],
+            "legs": legs, "encoder_ms_per_batch": t_enc * 1e3, "host_threads": cores,
+            "sample": f"oracle (PyTorch CPU; legs at {nthr} and at all {cores} hardware threads, the faster one is value): CLIP RN50x16 trunk + "
+                      f"prefix on 1 image x{B} ({t_enc*1e3:.0f} ms, fp32) + one full-size GPT-J block+adapter timed at prefill B={B},S={S0} "
+                      f"and at the cached decode shape, x{L} layers + lm_head x {args.gen} steps (best leg: {best}); measured in {time.time()-t_used:.0f} s"}
 
 
 def decode_gemv_jobs(eng, st):
@@ -163,6 +168,12 @@ def decode_gemv_jobs(eng, st):
             r = ly.mlp_adapter[0].N
             t = st.ctx_t[:, eng.d: eng.d + r]
             add(lambda ly=ly, t=t: ops.gemm_skinny(st.h, ly.fc_dn, out=st.m, split=(eng.d, t, ops.MG_ACT_RELU, ly.fc_dn.bias_b)), ly.fc_dn)
+            add(lambda ly=ly, r=r: ops.gemm_skinny(st.ctx_t[:, : eng.d + r], ly.out_up, out=st.xb, residuals=(st.m, st.xa)), ly.out_up)
+            continue
+        if getattr(ly, "out_up", None) is not None:      # MAGMA_DECODE_FOLD=2: only the K-concatenated [W_out | W_up]
+            r = ly.mlp_adapter[0].N
+            add(lambda ly=ly: ops.gemm_skinny(st.h, ly.fc_out, out=st.m), ly.fc_out)
+            add(lambda ly=ly, r=r: ops.gemm_skinny(st.m, ly.mlp_adapter[0], out=st.ctx_t[:, eng.d: eng.d + r], act=ops.MG_ACT_RELU), ly.mlp_adapter[0])
             add(lambda ly=ly, r=r: ops.gemm_skinny(st.ctx_t[:, : eng.d + r], ly.out_up, out=st.xb, residuals=(st.m, st.xa)), ly.out_up)
             continue
         add(lambda ly=ly: ops.gemm_skinny(st.ctx, ly.out, out=st.a), ly.out)
@@ -357,6 +368,40 @@ def bench_train(model, args, rank, world, dev):
                             "global_batch": world * B}
     out["max_memory_allocated_GB"] = torch.cuda.max_memory_allocated() / 2 ** 30
     return out
+
+
+def gemm_roofline(model, args, dev):
+    """The dominant kernel of the TRAINING half of the metric, live: the 256x256 MFMA GEMM on the four frozen-weight projections
+    of a GPT-J block at the training shape (M = per-GPU batch x 2048 rows; qkv, out_proj, fc_in + gelu_new, fc_out), random
+    operands, layer-0 weights, HIP events on the launch stream.  achieved = 2 M N K summed / time."""
+    from magma_amd import ops
+    eng = model.lm.engine
+    ly = eng.layers[0]
+    M = args.train_batch * model.seq_len
+    g = torch.Generator(device=dev).manual_seed(7)
+    a_d = torch.randn(M, eng.d, device=dev, generator=g).to(torch.bfloat16)
+    a_ff = torch.randn(M, ly.fc_in.N, device=dev, generator=g).to(torch.bfloat16)
+    jobs = [(a_d, ly.qkv, {}), (a_d, ly.out, {}), (a_d, ly.fc_in, {"act": ops.MG_ACT_GELU_NEW}), (a_ff, ly.fc_out, {})]
+    outs = [torch.empty(M, w.N, dtype=torch.bfloat16, device=dev) for _, w, _ in jobs]
+    flops = sum(2.0 * M * w.N * w.K for _, w, _ in jobs)
+
+    def sweep():
+        for (a, w, kw), o in zip(jobs, outs):
+            ops.gemm(a, w, out=o, **kw)
+    sweep()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 5
+    e0.record()
+    for _ in range(n):
+        sweep()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    tf = flops / ms / 1e9
+    return {"bound": "mfma", "kernel": "gemm256_kernel (256x256x64 tiles, v_mfma_f32_16x16x32_bf16)", "achieved": tf, "peak": 2500.0,
+            "unit": "TFLOP/s", "frac": tf / 2500.0, "launches": len(jobs), "avg_launch_us": ms * 1e3 / len(jobs),
+            "shapes_MxNxK": [[M, w.N, w.K] for _, w, _ in jobs]}
 
 
 def variant_generate(model, args, dev, res):
@@ -581,7 +626,7 @@ def main():
                 "traffic": traffic, "traffic_source": traffic_src,
                 "bytes_per_launch": wbytes / len(jobs), "launches": len(jobs),
                 "streamed_bytes": sum(n * k * 2 for n, k in shapes), "algorithmic_bytes": wbytes,
-                "block": "3 launches (adapter-down folded through fc_out)" if getattr(eng.layers[0], "fc_dn", None) is not None else "4 launches",
+                "block": {0: "4 launches", 1: "3 launches (adapter-down folded through fc_out)", 2: "4 launches, [W_out | W_up] K-concatenated"}.get(eng.fold_dn, "?"),
                 "avg_launch_us": ms_sweep * 1e3 / len(jobs),
                 "token_step": {"ms": ms_tok, "decode_tokens_per_s": B / (ms_tok * 1e-3),
                                "hbm_frac_whole_step": wbytes / (ms_tok * 1e-3) / 8e12}}
@@ -673,6 +718,18 @@ def main():
             train = {"error": repr(e)[:300]}
     if rank == 0:
         line["train"] = train
+        # second half of the metric in the SAME roofline object the driver parses: the training step is MFMA-bound, its
+        # dominant kernel is the tile GEMM (measured live here, like the decode kernel above); flat copies for flat parsers
+        if args.train_steps > 0 and line.get("roofline") is not None:
+            try:
+                mf = gemm_roofline(model, args, dev)
+                line["roofline"]["train"] = mf
+                line["roofline"].update({"mfma_kernel": mf["kernel"], "mfma_achieved_tflops": mf["achieved"], "mfma_peak_tflops": mf["peak"],
+                                         "mfma_frac": mf["frac"]})
+                full_ = (train or {}).get("full_S2048") or {}
+                line["roofline"]["train_step_mfma_frac_executed"] = full_.get("mfma_frac_executed")
+            except Exception as e:  # noqa: BLE001
+                line["roofline"]["train"] = {"error": repr(e)[:200]}
         # data-parallel training throughput of the whole job (BASELINE metric, first half), next to the headline
         full = (train or {}).get("full_S2048") or {}
         line["train_images_per_s"] = full.get("images_per_s")

@@ -248,6 +248,193 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(
 
 constexpr float FA2_DEFER = 8.0f;                   // log2 units: rescale only when the running max grows by more than 256x (guide T13)
 
+// ---------------------------------------------------------------------------
+// flash attention forward, software-pipelined across KV tiles (round 4; the default).
+//
+// attn_prefill_kernel above runs a tile's four parts as ONE dependent chain per wave -- K reads -> S^T MFMAs -> softmax VALU
+// (~100 instructions, several dependent reductions) -> PV MFMAs -- and the two waves of a SIMD do so in lock-step behind the
+// per-tile barrier, so the matrix pipe idles through every softmax and the VALU through every MFMA burst (PMC, round 3:
+// MFMA pipe 0.30-0.34 busy with no pipe above 0.35).  Here the softmax of a tile is split in two halves that each sit beside
+// an MFMA burst of ANOTHER tile (the "att[2]" pipeline of the guide, T15):
+//     iteration t:   [ K(t+1) fragment reads  ||  part 2 of softmax(t): exp2, row sums, bf16 pack ]
+//                    [ S^T(t+1) = K(t+1) Q^T  : 16 MFMAs        ||  V^T(t) fragment reads          ]
+//                    [ O^T += V^T(t) P^T(t)   : 16 MFMAs        ||  part 1 of softmax(t+1): mask, row max, new running
+//                                                                    max, rescale factor (VALU placed between the MFMAs) ]
+// so a wave's chain per tile is  K reads -> 16 MFMAs -> 16 MFMAs  and the exponentials are off it.  Same arithmetic in the
+// same order per query as attn_prefill_kernel (same tiles, same deferred running max, same accumulation order): results
+// are bit-identical to it.  The K tile is read one iteration earlier than before, so the ring is waited one tile deeper
+// (tile t+1 complete at the top of iteration t; tiles t+2, t+3 in flight afterwards).
+// T13 (deferred max) order: P(t) is exponentiated against the maximum decided for tile t, O / l are rescaled by alpha(t)
+// BEFORE P(t) V(t) is added, and alpha(t+1) -- decided while P(t) V(t) is still in the pipe -- is applied in iteration t+1,
+// after that product has completed: nothing is ever scaled twice or not at all.
+// ---------------------------------------------------------------------------
+// ABL (timing ablations, WRONG results; `make ABL=1` library only, MAGMA_ATTN_ABL=n): 1 = no exponentials / row sums (P = the raw
+// scores), 2 = no LDS fragment reads after the first tile (stale registers), 3 = no MFMAs, 4 = no LDS-DMA after the prologue,
+// 5 = no barrier (and no DMA): each part's price is the time it removes.
+template <int ABL = 0>
+__global__ __launch_bounds__(512) void attn_prefill_sp_kernel(
+    const mg_bf16* __restrict__ q, const mg_bf16* __restrict__ kcache,
+    const mg_bf16* __restrict__ vt, mg_bf16* __restrict__ out, float* __restrict__ lse,
+    int B, int H, int S, int Smax, int vt_ld, float defer) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lq = lane >> 4;
+  const int nblk = (S + 127) >> 7;
+  const int wg = xcd_contiguous_index(blockIdx.x, gridDim.x);
+  const int bh = wg / nblk, b = bh / H, h = bh - b * H;
+  const int qt0 = (nblk - 1 - (wg - bh * nblk)) * 128;   // longest blocks first
+  const int qrow = qt0 + wave * 16 + li;                 // this lane's query
+  const int qrow_c = min(qrow, S - 1);
+  const mg_bf16* kbase = kcache + (int64_t)bh * Smax * DH;
+  const mg_bf16* vbase = vt + (int64_t)bh * DH * vt_ld;
+
+  const int kv_end = min(S, qt0 + 128);
+  const int ntiles = (kv_end + 31) >> 5;
+  const uint32_t smem_u = lds_u32(smem);
+  auto issue = [&](int t, int buf) {
+    const int c0 = min(t, ntiles - 1) * 32;
+    const uint32_t st = smem_u + (uint32_t)(buf * FA_STAGE);
+    dma_rows(st, kbase, DH, c0, S, wave, lane);
+    dma_cols(st + ROW_TILE, vbase, vt_ld, c0, wave, lane);
+  };
+#pragma unroll
+  for (int i = 0; i < FA_STAGES - 1; ++i) issue(i, i);
+
+  bf16x8 qf[8];
+  {
+    const mg_bf16* qp = q + ((int64_t)bh * S + qrow_c) * DH + lq * 8;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 32);
+  }
+  f32x4 o[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float m2 = -1e30f, lsum = 0.f;
+  const float sc2 = 0.0625f * 1.4426950408889634f;  // 1/sqrt(256) * log2(e)
+  const int my_first = qt0 + wave * 16;
+  const int my_last = my_first + 15;
+  const int n_act = min(ntiles, (my_last >> 5) + 1);   // this wave's tiles: 0 .. n_act-1 (later ones are fully masked for it)
+  const int tsw = t_swz(li);
+  const int krow0 = (li >> 2) * 8 + (li & 3);
+  const int sw0 = row_swz(krow0);
+  MG_USE8(qf);
+
+  // part 1 of the softmax of the tile whose scores are in st[]: mask, row maximum, running maximum, rescale factor.
+  // Leaves the masked scores in sv[], returns alpha; m2 becomes the reference point of this tile's exponentials.
+  // Branch-free (one basic block with the PV MFMAs it is scheduled between): key j of this lane's 8 is visible iff
+  // j <= min(query, S - 1) - kv0 - 8 lq.  A tile past this wave's last query comes out fully masked: row maximum -1e30,
+  // running maximum unchanged, alpha = 1 -- computed once at the end of a wave's tiles and never used.
+  float sv[8];
+  const int lim0 = min(qrow, S - 1) - lq * 8;
+  auto part1 = [&](const f32x4 (&st)[2], int kv0) -> float {
+    const int lim = lim0 - kv0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sv[j] = j > lim ? -1e30f : st[j >> 2][j & 3];
+    float tmax = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
+    tmax = quad_rows_max(tmax);
+    const float cand = tmax * sc2;
+    const float mnew = (cand > m2 + defer) ? cand : m2;
+    const float a = __builtin_amdgcn_exp2f(m2 - mnew);
+    m2 = mnew;
+    return a;
+  };
+
+  bf16x8 fa[8], fb[8];
+  f32x4 sn[2];
+  float alpha;
+  // ---- prologue: tiles 0 and 1 landed; S^T(0) and part 1 of its softmax ----
+  MG_WAIT_VMCNT(4);
+  MG_BARRIER_KEEP_DMA();
+  {
+    const char* kp = smem + krow0 * 512;
+    rd_row8(fa, kp, lq, sw0);
+    rd_row8(fb, kp + 4 * 512, lq, sw0);
+    sn[0] = mma8(fa, qf);
+    sn[1] = mma8(fb, qf);
+    alpha = part1(sn, 0);
+  }
+  int sc = 0;
+  for (int t = 0; t < ntiles; ++t) {
+    if constexpr (ABL != 4 && ABL != 5) MG_WAIT_VMCNT(4);   // this wave's pieces of tile t+1 landed (tile t+2 may be in flight)
+    if constexpr (ABL != 5) MG_BARRIER_KEEP_DMA();          // tile t+1 complete; everyone is done with iteration t-1 (K(t), V^T(t-1))
+    if constexpr (ABL != 4 && ABL != 5) issue(t + FA_STAGES - 1, sc == 0 ? FA_STAGES - 1 : sc - 1);
+    const int scn = sc == FA_STAGES - 1 ? 0 : sc + 1;
+    if (t < n_act) {
+      // ---- block A: K(t+1) fragment reads | part 2 of softmax(t) | S^T(t+1) MFMAs | V^T(t) fragment reads ----
+      // (tile t+1 exists in the ring even past the last tile: issue() clamps to it; its scores are then fully masked)
+      if (ABL != 2 || t == 0) {
+        const char* kp = smem + scn * FA_STAGE + krow0 * 512;
+        rd_row8(fa, kp, lq, sw0);
+        rd_row8(fb, kp + 4 * 512, lq, sw0);
+      }
+      float psum = 0.f;
+      float p[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        p[j] = ABL == 1 ? sv[j] : __builtin_amdgcn_exp2f(fmaf(sv[j], sc2, -m2));
+        if (ABL != 1) psum += p[j];
+      }
+      lsum = lsum * alpha + psum;
+      u32x4 pw;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) pw[j] = pack2bf(p[2 * j], p[2 * j + 1]);
+      // (pins part 2 HERE: its results are first used in block B, and LLVM would sink the whole computation there,
+      //  back onto the chain in front of the PV MFMAs)
+      asm volatile("" : "+v"(pw[0]), "+v"(pw[1]), "+v"(pw[2]), "+v"(pw[3]), "+v"(lsum));
+      const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
+      MG_SCHED_FENCE();
+      if constexpr (ABL != 3) {
+        sn[0] = mma8(fa, qf);
+        sn[1] = mma8(fb, qf);
+      } else {
+        sn[0] = __builtin_bit_cast(f32x4, fa[0]); sn[1] = __builtin_bit_cast(f32x4, fb[0]);
+      }
+      MG_SCHED_FENCE();
+      const char* tp = smem + sc * FA_STAGE + ROW_TILE + li * 64 + ((lq ^ tsw) << 4);
+      if (ABL != 2 || t == 0) {
+        rd_t8(fa, tp);
+        rd_t8(fb, tp + 8 * 1024);
+      }
+      if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {      // rare under the deferred running max
+#pragma unroll
+        for (int dt = 0; dt < 16; ++dt) o[dt] *= alpha;
+      }
+      // ---- block B: O^T += V^T(t) P^T(t), 16 MFMAs, with part 1 of softmax(t+1) placed between them ----
+      if constexpr (ABL != 3) {
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[dt], pf, o[dt], 0, 0, 0);
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) o[8 + dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[dt], pf, o[8 + dt], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) { asm volatile("" ::"v"(fa[dt]), "v"(fb[dt]), "v"(pf)); }
+      }
+      alpha = part1(sn, (t + 1) * 32);
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {       // 1 MFMA : 3 VALU for as long as part 1 lasts
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+      }
+    }
+    sc = scn;
+  }
+  MG_WAIT_VMCNT(0);
+  lsum = quad_rows_sum(lsum);
+  if (qrow < S) {
+    const float inv = 1.0f / lsum;
+    mg_bf16* op = out + (int64_t)(b * S + qrow) * (H * DH) + h * DH + lq * 4;
+#pragma unroll
+    for (int dt = 0; dt < 16; ++dt) {
+      u32x2 w;
+      w[0] = pack2bf(o[dt][0] * inv, o[dt][1] * inv);
+      w[1] = pack2bf(o[dt][2] * inv, o[dt][3] * inv);
+      *(u32x2*)(op + dt * 16) = w;
+    }
+    if (lse && lq == 0) lse[(int64_t)bh * S + qrow] = (m2 + log2f(lsum)) * 0.6931471805599453f;
+  }
+}
+
 template <bool FUSED>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnDecodeParams P) {
   __shared__ __attribute__((aligned(16))) char lds[ATTN_DEC_LDS];
@@ -307,12 +494,33 @@ extern "C" int mg_attn_prefill_bf16(const mg_bf16* q, const mg_bf16* kcache, con
   // 16-query waves x 8 (two per SIMD), deferred running max: 0.90 ms per layer at B = 16, S = 2048.  MAGMA_ATTN_FWD=0 keeps the
   // plain running max (1.00 ms).  The 32-query-wave structure on the 32x32x16 MFMA measured slower (1.10 ms,
   // profiles/r02_attention_variants.txt) and is gone from the library (git history: attn_prefill32_kernel).
-  static const int variant = [] { const char* e = getenv("MAGMA_ATTN_FWD"); return e ? atoi(e) : 3; }();
+  // MAGMA_ATTN_FWD: 4 (default) = software-pipelined across KV tiles; 3 = one dependent chain per tile (round 1-3); 0 = that
+  // with the plain running max.  All three give identical bits per defer setting.
+  static const int variant = [] { const char* e = getenv("MAGMA_ATTN_FWD"); return e ? atoi(e) : 4; }();
   const int lds = FA_STAGES * FA_STAGE;
-  if (int rc = mg_allow_dynamic_lds((const void*)attn_prefill_kernel, lds, "mg_attn_prefill_bf16")) return rc;
+  const void* fn = variant == 4 ? (const void*)attn_prefill_sp_kernel<0> : (const void*)attn_prefill_kernel;
+  if (int rc = mg_allow_dynamic_lds(fn, lds, "mg_attn_prefill_bf16")) return rc;
   dim3 grid((unsigned)(((S + 127) / 128) * B * H));
-  hipLaunchKernelGGL(attn_prefill_kernel, grid, dim3(512), lds, (hipStream_t)stream, q, kcache, vt, out, lse, B, H, S, Smax, vt_ld,
-                     variant == 0 ? 0.0f : FA2_DEFER);
+#ifdef MG_GEMM_ABLATIONS      // `make ABL=1`: timing ablations of the pipelined kernel (WRONG results), MAGMA_ATTN_ABL=1..5
+  {
+    const char* e = getenv("MAGMA_ATTN_ABL");
+    const int abl = e ? atoi(e) : 0;
+#define MG_ABL(N_)                                                                                                    \
+    if (abl == N_) {                                                                                                  \
+      if (int rc = mg_allow_dynamic_lds((const void*)attn_prefill_sp_kernel<N_>, lds, "mg_attn_prefill_bf16")) return rc; \
+      hipLaunchKernelGGL(attn_prefill_sp_kernel<N_>, grid, dim3(512), lds, (hipStream_t)stream, q, kcache, vt, out, lse, B, H, S, Smax, vt_ld, FA2_DEFER); \
+      MG_CHECK_LAUNCH();                                                                                              \
+      return MG_OK;                                                                                                   \
+    }
+    MG_ABL(1) MG_ABL(2) MG_ABL(3) MG_ABL(4) MG_ABL(5)
+#undef MG_ABL
+  }
+#endif
+  if (variant == 4)
+    hipLaunchKernelGGL(attn_prefill_sp_kernel<0>, grid, dim3(512), lds, (hipStream_t)stream, q, kcache, vt, out, lse, B, H, S, Smax, vt_ld, FA2_DEFER);
+  else
+    hipLaunchKernelGGL(attn_prefill_kernel, grid, dim3(512), lds, (hipStream_t)stream, q, kcache, vt, out, lse, B, H, S, Smax, vt_ld,
+                       variant == 0 ? 0.0f : FA2_DEFER);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }

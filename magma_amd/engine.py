@@ -155,7 +155,11 @@ class LMEngine:
         # GEMV over the concatenated input [ctx | t] against [W_out | W_up]  (x' = that + b_up + m + x: the same sum the
         # reference forms, reference adapters.py:38-39, in another association order -- the 2 x eager-bf16 criterion and the
         # exact-greedy-id tests hold, tests/test_fullwidth_gpu.py, test_fulldepth_gpu.py).  0 = the four-launch block.
-        self.fold_dn = os.environ.get("MAGMA_DECODE_FOLD", "1") == "1"
+        # Measured (round 4, profiles/r04_decode_fold_*): the fold is SLOWER, 2.70 vs 2.53 ms per token -- the co-launch grows from
+        # 256 to 320 weight tiles of 512 KB on 256 CUs (41.4 us against 29.6; a CU streams at a fixed rate, so a quarter of them
+        # now take two tiles' time), which costs more than the [W_out | W_up] launch saves (9.7 us against 13.2 + 5.0).  Mode 2
+        # keeps only the K-concatenation: attention || fc_out, adapter-down alone, then [W_out | W_up].  Default 0.
+        self.fold_dn = int(os.environ.get("MAGMA_DECODE_FOLD", "0"))
         self.fuse_in = os.environ.get("MAGMA_PREFILL_FUSE_IN", "1") == "1"      # [qkv | fc_in] as one prefill GEMM
         self.two_streams = os.environ.get("MAGMA_DECODE_STREAMS", "1") == "2"   # measured slower (3.07 vs 2.94 ms/step): off
 
@@ -187,7 +191,7 @@ class LMEngine:
           ly.fc_dn  = [W_fc_out ; W_dn W_fc_out]   (d + r rows over K = ff;  bias b_fc | W_dn b_fc + b_dn)
           ly.out_up = [W_out | W_up]               (d rows over K = d + r;   bias b_up)"""
         ly.fc_dn = ly.out_up = None
-        if not self.fold_dn or ly.mlp_adapter is None or ly.attn_adapter is not None or ly.mlp_par is not None:
+        if self.fold_dn not in (1, 2) or ly.mlp_adapter is None or ly.attn_adapter is not None or ly.mlp_par is not None:
             return
         dn, up = ly.mlp_adapter
         a, mlp = ly._src
@@ -196,8 +200,9 @@ class LMEngine:
         w_fc, b_fc = mlp.c_proj.weight.detach().float(), mlp.c_proj.bias.detach().float()
         w_dn = ops.PackedLinear.untile(dn.ft)[: dn.N, : dn.K].float()
         w_up = ops.PackedLinear.untile(up.ft)[: up.N, : up.K]
-        ly.fc_dn = ops.PackedLinear(torch.cat([mlp.c_proj.weight.detach().to(BF16), (w_dn @ w_fc).to(BF16)], dim=0), bias=b_fc)
-        ly.fc_dn.bias_b = (w_dn @ b_fc + dn.bias).contiguous()
+        if self.fold_dn == 1:
+            ly.fc_dn = ops.PackedLinear(torch.cat([mlp.c_proj.weight.detach().to(BF16), (w_dn @ w_fc).to(BF16)], dim=0), bias=b_fc)
+            ly.fc_dn.bias_b = (w_dn @ b_fc + dn.bias).contiguous()
         ly.out_up = ops.PackedLinear(torch.cat([a.out_proj.weight.detach().to(BF16), w_up], dim=1), bias=up.bias)
 
     def _ensure_decode_packs_w8(self):
@@ -515,6 +520,16 @@ class LMEngine:
             par = ly.mlp_par is not None or ly.attn_par is not None
             grouped = (not wide and self.group_launches and not par and ly.mlp_adapter is not None and ly.attn_adapter is None
                        and ly.fc_out.Kp % 128 == 0 and ly.out.Kp % 128 == 0 and ly.mlp_adapter[0].Kp % 128 == 0)
+            if grouped and not w8_on and ly.fc_dn is None and ly.out_up is not None:
+                # MAGMA_DECODE_FOLD=2: attention || fc_out (context row lands in st.ctx_t), adapter-down alone, [W_out | W_up] GEMV
+                r = ly.mlp_adapter[0].N
+                ctx, t = st.ctx_t[:, : self.d], st.ctx_t[:, self.d: self.d + r]
+                ops.decode_attn_gemv(st.qkv, cache.k[li], cache.v[li], ctx, B, self.H, cache.d_pos, self.rot, self.sin_t, self.cos_t,
+                                     (st.h, ly.fc_out, st.m, {}))
+                ops.gemm_skinny(st.m, ly.mlp_adapter[0], out=t, act=ops.MG_ACT_RELU)
+                ops.gemm_skinny(st.ctx_t[:, : self.d + r], ly.out_up, out=xn, residuals=(st.m, x))
+                x, xn = xn, x
+                continue
             if grouped and not w8_on and ly.fc_dn is not None:
                 # three launches (fold_dn).  launch 2: attention || [fc_out ; W_dn W_fc_out]: m and the adapter bottleneck t
                 # from ONE pass over h; the context row lands beside t in st.ctx_t

@@ -156,9 +156,9 @@ def test_greedy_ids_batch8_margin_rule(full):
     assert n_safe >= 0.75 * 8 * steps, n_safe
 
 
-@pytest.mark.parametrize("B", [2, 8, 16])
-def test_folded_three_launch_block_vs_four_launch_block_and_oracle(full, B):
-    """MAGMA_DECODE_FOLD (default): the cached MAGMA_v1 block as THREE dependent launches -- the adapter's down-projection
+@pytest.mark.parametrize("B,mode", [(2, 1), (8, 1), (16, 1), (8, 2)])
+def test_folded_three_launch_block_vs_four_launch_block_and_oracle(full, B, mode):
+    """MAGMA_DECODE_FOLD=1 (opt-in: parity-green, measured slower -- engine.py; mode 2 = only the K-concatenation): the cached MAGMA_v1 block as THREE dependent launches -- the adapter's down-projection
     multiplied through fc_out offline ([W_fc ; W_dn W_fc], bottleneck t as a second output segment of the fc_out launch) and the
     up-projection K-concatenated with out_proj ([W_out | W_up] over [ctx | t]) -- against the four-launch block (the
     reference's association order, reference adapters.py:38-39) AND against the fp32 oracle: a re-association of the same
@@ -173,14 +173,14 @@ def test_folded_three_launch_block_vs_four_launch_block_and_oracle(full, B):
 
     def run(fold):
         eng = LMEngine(model.lm)
-        eng.fold_dn = fold
+        eng.fold_dn = mode if fold else 0
         out = eng.forward(inputs_embeds=emb, use_cache=True, cache_hint=steps + 4, eos_token=cfg.eos_token)
         cache, toks, lgs = out.past_key_values, [out.next_token.clone()], []
         for _ in range(steps - 1):            # eager step, graph capture, graph replays
             lg, tk = eng.decode(None, cache)
             toks.append(tk.clone())
             lgs.append(lg.float().cpu().clone())
-        assert (eng.layers[0].fc_dn is not None) == fold
+        assert (eng.layers[0].out_up is not None) == fold and (eng.layers[0].fc_dn is not None) == (fold and mode == 1)
         return torch.stack(toks, 1).cpu(), lgs
 
     t4, l4 = run(False)
