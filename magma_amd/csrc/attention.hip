@@ -113,156 +113,23 @@ __global__ __launch_bounds__(256) void rotary_split_kernel(
 constexpr int FA_STAGE = ROW_TILE + T_TILE;   // K rows | V^T
 constexpr int FA_STAGES = 4;
 
-__global__ __launch_bounds__(512) void attn_prefill_kernel(
-    const mg_bf16* __restrict__ q, const mg_bf16* __restrict__ kcache,
-    const mg_bf16* __restrict__ vt, mg_bf16* __restrict__ out, float* __restrict__ lse,
-    int B, int H, int S, int Smax, int vt_ld, float defer) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int li = lane & 15, lq = lane >> 4;
-  // all query blocks of one (b,h) on ONE XCD: its K / V^T stream is re-read from that XCD's L2
-  const int nblk = (S + 127) >> 7;
-  const int wg = xcd_contiguous_index(blockIdx.x, gridDim.x);
-  const int bh = wg / nblk, b = bh / H, h = bh - b * H;
-  const int qt0 = (nblk - 1 - (wg - bh * nblk)) * 128;   // longest blocks first
-  const int qrow = qt0 + wave * 16 + li;       // this lane's query
-  const int qrow_c = min(qrow, S - 1);
-  const mg_bf16* kbase = kcache + (int64_t)bh * Smax * DH;
-  const mg_bf16* vbase = vt + (int64_t)bh * DH * vt_ld;
-
-  const int kv_end = min(S, qt0 + 128);          // causal: keys <= last query of the block
-  const int ntiles = (kv_end + 31) >> 5;
-  const uint32_t smem_u = lds_u32(smem);
-  auto issue = [&](int t, int buf) {
-    const int c0 = min(t, ntiles - 1) * 32;
-    const uint32_t st = smem_u + (uint32_t)(buf * FA_STAGE);
-    dma_rows(st, kbase, DH, c0, S, wave, lane);
-    dma_cols(st + ROW_TILE, vbase, vt_ld, c0, wave, lane);
-  };
-#pragma unroll
-  for (int i = 0; i < FA_STAGES - 1; ++i) issue(i, i);
-
-  // Q fragments (B operand of S^T): Q[q][ks*32 + lq*8 .. +7]
-  bf16x8 qf[8];
-  {
-    const mg_bf16* qp = q + ((int64_t)bh * S + qrow_c) * DH + lq * 8;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 32);
-  }
-  f32x4 o[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float m2 = -1e30f;   // running max in log2 domain
-  float lsum = 0.f;    // this lane's partial row sum (its 8 keys per tile)
-  const float sc2 = 0.0625f * 1.4426950408889634f;  // 1/sqrt(256) * log2(e)
-  const int my_last = qt0 + wave * 16 + 15;     // key tiles past this wave's last query are fully masked
-  const int tsw = t_swz(li);
-  const int krow0 = (li >> 2) * 8 + (li & 3);
-  const int sw0 = row_swz(krow0);
-
-  int sc = 0;
-  MG_USE8(qf);                        // retire the q loads in hipcc's scoreboard: it cannot see the asm DMA waits below and
-                                      // would otherwise wait for "its" loads inside the loop with counts that drain the ring
-  for (int t = 0; t < ntiles; ++t) {
-    MG_WAIT_VMCNT(8);                 // this wave's pieces of tile t landed (tiles t+1, t+2 may be in flight)
-    MG_BARRIER_KEEP_DMA();            // tile t complete; everyone is done with tile t-1
-    issue(t + FA_STAGES - 1, sc == 0 ? FA_STAGES - 1 : sc - 1);
-    const int kv0 = t * 32;
-    if (kv0 <= my_last) {
-      const char* kp = smem + sc * FA_STAGE + krow0 * 512;
-      const char* tp = smem + sc * FA_STAGE + ROW_TILE + li * 64 + ((lq ^ tsw) << 4);
-      bf16x8 fa[8], fb[8];
-      f32x4 st[2];
-      rd_row8(fa, kp, lq, sw0);                    // K keys tt=0
-      rd_row8(fb, kp + 4 * 512, lq, sw0);          // K keys tt=1
-      MG_SCHED_FENCE();
-      st[0] = mma8(fa, qf);
-      MG_SCHED_FENCE();
-      rd_t8(fa, tp);                               // V^T d-tiles 0..7
-      MG_SCHED_FENCE();
-      st[1] = mma8(fb, qf);
-      MG_SCHED_FENCE();
-      // lane holds keys kv0 + lq*8 + j, j = tt*4 + r, for query li.  Only the diagonal tiles of this wave (and the
-      // ragged last tile) need the mask: a masked score of -1e30 turns into exp2(-huge) = 0 further down.
-      float sv[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) sv[j] = st[j >> 2][j & 3];
-      if (kv0 + 31 > qt0 + wave * 16 || kv0 + 32 > S) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int key = kv0 + lq * 8 + j;
-          sv[j] = (key > qrow || key >= S) ? -1e30f : sv[j];
-        }
-      }
-      float tmax = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
-      tmax = quad_rows_max(tmax);                    // over the 4 key-slot lanes of this query (VALU lane swaps)
-      const float cand = tmax * sc2;                 // key 0 is visible to every query: finite from the first tile on
-      const float mnew = (cand > m2 + defer) ? cand : m2;   // defer == 0: plain running max; > 0: deferred (see FA2_DEFER)
-      const float alpha = __builtin_amdgcn_exp2f(m2 - mnew);
-      m2 = mnew;
-      float p[8];
-      float psum = 0.f;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        p[j] = __builtin_amdgcn_exp2f(fmaf(sv[j], sc2, -mnew));
-        psum += p[j];
-      }
-      lsum = lsum * alpha + psum;
-      u32x4 pw;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) pw[j] = pack2bf(p[2 * j], p[2 * j + 1]);
-      const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
-      MG_SCHED_FENCE();
-      rd_t8(fb, tp + 8 * 1024);                    // V^T d-tiles 8..15 land under the first 8 MFMAs
-      MG_SCHED_FENCE();
-      // ---- O^T = O^T * alpha + V^T P^T  (the rescale is skipped while no running max moved) ----
-      if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
-#pragma unroll
-        for (int dt = 0; dt < 16; ++dt) o[dt] *= alpha;
-      }
-#pragma unroll
-      for (int dt = 0; dt < 8; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[dt], pf, o[dt], 0, 0, 0);
-      MG_SCHED_FENCE();
-#pragma unroll
-      for (int dt = 0; dt < 8; ++dt) o[8 + dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[dt], pf, o[8 + dt], 0, 0, 0);
-    }
-    sc = sc == FA_STAGES - 1 ? 0 : sc + 1;
-  }
-  MG_WAIT_VMCNT(0);                   // drain the ring's trailing loads before the wave retires
-  // row sum across the 4 key-slot lanes of this query
-  lsum = quad_rows_sum(lsum);
-  if (qrow < S) {
-    const float inv = 1.0f / lsum;
-    mg_bf16* op = out + (int64_t)(b * S + qrow) * (H * DH) + h * DH + lq * 4;
-#pragma unroll
-    for (int dt = 0; dt < 16; ++dt) {
-      u32x2 w;
-      w[0] = pack2bf(o[dt][0] * inv, o[dt][1] * inv);
-      w[1] = pack2bf(o[dt][2] * inv, o[dt][3] * inv);
-      *(u32x2*)(op + dt * 16) = w;
-    }
-    if (lse && lq == 0) lse[(int64_t)bh * S + qrow] = (m2 + log2f(lsum)) * 0.6931471805599453f;
-  }
-}
-
 constexpr float FA2_DEFER = 8.0f;                   // log2 units: rescale only when the running max grows by more than 256x (guide T13)
 
 // ---------------------------------------------------------------------------
-// flash attention forward, software-pipelined across KV tiles (round 4; the default).
+// The kernel: software-pipelined across KV tiles (round 4).
 //
-// attn_prefill_kernel above runs a tile's four parts as ONE dependent chain per wave -- K reads -> S^T MFMAs -> softmax VALU
-// (~100 instructions, several dependent reductions) -> PV MFMAs -- and the two waves of a SIMD do so in lock-step behind the
-// per-tile barrier, so the matrix pipe idles through every softmax and the VALU through every MFMA burst (PMC, round 3:
-// MFMA pipe 0.30-0.34 busy with no pipe above 0.35).  Here the softmax of a tile is split in two halves that each sit beside
-// an MFMA burst of ANOTHER tile (the "att[2]" pipeline of the guide, T15):
+// Rounds 1-3 ran a tile's four parts as ONE dependent chain per wave -- K reads -> S^T MFMAs -> softmax VALU (~100
+// instructions, several dependent reductions) -> PV MFMAs (git history: attn_prefill_kernel; 0.926-0.953 ms per layer at
+// B = 16, S = 2048 against 0.901-0.949 for this one in the same runs, profiles/r04_attention_fwd_variants.txt).  Here the
+// softmax of a tile is split in two halves that each sit beside an MFMA burst of ANOTHER tile (the "att[2]" pipeline of the
+// guide, T15):
 //     iteration t:   [ K(t+1) fragment reads  ||  part 2 of softmax(t): exp2, row sums, bf16 pack ]
 //                    [ S^T(t+1) = K(t+1) Q^T  : 16 MFMAs        ||  V^T(t) fragment reads          ]
 //                    [ O^T += V^T(t) P^T(t)   : 16 MFMAs        ||  part 1 of softmax(t+1): mask, row max, new running
 //                                                                    max, rescale factor (VALU placed between the MFMAs) ]
 // so a wave's chain per tile is  K reads -> 16 MFMAs -> 16 MFMAs  and the exponentials are off it.  Same arithmetic in the
-// same order per query as attn_prefill_kernel (same tiles, same deferred running max, same accumulation order): results
-// are bit-identical to it.  The K tile is read one iteration earlier than before, so the ring is waited one tile deeper
+// same order per query as the chain form (same tiles, same deferred running max, same accumulation order): bit-identical
+// results (every attention test of rounds 1-3 passes unchanged).  The K tile is read one iteration earlier than before, so the ring is waited one tile deeper
 // (tile t+1 complete at the top of iteration t; tiles t+2, t+3 in flight afterwards).
 // T13 (deferred max) order: P(t) is exponentiated against the maximum decided for tile t, O / l are rescaled by alpha(t)
 // BEFORE P(t) V(t) is added, and alpha(t+1) -- decided while P(t) V(t) is still in the pipe -- is applied in iteration t+1,
@@ -494,12 +361,11 @@ extern "C" int mg_attn_prefill_bf16(const mg_bf16* q, const mg_bf16* kcache, con
   // 16-query waves x 8 (two per SIMD), deferred running max: 0.90 ms per layer at B = 16, S = 2048.  MAGMA_ATTN_FWD=0 keeps the
   // plain running max (1.00 ms).  The 32-query-wave structure on the 32x32x16 MFMA measured slower (1.10 ms,
   // profiles/r02_attention_variants.txt) and is gone from the library (git history: attn_prefill32_kernel).
-  // MAGMA_ATTN_FWD: 4 (default) = software-pipelined across KV tiles; 3 = one dependent chain per tile (round 1-3); 0 = that
-  // with the plain running max.  All three give identical bits per defer setting.
+  // MAGMA_ATTN_FWD=0: plain running max instead of the deferred one (guide T13; 1.00 vs 0.95 ms in round 2)
   static const int variant = [] { const char* e = getenv("MAGMA_ATTN_FWD"); return e ? atoi(e) : 4; }();
+  const float defer = variant == 0 ? 0.0f : FA2_DEFER;
   const int lds = FA_STAGES * FA_STAGE;
-  const void* fn = variant == 4 ? (const void*)attn_prefill_sp_kernel<0> : (const void*)attn_prefill_kernel;
-  if (int rc = mg_allow_dynamic_lds(fn, lds, "mg_attn_prefill_bf16")) return rc;
+  if (int rc = mg_allow_dynamic_lds((const void*)attn_prefill_sp_kernel<0>, lds, "mg_attn_prefill_bf16")) return rc;
   dim3 grid((unsigned)(((S + 127) / 128) * B * H));
 #ifdef MG_GEMM_ABLATIONS      // `make ABL=1`: timing ablations of the pipelined kernel (WRONG results), MAGMA_ATTN_ABL=1..5
   {
@@ -508,7 +374,7 @@ extern "C" int mg_attn_prefill_bf16(const mg_bf16* q, const mg_bf16* kcache, con
 #define MG_ABL(N_)                                                                                                    \
     if (abl == N_) {                                                                                                  \
       if (int rc = mg_allow_dynamic_lds((const void*)attn_prefill_sp_kernel<N_>, lds, "mg_attn_prefill_bf16")) return rc; \
-      hipLaunchKernelGGL(attn_prefill_sp_kernel<N_>, grid, dim3(512), lds, (hipStream_t)stream, q, kcache, vt, out, lse, B, H, S, Smax, vt_ld, FA2_DEFER); \
+      hipLaunchKernelGGL(attn_prefill_sp_kernel<N_>, grid, dim3(512), lds, (hipStream_t)stream, q, kcache, vt, out, lse, B, H, S, Smax, vt_ld, defer); \
       MG_CHECK_LAUNCH();                                                                                              \
       return MG_OK;                                                                                                   \
     }
@@ -516,11 +382,7 @@ extern "C" int mg_attn_prefill_bf16(const mg_bf16* q, const mg_bf16* kcache, con
 #undef MG_ABL
   }
 #endif
-  if (variant == 4)
-    hipLaunchKernelGGL(attn_prefill_sp_kernel<0>, grid, dim3(512), lds, (hipStream_t)stream, q, kcache, vt, out, lse, B, H, S, Smax, vt_ld, FA2_DEFER);
-  else
-    hipLaunchKernelGGL(attn_prefill_kernel, grid, dim3(512), lds, (hipStream_t)stream, q, kcache, vt, out, lse, B, H, S, Smax, vt_ld,
-                       variant == 0 ? 0.0f : FA2_DEFER);
+  hipLaunchKernelGGL(attn_prefill_sp_kernel<0>, grid, dim3(512), lds, (hipStream_t)stream, q, kcache, vt, out, lse, B, H, S, Smax, vt_ld, defer);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }

@@ -148,18 +148,19 @@ class LMEngine:
         self._dec_in_variant = int(os.environ.get("MAGMA_DEC_IN_VARIANT", "0"))   # tuning knob: nt | waves<<4 | kc<<8
         self._side_stream = torch.cuda.Stream(device=dev)
         self.group_launches = os.environ.get("MAGMA_DECODE_GROUPED", "1") == "1"
-        # MAGMA_DECODE_FOLD (default 1): three dependent launches per MAGMA_v1 block instead of four.  The adapter's
-        # down-projection reads the MLP output m = W_fc h + b_fc, so t = relu(W_dn m + b_dn) = relu((W_dn W_fc) h + (W_dn b_fc +
-        # b_dn)): with W_dn W_fc multiplied out ONCE per weight set (fp32, rounded to bf16; +25 MB per block) the bottleneck
-        # comes out of the fc_out launch as a second output segment, and the up-projection shares a launch with out_proj as ONE
-        # GEMV over the concatenated input [ctx | t] against [W_out | W_up]  (x' = that + b_up + m + x: the same sum the
-        # reference forms, reference adapters.py:38-39, in another association order -- the 2 x eager-bf16 criterion and the
-        # exact-greedy-id tests hold, tests/test_fullwidth_gpu.py, test_fulldepth_gpu.py).  0 = the four-launch block.
-        # Measured (round 4, profiles/r04_decode_fold_*): the fold is SLOWER, 2.70 vs 2.53 ms per token -- the co-launch grows from
-        # 256 to 320 weight tiles of 512 KB on 256 CUs (41.4 us against 29.6; a CU streams at a fixed rate, so a quarter of them
-        # now take two tiles' time), which costs more than the [W_out | W_up] launch saves (9.7 us against 13.2 + 5.0).  Mode 2
-        # keeps only the K-concatenation: attention || fc_out, adapter-down alone, then [W_out | W_up].  Default 0.
-        self.fold_dn = int(os.environ.get("MAGMA_DECODE_FOLD", "0"))
+        # MAGMA_DECODE_FOLD -- how the adapter of a MAGMA_v1 block is laid over the block's launches (round 4):
+        #   0  four launches as in rounds 1-3: [ln_1+qkv+fc_in] -> [attention || fc_out] -> [out_proj || adapter-down] -> [adapter-up]
+        #   2  (default) the up-projection shares a launch with out_proj as ONE GEMV over the concatenated input [ctx | t] against
+        #      [W_out | W_up]:  ... -> [attention || fc_out] -> [adapter-down] -> [[W_out | W_up]]: x' = that + b_up + m + x.  Same
+        #      bytes, same launch count, 2.500 against 2.522-2.528 ms per token (the 8 MB up-projection no longer pays a
+        #      launch of its own; adapter-down alone costs what the co-launch with out_proj hid).
+        #   1  THREE launches: the down-projection multiplied through fc_out offline -- t = relu(W_dn m + b_dn), m = W_fc h + b_fc,
+        #      so t = relu((W_dn W_fc) h + (W_dn b_fc + b_dn)), a second output segment of the fc_out launch (+25 MB per block).
+        #      Parity-green (re-association only: tests/test_fullwidth_gpu.py) and SLOWER, 2.70 ms per token: the co-launch grows
+        #      from 256 to 320 weight tiles of 512 KB on 256 CUs and takes 41.4 us instead of 29.6 (a quarter of the CUs stream two
+        #      tiles), more than the merged [W_out | W_up] launch saves (9.7 us for 13.2 + 5.0).  profiles/r04_decode_block_variants.txt
+        # The reference forms the same sum (reference adapters.py:38-39) in another association order.
+        self.fold_dn = int(os.environ.get("MAGMA_DECODE_FOLD", "2"))
         self.fuse_in = os.environ.get("MAGMA_PREFILL_FUSE_IN", "1") == "1"      # [qkv | fc_in] as one prefill GEMM
         self.two_streams = os.environ.get("MAGMA_DECODE_STREAMS", "1") == "2"   # measured slower (3.07 vs 2.94 ms/step): off
 
@@ -314,8 +315,19 @@ class LMEngine:
                 inputs_embeds = self.embed_ids(input_ids)
             return self.forward_loss(inputs_embeds, labels, output_hidden_states, return_logits)
         if past_key_values is not None:
-            if not feed_back and (input_ids is None or input_ids.shape[1] != 1):
-                raise NotImplementedError("cached decoding takes one new token id per sequence (reference sampling.py:88-90)")
+            if not feed_back and input_ids is None:
+                raise ValueError("cached decoding takes input_ids (reference sampling.py:88-90)")
+            if not feed_back and input_ids.shape[1] != 1:
+                # several new tokens against the cache (the reference LM takes any input_ids length with past_key_values; its
+                # generate() only ever sends one, sampling.py:86-90): the causal mask makes this exactly T single-token steps in
+                # order, each appending its K / V -- run as such, logits (B, T, V) stacked
+                T = input_ids.shape[1]
+                rows = []
+                for i in range(T):
+                    lg, tok = self.decode(input_ids[:, i:i + 1], past_key_values, sampling=sampling if i == T - 1 else None)
+                    rows.append(lg.clone())
+                return LMOutput(logits=torch.stack(rows, 1), past_key_values=past_key_values, next_token=tok, loss=None,
+                                eos_state=past_key_values.sample_state)
             logits, tok = self.decode(None if feed_back else input_ids, past_key_values, sampling=sampling)
             return LMOutput(logits=logits.unsqueeze(1), past_key_values=past_key_values, next_token=tok, loss=None,
                             eos_state=past_key_values.sample_state)

@@ -200,3 +200,24 @@ def test_full_logits_path(setup):
 def test_smoke_entry():
     import __graft_entry__ as g
     g.smoke()
+
+
+def test_multi_token_cached_step(setup):
+    """lm(input_ids=(B, T), past_key_values=...) with T > 1: the reference LM accepts any number of new tokens against the cache
+    (its generate() sends one, sampling.py:86-90).  Logits of all T positions against the oracle's single call with the same
+    T tokens and the same past; the cache afterwards continues like one that took the tokens one by one."""
+    from oracle.model import embed, lm_forward
+    cfg, p, model, images, ids = setup
+    pb = bf16_params(p)
+    emb_ref = embed(p, cfg, [images, ids])
+    g = torch.Generator().manual_seed(77)
+    new = torch.randint(0, 1000, (2, 3), generator=g)
+    r0 = lm_forward(p, cfg, inputs_embeds=emb_ref)
+    ref = lm_forward(p, cfg, input_ids=new, past=r0["past_key_values"])["logits"]
+    rb0 = lm_forward(pb, cfg, inputs_embeds=emb_ref.to(torch.bfloat16))
+    eb = rel(lm_forward(pb, cfg, input_ids=new, past=rb0["past_key_values"])["logits"], ref)
+    out = model.lm(inputs_embeds=emb_ref.to(torch.bfloat16).cuda(), use_cache=True, cache_hint=8)
+    o = model.lm(input_ids=new.cuda(), use_cache=True, past_key_values=out.past_key_values)
+    assert o.logits.shape == ref.shape == (2, 3, cfg.vocab_out)
+    check(rel(o.logits, ref), eb, "3-token cached step logits")
+    assert o.past_key_values.pos == emb_ref.shape[1] + 3
