@@ -164,13 +164,13 @@ def decode_gemv_jobs(eng, st):
         algo += 2 * (ly.dec_in.N * ly.dec_in.K + ly.out.N * ly.out.K + ly.fc_out.N * ly.fc_out.K)
         if ly.mlp_adapter:
             algo += 2 * sum(a.N * a.K for a in ly.mlp_adapter)
-        if getattr(ly, "fc_dn", None) is not None:
+        if eng.fold_dn == 1 and getattr(ly, "fc_dn", None) is not None:
             r = ly.mlp_adapter[0].N
             t = st.ctx_t[:, eng.d: eng.d + r]
             add(lambda ly=ly, t=t: ops.gemm_skinny(st.h, ly.fc_dn, out=st.m, split=(eng.d, t, ops.MG_ACT_RELU, ly.fc_dn.bias_b)), ly.fc_dn)
             add(lambda ly=ly, r=r: ops.gemm_skinny(st.ctx_t[:, : eng.d + r], ly.out_up, out=st.xb, residuals=(st.m, st.xa)), ly.out_up)
             continue
-        if getattr(ly, "out_up", None) is not None:      # MAGMA_DECODE_FOLD=2: only the K-concatenated [W_out | W_up]
+        if eng.fold_dn == 2 and getattr(ly, "out_up", None) is not None:      # MAGMA_DECODE_FOLD=2: only the K-concatenated [W_out | W_up]
             r = ly.mlp_adapter[0].N
             add(lambda ly=ly: ops.gemm_skinny(st.h, ly.fc_out, out=st.m), ly.fc_out)
             add(lambda ly=ly, r=r: ops.gemm_skinny(st.m, ly.mlp_adapter[0], out=st.ctx_t[:, eng.d: eng.d + r], act=ops.MG_ACT_RELU), ly.mlp_adapter[0])

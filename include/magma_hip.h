@@ -64,7 +64,7 @@ const char* mg_version(void);
 /* Binary interface revision.  A binder built against another revision must not call into the library: arguments moved.
  *   1  rounds 1-3.  Within it (before this counter existed) three signatures changed: mg_epilogue._pad became act_n0;
  *      mg_rotary_split_bf16 gained ld_qkv as its 2nd argument; mg_sample_f32's top_p went from float to double.
- *   2  round 4: mg_decode_attn_gemv_bf16 gained ld_attn_out (5th argument); removed: mg_decode_attn_2gemv_bf16,
+ *   2  round 4: mg_decode_attn_gemv_bf16 gained ld_attn_out (5th argument), mg_attn_prefill_bf16 gained ld_out (5th); removed: mg_decode_attn_2gemv_bf16,
  *      mg_decode_ctx_counter_ints, the persistent decode step's four entry points mg_decode_plan_* / mg_decode_step_* (in-launch hand-off
  *      experiments, measured slower than the launch chain: DESIGN.md 8).                                                        */
 #define MG_ABI_VERSION 2
@@ -250,6 +250,7 @@ int mg_rotary_split_train_bf16(const mg_bf16* qkv, int32_t B, int32_t S, int32_t
  * online softmax, scale 1/16.  q [B,H,S,256]; k rows from kcache [B,H,Smax,256];
  * vt [B,H,vt_ld/32,256,32]; out [B*S, H*256].  lse (nullable) [B,H,S] fp32.         */
 int mg_attn_prefill_bf16(const mg_bf16* q, const mg_bf16* kcache, const mg_bf16* vt, mg_bf16* out,
+                         int64_t ld_out /* row stride of out in elements; 0 = H*256 (ABI 2: see mg_decode_attn_gemv_bf16) */,
                          float* lse, int32_t B, int32_t H, int32_t S, int32_t Smax, int32_t vt_ld,
                          void* stream);
 

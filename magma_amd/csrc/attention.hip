@@ -141,7 +141,7 @@ constexpr float FA2_DEFER = 8.0f;                   // log2 units: rescale only 
 template <int ABL = 0>
 __global__ __launch_bounds__(512) void attn_prefill_sp_kernel(
     const mg_bf16* __restrict__ q, const mg_bf16* __restrict__ kcache,
-    const mg_bf16* __restrict__ vt, mg_bf16* __restrict__ out, float* __restrict__ lse,
+    const mg_bf16* __restrict__ vt, mg_bf16* __restrict__ out, int64_t ld_out, float* __restrict__ lse,
     int B, int H, int S, int Smax, int vt_ld, float defer) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(512) void attn_prefill_sp_kernel(
   lsum = quad_rows_sum(lsum);
   if (qrow < S) {
     const float inv = 1.0f / lsum;
-    mg_bf16* op = out + (int64_t)(b * S + qrow) * (H * DH) + h * DH + lq * 4;
+    mg_bf16* op = out + (int64_t)(b * S + qrow) * ld_out + h * DH + lq * 4;
 #pragma unroll
     for (int dt = 0; dt < 16; ++dt) {
       u32x2 w;
@@ -351,9 +351,11 @@ extern "C" int mg_rotary_split_train_bf16(const mg_bf16* qkv, int32_t B, int32_t
   return MG_OK;
 }
 
-extern "C" int mg_attn_prefill_bf16(const mg_bf16* q, const mg_bf16* kcache, const mg_bf16* vt, mg_bf16* out,
+extern "C" int mg_attn_prefill_bf16(const mg_bf16* q, const mg_bf16* kcache, const mg_bf16* vt, mg_bf16* out, int64_t ld_out,
                                     float* lse, int32_t B, int32_t H, int32_t S, int32_t Smax, int32_t vt_ld,
                                     void* stream) {
+  if (ld_out == 0) ld_out = (int64_t)H * DH;
+  if (ld_out < (int64_t)H * DH || (ld_out & 3)) MG_FAIL(MG_ERR_SHAPE, "mg_attn_prefill_bf16: ld_out must be 0 or a multiple of 4 >= H*256");
   if (B <= 0 || H <= 0 || S <= 0 || S > Smax) MG_FAIL(MG_ERR_SHAPE, "mg_attn_prefill_bf16: bad B/H/S/Smax");
   if ((vt_ld & 31) || vt_ld < ((S + 31) & ~31)) MG_FAIL(MG_ERR_SHAPE, "mg_attn_prefill_bf16: vt_ld must be a multiple of 32 and >= S");
   if (!q || !kcache || !vt || !out) MG_FAIL(MG_ERR_SHAPE, "mg_attn_prefill_bf16: null pointer");
@@ -374,7 +376,7 @@ extern "C" int mg_attn_prefill_bf16(const mg_bf16* q, const mg_bf16* kcache, con
 #define MG_ABL(N_)                                                                                                    \
     if (abl == N_) {                                                                                                  \
       if (int rc = mg_allow_dynamic_lds((const void*)attn_prefill_sp_kernel<N_>, lds, "mg_attn_prefill_bf16")) return rc; \
-      hipLaunchKernelGGL(attn_prefill_sp_kernel<N_>, grid, dim3(512), lds, (hipStream_t)stream, q, kcache, vt, out, lse, B, H, S, Smax, vt_ld, defer); \
+      hipLaunchKernelGGL(attn_prefill_sp_kernel<N_>, grid, dim3(512), lds, (hipStream_t)stream, q, kcache, vt, out, ld_out, lse, B, H, S, Smax, vt_ld, defer); \
       MG_CHECK_LAUNCH();                                                                                              \
       return MG_OK;                                                                                                   \
     }
@@ -382,7 +384,7 @@ extern "C" int mg_attn_prefill_bf16(const mg_bf16* q, const mg_bf16* kcache, con
 #undef MG_ABL
   }
 #endif
-  hipLaunchKernelGGL(attn_prefill_sp_kernel<0>, grid, dim3(512), lds, (hipStream_t)stream, q, kcache, vt, out, lse, B, H, S, Smax, vt_ld, defer);
+  hipLaunchKernelGGL(attn_prefill_sp_kernel<0>, grid, dim3(512), lds, (hipStream_t)stream, q, kcache, vt, out, ld_out, lse, B, H, S, Smax, vt_ld, defer);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }

@@ -388,7 +388,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 // 1 = every K-tile's DMA reads K-tile (t & 1) (operands always L2-hot: isolates memory latency), 2 = no fragment reads after
 // the first two K-tiles (isolates the LDS read segments), 3 = no MFMA, 4 = no DMA after the prologue, 6 = the first DMA
 // schedule (correct results), 7 = no epilogue, 8 = epilogue staging only, 10 = every tile stores to tile (0, 0).
-template <int WLAYOUT, bool LATE_LGKM, bool FP8 = false, bool MFMA32 = false, int ABL = 0>
+template <int WLAYOUT, bool LATE_LGKM, bool FP8 = false, bool MFMA32 = false, int ABL = 0, bool SPLITK = false>
 __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   static_assert(!(FP8 && MFMA32), "the 32x32 form is the bf16 path");
   bool abl_on = true;           // ABL 2 / 4: false once the pipeline is primed
@@ -398,10 +398,17 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int tm, tn;
-  tile_coords(blockIdx.x, p.tiles_m, p.tiles_n, tm, tn, p.group_m);
+  // split-K (long contractions with few output tiles -- the adapters' weight gradients over B*S rows): blocks
+  // [sp * tiles, (sp + 1) * tiles) reduce K-tiles [sp * kt_per, (sp + 1) * kt_per) into fp32 slab sp of the workspace through a
+  // plain epilogue (set up by the host); splitk_fixup_kernel adds the slabs in a fixed order and runs the real epilogue.
+  // (SPLITK is its own instantiation: the extra scalars cost the fp8 form, which lives at the register limit, 320 bytes of scratch)
+  int bid = blockIdx.x, sp = 0;
+  if constexpr (SPLITK) { const int tiles = p.tiles_m * p.tiles_n; sp = bid / tiles; bid -= sp * tiles; }
+  tile_coords(bid, p.tiles_m, p.tiles_n, tm, tn, p.group_m);
   const int m0 = tm * 256, n0 = tn * 256;
-  const int nkt = p.K >> 6;                       // even (K % 128 == 0)
-#define KT_SRC(kt) (ABL == 1 ? ((kt) & 1) : (kt))
+  const int nkt = SPLITK ? p.kt_per : p.K >> 6;     // even (K % 128 == 0; the host picks an even kt_per)
+  const int kt0 = SPLITK ? sp * p.kt_per : 0;
+#define KT_SRC(kt) (ABL == 1 ? ((kt) & 1) : (kt0 + (kt)))
   const int wr = wave >> 2, wc = wave & 3;        // wr is also the wave group
   const int li = lane & 15, lq = lane >> 4;
 
@@ -759,7 +766,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   // Barriers here are RAW s_barrier + lgkmcnt(0): the hazards are LDS-only (staging writes vs row reads), and __syncthreads()
   // would add s_waitcnt vmcnt(0) -- with the stores of pass 0 outstanding that is a full store drain in the middle of the
   // epilogue (vmcnt counts stores on this chip).  For the same reason the per-column vectors are loaded once, before pass 0.
-  const bool wide = epilogue_wide_ok(p.ep);   // 16-byte accesses when every row start allows it
+  mg_epilogue ep = p.ep;                      // split-K: the host's slab epilogue, moved to this split's slab
+  if constexpr (SPLITK) ep.C = (float*)ep.C + (int64_t)sp * p.M * p.ldws;
+  const bool wide = epilogue_wide_ok(ep);   // 16-byte accesses when every row start allows it
   // ABL 11: 100-MHz time stamps of wave 0 into p.ws[blockIdx.x * 8 ..] (start, K loop done, staged 0, walked 0, staged 1, walked 1, drained)
   unsigned long long* stamps = (unsigned long long*)p.ws + (size_t)blockIdx.x * 8;
 #define MG_STAMP(i) if (ABL == 11 && tid == 0) stamps[i] = __builtin_amdgcn_s_memrealtime()
@@ -800,21 +809,21 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
     constexpr bool FULL = decltype(fullc_)::value;      // interior column tile: no per-element tail code
     EpiColsW<W> c;
     const int n = nb + (lane % (256 / W)) * W;
-    if (n < p.N) epilogue_cols<W>(p.ep, n, p.N, c);
+    if (n < p.N) epilogue_cols<W>(ep, n, p.N, c);
     // an epilogue without aux / residual operands walks its rows in a build of the loop that contains no global load
     // (interior bf16-output tiles only: W == 8 and FULL): nothing in it waits for the stores of the rows before
-    const bool loads = p.ep.aux_mode != MG_AUX_NONE || p.ep.res0 || p.ep.res1 || p.ep.res2;
+    const bool loads = ep.aux_mode != MG_AUX_NONE || ep.res0 || ep.res1 || ep.res2;
     stage(std::integral_constant<int, 0>{});
     MG_STAMP(2);
-    if (FULL && W == 8 && !loads) epilogue_rows_c<256, EPI256_ROWB, W, NT, FULL, false>(p.ep, c, smem, 128, 8, wave, lane, mb0, 128, nb, mlim, p.N, p.row_scale);
-    else epilogue_rows_c<256, EPI256_ROWB, W, NT, FULL>(p.ep, c, smem, 128, 8, wave, lane, mb0, 128, nb, mlim, p.N, p.row_scale);
+    if (FULL && W == 8 && !loads) epilogue_rows_c<256, EPI256_ROWB, W, NT, FULL, false>(ep, c, smem, 128, 8, wave, lane, mb0, 128, nb, mlim, p.N, p.row_scale);
+    else epilogue_rows_c<256, EPI256_ROWB, W, NT, FULL>(ep, c, smem, 128, 8, wave, lane, mb0, 128, nb, mlim, p.N, p.row_scale);
     MG_WAIT_LGKM0();
     MG_BAR();                                 // pass 0 has been read
     MG_STAMP(3);
     stage(std::integral_constant<int, 1>{});
     MG_STAMP(4);
-    if (FULL && W == 8 && !loads) epilogue_rows_c<256, EPI256_ROWB, W, NT, FULL, false>(p.ep, c, smem, 128, 8, wave, lane, mb0 + 64, 128, nb, mlim, p.N, p.row_scale);
-    else epilogue_rows_c<256, EPI256_ROWB, W, NT, FULL>(p.ep, c, smem, 128, 8, wave, lane, mb0 + 64, 128, nb, mlim, p.N, p.row_scale);
+    if (FULL && W == 8 && !loads) epilogue_rows_c<256, EPI256_ROWB, W, NT, FULL, false>(ep, c, smem, 128, 8, wave, lane, mb0 + 64, 128, nb, mlim, p.N, p.row_scale);
+    else epilogue_rows_c<256, EPI256_ROWB, W, NT, FULL>(ep, c, smem, 128, 8, wave, lane, mb0 + 64, 128, nb, mlim, p.N, p.row_scale);
     MG_STAMP(5);
     if (ABL == 11) {
       MG_WAIT_VM(0);
@@ -886,14 +895,31 @@ int group_m_256(int tiles_m, int tiles_n, int K) {
   return 4;
 }
 
-template <int WLAYOUT, bool LATE_LGKM, bool FP8 = false, bool MFMA32 = false, int ABL = 0>
+// the automatic rule for the un-split 256x256 kernel (enough tiles to fill the chip)
+inline bool want256_noforce(int tile_hint, int64_t wgs256, int M, int N) { return tile_hint == 0 && wgs256 >= 192 && M >= 1024 && N >= 512; }
+
+template <int WLAYOUT, bool LATE_LGKM, bool FP8 = false, bool MFMA32 = false, int ABL = 0, bool SPLITK = false>
 int launch_gemm256(GemmParams gp, hipStream_t s) {
-  if (int rc = mg_allow_dynamic_lds((const void*)gemm256_kernel<WLAYOUT, LATE_LGKM, FP8, MFMA32, ABL>, G256_LDS, "mg_gemm")) return rc;
+  if (int rc = mg_allow_dynamic_lds((const void*)gemm256_kernel<WLAYOUT, LATE_LGKM, FP8, MFMA32, ABL, SPLITK>, G256_LDS, "mg_gemm")) return rc;
+  if (SPLITK != (gp.splits > 1)) MG_FAIL(MG_ERR_SHAPE, "mg_gemm: internal: split-K form of the 256x256 kernel selected inconsistently");
   gp.tiles_m = (gp.M + 255) / 256; gp.tiles_n = (gp.N + 255) / 256;
   gp.group_m = group_m_256(gp.tiles_m, gp.tiles_n, gp.K);
   gp.a_kt = 64;
-  hipLaunchKernelGGL((gemm256_kernel<WLAYOUT, LATE_LGKM, FP8, MFMA32, ABL>), dim3(gp.tiles_m * gp.tiles_n), dim3(512), G256_LDS, s, gp);
+  const mg_epilogue real_ep = gp.ep;
+  if (gp.splits > 1) {      // the kernel writes raw fp32 partial sums: slab `sp` = ws + sp * M * ldws (rows of ldws floats)
+    mg_epilogue slab;
+    memset(&slab, 0, sizeof(slab));
+    slab.C = gp.ws; slab.ldc = gp.ldws; slab.out_f32 = 1;
+    gp.ep = slab;
+    gp.nt = 0;
+  }
+  hipLaunchKernelGGL((gemm256_kernel<WLAYOUT, LATE_LGKM, FP8, MFMA32, ABL, SPLITK>), dim3(gp.tiles_m * gp.tiles_n * gp.splits), dim3(512), G256_LDS, s, gp);
   MG_CHECK_LAUNCH();
+  if (gp.splits > 1) {
+    const int64_t quads = (int64_t)gp.M * ((gp.N + 3) >> 2);
+    hipLaunchKernelGGL(splitk_fixup_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, gp.ws, gp.splits, gp.M, gp.N, gp.ldws, real_ep, gp.row_scale);
+    MG_CHECK_LAUNCH();
+  }
   return MG_OK;
 }
 
@@ -957,6 +983,29 @@ int gemm_dispatch(const mg_gemm_desc* d, bool fp8, const float* row_scale, hipSt
   // bf16: 32x32x16 MFMA (tile_hint 258) or 16x16x32 (259); 0 / 256 follow MAGMA_GEMM256_MFMA (default below)
   static const int mfma_env = [] { const char* e = getenv("MAGMA_GEMM256_MFMA"); return e ? atoi(e) : MG_GEMM256_MFMA_DEFAULT; }();
   const bool mfma32 = !fp8 && (d->tile_hint == 258 || (d->tile_hint != 259 && d->tile_hint != 257 && mfma_env == 32));
+  // 256x256 kernel with split-K: too few 256x256 tiles to fill the chip but a LONG contraction (the adapters' weight gradients:
+  // 4096 x 1024 outputs over K = B*S = 32768 -> 64 tiles x 4 splits = 256 workgroups of 128 K-tiles each).  The 128x128 kernel
+  // with two splits ran these at 0.92 PF (298 us, profiles/r04_train_trace_by_grid.txt).  tile_hint 256 + split_k n forces it.
+  int split256 = 0;
+  if (can256 && !fp8 && d->workspace && d->split_k != 1 && d->a_mode == MG_A_DENSE && (d->tile_hint == 0 || d->tile_hint == 256) &&
+      !want256_noforce(d->tile_hint, wgs256, d->M, d->N)) {
+    const int nkt256 = gp.K >> 6;
+    const int64_t slab = (int64_t)d->M * (((d->N + 255) / 256) * 256) * 4;
+    int want = d->split_k;
+    if (want == 0 && d->tile_hint == 0 && wgs256 >= 32 && wgs256 < 192 && nkt256 >= 256 && d->M >= 512 && d->N >= 512) {
+      want = 1;
+      while (wgs256 * want * 2 <= 320 && want < 8) want *= 2;      // 192 .. 320 workgroups
+    }
+    if (want > 1 && nkt256 % (2 * want) == 0 && (int64_t)want * slab <= d->workspace_bytes && (d->tile_hint == 256 || want * wgs256 >= 192))
+      split256 = want;
+    else if (d->tile_hint == 256 && d->split_k > 1)
+      MG_FAIL(MG_ERR_SHAPE, "%s: the 256x256 kernel cannot split K=%d %d ways (needs K %% (128 * splits) == 0 and %lld bytes of workspace)", who, d->K, d->split_k, (long long)(want * slab));
+  }
+  if (split256 > 1) {
+    gp.splits = split256; gp.kt_per = (gp.K >> 6) / split256;
+    gp.ws = d->workspace; gp.ldws = (int64_t)((d->N + 255) / 256) * 256;
+    return rm ? launch_gemm256<MG_W_ROWMAJOR, false, false, false, 0, true>(gp, s) : launch_gemm256<MG_W_FRAGTILED, false, false, false, 0, true>(gp, s);
+  }
   if (can256 && want256) {
     if (d->tile_hint >= 261) {      // timing ablations / A-B variants of the bf16 kernel (tools/kbench.py abl, ksweep)
 #ifdef MG_GEMM_ABLATIONS            // `make ABL=1`: each one is another copy of the kernel and its epilogue (minutes of compile time)

@@ -162,6 +162,7 @@ class LMEngine:
         # The reference forms the same sum (reference adapters.py:38-39) in another association order.
         self.fold_dn = int(os.environ.get("MAGMA_DECODE_FOLD", "2"))
         self.fuse_in = os.environ.get("MAGMA_PREFILL_FUSE_IN", "1") == "1"      # [qkv | fc_in] as one prefill GEMM
+        self.cat_up = os.environ.get("MAGMA_PREFILL_CAT", "1") == "1"           # out_proj + adapter-up as one GEMM over [ctx | t]
         self.two_streams = os.environ.get("MAGMA_DECODE_STREAMS", "1") == "2"   # measured slower (3.07 vs 2.94 ms/step): off
 
     def _ensure_decode_packs(self):
@@ -186,25 +187,38 @@ class LMEngine:
         self.head_dec = ops.PackedLinear(w2, bias=b2)
         self.head_dec.colsum = cs
 
-    def _fold_adapter_down(self, ly):
-        """Decode-only operands of the three-launch block (self.fold_dn), or None where a block does not have the MAGMA_v1
-        shape (mlp adapter of the 'normal' type only, K % 128 == 0):
-          ly.fc_dn  = [W_fc_out ; W_dn W_fc_out]   (d + r rows over K = ff;  bias b_fc | W_dn b_fc + b_dn)
-          ly.out_up = [W_out | W_up]               (d rows over K = d + r;   bias b_up)"""
-        ly.fc_dn = ly.out_up = None
-        if self.fold_dn not in (1, 2) or ly.mlp_adapter is None or ly.attn_adapter is not None or ly.mlp_par is not None:
-            return
+    def _v1_block(self, ly) -> bool:
+        """MAGMA_v1 block shape: mlp adapter of the 'normal' type only, every K a multiple of 128."""
+        if ly.mlp_adapter is None or ly.attn_adapter is not None or ly.mlp_par is not None:
+            return False
         dn, up = ly.mlp_adapter
-        a, mlp = ly._src
-        if dn.N % 16 or (self.d + dn.N) % 128 or ly.fc_out.Kp % 128 or dn.K != self.d or up.K != dn.N or up.Kp != up.K:
+        return not (dn.N % 16 or (self.d + dn.N) % 128 or ly.fc_out.Kp % 128 or dn.K != self.d or up.K != dn.N or up.Kp != up.K)
+
+    def _ensure_out_up(self, ly):
+        """[W_out | W_up] (d rows over K = d + r, bias b_up) of a MAGMA_v1 block -- the operand of the ONE GEMM / GEMV that
+        replaces out_proj and the adapter's up-projection (prefill / forward blocks and the decode step) -- or None where a
+        block does not have that shape.  Built on first use, dropped by repack_adapters (it contains W_up)."""
+        if "out_up" not in ly.__dict__:
+            ly.out_up = None
+            if self._v1_block(ly):
+                a, _ = ly._src
+                up = ly.mlp_adapter[1]
+                w_up = ops.PackedLinear.untile(up.ft)[: up.N, : up.K]
+                ly.out_up = ops.PackedLinear(torch.cat([a.out_proj.weight.detach().to(BF16), w_up], dim=1), bias=up.bias)
+        return ly.out_up
+
+    def _fold_adapter_down(self, ly):
+        """Decode-only operand of the three-launch block (MAGMA_DECODE_FOLD=1), or None:
+          ly.fc_dn = [W_fc_out ; W_dn W_fc_out]   (d + r rows over K = ff;  bias b_fc | W_dn b_fc + b_dn)"""
+        ly.fc_dn = None
+        if self.fold_dn != 1 or not self._v1_block(ly):
             return
+        dn, _ = ly.mlp_adapter
+        _, mlp = ly._src
         w_fc, b_fc = mlp.c_proj.weight.detach().float(), mlp.c_proj.bias.detach().float()
         w_dn = ops.PackedLinear.untile(dn.ft)[: dn.N, : dn.K].float()
-        w_up = ops.PackedLinear.untile(up.ft)[: up.N, : up.K]
-        if self.fold_dn == 1:
-            ly.fc_dn = ops.PackedLinear(torch.cat([mlp.c_proj.weight.detach().to(BF16), (w_dn @ w_fc).to(BF16)], dim=0), bias=b_fc)
-            ly.fc_dn.bias_b = (w_dn @ b_fc + dn.bias).contiguous()
-        ly.out_up = ops.PackedLinear(torch.cat([a.out_proj.weight.detach().to(BF16), w_up], dim=1), bias=up.bias)
+        ly.fc_dn = ops.PackedLinear(torch.cat([mlp.c_proj.weight.detach().to(BF16), (w_dn @ w_fc).to(BF16)], dim=0), bias=b_fc)
+        ly.fc_dn.bias_b = (w_dn @ b_fc + dn.bias).contiguous()
 
     def _ensure_decode_packs_w8(self):
         """e4m3 copies of every decode operand (same LayerNorm folds; the fold's column sums are taken from the
@@ -249,7 +263,9 @@ class LMEngine:
                     ly.mlp_par = torch.full((self.d,), blk.mlp.scale_value(), dtype=torch.float32, device=ly.mlp_par.device)
             ly.fp8 = {}
             ly.__dict__.pop("up_cat", None)
-            if self.head_dec is not None:          # decode operands exist: the folded ones contain the adapter weights
+            ly.__dict__.pop("out_up", None)        # [W_out | W_up] contains the adapter weights: rebuilt on next use
+            ly.__dict__.pop("fc_dn", None)
+            if self.head_dec is not None:          # decode operands exist: rebuild the folded ones now
                 self._fold_adapter_down(ly)
 
     @staticmethod
@@ -374,7 +390,16 @@ class LMEngine:
         if cache is None:   # no cache requested: one scratch K/V shared by all layers
             kscr = torch.empty(B, self.H, S, 256, dtype=BF16, device=dev)
             vscr = torch.empty(B, self.H, S, 256, dtype=BF16, device=dev)
-        ctx = torch.empty(M, d, dtype=BF16, device=dev)
+        # MAGMA_v1 blocks (mlp adapter of the 'normal' type): out_proj and the adapter's up-projection are ONE GEMM over the
+        # concatenated input [ctx | t] against [W_out | W_up] -- x' = that + b_up + m + x, the sum the reference forms (reference
+        # adapters.py:38-39 + the block's residual) in another association order.  One launch, one epilogue and one (M, d)
+        # round trip (the attention output `a`) less per block; at M = 456 also one split-K fix-up less.  MAGMA_PREFILL_CAT=0: off.
+        r_cat = 0
+        if self.cat_up and not self.fp8_mode:
+            r_cat = max([ly.mlp_adapter[0].N for ly in self.layers if ly.mlp_adapter is not None and ly.attn_adapter is None
+                         and ly.mlp_par is None and self._ensure_out_up(ly) is not None] + [0])
+        ctx_t = torch.empty(M, d + r_cat, dtype=BF16, device=dev)
+        ctx = ctx_t[:, :d]
         hs = [x.view(B, S, d)] if want_hidden else None
         for li, ly in enumerate(self.layers):
             ln = ops.layernorm(x, ly.ln_g, ly.ln_b, self.eps)
@@ -393,6 +418,14 @@ class LMEngine:
             kc, vc = (cache.k[li], cache.v[li]) if cache is not None else (kscr, vscr)
             ops.rotary_split(qkv, B, S, self.H, self.rot, self.sin_t, self.cos_t, q, kc, vc, pos0=0, vt=vt)
             ops.attn_prefill(q, kc, vt, ctx, B, self.H, S, lse=None if lse_out is None else lse_out[li])
+            if r_cat and ly.__dict__.get("out_up") is not None and ly.mlp_adapter[0].N == r_cat:
+                h = h_fused if h_fused is not None else self._linear(ly, "fc_in", ly.fc_in, ln, lnq, act=ops.MG_ACT_GELU_NEW)
+                m = ops.gemm(h, ly.fc_out)
+                ops.gemm(m, ly.mlp_adapter[0], out=ctx_t[:, d:], act=ops.MG_ACT_RELU)
+                x = ops.gemm(ctx_t, ly.out_up, residuals=(m, x))
+                if want_hidden:
+                    hs.append(x.view(B, S, d))
+                continue
             a = self._linear(ly, "out", ly.out, ctx)
             if ly.attn_adapter is not None and ly.attn_par is not None:      # parallel: adapter reads the attention INPUT
                 sc, up = self._par_up(ly.attn_adapter[1], ly.attn_par)
@@ -532,7 +565,8 @@ class LMEngine:
             par = ly.mlp_par is not None or ly.attn_par is not None
             grouped = (not wide and self.group_launches and not par and ly.mlp_adapter is not None and ly.attn_adapter is None
                        and ly.fc_out.Kp % 128 == 0 and ly.out.Kp % 128 == 0 and ly.mlp_adapter[0].Kp % 128 == 0)
-            if grouped and not w8_on and ly.fc_dn is None and ly.out_up is not None:
+            out_up = self._ensure_out_up(ly) if (grouped and not w8_on and self.fold_dn in (1, 2)) else None
+            if out_up is not None and self.fold_dn == 2:
                 # MAGMA_DECODE_FOLD=2: attention || fc_out (context row lands in st.ctx_t), adapter-down alone, [W_out | W_up] GEMV
                 r = ly.mlp_adapter[0].N
                 ctx, t = st.ctx_t[:, : self.d], st.ctx_t[:, self.d: self.d + r]
@@ -542,7 +576,7 @@ class LMEngine:
                 ops.gemm_skinny(st.ctx_t[:, : self.d + r], ly.out_up, out=xn, residuals=(st.m, x))
                 x, xn = xn, x
                 continue
-            if grouped and not w8_on and ly.fc_dn is not None:
+            if out_up is not None and self.fold_dn == 1 and getattr(ly, "fc_dn", None) is not None:
                 # three launches (fold_dn).  launch 2: attention || [fc_out ; W_dn W_fc_out]: m and the adapter bottleneck t
                 # from ONE pass over h; the context row lands beside t in st.ctx_t
                 r = ly.mlp_adapter[0].N

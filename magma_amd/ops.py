@@ -363,7 +363,8 @@ def rotary_split_train(qkv, B, S, H, rot_dim, sin_t, cos_t, q, k, v, vt, qt, kt)
 
 def attn_prefill(q, kcache, vt, out, B, H, S, lse: Optional[torch.Tensor] = None):
     _need_gpu(q)
-    check(L.load().mg_attn_prefill_bf16(q.data_ptr(), kcache.data_ptr(), vt.data_ptr(), out.data_ptr(), _p(lse),
+    assert out.ndim == 2 and out.stride(1) == 1 and out.shape[1] == H * 256      # a column range of a wider row is fine
+    check(L.load().mg_attn_prefill_bf16(q.data_ptr(), kcache.data_ptr(), vt.data_ptr(), out.data_ptr(), out.stride(0), _p(lse),
                                         B, H, S, kcache.shape[2], vt.shape[2] * 32, _stream()), "mg_attn_prefill_bf16")
     return out
 

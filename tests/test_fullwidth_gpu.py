@@ -180,7 +180,7 @@ def test_folded_three_launch_block_vs_four_launch_block_and_oracle(full, B, mode
             lg, tk = eng.decode(None, cache)
             toks.append(tk.clone())
             lgs.append(lg.float().cpu().clone())
-        assert (eng.layers[0].out_up is not None) == fold and (eng.layers[0].fc_dn is not None) == (fold and mode == 1)
+        assert (getattr(eng.layers[0], "fc_dn", None) is not None) == (fold and mode == 1) and eng.layers[0].out_up is not None
         return torch.stack(toks, 1).cpu(), lgs
 
     t4, l4 = run(False)

@@ -500,3 +500,26 @@ def test_gemm_split_k(dev, layout):
         assert_close(ops.gemm(xn, linc, conv=(H, W, Cin), layout=layout, split_k=sk), refc, GEMM_TOL, f"conv split_k={sk}")
     with pytest.raises(Exception, match="split_k"):
         ops.gemm(a, lin, split_k=65)
+
+
+@pytest.mark.parametrize("M,N,K,split", [(4096, 1024, 32768, 0), (1024, 4096, 32768, 0), (1024, 1024, 4096, 2), (600, 520, 2048, 4), (4096, 1024, 32768, 4)])
+def test_gemm256_split_k(dev, M, N, K, split):
+    """The 256x256 kernel with the contraction cut across workgroups (round 4: the adapters' weight gradients, few output tiles over
+    K = B*S = 32768): fp32 slabs + the deterministic fix-up, against fp32 and against the 128x128 kernel; split = 0 lets the library
+    choose (it picks the split 256x256 form for the two wgrad shapes), otherwise tile 256 + split_k are forced; ragged M / N included;
+    two launches give identical bits."""
+    from magma_amd import ops
+    a = rnd(M, K, dev=dev, seed=500).to(BF16)
+    w = rnd(N, K, dev=dev, seed=501, scale=0.05).to(BF16)
+    bias = rnd(N, dev=dev, seed=502)
+    res = rnd(M, ops.ceil_to(N, 8), dev=dev, seed=503).to(BF16)[:, :N]
+    lin = ops.PackedLinear(w, bias=bias, tiled=True, rowmajor=True)
+    ref = a.float() @ w.float().t() + bias + res.float()
+    for layout in ("rm", "ft"):
+        kw = dict(layout=layout, residuals=(res,), out_dtype=torch.float32)
+        out = ops.gemm(a, lin, tile=256 if split else 0, split_k=split, **kw)
+        assert_close(out, ref, GEMM_TOL, f"gemm256 split-K {layout} {M}x{N}x{K} split {split}")
+        out2 = ops.gemm(a, lin, tile=256 if split else 0, split_k=split, **kw)
+        assert torch.equal(out, out2)
+        o128 = ops.gemm(a, lin, tile=128, **kw)
+        assert float((out - o128).abs().max()) <= 2e-3 * float(ref.abs().max())

@@ -15,5 +15,5 @@ for f in glob.glob(os.path.join(root, "**", "*kernel_trace.csv"), recursive=True
     tot = sum(v[0] for v in agg.values())
     span = int(rows[-1]["End_Timestamp"]) - int(rows[0]["Start_Timestamp"])
     print(f"== {len(rows)} launches, busy {tot/1e6:.3f} ms, span {span/1e6:.3f} ms")
-    for (n, g), (t, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:25]:
+    for (n, g), (t, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:int(os.environ.get("TOP", 25))]:
         print(f"{n:50s} grid={g:>9s} calls={c:5d} total_ms={t/1e6:8.3f} avg_us={t/c/1e3:8.2f}")
