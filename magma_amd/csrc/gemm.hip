@@ -987,7 +987,8 @@ int gemm_dispatch(const mg_gemm_desc* d, bool fp8, const float* row_scale, hipSt
   // 4096 x 1024 outputs over K = B*S = 32768 -> 64 tiles x 4 splits = 256 workgroups of 128 K-tiles each).  The 128x128 kernel
   // with two splits ran these at 0.92 PF (298 us, profiles/r04_train_trace_by_grid.txt).  tile_hint 256 + split_k n forces it.
   int split256 = 0;
-  if (can256 && !fp8 && d->workspace && d->split_k != 1 && d->a_mode == MG_A_DENSE && (d->tile_hint == 0 || d->tile_hint == 256) &&
+  static const bool split256_on = [] { const char* e = getenv("MAGMA_G256_SPLITK"); return !e || atoi(e) != 0; }();   // A/B knob
+  if ((split256_on || d->tile_hint == 256) && can256 && !fp8 && d->workspace && d->split_k != 1 && d->a_mode == MG_A_DENSE && (d->tile_hint == 0 || d->tile_hint == 256) &&
       !want256_noforce(d->tile_hint, wgs256, d->M, d->N)) {
     const int nkt256 = gp.K >> 6;
     const int64_t slab = (int64_t)d->M * (((d->N + 255) / 256) * 256) * 4;

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Decode A/B on one MI355X: token-step time of the full-size MAGMA_v1 graph for each knob setting given as arguments
 # ("NAME=VALUE[,NAME=VALUE...]" per run; "-" = defaults), then a kernel trace of the default step summarised per (kernel, grid).
-#   tools/gpu_decode_ab.sh - MAGMA_DECODE_CTXWAIT=0
+#   tools/gpu_decode_ab.sh - MAGMA_DECODE_FOLD=0
 cd "${GRAFT_REPO_ROOT:-.}"; ROOT=$(pwd); mkdir -p gpurun_out; export TMPDIR=/tmp
 OUT=$ROOT/gpurun_out/decode_ab.jsonl; : > $OUT
 for knobs in "$@"; do

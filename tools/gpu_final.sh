@@ -1,9 +1,9 @@
 #!/bin/bash
-# End-of-round evidence on one MI355X (ROUND=rNN, default r03): full GPU test suite, smoke, the default bench line, train.py
+# End-of-round evidence on one MI355X (ROUND=rNN, default r04): full GPU test suite, smoke, the default bench line, train.py
 # smoke, kernel-trace stats of the bench, the PMC FETCH_SIZE pass behind roofline.traffic, and per-(kernel, grid) traces of the
 # decode step, the prefill and one training step.  Everything lands in gpurun_out/; copy what is to be judged into profiles/.
-cd "${GRAFT_REPO_ROOT:-.}"; ROOT=$(pwd); mkdir -p gpurun_out; export TMPDIR=/tmp; R=${ROUND:-r03}
-timeout 1100 python -m pytest tests -q -m gpu > gpurun_out/${R}_final_pytest_gpu.log 2>&1; tail -3 gpurun_out/${R}_final_pytest_gpu.log
+cd "${GRAFT_REPO_ROOT:-.}"; ROOT=$(pwd); mkdir -p gpurun_out; export TMPDIR=/tmp; R=${ROUND:-r04}
+timeout 1500 python -m pytest tests -q -m gpu --durations=12 > gpurun_out/${R}_final_pytest_gpu.log 2>&1; tail -3 gpurun_out/${R}_final_pytest_gpu.log
 timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${R}_final_smoke.log 2>&1; tail -2 gpurun_out/${R}_final_smoke.log
 cd /tmp; rm -rf $ROOT/gpurun_out/pmc_dec
 timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $ROOT/gpurun_out/pmc_dec -o t -- python $ROOT/tools/pmc_decode_sweep.py > $ROOT/gpurun_out/pmc_dec.log 2>&1
@@ -25,5 +25,8 @@ rm -rf $ROOT/gpurun_out/prefill_trace; PHASE=prefill timeout 300 rocprofv3 --ker
 python $ROOT/tools/trace_by_grid.py $ROOT/gpurun_out/prefill_trace cast_f32_bf16 > $ROOT/gpurun_out/${R}_prefill_trace_by_grid.txt 2>&1
 rm -rf $ROOT/gpurun_out/train_trace; timeout 600 rocprofv3 --kernel-trace --output-format csv -d $ROOT/gpurun_out/train_trace -o t -- python $ROOT/tools/train_trace.py > /dev/null 2>&1
 TOP=45 python $ROOT/tools/trace_summary.py $ROOT/gpurun_out/train_trace advance_pos > $ROOT/gpurun_out/${R}_train_step_kernel_trace_summary.txt 2>&1
+TOP=70 python $ROOT/tools/trace_by_grid.py $ROOT/gpurun_out/train_trace advance_pos > $ROOT/gpurun_out/${R}_train_trace_by_grid.txt 2>&1 || true
 for d in decode_trace prefill_trace train_trace; do find $ROOT/gpurun_out/$d -name "*.csv" -size +2M -delete; done
 head -8 $ROOT/gpurun_out/${R}_decode_trace_by_grid.txt; head -6 $ROOT/gpurun_out/${R}_prefill_trace_by_grid.txt; head -12 $ROOT/gpurun_out/${R}_train_step_kernel_trace_summary.txt
+# attention PMC summary of the round (six counter passes over tools/attn_bench.py)
+[ "${SKIP_ATTN_PMC:-0}" = "1" ] || { bash $ROOT/tools/gpu_pmc_attn.sh > /dev/null 2>&1; cp $ROOT/gpurun_out/pmc_attn_summary.txt $ROOT/gpurun_out/${R}_attention_pmc_summary.txt 2>/dev/null; tail -8 $ROOT/gpurun_out/${R}_attention_pmc_summary.txt; }
