@@ -443,6 +443,11 @@ int mg_attn_bwd_merged_bf16(const mg_bf16* q, const mg_bf16* k, const mg_bf16* v
 /* CLIP trunk backward helpers */
 int mg_avgpool2_bwd_nhwc_bf16(const mg_bf16* dy, const mg_bf16* gate, mg_bf16* dx, int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
 int mg_mul_bf16(const mg_bf16* a, const mg_bf16* b, mg_bf16* out, int64_t n, void* stream);
+/* torch.nn.GELU() (erf form) for adapters built with activation=nn.GELU (reference magma/adapters.py:11,20): y = gelu(x) when g is NULL,
+ * y = g * gelu'(x) otherwise, over [rows, cols] bf16 with row strides (elements; cols % 8 == 0); in place allowed.  A pass of its own:
+ * the erf polynomial is kept out of the GEMM epilogues (it cost the 256x256 kernels registers).                                      */
+int mg_gelu_erf_bf16(const mg_bf16* x, int64_t ldx, const mg_bf16* g, int64_t ldg, mg_bf16* y, int64_t ldy, int32_t rows,
+                     int32_t cols, void* stream);
 int mg_scale_rows_acc_f32(float* dst, const float* src, int64_t ld_src, const float* row_scale, int32_t rows,
                           int32_t cols, void* stream);
 int mg_add_gate_bf16(const mg_bf16* a, const mg_bf16* b, const mg_bf16* gate, mg_bf16* out, int64_t n, void* stream);

@@ -17,18 +17,58 @@ import torch
 import torch.nn as nn
 
 
+def activation_codes(act: nn.Module):
+    """(epilogue activation, epilogue gradient mode, gradient needs the PRE-activation) of an adapter activation module.
+    reference adapters.py:11,20 takes any nn.Module class; the fused epilogues cover ReLU (the default), torch.nn.GELU() (erf) and
+    its tanh form (= HF's gelu_new); anything else has no kernel and is refused loudly."""
+    from . import ops
+    if isinstance(act, nn.ReLU):
+        return ops.MG_ACT_RELU, ops.MG_AUX_RELU_GATE, False          # gate from the OUTPUT (t > 0), nothing else to keep
+    if isinstance(act, nn.GELU):
+        if getattr(act, "approximate", "none") == "tanh":
+            return ops.MG_ACT_GELU_NEW, ops.MG_AUX_GELU_GRAD, True
+        return ops.MG_ACT_GELU_ERF, ops.MG_AUX_GELU_ERF_GRAD, True
+    raise NotImplementedError(f"adapter activation {type(act).__name__}: the fused epilogues cover nn.ReLU and nn.GELU (erf / tanh)")
+
+
 class Adapter(nn.Module):
+    """reference adapters.py:6-39.  ``adapter`` = Sequential([LayerNorm(dim)] if add_layernorm, Linear(dim, dim // f), activation(),
+    Linear(dim // f, dim)) -- same module indices, hence the same checkpoint keys, as the reference for every option."""
+
     def __init__(self, dim: int, downsample_factor: int = 4, activation=nn.ReLU, add_layernorm: bool = False,
                  device=None, dtype=None):
         super().__init__()
-        if add_layernorm or activation is not nn.ReLU:
-            raise NotImplementedError("only ReLU adapters without LayerNorm are on the MAGMA_v1/v2 path (SURVEY Q12)")
         kw = dict(device=device, dtype=dtype)
-        self.adapter = nn.Sequential(nn.Linear(dim, dim // downsample_factor, **kw), nn.ReLU(),
-                                     nn.Linear(dim // downsample_factor, dim, **kw))
+        act = activation()
+        activation_codes(act)                     # refuse what no kernel computes, at construction
+        layers = [nn.LayerNorm(dim, **kw)] if add_layernorm else []
+        layers += [nn.Linear(dim, dim // downsample_factor, **kw), act, nn.Linear(dim // downsample_factor, dim, **kw)]
+        self.adapter = nn.Sequential(*layers)
         for m in self.adapter:
             m._is_adapter = True   # GPTJForCausalLM.init_weights leaves adapters alone
         self.adapter.apply(self.init_weights)
+
+    # the three pieces, whatever the option set (the engines never index the Sequential themselves)
+    @property
+    def ln(self):
+        return self.adapter[0] if isinstance(self.adapter[0], nn.LayerNorm) else None
+
+    @property
+    def down(self) -> nn.Linear:
+        return self.adapter[1] if isinstance(self.adapter[0], nn.LayerNorm) else self.adapter[0]
+
+    @property
+    def up(self) -> nn.Linear:
+        return self.adapter[-1]
+
+    @property
+    def act(self) -> nn.Module:
+        return self.adapter[-2]
+
+    @property
+    def plain(self) -> bool:
+        """ReLU bottleneck without LayerNorm: the shape every fused / folded launch structure is written for."""
+        return self.ln is None and isinstance(self.act, nn.ReLU)
 
     @staticmethod
     def init_weights(m: nn.Module, std=1e-3):
@@ -36,19 +76,36 @@ class Adapter(nn.Module):
             with torch.no_grad():
                 m.weight.normal_(std=std).clamp_(-2 * std, 2 * std)
                 m.bias.normal_(std=std).clamp_(-2 * std, 2 * std)
+        elif isinstance(m, nn.LayerNorm):
+            with torch.no_grad():
+                m.bias.zero_()
+                m.weight.fill_(1.0)
 
     def adapter_branch(self, x: torch.Tensor, residual: torch.Tensor = None) -> torch.Tensor:
-        """W_up relu(W_dn x + b_dn) + b_up (+ residual) for x (..., dim) on the GPU: two MFMA GEMMs."""
+        """W_up act(W_dn [LN] x + b_dn) + b_up (+ residual) for x (..., dim) on the GPU: two MFMA GEMMs (+ a LayerNorm launch)."""
         from . import ops
-        dn, up = self.adapter[0], self.adapter[2]
+        dn, up = self.down, self.up
+        code, _, _ = activation_codes(self.act)
         shape = x.shape
         x2 = x.reshape(-1, shape[-1]).to(torch.bfloat16).contiguous()
         with torch.cuda.device(x2.device):
-            t = ops.gemm(x2, ops.RawWeight(ops.pad_k_rowmajor(dn.weight.detach().to(torch.bfloat16)), K=dn.weight.shape[1],
-                                           bias=dn.bias.detach().float().contiguous()), act=ops.MG_ACT_RELU, layout="rm")
+            xin = x2
+            if self.ln is not None:
+                xin = ops.layernorm(x2, self.ln.weight.detach().float().contiguous(), self.ln.bias.detach().float().contiguous(), self.ln.eps)
+            packs = self.__dict__.get("_packs")
+            key = (dn.weight._version, up.weight._version, dn.weight.data_ptr(), up.weight.data_ptr())
+            if packs is None or packs[0] != key:        # padded row-major operands, rebuilt only when the weights changed
+                packs = self.__dict__["_packs"] = (key,
+                    ops.RawWeight(ops.pad_k_rowmajor(dn.weight.detach().to(torch.bfloat16)), K=dn.weight.shape[1],
+                                  bias=dn.bias.detach().float().contiguous()),
+                    ops.RawWeight(ops.pad_k_rowmajor(up.weight.detach().to(torch.bfloat16)), K=up.weight.shape[1],
+                                  bias=up.bias.detach().float().contiguous()))
+            erf = code == ops.MG_ACT_GELU_ERF
+            t = ops.gemm(xin, packs[1], act=ops.MG_ACT_NONE if erf else code, layout="rm")
+            if erf:
+                ops.gelu_erf(t, out=t)
             res = () if residual is None else (residual.reshape(-1, shape[-1]).to(torch.bfloat16).contiguous(),)
-            y = ops.gemm(t, ops.RawWeight(ops.pad_k_rowmajor(up.weight.detach().to(torch.bfloat16)), K=up.weight.shape[1],
-                                          bias=up.bias.detach().float().contiguous()), residuals=res, layout="rm")
+            y = ops.gemm(t, packs[2], residuals=res, layout="rm")
         return y.reshape(shape)
 
     def forward(self, x):

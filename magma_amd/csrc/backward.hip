@@ -554,6 +554,34 @@ __global__ __launch_bounds__(256) void mul_kernel(const mg_bf16* __restrict__ a,
   }
 }
 
+// torch.nn.GELU() (erf form) and its derivative as stand-alone element-wise passes over [rows, cols] bf16 matrices with row
+// strides (cols % 8 == 0): y = gelu(x), and g *= gelu'(pre).  Only adapters built with activation=nn.GELU (reference
+// adapters.py:11,20 -- an option no shipped config sets) come here; the erf polynomial stays out of the GEMM epilogues, where
+// it cost the 256x256 kernels registers (40-byte spills in the shipped bf16 kernel when it was tried there).
+MG_DEV float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
+MG_DEV float gelu_erf_grad_f(float x) {      // Phi(x) + x phi(x)
+  return 0.5f * (1.0f + erff(x * 0.7071067811865476f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+template <bool GRAD>
+__global__ __launch_bounds__(256) void gelu_erf_kernel(const mg_bf16* __restrict__ x, int64_t ldx, const mg_bf16* __restrict__ g,
+                                                       int64_t ldg, mg_bf16* __restrict__ y, int64_t ldy, int rows, int cv) {
+  const int64_t total = (int64_t)rows * cv;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int r = (int)(i / cv), c = (int)(i - (int64_t)r * cv) * 8;
+    const u32x4 v = *(const u32x4*)(x + (int64_t)r * ldx + c);
+    u32x4 o;
+    if constexpr (GRAD) {
+      const u32x4 gv = *(const u32x4*)(g + (int64_t)r * ldg + c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = pack2bf(bflo(gv[j]) * gelu_erf_grad_f(bflo(v[j])), bfhi(gv[j]) * gelu_erf_grad_f(bfhi(v[j])));
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = pack2bf(gelu_erf_f(bflo(v[j])), gelu_erf_f(bfhi(v[j])));
+    }
+    *(u32x4*)(y + (int64_t)r * ldy + c) = o;
+  }
+}
+
 // dst[r*cols + c] += src[r*lds + c] * (row_scale ? row_scale[r] : 1)   (fp32 gradient accumulation)
 __global__ __launch_bounds__(256) void scale_rows_acc_kernel(float* __restrict__ dst, const float* __restrict__ src,
                                                              int64_t lds_, const float* __restrict__ row_scale,
@@ -749,6 +777,18 @@ extern "C" int mg_mul_bf16(const mg_bf16* a, const mg_bf16* b, mg_bf16* out, int
   if (n <= 0 || (n & 7) || !a || !b || !out) MG_FAIL(MG_ERR_SHAPE, "mg_mul_bf16: n must be a positive multiple of 8");
   if (!MG_ALIGNED16(a) || !MG_ALIGNED16(b) || !MG_ALIGNED16(out)) MG_FAIL(MG_ERR_ALIGN, "mg_mul_bf16: 16-byte alignment required");
   hipLaunchKernelGGL(mul_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, a, b, out, n / 8);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
+// y = gelu_erf(x) (g == NULL) or y = g * gelu_erf'(x) over [rows, cols] bf16 with row strides; in place allowed (y == x or y == g)
+extern "C" int mg_gelu_erf_bf16(const mg_bf16* x, int64_t ldx, const mg_bf16* g, int64_t ldg, mg_bf16* y, int64_t ldy, int32_t rows,
+                                int32_t cols, void* stream) {
+  if (rows <= 0 || cols <= 0 || (cols & 7) || !x || !y) MG_FAIL(MG_ERR_SHAPE, "mg_gelu_erf_bf16: cols must be a positive multiple of 8");
+  if (!MG_ALIGNED16(x) || !MG_ALIGNED16(y) || !MG_ALIGNED16(g) || (ldx & 7) || (ldy & 7) || (g && (ldg & 7))) MG_FAIL(MG_ERR_ALIGN, "mg_gelu_erf_bf16: 16-byte aligned rows required");
+  const int cv = cols / 8;
+  if (g) hipLaunchKernelGGL(gelu_erf_kernel<true>, dim3(grid_for((int64_t)rows * cv)), dim3(256), 0, (hipStream_t)stream, x, ldx, g, ldg, y, ldy, rows, cv);
+  else hipLaunchKernelGGL(gelu_erf_kernel<false>, dim3(grid_for((int64_t)rows * cv)), dim3(256), 0, (hipStream_t)stream, x, ldx, g, ldg, y, ldy, rows, cv);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }

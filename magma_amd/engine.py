@@ -90,27 +90,27 @@ class LMEngine:
             # parallel adapters (reference adapters.py:42-92) read the block INPUT (ln_1 output) instead of the wrapped
             # module's output and are scaled by adapter_scale: *_par = fp32 [d] vector holding the scale, else None
             ly.attn_par = ly.mlp_par = None
+            # adapter options (reference adapters.py:11-24): *_act = epilogue code of the bottleneck activation, *_ad_ln =
+            # (gamma, beta, eps) of the LayerNorm in front of the down-projection or None
+            ly.attn_act = ly.mlp_act = ops.MG_ACT_RELU
+            ly.attn_ad_ln = ly.mlp_ad_ln = None
             if isinstance(attn, ParallelAdapter):    # ParallelAdapterWrapper
-                ad = attn.adapter
-                ly.attn_adapter = (ops.PackedLinear(ad[0].weight, ad[0].bias), ops.PackedLinear(ad[2].weight, ad[2].bias))
+                ly.attn_adapter, ly.attn_act, ly.attn_ad_ln = self._pack_adapter(attn)
                 ly.attn_par = torch.full((self.d,), attn.scale_value(), dtype=torch.float32, device=dev)
                 attn = attn.module
             elif hasattr(attn, "attn_block"):        # AdapterWrapper (v2)
-                ad = attn.adapter
-                ly.attn_adapter = (ops.PackedLinear(ad[0].weight, ad[0].bias), ops.PackedLinear(ad[2].weight, ad[2].bias))
+                ly.attn_adapter, ly.attn_act, ly.attn_ad_ln = self._pack_adapter(attn)
                 attn = attn.attn_block
             a = attn.attention
             ly.out = ops.PackedLinear(a.out_proj.weight)
             mlp = blk.mlp
             ly.mlp_adapter = None
             if isinstance(mlp, ParallelAdapter):
-                ad = mlp.adapter
-                ly.mlp_adapter = (ops.PackedLinear(ad[0].weight, ad[0].bias), ops.PackedLinear(ad[2].weight, ad[2].bias))
+                ly.mlp_adapter, ly.mlp_act, ly.mlp_ad_ln = self._pack_adapter(mlp)
                 ly.mlp_par = torch.full((self.d,), mlp.scale_value(), dtype=torch.float32, device=dev)
                 mlp = mlp.module
             elif isinstance(mlp, torch.nn.Sequential):  # Sequential(mlp, Adapter)  (reference magma.py:143-149)
-                ad = mlp[1].adapter
-                ly.mlp_adapter = (ops.PackedLinear(ad[0].weight, ad[0].bias), ops.PackedLinear(ad[2].weight, ad[2].bias))
+                ly.mlp_adapter, ly.mlp_act, ly.mlp_ad_ln = self._pack_adapter(mlp[1])
                 mlp = mlp[0]
             # qkv and fc_in read the same LayerNorm output: ONE operand [q | k | v | fc_in] (bias: zeros | b_fc) for the fused
             # prefill GEMM; ly.qkv / ly.fc_in are row ranges of it that share its storage
@@ -165,6 +165,31 @@ class LMEngine:
         self.cat_up = os.environ.get("MAGMA_PREFILL_CAT", "1") == "1"           # out_proj + adapter-up as one GEMM over [ctx | t]
         self.two_streams = os.environ.get("MAGMA_DECODE_STREAMS", "1") == "2"   # measured slower (3.07 vs 2.94 ms/step): off
 
+    @staticmethod
+    def _pack_adapter(mod):
+        """((down, up) packed, activation code, (gamma, beta, eps) | None) of an Adapter-like module, whatever its options."""
+        from .adapters import activation_codes
+        code, _, _ = activation_codes(mod.act)
+        ln = None
+        if mod.ln is not None:
+            ln = (mod.ln.weight.detach().float().contiguous(), mod.ln.bias.detach().float().contiguous(), float(mod.ln.eps))
+        return (ops.PackedLinear(mod.down.weight, mod.down.bias), ops.PackedLinear(mod.up.weight, mod.up.bias)), code, ln
+
+    @staticmethod
+    def _epi_act(code):
+        """Epilogue code of a bottleneck activation: torch.nn.GELU() (erf) is not an epilogue -- the GEMM runs without activation
+        and _act_fix applies it as its own pass."""
+        return ops.MG_ACT_NONE if code == ops.MG_ACT_GELU_ERF else code
+
+    @staticmethod
+    def _act_fix(t, code):
+        return ops.gelu_erf(t, out=t) if code == ops.MG_ACT_GELU_ERF else t
+
+    @staticmethod
+    def _ad_in(ln, x, out=None):
+        """Input of an adapter's down-projection: x, or LayerNorm(x) for an adapter built with add_layernorm."""
+        return x if ln is None else ops.layernorm(x, ln[0], ln[1], ln[2], out=out)
+
     def _ensure_decode_packs(self):
         """Decode operands with the LayerNorms folded in (frozen gamma/beta): per layer one
         fused [3d+ff, d] matrix W' = [Wqkv;Wfc]*gamma whose single weight-streaming launch
@@ -190,6 +215,8 @@ class LMEngine:
     def _v1_block(self, ly) -> bool:
         """MAGMA_v1 block shape: mlp adapter of the 'normal' type only, every K a multiple of 128."""
         if ly.mlp_adapter is None or ly.attn_adapter is not None or ly.mlp_par is not None:
+            return False
+        if ly.mlp_ad_ln is not None or ly.mlp_act != ops.MG_ACT_RELU:      # the folds are written for the plain ReLU bottleneck
             return False
         dn, up = ly.mlp_adapter
         return not (dn.N % 16 or (self.d + dn.N) % 128 or ly.fc_out.Kp % 128 or dn.K != self.d or up.K != dn.N or up.Kp != up.K)
@@ -239,7 +266,16 @@ class LMEngine:
             w8.fc_out = ops.PackedLinearW8(mlp.c_proj.weight, mlp.c_proj.bias)
             w8.mlp_adapter = None
             if ly.mlp_adapter is not None:
-                w8.mlp_adapter = tuple(ops.PackedLinearW8(ops.PackedLinear.untile(p.ft)[: p.N, : p.K], p.bias) for p in ly.mlp_adapter)
+                # (the up-projection alone is only used by the MAGMA_v1 step; in MAGMA_v2 -- K = 512 -- it lives in up_cat below)
+                w8.mlp_adapter = tuple(ops.PackedLinearW8(ops.PackedLinear.untile(p.ft)[: p.N, : p.K], p.bias) if p.K % 1024 == 0 else None
+                                       for p in ly.mlp_adapter)
+            # MAGMA_v2 (attention AND mlp adapters): the attention adapter's down-projection and the concatenated up-projection
+            w8.attn_adapter = w8.up_cat = None
+            cat = self._adapter_up_cat(ly)
+            if cat is not None and ly.attn_par is None and ly.mlp_par is None and cat.K % 1024 == 0:
+                w8.attn_adapter = (ops.PackedLinearW8(ops.PackedLinear.untile(ly.attn_adapter[0].ft)[: ly.attn_adapter[0].N, : ly.attn_adapter[0].K],
+                                                      ly.attn_adapter[0].bias),)
+                w8.up_cat = ops.PackedLinearW8(ops.PackedLinear.untile(cat.ft)[: cat.N, : cat.K], cat.bias)
             ly.w8 = w8
             del w, w2
         w2, b2, _ = ops.fold_layernorm(self._lm_head.weight, self._lm_head.bias, self.lnf_g, self.lnf_b)
@@ -251,14 +287,12 @@ class LMEngine:
         12 GB of frozen weights keep their packed copies."""
         for ly, blk in zip(self.layers, lm.transformer.h):
             if ly.attn_adapter is not None:
-                ad = blk.attn.adapter
-                ly.attn_adapter = (ops.PackedLinear(ad[0].weight, ad[0].bias), ops.PackedLinear(ad[2].weight, ad[2].bias))
+                ly.attn_adapter, ly.attn_act, ly.attn_ad_ln = self._pack_adapter(blk.attn)
                 if ly.attn_par is not None:           # scaled_parallel: the scale is a trained parameter too
                     ly.attn_par = torch.full((self.d,), blk.attn.scale_value(), dtype=torch.float32, device=ly.attn_par.device)
             if ly.mlp_adapter is not None:
                 par = ly.mlp_par is not None
-                ad = blk.mlp.adapter if par else blk.mlp[1].adapter
-                ly.mlp_adapter = (ops.PackedLinear(ad[0].weight, ad[0].bias), ops.PackedLinear(ad[2].weight, ad[2].bias))
+                ly.mlp_adapter, ly.mlp_act, ly.mlp_ad_ln = self._pack_adapter(blk.mlp if par else blk.mlp[1])
                 if par:
                     ly.mlp_par = torch.full((self.d,), blk.mlp.scale_value(), dtype=torch.float32, device=ly.mlp_par.device)
             ly.fp8 = {}
@@ -282,7 +316,9 @@ class LMEngine:
 
     def _adapter_up_cat(self, ly):
         """[W_up_mlp | W_up_attn] along K (bias = sum) for blocks that carry both adapters, or None."""
-        if ly.mlp_adapter is None or ly.attn_adapter is None:
+        if ly.mlp_adapter is None or ly.attn_adapter is None or ly.mlp_ad_ln is not None or ly.attn_ad_ln is not None:
+            return None
+        if ops.MG_ACT_GELU_ERF in (ly.mlp_act, ly.attn_act):       # its own pass after the down-projection: generic block
             return None
         cat = ly.__dict__.get("up_cat")
         if cat is None:
@@ -429,20 +465,20 @@ class LMEngine:
             a = self._linear(ly, "out", ly.out, ctx)
             if ly.attn_adapter is not None and ly.attn_par is not None:      # parallel: adapter reads the attention INPUT
                 sc, up = self._par_up(ly.attn_adapter[1], ly.attn_par)
-                t = self._linear(ly, "attn_dn", ly.attn_adapter[0], ln, act=ops.MG_ACT_RELU)
+                t = self._act_fix(self._linear(ly, "attn_dn", ly.attn_adapter[0], self._ad_in(ly.attn_ad_ln, ln), act=self._epi_act(ly.attn_act)), ly.attn_act)
                 a = ops.gemm(t, up, scale=sc, residuals=(a,))
             elif ly.attn_adapter is not None:
-                t = self._linear(ly, "attn_dn", ly.attn_adapter[0], a, act=ops.MG_ACT_RELU)
+                t = self._act_fix(self._linear(ly, "attn_dn", ly.attn_adapter[0], self._ad_in(ly.attn_ad_ln, a), act=self._epi_act(ly.attn_act)), ly.attn_act)
                 a = self._linear(ly, "attn_up", ly.attn_adapter[1], t, residuals=(a,))
             h = h_fused if h_fused is not None else self._linear(ly, "fc_in", ly.fc_in, ln, lnq, act=ops.MG_ACT_GELU_NEW)
             if ly.mlp_adapter is not None and ly.mlp_par is not None:        # parallel: adapter reads the MLP INPUT
                 sc, up = self._par_up(ly.mlp_adapter[1], ly.mlp_par)
                 m = self._linear(ly, "fc_out", ly.fc_out, h)
-                t = self._linear(ly, "mlp_dn", ly.mlp_adapter[0], ln, act=ops.MG_ACT_RELU)
+                t = self._act_fix(self._linear(ly, "mlp_dn", ly.mlp_adapter[0], self._ad_in(ly.mlp_ad_ln, ln), act=self._epi_act(ly.mlp_act)), ly.mlp_act)
                 x = ops.gemm(t, up, scale=sc, residuals=(m, a, x))
             elif ly.mlp_adapter is not None:
                 m = self._linear(ly, "fc_out", ly.fc_out, h)
-                t = self._linear(ly, "mlp_dn", ly.mlp_adapter[0], m, act=ops.MG_ACT_RELU)
+                t = self._act_fix(self._linear(ly, "mlp_dn", ly.mlp_adapter[0], self._ad_in(ly.mlp_ad_ln, m), act=self._epi_act(ly.mlp_act)), ly.mlp_act)
                 x = self._linear(ly, "mlp_up", ly.mlp_adapter[1], t, residuals=(m, a, x))
             else:
                 x = self._linear(ly, "fc_out", ly.fc_out, h, residuals=(a, x))
@@ -507,6 +543,7 @@ class LMEngine:
         st.tcat = e(B, r_mlp + r_att)      # [mlp bottleneck | attention bottleneck] side by side (fused up-projection)
         st.ctx_t = e(B, d + r_mlp)         # [attention context | mlp bottleneck]: input of the [W_out | W_up] GEMV (fold_dn)
         st.lnf = e(B, d)
+        st.ad_ln = e(B, d)                 # LayerNorm output in front of an adapter built with add_layernorm
         st.logits = e(B, self.Vp, dt=torch.float32)
         st.token = torch.zeros(B, dtype=torch.int64, device=dev)
         st.graphs = {}             # token-selection mode (None = greedy | (temperature, top_k, top_p)) -> captured hipGraph
@@ -564,7 +601,7 @@ class LMEngine:
             # underneath the MLP branch's weight streaming; both join at the adapter-up GEMV
             par = ly.mlp_par is not None or ly.attn_par is not None
             grouped = (not wide and self.group_launches and not par and ly.mlp_adapter is not None and ly.attn_adapter is None
-                       and ly.fc_out.Kp % 128 == 0 and ly.out.Kp % 128 == 0 and ly.mlp_adapter[0].Kp % 128 == 0)
+                       and ly.mlp_ad_ln is None and ly.mlp_act != ops.MG_ACT_GELU_ERF and ly.fc_out.Kp % 128 == 0 and ly.out.Kp % 128 == 0 and ly.mlp_adapter[0].Kp % 128 == 0)
             out_up = self._ensure_out_up(ly) if (grouped and not w8_on and self.fold_dn in (1, 2)) else None
             if out_up is not None and self.fold_dn == 2:
                 # MAGMA_DECODE_FOLD=2: attention || fc_out (context row lands in st.ctx_t), adapter-down alone, [W_out | W_up] GEMV
@@ -594,23 +631,25 @@ class LMEngine:
                                      self.sin_t, self.cos_t, (st.h, src.fc_out, st.m, {}))
                 # launch 3: out_proj || adapter-down
                 t = st.t[:, : ly.mlp_adapter[0].N]
-                ops.gemm_skinny2((st.ctx, src.out, st.a, {}), (st.m, src.mlp_adapter[0], t, {"act": ops.MG_ACT_RELU}))
+                ops.gemm_skinny2((st.ctx, src.out, st.a, {}), (st.m, src.mlp_adapter[0], t, {"act": ly.mlp_act}))
                 # launch 4: adapter-up + the block's three residuals
                 ops.gemm_skinny(t, src.mlp_adapter[1], out=xn, residuals=(st.m, st.a, x))
                 x, xn = xn, x
                 continue
-            if w8_on:
-                raise NotImplementedError("W8A16 decode covers the grouped MAGMA_v1 step (mlp adapters, K % 128 == 0) only")
             up_cat = self._adapter_up_cat(ly) if self.group_launches and not par and not wide else None
+            if w8_on and (up_cat is None or src.up_cat is None or src.mlp_adapter[0] is None):
+                raise NotImplementedError("W8A16 decode covers the grouped MAGMA_v1 and MAGMA_v2 steps ('normal' adapters, K % 1024 == 0) only")
             if up_cat is not None:
                 # MAGMA_v2 (attention AND mlp adapters): 5 launches.  x' = up_m(t) + up_a(ta) + m + a + x is ONE GEMV over
                 # the concatenated bottlenecks [t | ta] against [W_up_m | W_up_a] (the adapter outputs only ever appear summed).
                 r1 = ly.mlp_adapter[0].N
                 t, ta = st.tcat[:, :r1], st.tcat[:, r1: r1 + ly.attn_adapter[0].N]
+                if w8_on:
+                    up_cat = src.up_cat
                 ops.decode_attn_gemv(st.qkv, cache.k[li], cache.v[li], st.ctx, B, self.H, cache.d_pos, self.rot,
-                                     self.sin_t, self.cos_t, (st.h, ly.fc_out, st.m, {}))
-                ops.gemm_skinny2((st.ctx, ly.out, st.a, {}), (st.m, ly.mlp_adapter[0], t, {"act": ops.MG_ACT_RELU}))
-                ops.gemm_skinny(st.a, ly.attn_adapter[0], out=ta, act=ops.MG_ACT_RELU)
+                                     self.sin_t, self.cos_t, (st.h, src.fc_out, st.m, {}))
+                ops.gemm_skinny2((st.ctx, src.out, st.a, {}), (st.m, src.mlp_adapter[0], t, {"act": ly.mlp_act}))
+                ops.gemm_skinny(st.a, src.attn_adapter[0], out=ta, act=ly.attn_act)
                 ops.gemm_skinny(st.tcat[:, : up_cat.Kp], up_cat, out=xn, residuals=(st.m, st.a, x))
                 x, xn = xn, x
                 continue
@@ -626,10 +665,10 @@ class LMEngine:
                 ta = st.ta[:, : ly.attn_adapter[0].N]
                 if ly.attn_par is not None:
                     sc, up = self._par_up(ly.attn_adapter[1], ly.attn_par)
-                    G(st.ln, ly.attn_adapter[0], out=ta, act=ops.MG_ACT_RELU)
+                    self._act_fix(G(self._ad_in(ly.attn_ad_ln, st.ln, out=st.ad_ln), ly.attn_adapter[0], out=ta, act=self._epi_act(ly.attn_act)), ly.attn_act)
                     a = G(ta, up, out=st.a2, scale=sc, residuals=(a,))
                 else:
-                    G(a, ly.attn_adapter[0], out=ta, act=ops.MG_ACT_RELU)
+                    self._act_fix(G(self._ad_in(ly.attn_ad_ln, a, out=st.ad_ln), ly.attn_adapter[0], out=ta, act=self._epi_act(ly.attn_act)), ly.attn_act)
                     a = G(ta, ly.attn_adapter[1], out=st.a2, residuals=(a,))
             if side is not None:
                 torch.cuda.set_stream(main)
@@ -640,10 +679,10 @@ class LMEngine:
                     main.wait_stream(side)
                 if ly.mlp_par is not None:
                     sc, up = self._par_up(ly.mlp_adapter[1], ly.mlp_par)
-                    G(st.ln, ly.mlp_adapter[0], out=t, act=ops.MG_ACT_RELU)
+                    self._act_fix(G(self._ad_in(ly.mlp_ad_ln, st.ln, out=st.ad_ln), ly.mlp_adapter[0], out=t, act=self._epi_act(ly.mlp_act)), ly.mlp_act)
                     G(t, up, out=xn, scale=sc, residuals=(st.m, a, x))
                 else:
-                    G(st.m, ly.mlp_adapter[0], out=t, act=ops.MG_ACT_RELU)
+                    self._act_fix(G(self._ad_in(ly.mlp_ad_ln, st.m, out=st.ad_ln), ly.mlp_adapter[0], out=t, act=self._epi_act(ly.mlp_act)), ly.mlp_act)
                     G(t, ly.mlp_adapter[1], out=xn, residuals=(st.m, a, x))
             else:
                 if side is not None:

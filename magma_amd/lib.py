@@ -124,6 +124,7 @@ SYMBOLS = {
     "mg_attn_bwd_merged_bf16": (C.c_int, [_vp] * 11 + [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mg_avgpool2_bwd_nhwc_bf16": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mg_mul_bf16": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
+    "mg_gelu_erf_bf16": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _vp]),
     "mg_scale_rows_acc_f32": (C.c_int, [_vp, _vp, _i64, _vp, _i32, _i32, _vp]),
     "mg_add_gate_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
     "mg_bn_param_grad_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),

@@ -677,6 +677,32 @@ def cross_entropy_fwd_bwd(logits: torch.Tensor, targets: torch.Tensor, ld_out: i
     return stats[0], dl
 
 
+MG_ACT_GELU_ERF = 100      # NOT an epilogue code: torch.nn.GELU() runs as its own pass (gelu_erf / gelu_erf_grad_mul below)
+MG_AUX_GELU_ERF_GRAD = 100
+
+
+def gelu_erf(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """torch.nn.GELU() (erf) over a [rows, cols] bf16 matrix (row stride allowed); ``out`` may be x."""
+    _need_gpu(x)
+    assert x.dtype == BF16 and x.ndim == 2 and x.stride(1) == 1 and x.shape[1] % 8 == 0
+    if out is None:
+        out = torch.empty_like(x)
+    check(L.load().mg_gelu_erf_bf16(x.data_ptr(), x.stride(0), None, 0, out.data_ptr(), out.stride(0), x.shape[0], x.shape[1], _stream()),
+          "mg_gelu_erf_bf16")
+    return out
+
+
+def gelu_erf_grad_mul(g: torch.Tensor, pre: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """g * gelu'(pre) (erf form), same shapes; ``out`` may be g."""
+    _need_gpu(g, pre)
+    assert g.dtype == BF16 and pre.dtype == BF16 and g.shape == pre.shape and g.stride(1) == 1 and pre.stride(1) == 1 and g.shape[1] % 8 == 0
+    if out is None:
+        out = torch.empty_like(g)
+    check(L.load().mg_gelu_erf_bf16(pre.data_ptr(), pre.stride(0), g.data_ptr(), g.stride(0), out.data_ptr(), out.stride(0),
+                                    g.shape[0], g.shape[1], _stream()), "mg_gelu_erf_bf16")
+    return out
+
+
 def rotary_merge_bwd(dq, dk, dv, B, S, H, rot_dim, sin_t, cos_t):
     _need_gpu(dq)
     out = torch.empty(B * S, 3 * H * 256, dtype=BF16, device=dq.device)

@@ -384,9 +384,9 @@ class MagmaEngine:
             self._lm_train_packs = (packs, PackedLinear(wt))
         return self._lm_train_packs
 
-    def _adapter_ops(self, ad):
-        """(down, up) RawWeights on the live bf16 parameters, biases = fp32 master views."""
-        dn, up = ad[0], ad[2]
+    def _adapter_ops(self, mod):
+        """(down, up) RawWeights on the live bf16 parameters of an Adapter-like module, biases = fp32 master views."""
+        dn, up = mod.down, mod.up
         return (RawWeight(dn.weight.data, bias=self.master_of(dn.bias)),
                 RawWeight(up.weight.data, bias=self.master_of(up.bias)))
 
@@ -394,8 +394,7 @@ class MagmaEngine:
         """(down, up, scale vector or None) of a ParallelAdapter / ParallelAdapterWrapper on the live parameters.  The GEMM
         epilogue computes acc * scale[n] + bias[n]; the reference (acc + b_up) * adapter_scale, so the up bias handed to the
         epilogue is pre-multiplied by the (device-resident, trainable) scale."""
-        ad = wrapper.adapter
-        dn, up = ad[0], ad[2]
+        dn, up = wrapper.down, wrapper.up
         dnw = RawWeight(dn.weight.data, bias=self.master_of(dn.bias))
         sp = wrapper.adapter_scale
         if not torch.is_tensor(sp):
@@ -404,6 +403,24 @@ class MagmaEngine:
         sval = self.master_of(sp) if self.is_trainable(sp) else sp.detach().float()
         sc = sval.reshape(1).to(F32).expand(up.weight.shape[0]).contiguous()
         return dnw, RawWeight(up.weight.data, bias=(self.master_of(up.bias) * sc).contiguous()), sc
+
+    def _adapter_down(self, mod, x_in, dn, sv, key):
+        """t = act(W_dn [LayerNorm] x_in + b_dn) for an Adapter-like module with any of the reference's options
+        (reference adapters.py:11-24).  Saves what the backward needs under sv[key] (t) and sv[key + "_pre"] (the
+        pre-activation, for activations whose derivative is not a function of the output)."""
+        from .adapters import activation_codes
+        code, _, needs_pre = activation_codes(mod.act)
+        xin = x_in if mod.ln is None else ops.layernorm(x_in, self._vec(mod.ln.weight), self._vec(mod.ln.bias), mod.ln.eps)
+        if code == ops.MG_ACT_GELU_ERF:           # torch.nn.GELU(): its own pass, not an epilogue (ops.gelu_erf)
+            pre = ops.gemm(xin, dn, layout="rm")
+            t = ops.gelu_erf(pre)
+        else:
+            pre = torch.empty(x_in.shape[0], dn.N, dtype=BF16, device=x_in.device) if needs_pre else None
+            t = ops.gemm(xin, dn, act=code, layout="rm", out2=pre)
+        sv[key] = t
+        if needs_pre:
+            sv[key + "_pre"] = pre
+        return t
 
     def _fgemm(self, key, x, lin, xq=None, **kw):
         """GEMM against a FROZEN packed weight: bf16 tile GEMM, or (self.fp8) the fp8 MFMA on a per-row quantised x."""
@@ -478,14 +495,13 @@ class MagmaEngine:
             if ly.attn_adapter is not None and ly.attn_par is not None:
                 # parallel / scaled_parallel (reference adapters.py:42-92): the adapter reads the attention INPUT (ln_1 output)
                 dn, up, sc = self._par_adapter_ops(blk.attn)
-                ta = ops.gemm(ln, dn, act=ops.MG_ACT_RELU, layout="rm")
+                ta = self._adapter_down(blk.attn, ln, dn, sv, "ta")
                 a = ops.gemm(ta, up, scale=sc, residuals=(a,), layout="rm")
-                sv.update(ta=ta)
             elif ly.attn_adapter is not None:
-                dn, up = self._adapter_ops(blk.attn.adapter)
-                ta = ops.gemm(a, dn, act=ops.MG_ACT_RELU, layout="rm")
+                dn, up = self._adapter_ops(blk.attn)
+                ta = self._adapter_down(blk.attn, a, dn, sv, "ta")
                 a2 = ops.gemm(ta, up, residuals=(a,), layout="rm")
-                sv.update(a=a, ta=ta)
+                sv.update(a=a)
                 a = a2
             hpre = torch.empty(M, ly.fc_in.N, dtype=BF16, device=dev)
             h = self._fgemm((li, "fc_in"), ln, ly.fc_in, lnq, act=ops.MG_ACT_GELU_NEW, out2=hpre)
@@ -495,15 +511,14 @@ class MagmaEngine:
             if ly.mlp_adapter is not None and ly.mlp_par is not None:
                 dn, up, sc = self._par_adapter_ops(blk.mlp)
                 m = self._fgemm((li, "fc_out"), h, ly.fc_out)
-                t = ops.gemm(ln, dn, act=ops.MG_ACT_RELU, layout="rm")
+                t = self._adapter_down(blk.mlp, ln, dn, sv, "t")
                 x = ops.gemm(t, up, scale=sc, residuals=(m, a, x), layout="rm")
-                sv.update(t=t)
             elif ly.mlp_adapter is not None:
-                dn, up = self._adapter_ops(blk.mlp[1].adapter)
+                dn, up = self._adapter_ops(blk.mlp[1])
                 m = self._fgemm((li, "fc_out"), h, ly.fc_out)
-                t = ops.gemm(m, dn, act=ops.MG_ACT_RELU, layout="rm")
+                t = self._adapter_down(blk.mlp[1], m, dn, sv, "t")
                 x = ops.gemm(t, up, residuals=(m, a, x), layout="rm")
-                sv.update(m=m, t=t)
+                sv.update(m=m)
             else:
                 x = self._fgemm((li, "fc_out"), h, ly.fc_out, residuals=(a, x))
             del h, qkv, ln
@@ -550,25 +565,40 @@ class MagmaEngine:
         gview = self.grad_of(param).view(param.shape[0], -1)
         ops.scale_rows_acc(gview, tmp[:, : gview.shape[1]], row_scale)
 
-    def _adapter_backward(self, ad, g, x_in, t):
-        """y = x_in + Wup relu(Wdn x_in + bdn) + bup.  Given g = dL/dy returns dL/dx_in
-        WITHOUT the identity term (caller adds g through the residual epilogue)."""
-        dn, up = ad[0], ad[2]
+    def _adapter_backward(self, mod, g, x_in, t, pre=None):
+        """y = x_in + Wup act(Wdn [LN] x_in + bdn) + bup.  Given g = dL/dy accumulates the adapter's parameter gradients and
+        returns (dt, Wdn^T): dL/d([LN] x_in) through the adapter is dt Wdn (see _adapter_dx for the way back to x_in)."""
+        from .adapters import activation_codes
+        dn, up = mod.down, mod.up
+        _, gmode, needs_pre = activation_codes(mod.act)
         ops.colsum(g, self.grad_of(up.bias))
         gT = _t(g)
         self._acc_wgrad(up.weight, gT, _t(t))
-        dt = ops.gemm(g, _t(up.weight.data), aux=t, aux_mode=ops.MG_AUX_RELU_GATE, layout="rm", use_bias=False)
+        if gmode == ops.MG_AUX_GELU_ERF_GRAD:
+            dt = ops.gemm(g, _t(up.weight.data), layout="rm", use_bias=False)
+            ops.gelu_erf_grad_mul(dt, pre, out=dt)
+        else:
+            dt = ops.gemm(g, _t(up.weight.data), aux=pre if needs_pre else t, aux_mode=gmode, layout="rm", use_bias=False)
         ops.colsum(dt, self.grad_of(dn.bias))
-        self._acc_wgrad(dn.weight, _t(dt), _t(x_in))
+        xin = x_in if mod.ln is None else ops.layernorm(x_in, self._vec(mod.ln.weight), self._vec(mod.ln.bias), mod.ln.eps)
+        self._acc_wgrad(dn.weight, _t(dt), _t(xin))
         return dt, _t(dn.weight.data)
 
-    def _par_adapter_backward(self, wrapper, g, x_in, t):
+    def _adapter_dx(self, mod, dt, dn_t, x_in, res=None):
+        """dL/dx_in through the adapter's down-projection (+ res): dt Wdn, taken back through the adapter's LayerNorm (with its
+        parameter gradients) when the adapter has one."""
+        if mod.ln is None:
+            return ops.gemm(dt, dn_t, residuals=() if res is None else (res,), layout="rm", use_bias=False)
+        return self._ln_bwd(mod.ln, ops.gemm(dt, dn_t, layout="rm", use_bias=False), x_in, res=res)
+
+    def _par_adapter_backward(self, wrapper, g, x_in, t, pre=None):
         """y = f(x_in) + s * (Wup relu(Wdn x_in + bdn) + bup)  (reference adapters.py:59-63, :84-91).  Given g = dL/dy:
         accumulates the adapter's parameter gradients (and ds = <g, z>, z the unscaled adapter output, computed from the
         unscaled weight / bias gradients: <g^T t, Wup> + <colsum g, bup>) and returns (dt, Wdn^T): dL/dx_in through the
         adapter is dt Wdn, added by the caller."""
-        ad = wrapper.adapter
-        dn, up = ad[0], ad[2]
+        from .adapters import activation_codes
+        dn, up = wrapper.down, wrapper.up
+        _, gmode, needs_pre = activation_codes(wrapper.act)
         sp = wrapper.adapter_scale
         scaled = torch.is_tensor(sp)
         N = up.weight.shape[0]
@@ -586,10 +616,15 @@ class MagmaEngine:
             ds = (gw[:, : gview.shape[1]] * up.weight.data.float()).sum() + (gb * self.master_of(up.bias)).sum()
             self.grad_of(sp).add_(ds.reshape(self.grad_of(sp).shape))
         K = up.weight.shape[1]
-        dt = ops.gemm(g, _t(up.weight.data), aux=t, aux_mode=ops.MG_AUX_RELU_GATE, layout="rm", use_bias=False,
-                      scale=None if sc is None else sc[:K].contiguous())
+        if gmode == ops.MG_AUX_GELU_ERF_GRAD:
+            dt = ops.gemm(g, _t(up.weight.data), layout="rm", use_bias=False, scale=None if sc is None else sc[:K].contiguous())
+            ops.gelu_erf_grad_mul(dt, pre, out=dt)
+        else:
+            dt = ops.gemm(g, _t(up.weight.data), aux=pre if needs_pre else t, aux_mode=gmode, layout="rm", use_bias=False,
+                          scale=None if sc is None else sc[:K].contiguous())
         ops.colsum(dt, self.grad_of(dn.bias))
-        self._acc_wgrad(dn.weight, _t(dt), _t(x_in))
+        xin = x_in if wrapper.ln is None else ops.layernorm(x_in, self._vec(wrapper.ln.weight), self._vec(wrapper.ln.bias), wrapper.ln.eps)
+        self._acc_wgrad(dn.weight, _t(dt), _t(xin))
         return dt, _t(dn.weight.data)
 
     def _lm_backward(self, tape):
@@ -621,12 +656,12 @@ class MagmaEngine:
             ln = ops.layernorm(sv["x"], ly.ln_g, ly.ln_b, eng.eps) if par else None   # the parallel adapters' input, recomputed
             extra = []                                                                 # dL/d ln through the parallel adapters
             if ly.mlp_adapter is not None and ly.mlp_par is not None:
-                dt, dn_t = self._par_adapter_backward(blk.mlp, g, ln, sv["t"])
-                extra.append(ops.gemm(dt, dn_t, layout="rm", use_bias=False))
+                dt, dn_t = self._par_adapter_backward(blk.mlp, g, ln, sv["t"], sv.get("t_pre"))
+                extra.append(self._adapter_dx(blk.mlp, dt, dn_t, ln))
                 dm = g
             elif ly.mlp_adapter is not None:
-                dt, dn_t = self._adapter_backward(blk.mlp[1].adapter, g, sv["m"], sv["t"])
-                dm = ops.gemm(dt, dn_t, residuals=(g,), layout="rm", use_bias=False)
+                dt, dn_t = self._adapter_backward(blk.mlp[1], g, sv["m"], sv["t"], sv.get("t_pre"))
+                dm = self._adapter_dx(blk.mlp[1], dt, dn_t, sv["m"], res=g)
             else:
                 dm = g
             dhpre = self._fgemm((li, "fc_out_t"), dm, pk["fc_out_t"], aux=sv["hpre"], aux_mode=ops.MG_AUX_GELU_GRAD)
@@ -642,12 +677,12 @@ class MagmaEngine:
             del dhpre, dm
             # ---- attention branch ----
             if ly.attn_adapter is not None and ly.attn_par is not None:
-                dta, dn_t = self._par_adapter_backward(blk.attn, g, ln, sv["ta"])
-                extra.append(ops.gemm(dta, dn_t, layout="rm", use_bias=False))
+                dta, dn_t = self._par_adapter_backward(blk.attn, g, ln, sv["ta"], sv.get("ta_pre"))
+                extra.append(self._adapter_dx(blk.attn, dta, dn_t, ln))
                 da = g
             elif ly.attn_adapter is not None:
-                dta, dn_t = self._adapter_backward(blk.attn.adapter, g, sv["a"], sv["ta"])
-                da = ops.gemm(dta, dn_t, residuals=(g,), layout="rm", use_bias=False)
+                dta, dn_t = self._adapter_backward(blk.attn, g, sv["a"], sv["ta"], sv.get("ta_pre"))
+                da = self._adapter_dx(blk.attn, dta, dn_t, sv["a"], res=g)
             else:
                 da = g
             dctx = self._fgemm((li, "out_t"), da, pk["out_t"])

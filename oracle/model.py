@@ -51,6 +51,11 @@ class OracleConfig:
     # (adapters.py:42-92), the latter with the trainable scalar ``adapter_scale``
     mlp_adapter_type: str = "normal"
     attn_adapter_type: str = "normal"
+    # adapter options (reference magma/adapters.py:11-24): the bottleneck activation ("relu" = nn.ReLU, the default; "gelu" =
+    # nn.GELU(), erf; "gelu_tanh" = nn.GELU(approximate="tanh")) and a LayerNorm(dim) in front of the down-projection
+    # (add_layernorm: the Sequential's indices shift -- 0 = LayerNorm, 1 = down, 3 = up -- and with them the state-dict keys)
+    adapter_act: str = "relu"
+    adapter_layernorm: bool = False
     # image side
     enc_width: int = 96  # RN50x16
     enc_layers: Tuple[int, int, int, int] = (6, 8, 18, 8)
@@ -154,10 +159,17 @@ def init_params(cfg: OracleConfig, seed: int = 0, dtype=torch.float32,
     def normal(*shape, std):
         return torch.randn(*shape, generator=g, dtype=torch.float32) * std
 
-    def adapter(prefix, hidden):
-        for idx, (o, i_) in (("0", (hidden, d)), ("2", (d, hidden))):
+    def adapter(prefix, hidden, normal=None):
+        normal = normal or globals_normal[0]
+        dn_i, up_i = ("1", "3") if cfg.adapter_layernorm else ("0", "2")
+        for idx, (o, i_) in ((dn_i, (hidden, d)), (up_i, (d, hidden))):
             p[f"{prefix}{idx}.weight"] = normal(o, i_, std=1e-3).clamp_(-2e-3, 2e-3)
             p[f"{prefix}{idx}.bias"] = normal(o, std=1e-3).clamp_(-2e-3, 2e-3)
+        if cfg.adapter_layernorm:      # (the reference initialises it to identity, adapters.py:34-36; perturbed here so that it matters)
+            p[f"{prefix}0.weight"] = 1.0 + normal(d, std=0.05)
+            p[f"{prefix}0.bias"] = normal(d, std=0.02)
+
+    globals_normal = [normal]
 
     def block(i, normal, adapter):
         h = f"lm.transformer.h.{i}."
@@ -194,9 +206,7 @@ def init_params(cfg: OracleConfig, seed: int = 0, dtype=torch.float32,
                 return torch.randn(*shape, generator=gi, dtype=torch.float32) * std
 
             def adapter_i(prefix, hidden):
-                for idx, (o, i_) in (("0", (hidden, d)), ("2", (d, hidden))):
-                    p[f"{prefix}{idx}.weight"] = normal_i(o, i_, std=1e-3).clamp_(-2e-3, 2e-3)
-                    p[f"{prefix}{idx}.bias"] = normal_i(o, std=1e-3).clamp_(-2e-3, 2e-3)
+                adapter(prefix, hidden, normal_i)
             block(i, normal_i, adapter_i)
 
         with ThreadPoolExecutor(max_workers=min(16, max(1, cfg.n_layer))) as ex:
@@ -267,21 +277,31 @@ def apply_rotary(x: torch.Tensor, pos: torch.Tensor, rotary_dim: int) -> torch.T
     return torch.cat((xr * cos + rot * sin, xp), dim=-1)
 
 
-def adapter_branch(p: Params, prefix: str, x: torch.Tensor) -> torch.Tensor:
-    """The adapter Sequential itself: Linear -> ReLU -> Linear (adapters.py:18-25, defaults: ReLU, no LayerNorm)."""
-    h = F.relu(F.linear(x, p[prefix + "0.weight"], p[prefix + "0.bias"]))
-    return F.linear(h, p[prefix + "2.weight"], p[prefix + "2.bias"])
+ADAPTER_ACTS = {"relu": F.relu, "gelu": F.gelu, "gelu_tanh": lambda v: F.gelu(v, approximate="tanh")}
 
 
-def adapter_fwd(p: Params, prefix: str, x: torch.Tensor) -> torch.Tensor:
+def adapter_branch(p: Params, prefix: str, x: torch.Tensor, act: str = "relu") -> torch.Tensor:
+    """The adapter Sequential itself (adapters.py:14-26): [LayerNorm ->] Linear -> activation -> Linear.  The LayerNorm variant
+    is recognised by its keys (a fourth module: ``3.weight`` is the up-projection then)."""
+    if prefix + "3.weight" in p:
+        x = F.layer_norm(x, (x.shape[-1],), p[prefix + "0.weight"], p[prefix + "0.bias"], 1e-5)
+        dn, up = "1", "3"
+    else:
+        dn, up = "0", "2"
+    h = ADAPTER_ACTS[act](F.linear(x, p[prefix + dn + ".weight"], p[prefix + dn + ".bias"]))
+    return F.linear(h, p[prefix + up + ".weight"], p[prefix + up + ".bias"])
+
+
+def adapter_fwd(p: Params, prefix: str, x: torch.Tensor, act: str = "relu") -> torch.Tensor:
     """reference magma/adapters.py:38-39: adapter(x) + x."""
-    return adapter_branch(p, prefix, x) + x
+    return adapter_branch(p, prefix, x, act) + x
 
 
-def parallel_adapter_fwd(p: Params, prefix: str, scale_key: Optional[str], x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+def parallel_adapter_fwd(p: Params, prefix: str, scale_key: Optional[str], x: torch.Tensor, y: torch.Tensor,
+                         act: str = "relu") -> torch.Tensor:
     """reference magma/adapters.py:62-65 / 88-92: y = module(x); return y + adapter(x) * adapter_scale
     (adapter_scale = 1 for "parallel", the trainable scalar for "scaled_parallel")."""
-    z = adapter_branch(p, prefix, x)
+    z = adapter_branch(p, prefix, x, act)
     return y + z * (p[scale_key] if scale_key is not None and scale_key in p else 1)
 
 
@@ -313,10 +333,10 @@ def attention_fwd(p: Params, cfg: OracleConfig, i: int, x: torch.Tensor,
     o = F.linear(o, p[ap + "out_proj.weight"])
     if cfg.attn_adapter_hidden and cfg.attn_adapter_type == "normal":
         # reference magma/adapters.py:109-116 AdapterWrapper
-        o = adapter_fwd(p, f"lm.transformer.h.{i}.attn.adapter.", o)
+        o = adapter_fwd(p, f"lm.transformer.h.{i}.attn.adapter.", o, cfg.adapter_act)
     elif cfg.attn_adapter_hidden:
         # reference magma/adapters.py:82-92 ParallelAdapterWrapper: the adapter reads the attention block's input x
-        o = parallel_adapter_fwd(p, f"lm.transformer.h.{i}.attn.adapter.", f"lm.transformer.h.{i}.attn.adapter_scale", x, o)
+        o = parallel_adapter_fwd(p, f"lm.transformer.h.{i}.attn.adapter.", f"lm.transformer.h.{i}.attn.adapter_scale", x, o, cfg.adapter_act)
     return o, present
 
 
@@ -326,10 +346,10 @@ def mlp_fwd(p: Params, cfg: OracleConfig, i: int, x: torch.Tensor) -> torch.Tens
     m = F.linear(h, p[mp + "c_proj.weight"], p[mp + "c_proj.bias"])
     if cfg.mlp_adapter_hidden and cfg.mlp_adapter_type == "normal":
         # reference magma/magma.py:143-149: Sequential(mlp, Adapter)
-        m = adapter_fwd(p, mlp_adapter_prefix(cfg, i), m)
+        m = adapter_fwd(p, mlp_adapter_prefix(cfg, i), m, cfg.adapter_act)
     elif cfg.mlp_adapter_hidden:
         # reference magma/magma.py:129-136 + adapters.py:62-65: ParallelAdapter(module=mlp)
-        m = parallel_adapter_fwd(p, mlp_adapter_prefix(cfg, i), f"lm.transformer.h.{i}.mlp.adapter_scale", x, m)
+        m = parallel_adapter_fwd(p, mlp_adapter_prefix(cfg, i), f"lm.transformer.h.{i}.mlp.adapter_scale", x, m, cfg.adapter_act)
     return m
 
 

@@ -169,6 +169,27 @@ def main():
     strs = sampling.generate(tm2, emb, max_steps=6, temperature=0.0, decode=True)
     pins["generate_toy"] = {"emb": emb, "tokens": toks, "strings": strs, "calls": tm.lm.calls}
 
+    # ---- Adapter options (reference magma/adapters.py:11-24): activation, add_layernorm -- appended last, own seed, so that every
+    #      entry above keeps its random stream ----
+    import functools
+    torch.manual_seed(4321)
+    xo = torch.randn(3, 5, 64)
+    opts = {}
+    for name, kw in (("gelu", dict(activation=torch.nn.GELU)),
+                     ("gelu_tanh", dict(activation=functools.partial(torch.nn.GELU, approximate="tanh"))),
+                     ("ln", dict(add_layernorm=True)),
+                     ("ln_gelu", dict(add_layernorm=True, activation=torch.nn.GELU))):
+        ad = adapters.Adapter(dim=64, downsample_factor=4, **kw)
+        with torch.no_grad():                       # weights large enough for the activation's shape to matter; LayerNorm off identity
+            for prm in ad.parameters():
+                prm.mul_(300.0) if prm.ndim == 2 else None
+            for m in ad.modules():
+                if isinstance(m, torch.nn.LayerNorm):
+                    m.weight.add_(torch.randn(64) * 0.1)
+                    m.bias.add_(torch.randn(64) * 0.1)
+        opts[name] = {"sd": {k: v.clone() for k, v in ad.state_dict().items()}, "x": xo, "y": ad(xo).detach()}
+    pins["adapter_options"] = opts
+
     torch.save(pins, OUT)
     print("wrote", OUT, {k: type(v).__name__ for k, v in pins.items()})
 

@@ -185,13 +185,15 @@ def test_w8a16_layernorm_fold_and_pairs(dev):
     assert rel(o2, torch.relu(xf @ linb.dequant().t())) < 4e-3
 
 
-def test_w8a16_generate_tracks_bf16(dev):
+@pytest.mark.parametrize("config", ["MAGMA_v1", "MAGMA_v2"])
+def test_w8a16_generate_tracks_bf16(dev, config):
     """Full-width 2-block model: greedy decode with e4m3 weights stays close to the bf16 decode (stated tolerance:
-    rel-L2 of the step logits <= 0.08; identical tokens where the bf16 top-1 margin is clear)."""
+    rel-L2 of the step logits <= 0.08; identical tokens where the bf16 top-1 margin is clear).  MAGMA_v2 (round 4): the
+    five-launch block with the attention adapter and the concatenated up-projection in e4m3 as well."""
     from magma_amd import Magma
     from magma_amd.language_model import GPTJConfig
     torch.manual_seed(7)
-    model = Magma("MAGMA_v1", device=dev, lm_config=GPTJConfig(num_layers=2, vocab_size=50258))
+    model = Magma(config, device=dev, lm_config=GPTJConfig(num_layers=2, vocab_size=50258))
     model.eval()
     eng = model.lm.engine
     g = torch.Generator(device=dev).manual_seed(3)

@@ -523,3 +523,19 @@ def test_gemm256_split_k(dev, M, N, K, split):
         assert torch.equal(out, out2)
         o128 = ops.gemm(a, lin, tile=128, **kw)
         assert float((out - o128).abs().max()) <= 2e-3 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("M,N,ld", [(300, 520, 528), (2048, 1024, 1024)])
+def test_gelu_erf_passes(dev, M, N, ld):
+    """torch.nn.GELU() (erf) and g * gelu'(pre) as stand-alone passes (adapters built with activation=nn.GELU, reference
+    adapters.py:11,20), strided rows and in place, against torch."""
+    from magma_amd import ops
+    x = (rnd(M, ld, dev=dev, seed=600) * 2).to(BF16)[:, :N]
+    g = rnd(M, ld, dev=dev, seed=601).to(BF16)[:, :N]
+    assert_close(ops.gelu_erf(x), F.gelu(x.float()), 3e-3, "gelu (erf)")
+    xr = x.float().clone().requires_grad_(True)
+    F.gelu(xr).backward(torch.ones_like(xr))
+    assert_close(ops.gelu_erf_grad_mul(g, x), g.float() * xr.grad, 3e-3, "gelu (erf) gradient")
+    y = x.clone()
+    ops.gelu_erf(y, out=y)
+    assert torch.equal(y, ops.gelu_erf(x))

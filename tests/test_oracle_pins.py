@@ -141,3 +141,24 @@ def test_parallel_adapters_match_reference():
     assert "adapter_scale" not in PINS["parallel_adapter"]["sd"]          # plain "parallel": the scale is the constant 1
     assert float(PINS["parallel_adapter_scaled"]["sd"]["adapter_scale"]) == 1.75
     assert PINS["parallel_adapter_wrapper"]["rest"] == ["present", "weights"]
+
+
+@pytest.mark.parametrize("name,act", [("gelu", "gelu"), ("gelu_tanh", "gelu_tanh"), ("ln", "relu"), ("ln_gelu", "gelu")])
+def test_adapter_options_match_reference(name, act):
+    """reference adapters.py:11-24: ``activation`` and ``add_layernorm`` -- the reference's own Adapter run in place with each
+    option (tests/golden/make_golden.py), against the oracle's statement of it; and the product module builds the same
+    state-dict keys for every option set."""
+    import functools
+    pin = PINS["adapter_options"][name]
+    p = {"a." + k.replace("adapter.", ""): v for k, v in pin["sd"].items()}
+    y = O.adapter_fwd(p, "a.", pin["x"], act)
+    assert torch.allclose(y, pin["y"], atol=2e-6, rtol=1e-5)
+    from magma_amd.adapters import Adapter
+    kw = {"gelu": dict(activation=torch.nn.GELU), "gelu_tanh": dict(activation=functools.partial(torch.nn.GELU, approximate="tanh")),
+          "ln": dict(add_layernorm=True), "ln_gelu": dict(add_layernorm=True, activation=torch.nn.GELU)}[name]
+    mod = Adapter(dim=64, downsample_factor=4, **kw)
+    assert set(mod.state_dict()) == set(pin["sd"])
+    assert (mod.ln is not None) == name.startswith("ln") and mod.down.weight.shape == (16, 64) and mod.up.weight.shape == (64, 16)
+    assert not mod.plain
+    with pytest.raises(NotImplementedError):
+        Adapter(dim=64, activation=torch.nn.Tanh)

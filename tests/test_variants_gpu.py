@@ -413,3 +413,132 @@ def test_magma_with_clip_vit_encoder(dev):
     assert emb.shape == (2, 4 + 5, 512) and bool(torch.isfinite(emb.float()).all())
     toks = model.generate(emb, max_steps=3, temperature=0.0, decode=False, stop_on_eos=False)
     assert toks.shape == (2, 9 + 3)
+
+
+# ----------------------------------------------------------------------------------------------------------------------------
+# Adapter options of the reference (magma/adapters.py:11-24): ``activation`` and ``add_layernorm``
+# ----------------------------------------------------------------------------------------------------------------------------
+import functools  # noqa: E402
+
+_ACTS = {"relu": torch.nn.ReLU, "gelu": torch.nn.GELU, "gelu_tanh": functools.partial(torch.nn.GELU, approximate="tanh")}
+OPTION_CASES = [("normal", None, "gelu", True), ("normal", "normal", "relu", True), ("parallel", "scaled_parallel", "gelu_tanh", True),
+                ("normal", None, "gelu_tanh", False)]
+
+
+def _build_opts(dev, mlp_type, attn_type, act, ln):
+    from magma_amd.config import MultimodalConfig
+    from magma_amd.image_encoders import ModifiedResNetTrunk
+    from magma_amd.language_model import GPTJConfig
+    from magma_amd.magma import Magma
+    extra = dict(add_layernorm=ln, activation=_ACTS[act])
+    ad = {"mlp": dict(adapter_type=mlp_type, downsample_factor=4, **extra)}
+    if attn_type:
+        ad["attention"] = dict(adapter_type=attn_type, downsample_factor=8, **extra)
+    cfg = MultimodalConfig(batch_size=2, train_steps=1, encoder_name="clip_resnet_large", adapter_config=ad, image_size=64,
+                           freeze_img_encoder=False, use_image_embed_layernorm=True, image_embed_dropout_prob=0.1)
+    lm_cfg = GPTJConfig(vocab_size=1056, hidden_size=512, num_layers=2, num_heads=2, rotary_dim=64, intermediate_size=2048,
+                        max_position_embeddings=256)
+    enc = ModifiedResNetTrunk((1, 1, 2, 1), 16, 64, device=dev, dtype=torch.bfloat16)
+    return Magma(cfg, device=dev, lm_config=lm_cfg, enc=enc)
+
+
+def _opt_params(mlp_type, attn_type, act, ln, seed):
+    from oracle.model import OracleConfig, init_params
+    cfg = OracleConfig.tiny(mlp_adapter_hidden=128, attn_adapter_hidden=64 if attn_type else 0, mlp_adapter_type=mlp_type,
+                            attn_adapter_type=attn_type or "normal", adapter_act=act, adapter_layernorm=ln)
+    p = init_params(cfg, seed=seed)
+    lin = ("1.", "3.") if ln else ("0.", "2.")
+    for k in p:        # larger projections than the 1e-3 init so that the adapter arithmetic is visible; the LayerNorm stays O(1)
+        if ".adapter." in k and k.split(".adapter.")[1].startswith(lin):
+            p[k] = p[k] * 20
+    return cfg, p
+
+
+@pytest.mark.parametrize("mlp_type,attn_type,act,ln", OPTION_CASES)
+def test_adapter_options_inference_vs_oracle(dev, mlp_type, attn_type, act, ln):
+    """Prefill, cached steps (whatever launch structure the option set allows: the folded / grouped blocks for plain ReLU adapters
+    with another activation code, the generic block with an extra LayerNorm launch otherwise) and the full-sequence forward."""
+    from oracle.model import generate_greedy, lm_forward
+    cfg, p = _opt_params(mlp_type, attn_type, act, ln, seed=7)
+    model = _build_opts(dev, mlp_type, attn_type, act, ln)
+    missing, unexpected = model.load_checkpoint_state(p)
+    assert not unexpected and not missing, (missing, unexpected)
+    model.eval()
+    lm = {k: v for k, v in p.items() if k.startswith("lm.")}
+    lmb = bf16_params(lm)
+    g = torch.Generator().manual_seed(2)
+    emb = torch.randn(2, 10, cfg.d_model, generator=g).to(torch.bfloat16).float()
+    steps = 4
+    with torch.no_grad():
+        ref_toks, ref_logits = generate_greedy(lm, cfg, emb, steps, stop_on_eos=False)
+        _, bf_logits = generate_greedy(lmb, cfg, emb.to(torch.bfloat16), steps, stop_on_eos=False)
+        # the option must matter: the same weights under the default activation give other logits
+        import dataclasses
+        other = dataclasses.replace(cfg, adapter_act="relu" if act != "relu" else "gelu")
+        assert rel(lm_forward(lm, other, inputs_embeds=emb)["logits"], lm_forward(lm, cfg, inputs_embeds=emb)["logits"]) > 5e-3
+        out = model.lm(inputs_embeds=emb.to(torch.bfloat16).cuda(), use_cache=True, cache_hint=steps)
+        assert rel(out.logits[:, -1], ref_logits[0]) <= 2 * rel(bf_logits[0], ref_logits[0]) + 2e-3
+        cache, S0 = out.past_key_values, emb.shape[1]
+        for i in range(1, steps):
+            o = model.lm(input_ids=ref_toks[:, S0 + i - 1: S0 + i].cuda(), use_cache=True, past_key_values=cache)
+            assert rel(o.logits[:, -1], ref_logits[i]) <= 2 * max(rel(bf_logits[i], ref_logits[i]), 5e-3) + 2e-3, i
+        full = model.lm(inputs_embeds=emb.to(torch.bfloat16).cuda())
+        assert rel(full.logits, lm_forward(lm, cfg, inputs_embeds=emb)["logits"]) < 2e-2
+
+
+@pytest.mark.parametrize("mlp_type,attn_type,act,ln", OPTION_CASES[:3])
+def test_adapter_options_train_gradients(dev, mlp_type, attn_type, act, ln):
+    """Gradients of every trainable tensor -- the adapters' LayerNorm gains / biases included -- against autograd through the oracle."""
+    from magma_amd.train_engine import MagmaEngine
+    from oracle.model import magma_forward
+    cfg, params = _opt_params(mlp_type, attn_type, act, ln, seed=29)
+    model = _build_opts(dev, mlp_type, attn_type, act, ln)
+    missing, unexpected = model.load_checkpoint_state(params)
+    assert not unexpected and not missing, (missing, unexpected)
+    model.config.gradient_accumulation_steps = 1
+    eng = MagmaEngine(model)
+    eng.train()
+    g = torch.Generator().manual_seed(3)
+    B, S = 2, model.seq_len
+    images = torch.randn(B, 3, 64, 64, generator=g)
+    caps = torch.full((B, S), cfg.eos_token, dtype=torch.int64)
+    caps[0, :23] = torch.randint(0, 1000, (23,), generator=g)
+    caps[1, :11] = torch.randint(0, 1000, (11,), generator=g)
+    mask = (torch.rand(B, 4, cfg.d_model, generator=g) < 0.9).float() / 0.9
+
+    def oracle_grads(dtype):
+        p = {k: (v.detach().to(dtype).clone() if v.is_floating_point() else v) for k, v in params.items()}
+        names = [k for k in p if (".adapter." in k or "adapter_scale" in k or k.startswith("image_prefix.")) and "running_" not in k]
+        for k in names:
+            p[k].requires_grad_(True)
+        out = magma_forward(p, cfg, images.to(dtype), caps, dropout_mask=mask.to(dtype))
+        out["loss"].backward()
+        return float(out["loss"]), {k: p[k].grad.float() for k in names}
+
+    loss_ref, g_ref = oracle_grads(torch.float32)
+    loss_bf, g_bf = oracle_grads(torch.bfloat16)
+    out = eng(images.to(dev), caps.to(dev), dropout_mask=mask.to(dev))
+    assert abs(float(out.loss) - loss_ref) <= 2 * abs(loss_bf - loss_ref) + 3e-3 * abs(loss_ref)
+    eng.backward(out.loss)
+    name_of = {id(p): n for n, p in model.named_parameters()}
+    dots = n1 = n2 = 0.0
+    seen, bad = set(), []
+    for grp in eng.groups:
+        for p in grp.params:
+            n = name_of[id(p)]
+            n = "lm." + n if n.startswith("transformer.") else n
+            if n in seen or n not in g_ref:
+                continue
+            seen.add(n)
+            got, ref = eng.grad_of(p).float().cpu().reshape(-1), g_ref[n].reshape(-1)
+            e_hip, e_bf = rel(got, ref), rel(g_bf[n].reshape(-1), ref)
+            if "adapter_scale" not in n and e_hip > 2 * e_bf + 3e-2:
+                bad.append((n, e_hip, e_bf))
+            dots += float((got * ref).sum()); n1 += float((got * got).sum()); n2 += float((ref * ref).sum())
+    assert not bad, bad
+    assert len(seen) == len(g_ref), set(g_ref) - seen
+    assert any(".adapter.0.weight" in n and g_ref[n].ndim == 1 for n in seen) == ln      # the adapters' LayerNorm gains are trained
+    assert dots / (n1 ** 0.5 * n2 ** 0.5) > 0.999
+    eng.step()
+    eng.eval()
+    assert torch.isfinite(eng(images.to(dev), caps.to(dev)).loss)
