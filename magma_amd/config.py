@@ -13,7 +13,6 @@ existing MAGMA_v1.yml / MAGMA_v2.yml parse unchanged.  What differs:
 from __future__ import annotations
 
 import dataclasses
-import os
 import uuid
 from pathlib import Path
 from pprint import pprint

@@ -19,7 +19,7 @@ Per block (parallel residual, adapters after attention/MLP):
 from __future__ import annotations
 
 import os
-from typing import Any, List, Optional
+from typing import List, Optional
 
 import torch
 
