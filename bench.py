@@ -2,8 +2,8 @@
 """bench.py -- MAGMA_v1 on MI355X: generate tokens/sec (BASELINE.json config[1]:
 bf16 inference, batch-8 images, 32 generated tokens) on synthetic data.
 
-    python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: starts its N ranks itself)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...     (--gpus must equal the rank count)
 
 One "step" = one full pass of the inference hot path over one batch: CLIP
 RN50x16 trunk + ImagePrefix on 8 images, word embeddings of an 8-token prompt,
@@ -16,7 +16,10 @@ Extra objects on the JSON line:
   roofline      dominant kernel = the decode weight-streaming GEMM (HBM-bound):
                 algorithmic bytes = every LM + adapter + head weight byte once
                 per token step (12.16 GB at full size) / time of the decode
-                graph, measured live with HIP events on the launch stream.
+                graph, measured live with HIP events on the launch stream;
+                roofline.train = the training half's dominant kernel (the 256x256
+                MFMA GEMM at the four block-projection shapes, M = 16 x 2048),
+                measured live the same way against 2.5 PF/s.
   cpu_baseline  the oracle (CPU restatement, "port") timed on the host cores on
                 a bounded sample of the same workload, extrapolated linearly in
                 layers (stated in "sample").
@@ -770,6 +773,7 @@ def main():
                     line["magma_v2"] = {"error": repr(e)[:300]}
         print(json.dumps(line), flush=True)
     if world > 1:
+        torch.distributed.barrier()          # rank 0 measured the roofline objects alone: leave together
         torch.distributed.destroy_process_group()
 
 
