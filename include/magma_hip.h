@@ -394,6 +394,10 @@ int mg_ce_reduce_f32(const float* loss_row, const int64_t* tgt, int32_t R, float
  * row index M of activations: dW[N,K] = dY^T[N,M] * (X^T[K,M])^T.                 */
 int mg_transpose_bf16(const mg_bf16* in, int64_t ld_in, int64_t bs_in, mg_bf16* out, int64_t ld_out,
                       int64_t bs_out, int32_t R, int32_t C, int32_t batch, void* stream);
+/* The same transpose of ONE matrix that also accumulates colsum[c] += sum_r in[r][c] (fp32): the bias gradient and the weight-gradient
+ * operand of a Linear (reference adapters.py:18-25 Linear layers; torch.autograd in the reference) from one pass over its output gradient. */
+int mg_transpose_colsum_bf16(const mg_bf16* in, int64_t ld_in, mg_bf16* out, int64_t ld_out, int32_t R, int32_t C,
+                             float* colsum, void* stream);
 
 /* per-head transposes for the attention kernels, column-tiled: dst[(((b*H+h)*(ld/32) + s/32)*256 + d)*32 + s%32]
  * = src[b*sb + s*ss + h*sh + d]; ld = round_up(S,32), zero filled.                                              */

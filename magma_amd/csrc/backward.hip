@@ -10,9 +10,12 @@ namespace {
 // transpose: in [R, C] (ld_in) -> out [C, R] (ld_out); 64x64 tiles through LDS.
 // R, C multiples of 8.  batched through blockIdx.z.
 // ---------------------------------------------------------------------------
+// COLSUM: also colsum[c] += sum_r in[r][c] (fp32 atomics, 64 per workgroup) from the tile already in LDS -- the bias gradient of a
+// Linear whose weight gradient needs this very transpose (adapters: one pass over g instead of colsum_kernel + transpose_kernel).
+template <bool COLSUM>
 __global__ __launch_bounds__(256) void transpose_kernel(const mg_bf16* __restrict__ in, int64_t ld_in,
                                                         int64_t bs_in, mg_bf16* __restrict__ out,
-                                                        int64_t ld_out, int64_t bs_out, int R, int C) {
+                                                        int64_t ld_out, int64_t bs_out, int R, int C, float* __restrict__ colsum) {
   __shared__ mg_bf16 tile[64][64 + 2];
   const int tid = threadIdx.x;
   in += (int64_t)blockIdx.z * bs_in;
@@ -31,6 +34,14 @@ __global__ __launch_bounds__(256) void transpose_kernel(const mg_bf16* __restric
     }
   }
   __syncthreads();
+  if constexpr (COLSUM) {       // rows beyond R were stored as zeros: no bounds in the sum
+    if (tid < 64 && c0 + tid < C) {
+      float acc = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < 64; ++r) acc += bf2f(tile[r][tid]);
+      atomicAdd(colsum + c0 + tid, acc);
+    }
+  }
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
     const int ci = tid + it * 256;
@@ -606,7 +617,20 @@ extern "C" int mg_transpose_bf16(const mg_bf16* in, int64_t ld_in, int64_t bs_in
   if (!in || !out || !MG_ALIGNED16(in) || !MG_ALIGNED16(out) || (ld_in & 7) || (ld_out & 7) || (bs_in & 7) || (bs_out & 7))
     MG_FAIL(MG_ERR_ALIGN, "mg_transpose_bf16: 16-byte alignment required");
   dim3 grid((C + 63) / 64, (R + 63) / 64, batch);
-  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, ld_in, bs_in, out, ld_out, bs_out, R, C);
+  hipLaunchKernelGGL(transpose_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, in, ld_in, bs_in, out, ld_out, bs_out, R, C, (float*)nullptr);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
+// The same transpose (one matrix) that also ACCUMULATES the column sums of `in` into colsum[C] (fp32): d bias and the operand of d weight
+// of a Linear from one pass over its output gradient.
+extern "C" int mg_transpose_colsum_bf16(const mg_bf16* in, int64_t ld_in, mg_bf16* out, int64_t ld_out, int32_t R, int32_t C,
+                                        float* colsum, void* stream) {
+  if (R <= 0 || C <= 0 || (C & 7) || ld_out < ((R + 7) & ~7)) MG_FAIL(MG_ERR_SHAPE, "mg_transpose_colsum_bf16: C%%8==0 and ld_out >= round_up(R,8) required");
+  if (!in || !out || !colsum || !MG_ALIGNED16(in) || !MG_ALIGNED16(out) || (ld_in & 7) || (ld_out & 7))
+    MG_FAIL(MG_ERR_ALIGN, "mg_transpose_colsum_bf16: 16-byte alignment required");
+  dim3 grid((C + 63) / 64, (R + 63) / 64, 1);
+  hipLaunchKernelGGL(transpose_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, in, ld_in, (int64_t)0, out, ld_out, (int64_t)0, R, C, colsum);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }

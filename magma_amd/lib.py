@@ -115,6 +115,7 @@ SYMBOLS = {
     "mg_ce_reduce_f32": (C.c_int, [_vp, _vp, _i32, _vp, _vp]),
     # training path
     "mg_transpose_bf16": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
+    "mg_transpose_colsum_bf16": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp]),
     "mg_head_transpose_bf16": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mg_colsum_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _i32, _vp]),
     "mg_layernorm_bwd_bf16": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _f32, _vp]),

@@ -629,6 +629,17 @@ def transpose(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tens
     return out
 
 
+def transpose_colsum(x: torch.Tensor, colsum_out: torch.Tensor) -> torch.Tensor:
+    """transpose(x) that also accumulates the column sums of x into colsum_out (fp32 [C]): one pass instead of two."""
+    _need_gpu(x, colsum_out)
+    assert x.dtype == BF16 and x.ndim == 2 and x.stride(1) == 1 and colsum_out.dtype == torch.float32 and colsum_out.numel() >= x.shape[1]
+    R, Cc = x.shape
+    out = torch.empty(Cc, ceil_to(R, 8), dtype=BF16, device=x.device)
+    check(L.load().mg_transpose_colsum_bf16(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), R, Cc, colsum_out.data_ptr(), _stream()),
+          "mg_transpose_colsum_bf16")
+    return out
+
+
 def head_transpose(src: torch.Tensor, B: int, H: int, S: int, sb: int, ss: int, sh: int,
                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """-> column-tiled transposed layout [B, H, ceil(S/32), 256, 32]: out[b,h,t,d,i] = src[b, 32t+i, h, d], zero padded."""

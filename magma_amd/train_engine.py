@@ -571,17 +571,16 @@ class MagmaEngine:
         from .adapters import activation_codes
         dn, up = mod.down, mod.up
         _, gmode, needs_pre = activation_codes(mod.act)
-        ops.colsum(g, self.grad_of(up.bias))
-        gT = _t(g)
+        gT = RawWeight(ops.transpose_colsum(g, self.grad_of(up.bias)))         # g^T and d b_up from one pass over g
         self._acc_wgrad(up.weight, gT, _t(t))
         if gmode == ops.MG_AUX_GELU_ERF_GRAD:
             dt = ops.gemm(g, _t(up.weight.data), layout="rm", use_bias=False)
             ops.gelu_erf_grad_mul(dt, pre, out=dt)
         else:
             dt = ops.gemm(g, _t(up.weight.data), aux=pre if needs_pre else t, aux_mode=gmode, layout="rm", use_bias=False)
-        ops.colsum(dt, self.grad_of(dn.bias))
+        dtT = RawWeight(ops.transpose_colsum(dt, self.grad_of(dn.bias)))      # dt^T and d b_dn
         xin = x_in if mod.ln is None else ops.layernorm(x_in, self._vec(mod.ln.weight), self._vec(mod.ln.bias), mod.ln.eps)
-        self._acc_wgrad(dn.weight, _t(dt), _t(xin))
+        self._acc_wgrad(dn.weight, dtT, _t(xin))
         return dt, _t(dn.weight.data)
 
     def _adapter_dx(self, mod, dt, dn_t, x_in, res=None):

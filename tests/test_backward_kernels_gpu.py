@@ -263,3 +263,17 @@ def test_conv_weight_relayout(dev, cout, cin, k):
     d = ops.conv_weight_relayout(w, 1, scale)
     ref_d = (w.float() * scale.view(cout, 1, 1, 1)).flip(2, 3).permute(1, 2, 3, 0).reshape(cin, k * k * cout).to(BF16)
     assert d.shape[1] % 64 == 0 and torch.equal(d[:, : k * k * cout], ref_d) and bool((d[:, k * k * cout:] == 0).all())
+
+
+@pytest.mark.parametrize("R,C", [(4096, 1024), (1000, 520), (77, 64)])
+def test_transpose_colsum(dev, R, C):
+    """transpose + column sums in one pass == transpose and colsum separately (bias gradient and weight-gradient operand of a Linear)."""
+    from magma_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(R + C)
+    x = torch.randn(R, C, generator=g).to(torch.bfloat16).to(dev)
+    acc = torch.full((C,), 0.5, dtype=torch.float32, device=dev)           # accumulates on top of what is there
+    xt = ops.transpose_colsum(x, acc)
+    assert torch.equal(xt[:, :R], x.t())
+    assert bool((xt[:, R:] == 0).all())
+    ref = 0.5 + x.float().sum(0)
+    assert float((acc - ref).abs().max()) <= 1e-3 * float(ref.abs().max()) + 1e-3
