@@ -25,6 +25,7 @@ Extra objects on the JSON line:
                 layers (stated in "sample").
 """
 import argparse
+import datetime
 import json
 import os
 import sys
@@ -543,7 +544,8 @@ def main():
         if world > 1:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group(os.environ.get("MAGMA_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
+            dist.init_process_group(os.environ.get("MAGMA_BENCH_BACKEND", "nccl"), rank=rank, world_size=world,
+                                    timeout=datetime.timedelta(minutes=30))    # rank 0 measures the roofline objects alone while the others wait
         return rendezvous_only(args, rank, world)
     # one rank per GPU over RCCL.  MAGMA_BENCH_DEVICE / MAGMA_BENCH_BACKEND exist for ONE purpose: rehearsing the multi-rank
     # control flow (collective order, barriers, rank-0-only sections) with two processes on a single-GPU box (gloo, both
@@ -554,7 +556,8 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(os.environ.get("MAGMA_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
+        dist.init_process_group(os.environ.get("MAGMA_BENCH_BACKEND", "nccl"), rank=rank, world_size=world,
+                                    timeout=datetime.timedelta(minutes=30))    # rank 0 measures the roofline objects alone while the others wait
     from magma_amd import Magma
     from magma_amd.language_model import GPTJConfig
 
