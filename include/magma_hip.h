@@ -64,7 +64,8 @@ const char* mg_version(void);
 /* Binary interface revision.  A binder built against another revision must not call into the library: arguments moved.
  *   1  rounds 1-3.  Within it (before this counter existed) three signatures changed: mg_epilogue._pad became act_n0;
  *      mg_rotary_split_bf16 gained ld_qkv as its 2nd argument; mg_sample_f32's top_p went from float to double.
- *   2  round 4: mg_decode_attn_gemv_bf16 gained ld_attn_out (5th argument), mg_attn_prefill_bf16 gained ld_out (5th); removed: mg_decode_attn_2gemv_bf16,
+ *   2  round 4: mg_decode_attn_gemv_bf16 gained ld_attn_out (5th argument), mg_attn_prefill_bf16 gained ld_out (5th), mg_attn_bwd_bf16 /
+ *      mg_attn_bwd_merged_bf16 gained ld_o (before the stream); removed: mg_decode_attn_2gemv_bf16,
  *      mg_decode_ctx_counter_ints, the persistent decode step's four entry points mg_decode_plan_* / mg_decode_step_* (in-launch hand-off
  *      experiments, measured slower than the launch chain: DESIGN.md 8).                                                        */
 #define MG_ABI_VERSION 2
@@ -426,12 +427,13 @@ int mg_rotary_merge_bwd_bf16(const mg_bf16* dq, const mg_bf16* dk, const mg_bf16
 /* causal flash-attention backward, head dim 256 (recomputes P from q,k,lse).
  * q,k,v [B,H,S,256]; qt,kt,dOt [B,H,ld_t/32,256,32] (column-tiled transposes from mg_head_transpose_bf16,
  * ld_t = round_up(S,32), zero padded);
- * dO,O [B*S,H*256]; lse [B,H,S]; D = fp32 workspace of 2*B*H*S floats ({lse*log2e, rowsum(dO o O)}
+ * dO [B*S,H*256]; O [B*S, >= H*256] with row stride ld_o elements (ABI 2: the attention output may sit in a wider
+ * [ctx | t] buffer, the operand of the [W_out | W_up] GEMM); lse [B,H,S]; D = fp32 workspace of 2*B*H*S floats ({lse*log2e, rowsum(dO o O)}
  * per query, written by the first launch).                                           */
 int mg_attn_bwd_bf16(const mg_bf16* q, const mg_bf16* k, const mg_bf16* v, const mg_bf16* qt,
                      const mg_bf16* kt, const mg_bf16* dO, const mg_bf16* dOt, const mg_bf16* O,
                      const float* lse, float* D, mg_bf16* dq, mg_bf16* dk, mg_bf16* dv, int32_t B,
-                     int32_t H, int32_t S, int32_t ld_t, void* stream);
+                     int32_t H, int32_t S, int32_t ld_t, int64_t ld_o, void* stream);
 
 /* The same backward written straight into the gradient of the fused qkv projection (autograd through
  * GPTJAttention's rotary + head split, /root/reference call site magma/magma.py:263-276 -> HF modeling_gptj):
@@ -442,7 +444,7 @@ int mg_attn_bwd_bf16(const mg_bf16* q, const mg_bf16* k, const mg_bf16* v, const
 int mg_attn_bwd_merged_bf16(const mg_bf16* q, const mg_bf16* k, const mg_bf16* v, const mg_bf16* qt,
                             const mg_bf16* kt, const mg_bf16* dO, mg_bf16* dOt, const mg_bf16* O,
                             const float* lse, float* D, mg_bf16* dqkv, int32_t rot_dim, const float* sin_t,
-                            const float* cos_t, int32_t B, int32_t H, int32_t S, int32_t ld_t, void* stream);
+                            const float* cos_t, int32_t B, int32_t H, int32_t S, int32_t ld_t, int64_t ld_o, void* stream);
 
 /* CLIP trunk backward helpers */
 int mg_avgpool2_bwd_nhwc_bf16(const mg_bf16* dy, const mg_bf16* gate, mg_bf16* dx, int32_t B, int32_t H, int32_t W, int32_t C, void* stream);

@@ -88,12 +88,12 @@ constexpr int DV_STAGES = 4;
 // ld2[b,h,s] = {lse * log2(e), D = rowsum(dO o O)}; one wave per (b, s, h) row of 256
 __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const mg_bf16* __restrict__ dO, const mg_bf16* __restrict__ O,
                                                             const float* __restrict__ lse, float* __restrict__ ld2,
-                                                            int B, int H, int S) {
+                                                            int B, int H, int S, int64_t ld_o) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t row = (int64_t)blockIdx.x * 4 + wave;   // over B*S*H, (b,s,h) order = memory order of [M, H*256]
   if (row >= (int64_t)B * S * H) return;
   const u32x2 a = *(const u32x2*)(dO + row * DH + lane * 4);
-  const u32x2 o = *(const u32x2*)(O + row * DH + lane * 4);
+  const u32x2 o = *(const u32x2*)(O + (row / H) * ld_o + (row % H) * DH + lane * 4);   // O rows may sit in a wider buffer ([ctx | t])
   float s = bflo(a[0]) * bflo(o[0]) + bfhi(a[0]) * bfhi(o[0]) + bflo(a[1]) * bflo(o[1]) + bfhi(a[1]) * bfhi(o[1]);
   s = wave_sum(s);
   if (lane == 0) {
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const mg_bf16* __res
 // dO transpose of the two-pass form in one.  grid (ceil(S/32), B*H), 256 threads; a row is 32 consecutive lanes.
 __global__ __launch_bounds__(256) void attn_bwd_prep_t_kernel(const mg_bf16* __restrict__ dO, const mg_bf16* __restrict__ O,
                                                               const float* __restrict__ lse, float* __restrict__ ld2,
-                                                              mg_bf16* __restrict__ dOt, int ld_t, int B, int H, int S) {
+                                                              mg_bf16* __restrict__ dOt, int ld_t, int B, int H, int S, int64_t ld_o) {
   __shared__ __attribute__((aligned(16))) mg_bf16 tile[32 * DH];
   const int tid = threadIdx.x;
   const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_t_kernel(const mg_bf16* __r
     if (sidx < S) {
       const int64_t off = ((int64_t)b * S + sidx) * dmodel + h * DH + c * 8;
       a = *(const u32x4*)(dO + off);
-      const u32x4 o = *(const u32x4*)(O + off);
+      const u32x4 o = *(const u32x4*)(O + ((int64_t)b * S + sidx) * ld_o + h * DH + c * 8);
 #pragma unroll
       for (int w = 0; w < 4; ++w) dot += bflo(a[w]) * bflo(o[w]) + bfhi(a[w]) * bfhi(o[w]);
     }
@@ -433,7 +433,8 @@ namespace {
 int attn_bwd_launch(const mg_bf16* q, const mg_bf16* k, const mg_bf16* v, const mg_bf16* qt, const mg_bf16* kt,
                     const mg_bf16* dO, const mg_bf16* dOt, const mg_bf16* O, const float* lse, float* D,
                     const GradOut& gq, const GradOut& gk, const GradOut& gv, int32_t B, int32_t H, int32_t S, int32_t ld_t,
-                    bool make_dOt, hipStream_t s, const char* who) {
+                    int64_t ld_o, bool make_dOt, hipStream_t s, const char* who) {
+  if (ld_o < (int64_t)H * DH || (ld_o & 7)) MG_FAIL(MG_ERR_SHAPE, "%s: ld_o must be a multiple of 8 and >= H * 256", who);
   if (B <= 0 || H <= 0 || S <= 0 || (ld_t & 31) || ld_t < ((S + 31) & ~31)) MG_FAIL(MG_ERR_SHAPE, "%s: ld_t must be a multiple of 32 and >= S", who);
   const void* ptrs[] = {q, k, v, qt, kt, dO, dOt, O, lse, D};
   for (const void* p : ptrs) {
@@ -446,9 +447,9 @@ int attn_bwd_launch(const mg_bf16* q, const mg_bf16* k, const mg_bf16* v, const 
   const int64_t rows = (int64_t)B * S * H;
   const dim3 grid((unsigned)(((S + 127) / 128) * B * H));
   if (make_dOt)
-    hipLaunchKernelGGL(attn_bwd_prep_t_kernel, dim3((S + 31) / 32, B * H), dim3(256), 0, s, dO, O, lse, D, (mg_bf16*)dOt, ld_t, B, H, S);
+    hipLaunchKernelGGL(attn_bwd_prep_t_kernel, dim3((S + 31) / 32, B * H), dim3(256), 0, s, dO, O, lse, D, (mg_bf16*)dOt, ld_t, B, H, S, ld_o);
   else
-    hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, dO, O, lse, D, B, H, S);
+    hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, dO, O, lse, D, B, H, S, ld_o);
   hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(512), DQ_STAGES * DQ_STAGE, s, q, k, v, kt, dO, D, gq, B, H, S, ld_t);
   hipLaunchKernelGGL(attn_bwd_dkdv_kernel<false>, grid, dim3(512), DV_STAGES * DV_STAGE, s, q, k, v, qt, dO, dOt, D, gv, B, H, S, ld_t);
   hipLaunchKernelGGL(attn_bwd_dkdv_kernel<true>, grid, dim3(512), DK_STAGES * DK_STAGE, s, q, k, v, qt, dO, dOt, D, gk, B, H, S, ld_t);
@@ -458,15 +459,15 @@ int attn_bwd_launch(const mg_bf16* q, const mg_bf16* k, const mg_bf16* v, const 
 }  // namespace
 
 // q,k,v [B,H,S,256]; kt,qt,dOt column-tiled transposed [B,H,ld_t/32,256,32] (mg_head_transpose_bf16; zero padded);
-// dO, O [B*S, H*256]; lse [B,H,S]; D [B,H,S,2] workspace; dq,dk,dv [B,H,S,256]
+// dO [B*S, H*256]; O [B*S, >= H*256] with row stride ld_o (elements); lse [B,H,S]; D [B,H,S,2] workspace; dq,dk,dv [B,H,S,256]
 extern "C" int mg_attn_bwd_bf16(const mg_bf16* q, const mg_bf16* k, const mg_bf16* v, const mg_bf16* qt,
                                 const mg_bf16* kt, const mg_bf16* dO, const mg_bf16* dOt, const mg_bf16* O,
                                 const float* lse, float* D, mg_bf16* dq, mg_bf16* dk, mg_bf16* dv, int32_t B,
-                                int32_t H, int32_t S, int32_t ld_t, void* stream) {
+                                int32_t H, int32_t S, int32_t ld_t, int64_t ld_o, void* stream) {
   if (!dq || !dk || !dv) MG_FAIL(MG_ERR_SHAPE, "mg_attn_bwd_bf16: null pointer");
   if (!MG_ALIGNED16(dq) || !MG_ALIGNED16(dk) || !MG_ALIGNED16(dv)) MG_FAIL(MG_ERR_ALIGN, "mg_attn_bwd_bf16: pointers must be 16-byte aligned");
   const GradOut gq{dq, nullptr, nullptr, nullptr, 0, 0}, gk{dk, nullptr, nullptr, nullptr, 1, 0}, gv{dv, nullptr, nullptr, nullptr, 2, 0};
-  return attn_bwd_launch(q, k, v, qt, kt, dO, dOt, O, lse, D, gq, gk, gv, B, H, S, ld_t, false, (hipStream_t)stream, "mg_attn_bwd_bf16");
+  return attn_bwd_launch(q, k, v, qt, kt, dO, dOt, O, lse, D, gq, gk, gv, B, H, S, ld_t, ld_o, false, (hipStream_t)stream, "mg_attn_bwd_bf16");
 }
 
 // Same backward, written straight into the gradient of the fused qkv projection: dqkv [B*S, 3*H*256] = [dq | dk | dv]
@@ -476,10 +477,10 @@ extern "C" int mg_attn_bwd_bf16(const mg_bf16* q, const mg_bf16* k, const mg_bf1
 extern "C" int mg_attn_bwd_merged_bf16(const mg_bf16* q, const mg_bf16* k, const mg_bf16* v, const mg_bf16* qt,
                                        const mg_bf16* kt, const mg_bf16* dO, mg_bf16* dOt, const mg_bf16* O,
                                        const float* lse, float* D, mg_bf16* dqkv, int32_t rot_dim, const float* sin_t,
-                                       const float* cos_t, int32_t B, int32_t H, int32_t S, int32_t ld_t, void* stream) {
+                                       const float* cos_t, int32_t B, int32_t H, int32_t S, int32_t ld_t, int64_t ld_o, void* stream) {
   if (!dqkv || !MG_ALIGNED16(dqkv)) MG_FAIL(MG_ERR_ALIGN, "mg_attn_bwd_merged_bf16: dqkv must be a 16-byte aligned pointer");
   if (rot_dim < 0 || rot_dim > 256 || (rot_dim & 7)) MG_FAIL(MG_ERR_SHAPE, "mg_attn_bwd_merged_bf16: rot_dim must be a multiple of 8 in [0,256]");
   if (rot_dim && (!sin_t || !cos_t)) MG_FAIL(MG_ERR_SHAPE, "mg_attn_bwd_merged_bf16: rotary tables missing");
   const GradOut gq{nullptr, dqkv, sin_t, cos_t, 0, rot_dim}, gk{nullptr, dqkv, sin_t, cos_t, 1, rot_dim}, gv{nullptr, dqkv, sin_t, cos_t, 2, 0};
-  return attn_bwd_launch(q, k, v, qt, kt, dO, dOt, O, lse, D, gq, gk, gv, B, H, S, ld_t, true, (hipStream_t)stream, "mg_attn_bwd_merged_bf16");
+  return attn_bwd_launch(q, k, v, qt, kt, dO, dOt, O, lse, D, gq, gk, gv, B, H, S, ld_t, ld_o, true, (hipStream_t)stream, "mg_attn_bwd_merged_bf16");
 }

@@ -121,8 +121,8 @@ SYMBOLS = {
     "mg_layernorm_bwd_bf16": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _f32, _vp]),
     "mg_ce_bwd_bf16": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "mg_rotary_merge_bwd_bf16": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
-    "mg_attn_bwd_bf16": (C.c_int, [_vp] * 13 + [_i32, _i32, _i32, _i32, _vp]),
-    "mg_attn_bwd_merged_bf16": (C.c_int, [_vp] * 11 + [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "mg_attn_bwd_bf16": (C.c_int, [_vp] * 13 + [_i32, _i32, _i32, _i32, _i64, _vp]),
+    "mg_attn_bwd_merged_bf16": (C.c_int, [_vp] * 11 + [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _i64, _vp]),
     "mg_avgpool2_bwd_nhwc_bf16": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mg_mul_bf16": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "mg_gelu_erf_bf16": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _vp]),

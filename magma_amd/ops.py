@@ -724,14 +724,16 @@ def rotary_merge_bwd(dq, dk, dv, B, S, H, rot_dim, sin_t, cos_t):
 
 
 def attn_bwd(q, k, v, qt, kt, dO, dOt, O, lse, B, H, S):
-    """q,k,v [B,H,S,256]; qt,kt,dOt [B,H,256,ld]; dO,O [B*S,H*256]; lse [B,H,S] -> dq,dk,dv [B,H,S,256]."""
+    """q,k,v [B,H,S,256]; qt,kt,dOt [B,H,256,ld]; dO [B*S,H*256]; O [B*S, >= H*256] (any row stride); lse [B,H,S]
+    -> dq,dk,dv [B,H,S,256]."""
     _need_gpu(q)
+    assert O.ndim == 2 and O.stride(1) == 1 and dO.is_contiguous()
     dev = q.device
     D = torch.empty(B, H, S, 2, dtype=torch.float32, device=dev)   # {lse*log2e, rowsum(dO o O)} per query
     dq, dk, dv = (torch.empty(B, H, S, 256, dtype=BF16, device=dev) for _ in range(3))
     check(L.load().mg_attn_bwd_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), qt.data_ptr(), kt.data_ptr(),
                                     dO.data_ptr(), dOt.data_ptr(), O.data_ptr(), lse.data_ptr(), D.data_ptr(),
-                                    dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, H, S, qt.shape[2] * 32, _stream()),
+                                    dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, H, S, qt.shape[2] * 32, O.stride(0), _stream()),
           "mg_attn_bwd_bf16")
     return dq, dk, dv
 
@@ -740,6 +742,7 @@ def attn_bwd_merged(q, k, v, qt, kt, dO, O, lse, B, H, S, rot_dim, sin_t, cos_t)
     """dO transpose + attn_bwd + rotary_merge_bwd in one call: -> dqkv [B*S, 3*H*256] (gradient of the fused qkv
     projection)."""
     _need_gpu(q)
+    assert O.ndim == 2 and O.stride(1) == 1 and dO.is_contiguous()       # O may be the [:, :d] view of a [ctx | t] buffer
     dev = q.device
     D = torch.empty(B, H, S, 2, dtype=torch.float32, device=dev)
     dOt = torch.empty_like(qt)                                       # workspace, filled by the first launch
@@ -747,7 +750,7 @@ def attn_bwd_merged(q, k, v, qt, kt, dO, O, lse, B, H, S, rot_dim, sin_t, cos_t)
     check(L.load().mg_attn_bwd_merged_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), qt.data_ptr(), kt.data_ptr(),
                                            dO.data_ptr(), dOt.data_ptr(), O.data_ptr(), lse.data_ptr(), D.data_ptr(),
                                            dqkv.data_ptr(), rot_dim, sin_t.data_ptr(), cos_t.data_ptr(), B, H, S,
-                                           qt.shape[2] * 32, _stream()), "mg_attn_bwd_merged_bf16")
+                                           qt.shape[2] * 32, O.stride(0), _stream()), "mg_attn_bwd_merged_bf16")
     return dqkv
 
 

@@ -147,6 +147,11 @@ class MagmaEngine:
         if self.fp8 and self.lm_trainable:
             raise NotImplementedError("MAGMA_TRAIN_FP8 quantises the FROZEN block weights once; with freeze_lm: false they change every step")
         self._fp8_packs = {}
+        # MAGMA_v1 blocks: out_proj and the MLP adapter's up-projection as ONE GEMM over [ctx | t] against [W_out | W_up] (K = d + r):
+        # the attention output `a` is never written or read back (2 x M x d x 2 bytes per block) and the K = 1024 up-projection no
+        # longer pays a tile prologue + residual epilogue of its own.  bf16 step with a frozen LM only.  MAGMA_TRAIN_CAT=0: off.
+        self.cat_up = os.environ.get("MAGMA_TRAIN_CAT", "1") == "1"
+        self._out_up = {}
         self._nf_scales = {}
         self._bn_stats = {}
         # the reference's CLIP tower runs BatchNorm on its frozen statistics until the first eval phase and on
@@ -384,6 +389,29 @@ class MagmaEngine:
             self._lm_train_packs = (packs, PackedLinear(wt))
         return self._lm_train_packs
 
+    def _cat_out_up(self, li, ly, blk):
+        """[W_out | W_up] of block li as a row-major GEMM operand [d, d + r] (bias b_up), or None where the block does not have
+        the shape (plain ReLU MLP adapter without LayerNorm, no attention adapter, out_proj without a bias, bf16, frozen LM).
+        The W_out columns are written once; the W_up columns are refreshed from the live parameter on every forward."""
+        if not self.cat_up or self.fp8 or self.lm_trainable:
+            return None
+        if ly.mlp_adapter is None or ly.mlp_par is not None or ly.attn_adapter is not None:
+            return None
+        mod = blk.mlp[1]
+        a_mod, _ = ly._src
+        if not getattr(mod, "plain", False) or a_mod.out_proj.bias is not None:
+            return None
+        up = mod.up
+        d, r = up.weight.shape
+        if r % 8 or d % 8:            # 16-byte aligned [:, d:] view
+            return None
+        buf = self._out_up.get(li)
+        if buf is None or buf.shape != (d, d + r):
+            buf = self._out_up[li] = torch.empty(d, d + r, dtype=BF16, device=self.device)
+            buf[:, :d].copy_(a_mod.out_proj.weight.detach())
+        buf[:, d:].copy_(up.weight.data)
+        return RawWeight(buf, bias=self.master_of(up.bias))
+
     def _adapter_ops(self, mod):
         """(down, up) RawWeights on the live bf16 parameters of an Adapter-like module, biases = fp32 master views."""
         dn, up = mod.down, mod.up
@@ -487,11 +515,16 @@ class MagmaEngine:
             qt = torch.empty(B, H, vt_ld // 32, 256, 32, dtype=BF16, device=dev)
             kt = torch.empty(B, H, vt_ld // 32, 256, 32, dtype=BF16, device=dev)
             ops.rotary_split_train(qkv, B, S, H, eng.rot, eng.sin_t, eng.cos_t, q, k, v, vt, qt, kt)
-            ctx = torch.empty(M, d, dtype=BF16, device=dev)
+            out_up = self._cat_out_up(li, ly, blk)
+            if out_up is not None:
+                ctx_t = torch.empty(M, out_up.K, dtype=BF16, device=dev)        # [ctx | t]: one saved buffer, one GEMM operand
+                ctx = ctx_t[:, :d]
+            else:
+                ctx = torch.empty(M, d, dtype=BF16, device=dev)
             lse = torch.empty(B, H, S, dtype=F32, device=dev)
             ops.attn_prefill(q, k, vt, ctx, B, H, S, lse=lse)
             sv.update(q=q, k=k, v=v, qt=qt, kt=kt, ctx=ctx, lse=lse)
-            a = self._fgemm((li, "out"), ctx, ly.out)
+            a = None if out_up is not None else self._fgemm((li, "out"), ctx, ly.out)
             if ly.attn_adapter is not None and ly.attn_par is not None:
                 # parallel / scaled_parallel (reference adapters.py:42-92): the adapter reads the attention INPUT (ln_1 output)
                 dn, up, sc = self._par_adapter_ops(blk.attn)
@@ -508,7 +541,14 @@ class MagmaEngine:
             sv["hpre"] = hpre
             if self.lm_trainable:
                 sv["h"] = h                    # operand of the fc_out weight gradient
-            if ly.mlp_adapter is not None and ly.mlp_par is not None:
+            if out_up is not None:
+                # x' = [ctx | t] [W_out | W_up]^T + b_up + m + x   (reference adapters.py:38-39 on the MLP output + GPT-J's residual sum)
+                dn, _ = self._adapter_ops(blk.mlp[1])
+                m = self._fgemm((li, "fc_out"), h, ly.fc_out)
+                sv["t"] = ops.gemm(m, dn, act=ops.MG_ACT_RELU, layout="rm", out=ctx_t[:, d:])
+                x = ops.gemm(ctx_t, out_up, residuals=(m, x), layout="rm")
+                sv.update(m=m)
+            elif ly.mlp_adapter is not None and ly.mlp_par is not None:
                 dn, up, sc = self._par_adapter_ops(blk.mlp)
                 m = self._fgemm((li, "fc_out"), h, ly.fc_out)
                 t = self._adapter_down(blk.mlp, ln, dn, sv, "t")
@@ -1298,6 +1338,7 @@ class MagmaEngine:
         self.module.invalidate_packed()
         self._lm_train_packs = None        # transposed dgrad copies / e4m3 copies of the old frozen weights are stale now
         self._fp8_packs = {}
+        self._out_up = {}
         return str(path), sd
 
 

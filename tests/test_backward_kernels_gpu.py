@@ -163,6 +163,12 @@ def test_attention_backward_merged_output(dev, B, H, S):
         # columns outside the rotary: same arithmetic except the summation order of D = rowsum(dO o O) (fused prep)
         assert rel(a[..., rot:], b[..., rot:]) < 2e-3, (name, rel(a[..., rot:], b[..., rot:]))
         assert rel(a[..., :rot], b[..., :rot]) < 6e-3, (name, rel(a[..., :rot], b[..., :rot]))
+    # O at the row stride of a wider buffer (the [ctx | t] operand of the training step's [W_out | W_up] GEMM): bit-identical
+    wide = torch.full((B * S, d + 136), float("nan"), dtype=BF16, device=dev)
+    wide[:, :d] = out
+    assert torch.equal(ops.attn_bwd_merged(q, k, v, qt, kt, dO, wide[:, :d], lse, B, H, S, rot, sin_t, cos_t), merged)
+    for got, ref in zip(ops.attn_bwd(q, k, v, qt, kt, dO, dOt, wide[:, :d], lse, B, H, S), (dq, dk, dv)):
+        assert torch.equal(got, ref)
 
 
 def test_rotary_split_train_emits_all_transposes(dev):

@@ -406,3 +406,58 @@ def test_train_step_on_an_on_disk_dataset_with_mixed_image_modes(dev, tmp_path):
     engine.eval()
     ev = eval_step(cfg, eloader, engine)
     assert all(float(v) > 0 and float(v) == float(v) for v in (l0, l1, ev))
+
+
+def test_out_proj_and_adapter_up_as_one_gemm(dev):
+    """MAGMA_v1 training blocks run out_proj and the adapter's up-projection as ONE GEMM over [ctx | t] against
+    [W_out | W_up] (train_engine._cat_out_up; the attention output is never written as a tensor of its own, the attention
+    backward reads O at the row stride of the wider buffer).  Checked three ways: the path IS taken; loss and every gradient
+    satisfy the same oracle criterion as the two-GEMM form (err <= 2 x bf16-oracle error + 1e-2); the two forms agree with
+    each other to bf16 rounding of `a` (the fused form keeps out_proj's result in fp32 until the residual sum)."""
+    from magma_amd.testing import build_reduced_magma
+    from magma_amd.train_engine import MagmaEngine
+    from oracle.model import OracleConfig, init_params
+    cfg = OracleConfig.tiny(mlp_adapter_hidden=128, attn_adapter_hidden=0, n_positions=128)
+    params = init_params(cfg, seed=23)
+    for k in params:
+        if ".adapter." in k:
+            params[k] = params[k] * 20
+    g = torch.Generator().manual_seed(5)
+    B, P = 2, 4
+    images = torch.randn(B, 3, 64, 64, generator=g)
+    caps = torch.full((B, 128), cfg.eos_token, dtype=torch.int64)
+    caps[0, :31] = torch.randint(0, 1000, (31,), generator=g)
+    caps[1, :9] = torch.randint(0, 1000, (9,), generator=g)
+    mask = (torch.rand(B, P, cfg.d_model, generator=g) < 0.9).float() / 0.9
+    loss_ref, g_ref = oracle_grads(cfg, params, images, caps, mask, torch.float32)
+    loss_bf, g_bf = oracle_grads(cfg, params, images, caps, mask, torch.bfloat16)
+
+    def run(cat):
+        model = build_reduced_magma(dev, mlp_factor=4, attn_factor=None, n_positions=128)
+        model.load_checkpoint_state(params)
+        model.config.gradient_accumulation_steps = 1
+        eng = MagmaEngine(model)
+        eng.cat_up = cat
+        eng.train()
+        out = eng(images.to(dev), caps.to(dev), dropout_mask=mask.to(dev))
+        eng.backward(out.loss)
+        name_of = {id(p): n for n, p in model.named_parameters()}
+        grads = {}
+        for grp in eng.groups:
+            for p in grp.params:
+                n = name_of[id(p)]
+                grads["lm." + n if n.startswith("transformer.") else n] = eng.grad_of(p).float().cpu().clone()
+        return float(out.loss), grads, len(eng._out_up)
+
+    loss_c, g_c, n_cat = run(True)
+    loss_p, g_p, n_plain = run(False)
+    assert n_cat == cfg.n_layer and n_plain == 0, (n_cat, n_plain)
+    for loss in (loss_c, loss_p):
+        assert abs(loss - loss_ref) <= 2 * abs(loss_bf - loss_ref) + 3e-3 * abs(loss_ref), (loss, loss_ref, loss_bf)
+    bad = []
+    for n, ref in g_ref.items():
+        e_c, e_p, e_bf = rel(g_c[n], ref), rel(g_p[n], ref), rel(g_bf[n], ref)
+        if e_c > 2 * e_bf + 1e-2 or e_p > 2 * e_bf + 1e-2 or rel(g_c[n], g_p[n]) > 2 * e_bf + 1e-2:
+            bad.append((n, e_c, e_p, e_bf, rel(g_c[n], g_p[n])))
+    assert not bad, bad[:6]
+    assert abs(loss_c - loss_p) <= 2e-3 * abs(loss_ref), (loss_c, loss_p)
