@@ -361,17 +361,29 @@ __global__ __launch_bounds__(256) void bn_param_grad_kernel(const mg_bf16* __res
     float bt[8], ig[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { bt[j] = beta[n + j]; const float gm = gamma[n + j]; ig[j] = gm != 0.f ? 1.f / gm : 0.f; }
-    for (int m = m0 + rl; m < m1; m += 4) {
-      const u32x4 gv = *(const u32x4*)(g + (int64_t)m * C + n);
-      const u32x4 yv = *(const u32x4*)(y + (int64_t)m * C + n);
-      u32x4 sv = (u32x4){0u, 0u, 0u, 0u};
-      if (sub) sv = *(const u32x4*)(sub + (int64_t)m * C + n);
+    // four rows in flight per wave: a workgroup walks 256 rows with one wave per row -- 64 dependent round trips to HBM when
+    // every iteration waits for its own loads (the launch has fewer waves than the chip has SIMDs)
+    for (int m = m0 + rl; m < m1; m += 16) {
+      u32x4 gv[4], yv[4], sv[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float g0 = bflo(gv[j]), g1 = bfhi(gv[j]);
-        ab[2 * j] += g0; ab[2 * j + 1] += g1;
-        ag[2 * j] += g0 * (bflo(yv[j]) - bflo(sv[j]) - bt[2 * j]) * ig[2 * j];
-        ag[2 * j + 1] += g1 * (bfhi(yv[j]) - bfhi(sv[j]) - bt[2 * j + 1]) * ig[2 * j + 1];
+      for (int u = 0; u < 4; ++u) {
+        const int mm = m + 4 * u;
+        gv[u] = yv[u] = sv[u] = (u32x4){0u, 0u, 0u, 0u};      // a missing row adds g = 0 to both sums
+        if (mm < m1) {
+          gv[u] = *(const u32x4*)(g + (int64_t)mm * C + n);
+          yv[u] = *(const u32x4*)(y + (int64_t)mm * C + n);
+          if (sub) sv[u] = *(const u32x4*)(sub + (int64_t)mm * C + n);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float g0 = bflo(gv[u][j]), g1 = bfhi(gv[u][j]);
+          ab[2 * j] += g0; ab[2 * j + 1] += g1;
+          ag[2 * j] += g0 * (bflo(yv[u][j]) - bflo(sv[u][j]) - bt[2 * j]) * ig[2 * j];
+          ag[2 * j + 1] += g1 * (bfhi(yv[u][j]) - bfhi(sv[u][j]) - bt[2 * j + 1]) * ig[2 * j + 1];
+        }
       }
     }
   }

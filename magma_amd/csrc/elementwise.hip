@@ -70,6 +70,89 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const mg_bf16* __restric
   }
 }
 
+// The same arithmetic, LN_ROWS consecutive rows per workgroup, for the big activations of the forward / training step (M = 32768,
+// d = 4096): gamma / beta (fp32: 8 x the bytes of a bf16 row slice) are loaded ONCE per workgroup instead of once per row -- per row the
+// one-row kernel pulls 8 KB of x from HBM and 32 KB of gamma / beta from L2 -- and row r+1 is in flight while row r is reduced.
+// NV = 16-byte vectors per thread (d <= 2048 * NV).  Bit-identical to layernorm_kernel (same order of every sum).
+constexpr int LN_ROWS = 4;
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_rows_kernel(const mg_bf16* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, mg_bf16* __restrict__ y, int64_t ldy,
+                                                             int d, float eps, int rows) {
+  __shared__ float red[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nvec = d >> 3;
+  float g[NV][8], bb[NV][8];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int vi = tid + i * 256;
+    if (vi < nvec) {
+      const float4 g0 = *(const float4*)(gamma + vi * 8), g1 = *(const float4*)(gamma + vi * 8 + 4);
+      const float4 b0 = *(const float4*)(beta + vi * 8), b1 = *(const float4*)(beta + vi * 8 + 4);
+      g[i][0] = g0.x; g[i][1] = g0.y; g[i][2] = g0.z; g[i][3] = g0.w; g[i][4] = g1.x; g[i][5] = g1.y; g[i][6] = g1.z; g[i][7] = g1.w;
+      bb[i][0] = b0.x; bb[i][1] = b0.y; bb[i][2] = b0.z; bb[i][3] = b0.w; bb[i][4] = b1.x; bb[i][5] = b1.y; bb[i][6] = b1.z; bb[i][7] = b1.w;
+    }
+  }
+  const int row0 = blockIdx.x * LN_ROWS, row1 = min(rows, row0 + LN_ROWS);
+  u32x4 cur[NV], nxt[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int vi = tid + i * 256;
+    cur[i] = (u32x4){0u, 0u, 0u, 0u};
+    if (vi < nvec) cur[i] = *(const u32x4*)(x + (int64_t)row0 * ldx + vi * 8);
+  }
+  for (int row = row0; row < row1; ++row) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int vi = tid + i * 256;
+      nxt[i] = (u32x4){0u, 0u, 0u, 0u};
+      if (row + 1 < row1 && vi < nvec) nxt[i] = *(const u32x4*)(x + (int64_t)(row + 1) * ldx + vi * 8);
+    }
+    float v[NV][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      if (tid + i * 256 < nvec) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[i][2 * j] = bflo(cur[i][j]); v[i][2 * j + 1] = bfhi(cur[i][j]); }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += v[i][j];
+      }
+    }
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      if (tid + i * 256 < nvec) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float t = v[i][j] - mean; q += t * t; }
+      }
+    }
+    q = wave_sum(q);
+    if (lane == 0) red[4 + wave] = q;
+    __syncthreads();      // also: everybody has read red[0..3] of this row before the next row overwrites it
+    const float rstd = rsqrtf((red[4] + red[5] + red[6] + red[7]) / (float)d + eps);
+    mg_bf16* yr = y + (int64_t)row * ldy;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int vi = tid + i * 256;
+      if (vi < nvec) {
+        u32x4 w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          w[j] = pack2bf((v[i][2 * j] - mean) * rstd * g[i][2 * j] + bb[i][2 * j],
+                         (v[i][2 * j + 1] - mean) * rstd * g[i][2 * j + 1] + bb[i][2 * j + 1]);
+        *(u32x4*)(yr + vi * 8) = w;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) cur[i] = nxt[i];
+  }
+}
+
 // ---------------------------------------------------------------------------
 // embedding gather: one workgroup per token.
 // ---------------------------------------------------------------------------
@@ -292,7 +375,15 @@ extern "C" int mg_layernorm_bf16(const mg_bf16* x, int64_t ldx, const float* gam
   if (!x || !y || !gamma || !beta) MG_FAIL(MG_ERR_SHAPE, "mg_layernorm_bf16: null pointer");
   if (!MG_ALIGNED16(x) || !MG_ALIGNED16(y) || !MG_ALIGNED16(gamma) || !MG_ALIGNED16(beta) || (ldx & 7) || (ldy & 7))
     MG_FAIL(MG_ERR_ALIGN, "mg_layernorm_bf16: 16-byte alignment required");
-  hipLaunchKernelGGL(layernorm_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta, y, ldy, d, eps);
+  // big activations: LN_ROWS rows per workgroup (gamma / beta once per workgroup); small ones keep one row per workgroup to fill the chip
+  static const bool multi = [] { const char* e = getenv("MAGMA_LN_ROWS"); return !e || atoi(e) != 1; }();   // A/B knob
+  if (multi && rows >= 8192 && d <= 4096) {
+    const dim3 grid((unsigned)((rows + LN_ROWS - 1) / LN_ROWS));
+    if (d <= 2048) hipLaunchKernelGGL(layernorm_rows_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta, y, ldy, d, eps, rows);
+    else hipLaunchKernelGGL(layernorm_rows_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta, y, ldy, d, eps, rows);
+  } else {
+    hipLaunchKernelGGL(layernorm_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta, y, ldy, d, eps);
+  }
   MG_CHECK_LAUNCH();
   return MG_OK;
 }

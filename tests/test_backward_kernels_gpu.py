@@ -235,6 +235,15 @@ def test_conv_backward_helpers(dev):
     ops.bn_param_grad(g, y, sub, gamma, beta, dg, db)
     assert rel(db, g.float().sum(0)) < 1e-4
     assert rel(dg, (g.float() * (y.float() - sub.float() - beta) / gamma).sum(0)) < 1e-4
+    # ragged row counts around the kernel's 16-row groups / 256-row blocks, with and without the residual operand, C > 512
+    for M2, C2, with_sub in ((1, 8, True), (267, 520, False), (513 + 7, 40, True)):
+        g2, y2 = rnd(M2, C2, dev=dev, seed=52).to(BF16), rnd(M2, C2, dev=dev, seed=53).to(BF16)
+        s2 = rnd(M2, C2, dev=dev, seed=54).to(BF16) if with_sub else None
+        gm, bt = rnd(C2, dev=dev, seed=55) + 2, rnd(C2, dev=dev, seed=56)
+        dg2, db2 = torch.zeros(C2, device=dev), torch.zeros(C2, device=dev)
+        ops.bn_param_grad(g2, y2, s2, gm, bt, dg2, db2)
+        yy = y2.float() - (s2.float() if with_sub else 0)
+        assert rel(db2, g2.float().sum(0)) < 1e-4 and rel(dg2, (g2.float() * (yy - bt) / gm).sum(0)) < 1e-4, (M2, C2)
 
 
 def test_adamw_and_clip(dev):

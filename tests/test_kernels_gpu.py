@@ -170,6 +170,24 @@ def test_layernorm(dev, rows, d):
     assert_close(out, ref, 3e-3, "layernorm")
 
 
+@pytest.mark.parametrize("rows,d", [(8195, 4096), (8192, 2048), (9001, 264), (8194, 2056)])
+def test_layernorm_rows_per_workgroup_form(dev, rows, d):
+    """Activations of >= 8192 rows (d <= 4096) take the kernel that normalises four rows per workgroup (gamma / beta loaded once per
+    workgroup, the next row in flight): against the fp32 reference, and BIT-IDENTICAL to the one-row-per-workgroup kernel that the
+    same rows take when they are handed over in pieces of < 8192 rows; ragged row count, both vector-per-thread instantiations,
+    a row stride wider than d."""
+    from magma_amd import ops
+    wide = (rnd(rows, d + 24, dev=dev, seed=44) * 2 + 0.3).to(BF16)
+    x = wide[:, :d]
+    g = rnd(d, dev=dev, seed=45) * 0.1 + 1
+    b = rnd(d, dev=dev, seed=46) * 0.1
+    out = ops.layernorm(x, g, b, 1e-5)
+    ref = F.layer_norm(x.float(), (d,), g, b, 1e-5)
+    assert_close(out, ref, 3e-3, "layernorm, rows per workgroup")
+    pieces = torch.cat([ops.layernorm(x[i:i + 4096], g, b, 1e-5) for i in range(0, rows, 4096)])
+    assert torch.equal(out, pieces)
+
+
 def test_embedding(dev):
     from magma_amd import ops
     V, d, B, T = 1056, 512, 3, 7

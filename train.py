@@ -8,7 +8,8 @@ only the literal "synthetic" selects SyntheticImgCptDataset -- a missing directo
 import os
 import sys
 
-import torch
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL / tensor sharing across processes on this driver); before the runtime loads
+import torch  # noqa: E402
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from magma_amd import Magma  # noqa: E402
