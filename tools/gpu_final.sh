@@ -30,3 +30,5 @@ for d in decode_trace prefill_trace train_trace; do find $ROOT/gpurun_out/$d -na
 head -8 $ROOT/gpurun_out/${R}_decode_trace_by_grid.txt; head -6 $ROOT/gpurun_out/${R}_prefill_trace_by_grid.txt; head -12 $ROOT/gpurun_out/${R}_train_step_kernel_trace_summary.txt
 # attention PMC summary of the round (six counter passes over tools/attn_bench.py)
 [ "${SKIP_ATTN_PMC:-0}" = "1" ] || { bash $ROOT/tools/gpu_pmc_attn.sh > /dev/null 2>&1; cp $ROOT/gpurun_out/pmc_attn_summary.txt $ROOT/gpurun_out/${R}_attention_pmc_summary.txt 2>/dev/null; tail -8 $ROOT/gpurun_out/${R}_attention_pmc_summary.txt; }
+# MFMA-pipe busy / instruction mix of the 256x256 GEMM next to hipBLASLt's kernel on the training shapes (the kernel behind roofline.train)
+[ "${SKIP_GEMM_PMC:-0}" = "1" ] || { bash $ROOT/tools/gpu_pmc_gemm_util.sh > /dev/null 2>&1; cp $ROOT/gpurun_out/pmc_gemm_util_summary.txt $ROOT/gpurun_out/${R}_gemm256_pmc_summary.txt 2>/dev/null; tail -12 $ROOT/gpurun_out/${R}_gemm256_pmc_summary.txt; }
