@@ -424,6 +424,45 @@ def gemm_roofline(model, args, dev):
             "shapes_MxNxK": [[M, w.N, w.K] for _, w, _ in jobs]}
 
 
+def gemm_roofline_fp8(model, args, dev):
+    """BASELINE config[4]'s GEMM against ITS peak, live: the same four projections on the fp8 form of the 256x256 kernel (OCP e4m3 operands,
+    per-row activation scales from mg_quantize_rows_fp8 -- outside the timed region, as in the training step where one quantised copy
+    feeds qkv and fc_in -- per-output-channel weight scales, fp32 accumulate, bf16 output) against the 5 PF/s dense fp8 MFMA peak."""
+    from magma_amd import ops
+    eng = model.lm.engine
+    ly = eng.layers[0]
+    M = args.train_batch * model.seq_len
+    g = torch.Generator(device=dev).manual_seed(7)
+    a_d = torch.randn(M, eng.d, device=dev, generator=g).to(torch.bfloat16)
+    a_ff = torch.randn(M, ly.fc_in.N, device=dev, generator=g).to(torch.bfloat16)
+    q_d, q_ff = ops.quantize_rows_fp8(a_d), ops.quantize_rows_fp8(a_ff)
+    del a_d, a_ff
+
+    def w8(lin):
+        return ops.PackedLinearFP8(ops.PackedLinear.untile(lin.ft)[: lin.N, : lin.K], lin.bias)
+    jobs = [(q_d, w8(ly.qkv), {}), (q_d, w8(ly.out), {}), (q_d, w8(ly.fc_in), {"act": ops.MG_ACT_GELU_NEW}), (q_ff, w8(ly.fc_out), {})]
+    outs = [torch.empty(M, w.N, dtype=torch.bfloat16, device=dev) for _, w, _ in jobs]
+    flops = sum(2.0 * M * w.N * w.K for _, w, _ in jobs)
+
+    def sweep():
+        for ((q, sc), w, kw), o in zip(jobs, outs):
+            ops.gemm_fp8(q, sc, w, out=o, **kw)
+    sweep()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 5
+    e0.record()
+    for _ in range(n):
+        sweep()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    tf = flops / ms / 1e9
+    return {"bound": "mfma", "kernel": "gemm256_kernel<FP8> (256x256 tiles, v_mfma_scale_f32_16x16x128_f8f6f4, unit block scales)", "achieved": tf,
+            "peak": 5000.0, "unit": "TFLOP/s", "frac": tf / 5000.0, "launches": len(jobs), "avg_launch_us": ms * 1e3 / len(jobs),
+            "shapes_MxNxK": [[M, w.N, w.K] for _, w, _ in jobs]}
+
+
 def variant_generate(model, args, dev, res):
     """The headline call at another image resolution (384^2 = the model's own: 144 prefix tokens, prefill S0 = 152)."""
     B, gen = args.batch, args.gen
@@ -750,6 +789,11 @@ def main():
                                          "mfma_frac": mf["frac"]})
                 full_ = (train or {}).get("full_S2048") or {}
                 line["roofline"]["train_step_mfma_frac_executed"] = full_.get("mfma_frac_executed")
+                if args.fp8 != "off":                 # BASELINE config[4]: the fp8 GEMM against the 5 PF/s dense fp8 peak
+                    try:
+                        line["roofline"]["train_fp8"] = gemm_roofline_fp8(model, args, dev)
+                    except Exception as e:  # noqa: BLE001
+                        line["roofline"]["train_fp8"] = {"error": repr(e)[:200]}
             except Exception as e:  # noqa: BLE001
                 line["roofline"]["train"] = {"error": repr(e)[:200]}
         # data-parallel training throughput of the whole job (BASELINE metric, first half), next to the headline
