@@ -993,7 +993,7 @@ int gemm_dispatch(const mg_gemm_desc* d, bool fp8, const float* row_scale, hipSt
     const int nkt256 = gp.K >> 6;
     const int64_t slab = (int64_t)d->M * (((d->N + 255) / 256) * 256) * 4;
     int want = d->split_k;
-    if (want == 0 && d->tile_hint == 0 && wgs256 >= 32 && wgs256 < 192 && nkt256 >= 256 && d->M >= 512 && d->N >= 512) {
+    if (want == 0 && d->tile_hint == 0 && wgs256 >= 32 && wgs256 < 192 && nkt256 >= 256 && d->M > 256 && d->N >= 512) {     // M > 256: the prefill's fc_out at M = 456 (2 x 16 tiles x 8 splits)
       want = 1;
       while (wgs256 * want * 2 <= 320 && want < 8) want *= 2;      // 192 .. 320 workgroups
     }

@@ -520,7 +520,8 @@ def test_gemm_split_k(dev, layout):
         ops.gemm(a, lin, split_k=65)
 
 
-@pytest.mark.parametrize("M,N,K,split", [(4096, 1024, 32768, 0), (1024, 4096, 32768, 0), (1024, 1024, 4096, 2), (600, 520, 2048, 4), (4096, 1024, 32768, 4)])
+@pytest.mark.parametrize("M,N,K,split", [(4096, 1024, 32768, 0), (1024, 4096, 32768, 0), (1024, 1024, 4096, 2), (600, 520, 2048, 4), (4096, 1024, 32768, 4),
+                                           (456, 4096, 16384, 0)])     # the prefill's fc_out: 2 x 16 tiles x 8 splits by the automatic policy
 def test_gemm256_split_k(dev, M, N, K, split):
     """The 256x256 kernel with the contraction cut across workgroups (round 4: the adapters' weight gradients, few output tiles over
     K = B*S = 32768): fp32 slabs + the deterministic fix-up, against fp32 and against the 128x128 kernel; split = 0 lets the library
