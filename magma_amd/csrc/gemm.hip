@@ -1080,7 +1080,18 @@ extern "C" int64_t mg_gemm_workspace_bytes(int32_t M, int32_t N, int32_t K) {
   const int tiles = tiles_m * tiles_n;
   if (tiles >= 192 && !(tiles < 512 && nkt >= 128)) return 0;   // same policy as gemm_dispatch: enough tiles, no split
   const int want = tiles >= 192 ? 2 : std::max(1, std::min(std::min(16, nkt / 4), (512 + tiles - 1) / tiles));
-  return want > 1 ? (int64_t)want * M * tiles_n * BN * 4 : 0;
+  const int64_t bytes128 = want > 1 ? (int64_t)want * M * tiles_n * BN * 4 : 0;
+  // the split form of the 256x256 kernel (gemm_dispatch: few 256x256 tiles over a long contraction) takes more slabs of wider rows;
+  // with less than this the dispatch falls back to the 128x128 split above
+  int64_t bytes256 = 0;
+  const int64_t wgs256 = (int64_t)((M + 255) / 256) * ((N + 255) / 256);
+  const int nkt256 = K >> 6;
+  if (K % 128 == 0 && !want256_noforce(0, wgs256, M, N) && wgs256 >= 32 && wgs256 < 192 && nkt256 >= 256 && M > 256 && N >= 512) {
+    int w = 1;
+    while (wgs256 * w * 2 <= 320 && w < 8) w *= 2;
+    if (w > 1 && nkt256 % (2 * w) == 0 && w * wgs256 >= 192) bytes256 = (int64_t)w * M * (((N + 255) / 256) * 256) * 4;
+  }
+  return std::max(bytes128, bytes256);
 }
 
 extern "C" int mg_gemm_bf16(const mg_gemm_desc* d, void* stream) {

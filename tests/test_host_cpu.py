@@ -290,7 +290,7 @@ def test_base_transforms_contract():
 
 def test_workspace_query_is_consistent_with_the_split_policy():
     """mg_gemm_workspace_bytes (callers own all memory): 0 for shapes that fill the chip, else splits x M x
-    ceil(N/128)*128 fp32 -- pure host arithmetic, callable without a GPU."""
+    ceil(N/128)*128 fp32 (or the larger need of the split 256x256 form) -- pure host arithmetic, callable without a GPU."""
     import ctypes
     from magma_amd import lib
     if not lib.LIB_PATH.exists():
@@ -302,6 +302,7 @@ def test_workspace_query_is_consistent_with_the_split_policy():
     f = dll.mg_gemm_workspace_bytes
     f.restype, f.argtypes = ctypes.c_int64, [ctypes.c_int32] * 3
     assert f(32768, 16384, 4096) == 0                       # training shape: 32768 tiles
-    assert f(456, 4096, 16384) == 4 * 456 * 4096 * 4        # prefill fc_out: 128 tiles -> 4-way split of 256 K-tiles
+    assert f(456, 4096, 16384) == 8 * 456 * 4096 * 4        # prefill fc_out: 2 x 16 tiles of 256x256 -> 8-way split (the 128x128 form: 4-way)
+    assert f(4096, 1024, 32768) == 4 * 4096 * 1024 * 4      # adapter weight gradient: 16 x 4 tiles of 256x256 -> 4-way split
     assert f(456, 1024, 4096) == 16 * 456 * 1024 * 4        # adapter-down: 32 tiles -> 16-way
     assert f(0, 1, 1) == 0
