@@ -162,3 +162,173 @@ def test_adapter_options_match_reference(name, act):
     assert not mod.plain
     with pytest.raises(NotImplementedError):
         Adapter(dim=64, activation=torch.nn.Tanh)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/magma"), reason="the reference tree is only present in the build container")
+def test_oracle_forward_and_embed_plumbing_equal_the_reference_methods_run_in_place(monkeypatch):
+    """reference magma/magma.py:195-212 (Magma.embed) and :238-276 (Magma.forward): the two method bodies are extracted with ast and
+    executed IN PLACE on a stand-in `self` whose image_prefix / word_embedding are the oracle's pieces and whose `lm` records what it
+    is handed -- together with the reference's own build_labels (utils.py:334-364).  What the reference hands its LM (inputs_embeds:
+    prefix, then the caption embeddings cut so that the total is seq_len; labels) is exactly what oracle.magma_forward hands
+    oracle.lm_forward, and oracle.embed equals the reference's embed on a [image, tokens, image] list.  This pins the PLUMBING of
+    a3 / a11 (concat order, truncation, label construction); the arithmetic of the pieces is pinned elsewhere."""
+    import ast
+    from types import SimpleNamespace
+    from typing import List, Optional
+    import torch.nn.functional as F
+    import oracle.model as om
+
+    class TensorType:
+        def __class_getitem__(cls, item):
+            return cls
+
+    ns = {"torch": torch, "TensorType": TensorType, "List": List, "Optional": Optional, "ModelOutput": object}
+    for node in ast.parse(open("/root/reference/magma/utils.py").read()).body:
+        if isinstance(node, ast.FunctionDef) and node.name == "build_labels":
+            exec(compile(ast.Module(body=[node], type_ignores=[]), "/root/reference/magma/utils.py", "exec"), ns)
+    for node in ast.parse(open("/root/reference/magma/magma.py").read()).body:
+        if isinstance(node, ast.ClassDef) and node.name == "Magma":
+            for item in node.body:
+                if isinstance(item, ast.FunctionDef) and item.name in ("embed", "forward"):
+                    item.decorator_list = []
+                    exec(compile(ast.Module(body=[item], type_ignores=[]), "/root/reference/magma/magma.py", "exec"), ns)
+    cfg = om.OracleConfig.tiny(n_positions=64)
+    p = om.init_params(cfg, seed=5)
+    g = torch.Generator().manual_seed(11)
+    B = 2
+    images = torch.randn(B, 3, 64, 64, generator=g)
+    caps = torch.full((B, 64), cfg.eos_token, dtype=torch.int64)
+    caps[0, :13] = torch.randint(0, 1000, (13,), generator=g)
+    caps[1, :5] = torch.randint(0, 1000, (5,), generator=g)
+    handed = {}
+
+    def lm(inputs_embeds=None, labels=None, output_hidden_states=False):
+        handed["ref"] = (inputs_embeds.clone(), labels.clone())
+        return "lm-output"
+
+    fake = SimpleNamespace(image_prefix=lambda x: om.image_prefix_fwd(p, cfg, x.float()),
+                           word_embedding=lambda ids: F.embedding(ids, p["lm.transformer.wte.weight"]),
+                           lm=lm, seq_len=64, eos_token=cfg.eos_token, device=torch.device("cpu"))
+    assert ns["forward"](fake, images=images, captions=caps) == "lm-output"
+
+    def record(p_, cfg_, inputs_embeds=None, labels=None, **kw):
+        handed["oracle"] = (inputs_embeds.clone(), labels.clone())
+        return {"loss": torch.zeros(()), "logits": None}
+    monkeypatch.setattr(om, "lm_forward", record)
+    om.magma_forward(p, cfg, images, caps)
+    assert torch.equal(handed["ref"][1], handed["oracle"][1])                      # labels: integer, exact
+    assert handed["ref"][0].shape == handed["oracle"][0].shape == (B, 64, cfg.d_model)
+    assert torch.equal(handed["ref"][0], handed["oracle"][0])
+    with pytest.raises(AssertionError):
+        ns["forward"](fake, images=images, captions=caps[:, :60])                  # captions must be padded to seq_len
+    # embed: [image, tokens, image] (the reference casts images with .half(): the stand-in prefix takes them back to fp32)
+    toks = torch.randint(0, 1000, (B, 7), generator=g)
+    ref_emb = ns["embed"](fake, [images, toks, images])
+    assert torch.allclose(ref_emb, om.embed(p, cfg, [images.half().float(), toks, images.half().float()]), atol=0, rtol=0)
+    with pytest.raises(ValueError):
+        ns["embed"](fake, [torch.zeros(3)])
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/magma"), reason="the reference tree is only present in the build container")
+@pytest.mark.parametrize("adapter_type", ["normal", "parallel", "scaled_parallel"])
+@pytest.mark.parametrize("kwargs", [{}, {"add_layernorm": True}, {"downsample_factor": 8}])
+def test_add_adapters_builds_the_reference_module_tree(adapter_type, kwargs):
+    """reference magma/magma.py:102-174 (Magma.add_adapters), the method body extracted with ast and executed IN PLACE with the reference's
+    own adapter classes (magma/adapters.py imported in place) on a toy `self` (ModuleList of blocks with .attn / .mlp), next to this
+    repo's Magma.add_adapters on an identical toy: the same parameter names -- the checkpoint keys of SURVEY Q8 -- with the same shapes
+    for every adapter type at both locations and with the reference's options; a second call at the same location raises on both."""
+    import ast
+    import importlib.util
+    import sys
+    from types import SimpleNamespace
+    from typing import Literal
+    import torch.nn as nn
+    from magma_amd.magma import Magma
+    tt = types.ModuleType("torchtyping")
+
+    class TensorType:
+        def __class_getitem__(cls, item):
+            return cls
+    tt.TensorType, tt.patch_typeguard = TensorType, (lambda: None)
+    sys.modules.setdefault("torchtyping", tt)
+    spec = importlib.util.spec_from_file_location("ref_adapters_tree", "/root/reference/magma/adapters.py")
+    ra = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ra)
+    ns = {"nn": nn, "Literal": Literal, "Adapter": ra.Adapter, "ParallelAdapter": ra.ParallelAdapter,
+          "AdapterWrapper": ra.AdapterWrapper, "ParallelAdapterWrapper": ra.ParallelAdapterWrapper}
+    for node in ast.parse(open("/root/reference/magma/magma.py").read()).body:
+        if isinstance(node, ast.ClassDef) and node.name == "Magma":
+            for item in node.body:
+                if isinstance(item, ast.FunctionDef) and item.name == "add_adapters":
+                    exec(compile(ast.Module(body=[item], type_ignores=[]), "/root/reference/magma/magma.py", "exec"), ns)
+
+    class Block(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.attn = nn.Linear(16, 16, bias=False)
+            self.mlp = nn.Sequential(nn.Linear(16, 64), nn.Linear(64, 16))
+
+    def toy():
+        tr = nn.ModuleList([Block() for _ in range(3)])
+        return SimpleNamespace(transformer=tr, mlp_adapter_added=False, attn_adapter_added=False, device=torch.device("cpu"),
+                               dtype=torch.float32, lm=SimpleNamespace(config=SimpleNamespace(hidden_size=16), invalidate_packed=lambda: None))
+    theirs, mine = toy(), toy()
+    for location in ("mlp", "attention"):
+        ns["add_adapters"](theirs, adapter_type=adapter_type, location=location, **kwargs)
+        Magma.add_adapters(mine, adapter_type=adapter_type, location=location, **kwargs)
+    kt = {n: tuple(p.shape) for n, p in theirs.transformer.named_parameters()}
+    km = {n: tuple(p.shape) for n, p in mine.transformer.named_parameters()}
+    assert kt == km and len(kt) > 3 * 3
+    assert theirs.mlp_adapter_added and mine.mlp_adapter_added and theirs.attn_adapter_added and mine.attn_adapter_added
+    for obj, fn in ((theirs, ns["add_adapters"]), (mine, Magma.add_adapters)):
+        with pytest.raises(ValueError):
+            fn(obj, adapter_type=adapter_type, location="mlp")
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/magma"), reason="the reference tree is only present in the build container")
+def test_preprocess_inputs_equals_the_reference_method_run_in_place(tmp_path):
+    """reference magma/magma.py:176-193 (Magma.preprocess_inputs) with the reference's own ImageInput (magma/image_input.py:6-23), both
+    executed IN PLACE, next to this repo's method and ImageInput on the same stand-in `self` (same tokenizer, same transform, an embed
+    that records): the caller's list is mutated to the same tensors (token ids (1, T) int64, image (1, 3, n, n)), embed is handed the same
+    list, embed=False returns the list itself, an unknown item type raises."""
+    import ast
+    import importlib.util
+    from types import SimpleNamespace
+    from typing import List
+    import numpy as np
+    import PIL.Image as I
+    from magma_amd.image_input import ImageInput
+    from magma_amd.magma import Magma
+    from magma_amd.tokenizer import ByteTokenizer
+    from magma_amd.transforms import clip_preprocess
+    spec = importlib.util.spec_from_file_location("ref_image_input", "/root/reference/magma/image_input.py")
+    rii = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rii)
+    ns = {"torch": torch, "List": List, "ImageInput": rii.ImageInput}
+    for node in ast.parse(open("/root/reference/magma/magma.py").read()).body:
+        if isinstance(node, ast.ClassDef) and node.name == "Magma":
+            for item in node.body:
+                if isinstance(item, ast.FunctionDef) and item.name == "preprocess_inputs":
+                    exec(compile(ast.Module(body=[item], type_ignores=[]), "/root/reference/magma/magma.py", "exec"), ns)
+    path = str(tmp_path / "img.png")
+    I.fromarray((np.random.RandomState(0).rand(45, 70, 3) * 255).astype("uint8")).save(path)
+    tok, tf = ByteTokenizer(64), clip_preprocess(32)
+    seen = {}
+
+    def fake(tag):
+        def embed(lst):
+            seen[tag] = [t.clone() for t in lst]
+            return "embedded"
+        return SimpleNamespace(tokenizer=tok, transforms=tf, embed=embed)
+    l_ref = [rii.ImageInput(path), "Describe the painting:", rii.ImageInput(path)]
+    l_mine = [ImageInput(path), "Describe the painting:", ImageInput(path)]
+    assert ns["preprocess_inputs"](fake("ref"), l_ref) == "embedded" and Magma.preprocess_inputs(fake("mine"), l_mine) == "embedded"
+    assert len(l_ref) == len(l_mine) == 3
+    for a, b, c, d in zip(l_ref, l_mine, seen["ref"], seen["mine"]):
+        assert torch.is_tensor(a) and a.dtype == b.dtype and torch.equal(a, b) and torch.equal(c, d) and torch.equal(a, c)
+    assert l_mine[0].shape == (1, 3, 32, 32) and l_mine[1].dtype == torch.int64 and l_mine[1].shape[0] == 1
+    keep_ref, keep_mine = ["x"], ["x"]
+    assert ns["preprocess_inputs"](fake("r"), keep_ref, embed=False) is keep_ref and Magma.preprocess_inputs(fake("m"), keep_mine, embed=False) is keep_mine
+    for fn, who in ((ns["preprocess_inputs"], "ref"), (Magma.preprocess_inputs, "mine")):
+        with pytest.raises(Exception, match="Invalid input type"):
+            fn(fake(who), [3.14])
