@@ -332,3 +332,55 @@ def test_preprocess_inputs_equals_the_reference_method_run_in_place(tmp_path):
     for fn, who in ((ns["preprocess_inputs"], "ref"), (Magma.preprocess_inputs, "mine")):
         with pytest.raises(Exception, match="Invalid input type"):
             fn(fake(who), [3.14])
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/magma"), reason="the reference tree is only present in the build container")
+def test_oracle_image_prefix_plumbing_equals_the_reference_method_run_in_place():
+    """reference magma/image_prefix.py:78-109 (ImagePrefix.forward) extracted with ast and executed IN PLACE (with the file's own
+    ENCODER_SEQ_LENS table and einops.rearrange) on a stand-in `self` whose encoder / Linear / LayerNorm carry the oracle's tensors:
+    (a) sequence encoders (clip_resnet_large: features (B, HW, C), no reshape) == oracle.image_prefix_fwd; (b) pooled encoders
+    (features (B, C, 1, 1) -> Linear to seq*d -> "b (s d) -> b s d") == oracle.pooled_prefix_fwd."""
+    import ast
+    from types import SimpleNamespace
+    import torch.nn as nn
+    from einops import rearrange
+    import oracle.model as om
+    src = open("/root/reference/magma/image_prefix.py").read()
+    ns = {"torch": torch, "nn": nn, "rearrange": rearrange, "TensorType": type("T", (), {"__class_getitem__": classmethod(lambda c, i: c)})}
+    for node in ast.parse(src).body:
+        if isinstance(node, ast.Assign) and getattr(node.targets[0], "id", "") in ("ENCODER_SEQ_LENS", "ENCODER_OUT_DIMS"):
+            exec(compile(ast.Module(body=[node], type_ignores=[]), "/root/reference/magma/image_prefix.py", "exec"), ns)
+        if isinstance(node, ast.ClassDef) and node.name == "ImagePrefix":
+            for item in node.body:
+                if isinstance(item, ast.FunctionDef) and item.name == "forward":
+                    exec(compile(ast.Module(body=[item], type_ignores=[]), "/root/reference/magma/image_prefix.py", "exec"), ns)
+    assert ns["ENCODER_SEQ_LENS"]["clip_resnet_large"] == 144
+    cfg = om.OracleConfig.tiny()
+    p = om.init_params(cfg, seed=9)
+    images = torch.randn(2, 3, 64, 64, generator=torch.Generator().manual_seed(2))
+
+    def linear(w, b):
+        m = nn.Linear(w.shape[1], w.shape[0])
+        m.weight.data, m.bias.data = w.clone(), b.clone()
+        return m
+    ln = nn.LayerNorm(cfg.d_model, eps=cfg.ln_eps)
+    ln.weight.data, ln.bias.data = p["image_prefix.ln.weight"].clone(), p["image_prefix.ln.bias"].clone()
+    fake = SimpleNamespace(enc=lambda x: om.encoder_fwd(p, cfg, x), encoder_type="clip_resnet_large", dropout=nn.Identity(),
+                           proj=linear(p["image_prefix.proj.weight"], p["image_prefix.proj.bias"]), use_layernorm=cfg.use_prefix_ln, ln=ln,
+                           out_dim=cfg.d_model, out_seq_len=None)
+    with torch.no_grad():
+        got, want = ns["forward"](fake, images), om.image_prefix_fwd(p, cfg, images)
+    assert got.shape == want.shape and got.ndim == 3 and torch.allclose(got, want, atol=1e-6, rtol=1e-6)
+    # pooled encoder: (B, C, 1, 1) features, out_seq_len tokens from one Linear
+    C, S, d = 24, 3, 16
+    g = torch.Generator().manual_seed(4)
+    pp = {"image_prefix.proj.weight": torch.randn(S * d, C, generator=g) * 0.1, "image_prefix.proj.bias": torch.randn(S * d, generator=g) * 0.1,
+          "image_prefix.ln.weight": torch.rand(d, generator=g) + 0.5, "image_prefix.ln.bias": torch.randn(d, generator=g) * 0.1}
+    feats = torch.randn(2, C, generator=g)
+    ln2 = nn.LayerNorm(d)
+    ln2.weight.data, ln2.bias.data = pp["image_prefix.ln.weight"].clone(), pp["image_prefix.ln.bias"].clone()
+    fake2 = SimpleNamespace(enc=lambda x: feats[:, :, None, None], encoder_type="nfresnet50", dropout=nn.Identity(),
+                            proj=linear(pp["image_prefix.proj.weight"], pp["image_prefix.proj.bias"]), use_layernorm=True, ln=ln2, out_dim=d, out_seq_len=S)
+    with torch.no_grad():
+        got2, want2 = ns["forward"](fake2, images), om.pooled_prefix_fwd(pp, d, S, feats)
+    assert got2.shape == (2, S, d) and torch.allclose(got2, want2, atol=1e-6, rtol=1e-6)
