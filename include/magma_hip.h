@@ -428,7 +428,7 @@ int mg_rotary_merge_bwd_bf16(const mg_bf16* dq, const mg_bf16* dk, const mg_bf16
  * q,k,v [B,H,S,256]; qt,kt,dOt [B,H,ld_t/32,256,32] (column-tiled transposes from mg_head_transpose_bf16,
  * ld_t = round_up(S,32), zero padded);
  * dO [B*S,H*256]; O [B*S, >= H*256] with row stride ld_o elements (ABI 2: the attention output may sit in a wider
- * [ctx | t] buffer, the operand of the [W_out | W_up] GEMM); lse [B,H,S]; D = fp32 workspace of 2*B*H*S floats ({lse*log2e, rowsum(dO o O)}
+ * [ctx | t] buffer, the operand of the [W_out | W_up] GEMM); lse [B,H,S]; D = fp32 workspace of 2*B*H*S floats ({-16 lse, -rowsum(dO o O)}
  * per query, written by the first launch).                                           */
 int mg_attn_bwd_bf16(const mg_bf16* q, const mg_bf16* k, const mg_bf16* v, const mg_bf16* qt,
                      const mg_bf16* kt, const mg_bf16* dO, const mg_bf16* dOt, const mg_bf16* O,

@@ -29,22 +29,11 @@
 // (in bounds, never read) so the wait counts stay constant.
 #include "common.h"
 #include "attn_tile_device.h"
+#include "attn_bwd_device.h"
+#include <stdlib.h>
 
 namespace {
 
-constexpr int LD_TILE = 256;              // 32 x {lse*log2e, D}
-
-// Where a gradient row goes.  merged == nullptr: out[(bh*S + s)*256 + d] (dq / dk / dv as [B,H,S,256]).  Otherwise the
-// row lands in the gradient of the fused qkv projection, merged[(b*S + s)*3*H*256 + which*H*256 + h*256 + d], with the
-// inverse GPT-J rotary R(-theta_s) applied to the first rot_dim columns of dq and dk (what mg_rotary_merge_bwd_bf16 did
-// in a separate pass over 3 x [B,H,S,256]).
-struct GradOut {
-  mg_bf16* out;
-  mg_bf16* merged;
-  const float* sin_t;
-  const float* cos_t;
-  int which, rot_dim;
-};
 // acc[dt] = columns dt*16 + lq*4 .. +3 of row s (sequence position) of head (b, h).  A lane's 4 columns are 8 bytes; stored
 // like that the epilogue is 16 dwordx2 stores per lane and store-ISSUE-bound (MI355X_MICROARCH.md, attention epilogue store
 // tail).  v_permlane16_swap trades halves between the lane groups lq and lq^1 (same row): even groups end up with 8
@@ -66,8 +55,7 @@ MG_DEV void store_grad_row(const GradOut& g, const f32x4 (&acc)[16], int b, int 
     wlo[dt] = pack2bf(x0, x1);
     whi[dt] = pack2bf(x2, x3);
   }
-  mg_bf16* row = g.merged ? g.merged + ((int64_t)b * S + s) * (3 * H * DH) + (int64_t)g.which * H * DH + h * DH
-                          : g.out + (((int64_t)b * H + h) * S + s) * DH;
+  mg_bf16* row = grad_row_ptr(g, b, h, H, S, s);
   const int odd = lq & 1;
 #pragma unroll
   for (int dt = 0; dt < 16; dt += 2) {
@@ -85,7 +73,9 @@ constexpr int DK_STAGES = 3;
 constexpr int DV_STAGE = ROW_TILE + T_TILE + LD_TILE;       // Q rows | dO^T | lse,D
 constexpr int DV_STAGES = 4;
 
-// ld2[b,h,s] = {lse * log2(e), D = rowsum(dO o O)}; one wave per (b, s, h) row of 256
+// ld2[b,h,s] = {-16 lse, -D}, D = rowsum(dO o O): the two per-query statistics, negated and (the first) in raw-score units,
+// i.e. the initial values of the score accumulators of the 32-row kernels (S - 16 lse, dP - D: attention_bwd32.hip);
+// one wave per (b, s, h) row of 256
 __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const mg_bf16* __restrict__ dO, const mg_bf16* __restrict__ O,
                                                             const float* __restrict__ lse, float* __restrict__ ld2,
                                                             int B, int H, int S, int64_t ld_o) {
@@ -101,8 +91,8 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const mg_bf16* __res
     const int64_t bs = row / H;
     const int sidx = (int)(bs % S), b = (int)(bs / S);
     const int64_t i = ((int64_t)b * H + h) * S + sidx;
-    ld2[i * 2] = lse[i] * 1.4426950408889634f;
-    ld2[i * 2 + 1] = s;
+    ld2[i * 2] = -16.0f * lse[i];
+    ld2[i * 2 + 1] = -s;
   }
 }
 
@@ -135,8 +125,8 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_t_kernel(const mg_bf16* __r
     for (int o = 16; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 32);
     if (c == 0 && sidx < S) {
       const int64_t i = ((int64_t)bh * S + sidx);
-      ld2[i * 2] = lse[i] * 1.4426950408889634f;
-      ld2[i * 2 + 1] = dot;
+      ld2[i * 2] = -16.0f * lse[i];
+      ld2[i * 2 + 1] = -dot;
     }
   }
   __syncthreads();
@@ -193,8 +183,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(
     for (int ks = 0; ks < 8; ++ks) { qf[ks] = *(const bf16x8*)(qp + ks * 32); dof[ks] = *(const bf16x8*)(dp + ks * 32); }
   }
   const float sc2 = 0.0625f * 1.4426950408889634f;
-  const float lse2 = ld2[((int64_t)bh * S + qrow_c) * 2];
-  const float Dq = ld2[((int64_t)bh * S + qrow_c) * 2 + 1];
+  const float lse2 = -(ld2[((int64_t)bh * S + qrow_c) * 2] * sc2);     // lse log2 e
+  const float Dq = -ld2[((int64_t)bh * S + qrow_c) * 2 + 1];
   f32x4 acc[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -382,7 +372,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_kernel(
         s[1] = mma8(fb, kf);
         MG_SCHED_FENCE();
       }
-      // {lse2, D} of this lane's 8 queries: 64 contiguous bytes.  Read by hand: for a compiler-visible
+      // {-16 lse, -D} of this lane's 8 queries: 64 contiguous bytes.  Read by hand: for a compiler-visible
       // ds_read of the DMA-filled statistics hipcc inserts s_waitcnt vmcnt(0) and drains the ring.
       f32x4 l[4];
       asm volatile(
@@ -403,7 +393,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_kernel(
       float val[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float lse2 = l[j >> 1][(j & 1) * 2], Dq = l[j >> 1][(j & 1) * 2 + 1];
+        const float lse2 = -(l[j >> 1][(j & 1) * 2] * sc2), Dq = -l[j >> 1][(j & 1) * 2 + 1];
         const float p = __builtin_amdgcn_exp2f(fmaf(s[j >> 2][j & 3], sc2, -lse2));   // raw v_exp_f32; masked -> 0
         val[j] = DK ? p * (dp[j >> 2][j & 3] - Dq) * 0.0625f : p;
       }
@@ -450,7 +440,21 @@ int attn_bwd_launch(const mg_bf16* q, const mg_bf16* k, const mg_bf16* v, const 
     hipLaunchKernelGGL(attn_bwd_prep_t_kernel, dim3((S + 31) / 32, B * H), dim3(256), 0, s, dO, O, lse, D, (mg_bf16*)dOt, ld_t, B, H, S, ld_o);
   else
     hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, dO, O, lse, D, B, H, S, ld_o);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(512), DQ_STAGES * DQ_STAGE, s, q, k, v, kt, dO, D, gq, B, H, S, ld_t);
+  // MAGMA_ATTN_BWD: 0 = the three 16-row-wave kernels of rounds 1-4 (dQ | dV | dK: S computed three times, dP twice);
+  // 1 / 2 = dQ as before + dK and dV in ONE 32-key-wave kernel (attention_bwd32.hip; 1: all LDS-DMA pieces of a tile at the
+  // top of the step, 2: spread between the MFMA phases); 3 / 4 = the 32-query-wave dQ kernel as well (3: DMA at the top, 4: spread;
+  // the dK/dV kernel then in its spread form).
+  const char* env_v = getenv("MAGMA_ATTN_BWD");        // read per call: tests and A/B scripts switch it in-process
+  const int variant = env_v ? atoi(env_v) : 2;
+  if (variant >= 3) {
+    if (int rc = attn_bwd_dq32_launch(q, k, v, kt, dO, D, gq, B, H, S, ld_t, variant, s, who)) return rc;
+  } else {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(512), DQ_STAGES * DQ_STAGE, s, q, k, v, kt, dO, D, gq, B, H, S, ld_t);
+  }
+  if (variant >= 1) {
+    MG_CHECK_LAUNCH();
+    return attn_bwd_dkdv32_launch(q, k, v, qt, dO, dOt, D, gk, gv, B, H, S, ld_t, variant, s, who);
+  }
   hipLaunchKernelGGL(attn_bwd_dkdv_kernel<false>, grid, dim3(512), DV_STAGES * DV_STAGE, s, q, k, v, qt, dO, dOt, D, gv, B, H, S, ld_t);
   hipLaunchKernelGGL(attn_bwd_dkdv_kernel<true>, grid, dim3(512), DK_STAGES * DK_STAGE, s, q, k, v, qt, dO, dOt, D, gk, B, H, S, ld_t);
   MG_CHECK_LAUNCH();

@@ -1,0 +1,35 @@
+// attn_bwd_device.h -- what the two translation units of the flash-attention backward share
+// (attention_bwd.hip: statistics pass, 16-row-wave kernels, C entry points; attention_bwd32.hip: the 32-row-wave kernels).
+#pragma once
+#include "common.h"
+#include "attn_tile_device.h"
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;   // 32x32 MFMA accumulator
+
+constexpr int LD_TILE = 256;              // 32 x {lse*log2e, D}
+
+// Where a gradient row goes.  merged == nullptr: out[(bh*S + s)*256 + d] (dq / dk / dv as [B,H,S,256]).  Otherwise the
+// row lands in the gradient of the fused qkv projection, merged[(b*S + s)*3*H*256 + which*H*256 + h*256 + d], with the
+// inverse GPT-J rotary R(-theta_s) applied to the first rot_dim columns of dq and dk (what mg_rotary_merge_bwd_bf16 did
+// in a separate pass over 3 x [B,H,S,256]).
+struct GradOut {
+  mg_bf16* out;
+  mg_bf16* merged;
+  const float* sin_t;
+  const float* cos_t;
+  int which, rot_dim;
+};
+MG_DEV mg_bf16* grad_row_ptr(const GradOut& g, int b, int h, int H, int S, int s) {
+  return g.merged ? g.merged + ((int64_t)b * S + s) * (3 * H * DH) + (int64_t)g.which * H * DH + h * DH
+                  : g.out + (((int64_t)b * H + h) * S + s) * DH;
+}
+
+// attention_bwd32.hip: dK and dV of one (b, h, 128 keys) in ONE kernel (S and dP computed once), 4 waves x 32 keys on the
+// 32x32x16 MFMA, one wave per SIMD.  Same operands as the 16-row kernels.
+int attn_bwd_dkdv32_launch(const mg_bf16* q, const mg_bf16* k, const mg_bf16* v, const mg_bf16* qt, const mg_bf16* dO,
+                           const mg_bf16* dOt, const float* ld2, const GradOut& gk, const GradOut& gv, int B, int H, int S,
+                           int ld_t, int variant, hipStream_t s, const char* who);
+// dQ of one (b, h, 128 queries): 4 waves x 32 queries, same structure
+int attn_bwd_dq32_launch(const mg_bf16* q, const mg_bf16* k, const mg_bf16* v, const mg_bf16* kt, const mg_bf16* dO,
+                         const float* ld2, const GradOut& gq, int B, int H, int S, int ld_t, int variant, hipStream_t s,
+                         const char* who);

@@ -88,6 +88,13 @@ MG_DEV uint32_t lds_u32(const void* p) { return __builtin_amdgcn_readfirstlane((
 MG_DEV void glds16au(const void* g, uint32_t lds_addr) {
   asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(g), "s"(lds_addr) : "memory");
 }
+// SGPR base + 32-bit per-lane byte offset + 32-bit LDS address
+MG_DEV void glds16su(const void* base_uniform, uint32_t byte_off, uint32_t lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(byte_off), "s"(base_uniform), "s"(lds_addr) : "memory");
+}
+MG_DEV void glds4su(const void* base_uniform, uint32_t byte_off, uint32_t lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dword %0, %1" :: "v"(byte_off), "s"(base_uniform), "s"(lds_addr) : "memory");
+}
 MG_DEV void glds4au(const void* g, uint32_t lds_addr) {
   asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dword %0, off" :: "v"(g), "s"(lds_addr) : "memory");
 }

@@ -729,7 +729,7 @@ def attn_bwd(q, k, v, qt, kt, dO, dOt, O, lse, B, H, S):
     _need_gpu(q)
     assert O.ndim == 2 and O.stride(1) == 1 and dO.is_contiguous()
     dev = q.device
-    D = torch.empty(B, H, S, 2, dtype=torch.float32, device=dev)   # {lse*log2e, rowsum(dO o O)} per query
+    D = torch.empty(B, H, S, 2, dtype=torch.float32, device=dev)   # {-16 lse, -rowsum(dO o O)} per query (workspace)
     dq, dk, dv = (torch.empty(B, H, S, 256, dtype=BF16, device=dev) for _ in range(3))
     check(L.load().mg_attn_bwd_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), qt.data_ptr(), kt.data_ptr(),
                                     dO.data_ptr(), dOt.data_ptr(), O.data_ptr(), lse.data_ptr(), D.data_ptr(),

@@ -132,6 +132,49 @@ def test_attention_backward(dev, B, H, S):
             assert rel(got, ref) < 1.5e-2, (name, rel(got, ref))
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("B,H,S", [(1, 1, 1), (2, 2, 57), (1, 2, 300), (2, 1, 385), (1, 1, 1024)])
+def test_attention_backward_kernel_variants(dev, monkeypatch, variant, B, H, S):
+    """MAGMA_ATTN_BWD = 0 (three 16-row-wave kernels) / 1, 2 (dK and dV in one 32-key-wave kernel, S and dP computed once)
+    / 3, 4 (32-query-wave dQ as well): each against fp32 autograd of the same attention, separate [B,H,S,256] outputs and
+    the merged dqkv output with the inverse rotary (whole-row stores through the LDS staging image)."""
+    from magma_amd import ops
+    monkeypatch.setenv("MAGMA_ATTN_BWD", str(variant))
+    d = H * 256
+    q = rnd(B, H, S, 256, dev=dev, seed=50, scale=0.5).to(BF16)
+    k = rnd(B, H, S, 256, dev=dev, seed=51, scale=0.5).to(BF16)
+    v = rnd(B, H, S, 256, dev=dev, seed=52).to(BF16)
+    dO = rnd(B * S, d, dev=dev, seed=53).to(BF16)
+    vt = ops.head_transpose(v, B, H, S, sb=H * S * 256, ss=256, sh=S * 256)
+    out = torch.empty(B * S, d, dtype=BF16, device=dev)
+    lse = torch.empty(B, H, S, dtype=torch.float32, device=dev)
+    ops.attn_prefill(q, k, vt, out, B, H, S, lse=lse)
+    qt = ops.head_transpose(q, B, H, S, sb=H * S * 256, ss=256, sh=S * 256)
+    kt = ops.head_transpose(k, B, H, S, sb=H * S * 256, ss=256, sh=S * 256)
+    dOt = ops.head_transpose(dO, B, H, S, sb=S * d, ss=d, sh=256)
+    dq, dk, dv = ops.attn_bwd(q, k, v, qt, kt, dO, dOt, out, lse, B, H, S)
+    qf, kf, vf = (t.float().requires_grad_(True) for t in (q, k, v))
+    sc = qf @ kf.transpose(-1, -2) / 16.0
+    sc = sc.masked_fill(~torch.ones(S, S, dtype=torch.bool, device=dev).tril(), float("-inf"))
+    o = (torch.softmax(sc, -1) @ vf).permute(0, 2, 1, 3).reshape(B * S, d)
+    o.backward(dO.float())
+    for got, ref, name in ((dq, qf.grad, "dq"), (dk, kf.grad, "dk"), (dv, vf.grad, "dv")):
+        if float(ref.abs().max()) < 1e-6:      # S = 1: softmax over one key has zero gradient
+            assert float(got.float().abs().max()) < 1e-6, name
+        else:
+            assert rel(got, ref) < 1.5e-2, (variant, name, rel(got, ref))
+    rot = 64
+    inv = 1.0 / (10000 ** (torch.arange(0, rot, 2, dtype=torch.float32, device=dev) / rot))
+    ang = torch.arange(S + 3, dtype=torch.float32, device=dev)[:, None] * inv[None, :]
+    sin_t, cos_t = ang.sin().contiguous(), ang.cos().contiguous()
+    two_pass = ops.rotary_merge_bwd(dq, dk, dv, B, S, H, rot, sin_t, cos_t)
+    merged = ops.attn_bwd_merged(q, k, v, qt, kt, dO, out, lse, B, H, S, rot, sin_t, cos_t)
+    assert torch.equal(merged[:, 2 * d:], two_pass[:, 2 * d:])                     # dv: no rotary, same rounding
+    if S > 1:
+        for sl in (slice(0, d), slice(d, 2 * d)):
+            assert rel(merged[:, sl], two_pass[:, sl]) < 6e-3
+
+
 @pytest.mark.parametrize("B,H,S", [(2, 2, 57), (1, 2, 300)])
 def test_attention_backward_merged_output(dev, B, H, S):
     """mg_attn_bwd_merged_bf16 (gradients written straight into dqkv with the inverse rotary) == mg_attn_bwd_bf16 +

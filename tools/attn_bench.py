@@ -28,7 +28,12 @@ fwd = t(lambda: ops.attn_prefill(q, k, vt, out, B, H, S, lse=lse))
 qt = ops.head_transpose(q, B, H, S, sb=hs, ss=256, sh=S * 256)
 kt = ops.head_transpose(k, B, H, S, sb=hs, ss=256, sh=S * 256)
 dOt = ops.head_transpose(dO, B, H, S, sb=S * d, ss=d, sh=256)
-bwd = t(lambda: ops.attn_bwd(q, k, v, qt, kt, dO, dOt, out, lse, B, H, S))
 fl = B * H * 4 * S * S * 256 / 2
-print(json.dumps({"B": B, "S": S, "fwd_ms": fwd, "fwd_tflops_causal": fl / fwd / 1e9, "bwd_ms": bwd,
-                  "bwd_tflops_causal(2.5x fwd flops)": 2.5 * fl / bwd / 1e9}))
+res = {"B": B, "S": S, "fwd_ms": round(fwd, 4), "fwd_tflops_causal": round(fl / fwd / 1e9, 1)}
+# MAGMA_ATTN_BWD variants (attention_bwd.hip: 0 = three 16-row-wave kernels, 1/2 = merged dK+dV on 32-key waves, 3/4 = + 32-query dQ)
+for var in os.environ.get("ABWD", "0,1,2,3,4").split(","):
+    os.environ["MAGMA_ATTN_BWD"] = var
+    bwd = t(lambda: ops.attn_bwd(q, k, v, qt, kt, dO, dOt, out, lse, B, H, S))
+    res["bwd_ms_v" + var] = round(bwd, 4)
+    res["bwd_tflops_causal_v" + var + "(2.5x fwd flops)"] = round(2.5 * fl / bwd / 1e9, 1)
+print(json.dumps(res))
