@@ -445,7 +445,7 @@ int attn_bwd_launch(const mg_bf16* q, const mg_bf16* k, const mg_bf16* v, const 
   // top of the step, 2: spread between the MFMA phases); 3 / 4 = the 32-query-wave dQ kernel as well (3: DMA at the top, 4: spread;
   // the dK/dV kernel then in its spread form).
   const char* env_v = getenv("MAGMA_ATTN_BWD");        // read per call: tests and A/B scripts switch it in-process
-  const int variant = env_v ? atoi(env_v) : 2;
+  const int variant = env_v ? atoi(env_v) : 4;
   if (variant >= 3) {
     if (int rc = attn_bwd_dq32_launch(q, k, v, kt, dO, D, gq, B, H, S, ld_t, variant, s, who)) return rc;
   } else {

@@ -24,6 +24,7 @@
 // supplies as the k-operand of the two 16-deep MFMA steps of the next product -- no cross-lane movement (the 16x16 kernels
 // use (li >> 2) 8 + (li & 3) for the same purpose).
 #include "attn_bwd_device.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -38,14 +39,22 @@ MG_DEV void mfma32a(f32x16& c, const bf16x8 a, const bf16x8 b) {
 }
 // ... and with the accumulator pinned to the VGPR half (S, dP: read by the softmax arithmetic).  hipcc gives a builtin MFMA's
 // result AGPRs of its own choice under this register pressure -- on top of the 256 pinned ones, which it then shuffles through
-// VGPRs every step.  The VALU reads of an asm MFMA's result sit behind mfma_result_ready().
+// VGPRs every step.
 MG_DEV void mfma32v(f32x16& c, const bf16x8 a, const bf16x8 b) {
   asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
-// wait states between the last asm MFMA that wrote c and the first VALU instruction that reads it (8-pass XDL op: 12+)
-MG_DEV void mfma_result_ready(f32x16& c) { asm volatile("s_nop 15\n\ts_nop 3" : "+v"(c)); }
 // ... between VALU writes of a packed operand and the asm MFMA that reads it
 MG_DEV void mfma_operand_ready(bf16x8& a, bf16x8& b) { asm volatile("s_nop 3" : "+v"(a), "+v"(b)); }
+// The LAST MFMA of an accumulate chain carries its wait states itself (8-pass XDL op -> any other reader or writer of the
+// result: 12+): whatever hipcc schedules behind the statement -- the softmax arithmetic, but also register copies of its own
+// around a loop exit (seen: one accumulator register read right behind the loop, two gradient columns wrong) -- finds the
+// result written.  The pad is issue time of THIS wave only; the matrix pipe is busy with the MFMA meanwhile.
+MG_DEV void mfma32v_last(f32x16& c, const bf16x8 a, const bf16x8 b) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n\ts_nop 15\n\ts_nop 3" : "+v"(c) : "v"(a), "v"(b));
+}
+MG_DEV void mfma32a_last(f32x16& c, const bf16x8 a, const bf16x8 b) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n\ts_nop 15\n\ts_nop 3" : "+a"(c) : "v"(a), "v"(b));
+}
 MG_DEV int perm32(int i) { return (i & 19) | ((i & 4) << 1) | ((i & 8) >> 1); }
 
 constexpr int EP_ROW = 528;   // epilogue staging image: 512-B rows padded to 132 dwords (a lane group's 16 rows hit 16 bank quads)
@@ -107,7 +116,14 @@ constexpr int KV_LD_OFF = 2 * ROW_TILE + 2 * T_TILE;
 // ---------------------------------------------------------------------------
 // SPREAD: the 17 LDS-DMA pieces of the next tile are issued in four groups between the MFMA phases instead of all at
 // the top of the step (an LDS-DMA piece costs its wave 60-180 issue cycles, MI355X_MICROARCH.md).
-template <bool SPREAD>
+// ABL (timing ablations, WRONG results; `make ABL=1` library only, MAGMA_ATTN_BWD32_ABL=n): 1 = no LDS-DMA after the prologue,
+// 2 = no LDS fragment reads after a wave's first tile (stale registers), 3 = no MFMAs, 4 = no barrier (and no DMA), 5 = no
+// softmax arithmetic (P and dS are the raw accumulators): each part's price is the time it removes.
+#define MMV(c, a, b)  do { if constexpr (ABL != 3) mfma32v(c, a, b); else asm volatile("" : "+v"(c) : "v"(a), "v"(b)); } while (0)
+#define MMVL(c, a, b) do { if constexpr (ABL != 3) mfma32v_last(c, a, b); else asm volatile("" : "+v"(c) : "v"(a), "v"(b)); } while (0)
+#define MMA(c, a, b)  do { if constexpr (ABL != 3) mfma32a(c, a, b); else asm volatile("" : "+a"(c) : "v"(a), "v"(b)); } while (0)
+#define MMAL(c, a, b) do { if constexpr (ABL != 3) mfma32a_last(c, a, b); else asm volatile("" : "+a"(c) : "v"(a), "v"(b)); } while (0)
+template <bool SPREAD, int ABL = 0>
 __global__ __launch_bounds__(256) void attn_bwd_dkdv32_kernel(
     const mg_bf16* __restrict__ q, const mg_bf16* __restrict__ k, const mg_bf16* __restrict__ v,
     const mg_bf16* __restrict__ qt, const mg_bf16* __restrict__ dO, const mg_bf16* __restrict__ dOt,
@@ -186,20 +202,26 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv32_kernel(
     asm volatile("" ::"v"(v8[0]), "v"(v8[1]), "v"(v8[2]), "v"(v8[3]), "v"(v8[4]), "v"(v8[5]), "v"(v8[6]), "v"(v8[7]));
   }
   int sc = 0;
+  // Measured and NOT adopted (profiles/r05_attention_bwd32_notes.txt): walking the query tiles from the last one DOWN to the
+  // diagonal, so that the 16 key blocks of a (b, h) -- side by side on one XCD -- stream the same tile at the same time (one
+  // L2 fill serves all; walking up, block i is at tile 4 i + tau and two heads per XCD spread over 8 MB against 4 MB of L2):
+  // 1.70 ms against 1.42 at B = 16, S = 2048.  Sixty-four waves asking for the same 64 KB at once queue on the same L2
+  // channels; the Infinity Cache serves the spread-out order faster than L2 serves the aligned one.
   int t = t_begin;
   // query tiles that end before this wave's first key are fully masked for it (wave w: the first w tiles of the block): it
   // only moves its share of the data.  A loop of its own -- with the accumulators updated under a branch hipcc copies all
   // 256 of them around the control flow.
   for (const int t_act = min(t_begin + wave, t_end); t < t_act; ++t) {
-    MG_WAIT_VMCNT(0);
-    MG_BARRIER_KEEP_DMA();
-    if (t + 1 < t_end) issue(t + 1, sc ^ 1);
+    if constexpr (ABL != 1 && ABL != 4) MG_WAIT_VMCNT(0);
+    if constexpr (ABL != 4) MG_BARRIER_KEEP_DMA();
+    if (ABL != 1 && ABL != 4 && t + 1 < t_end) issue(t + 1, sc ^ 1);
     sc ^= 1;
   }
+  bool first = true;
   for (; t < t_end; ++t) {
-    MG_WAIT_VMCNT(0);                 // this wave's pieces of tile t have landed (issued one step ago)
-    MG_BARRIER_KEEP_DMA();            // tile t complete; everyone is done with tile t-1
-    const bool more = t + 1 < t_end;
+    if constexpr (ABL != 1 && ABL != 4) MG_WAIT_VMCNT(0);   // this wave's pieces of tile t have landed (issued one step ago)
+    if constexpr (ABL != 4) MG_BARRIER_KEEP_DMA();          // tile t complete; everyone is done with tile t-1
+    const bool more = (ABL == 1 || ABL == 4) ? false : t + 1 < t_end;
     if (more) { if (SPREAD) issue_part(t + 1, sc ^ 1, 0); else issue(t + 1, sc ^ 1); }
     const int q0 = t * 32;
     {
@@ -224,37 +246,37 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv32_kernel(
                                          __builtin_shufflevector(i2, i3, 0, 1, 2, 3, 4, 5, 6, 7),
                                          0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
       // ---- phase 1: S' = Q K^T - 16 lse (16 MFMAs), fragment bursts of four one burst ahead ----
-      rd_row4(fa, qrow, 0, hi, sw);
-      rd_row4(fb, qrow, 1, hi, sw);
+      if (ABL != 2 || first) rd_row4(fa, qrow, 0, hi, sw);
+      if (ABL != 2 || first) rd_row4(fb, qrow, 1, hi, sw);
       MG_SCHED_FENCE();
 #pragma unroll
-      for (int i = 0; i < 4; ++i) mfma32v(s, fa[i], kf[i]);
-      rd_row4(fa, qrow, 2, hi, sw);
+      for (int i = 0; i < 4; ++i) MMV(s, fa[i], kf[i]);
+      if (ABL != 2 || first) rd_row4(fa, qrow, 2, hi, sw);
       MG_SCHED_FENCE();
 #pragma unroll
-      for (int i = 0; i < 4; ++i) mfma32v(s, fb[i], kf[4 + i]);
-      rd_row4(fb, qrow, 3, hi, sw);
+      for (int i = 0; i < 4; ++i) MMV(s, fb[i], kf[4 + i]);
+      if (ABL != 2 || first) rd_row4(fb, qrow, 3, hi, sw);
       MG_SCHED_FENCE();
 #pragma unroll
-      for (int i = 0; i < 4; ++i) mfma32v(s, fa[i], kf[8 + i]);
+      for (int i = 0; i < 4; ++i) MMV(s, fa[i], kf[8 + i]);
       asm volatile("ds_read_b128 %0, %4 offset:128\n\tds_read_b128 %1, %4 offset:144\n\tds_read_b128 %2, %4 offset:192\n\t"
                    "ds_read_b128 %3, %4 offset:208"
                    : "=&v"(i0), "=&v"(i1), "=&v"(i2), "=&v"(i3) : "v"(lsa) : "memory");
       f32x16 dp = __builtin_shufflevector(__builtin_shufflevector(i0, i1, 0, 1, 2, 3, 4, 5, 6, 7),
                                           __builtin_shufflevector(i2, i3, 0, 1, 2, 3, 4, 5, 6, 7),
                                           0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
-      rd_row4(fa, dorow, 0, hi, sw);
+      if (ABL != 2 || first) rd_row4(fa, dorow, 0, hi, sw);
       MG_SCHED_FENCE();
 #pragma unroll
-      for (int i = 0; i < 4; ++i) mfma32v(s, fb[i], kf[12 + i]);
-      rd_row4(fb, dorow, 1, hi, sw);
+      for (int i = 0; i < 3; ++i) MMV(s, fb[i], kf[12 + i]);
+      MMVL(s, fb[3], kf[15]);
+      if (ABL != 2 || first) rd_row4(fb, dorow, 1, hi, sw);
       MG_SCHED_FENCE();
       if (SPREAD && more) issue_part(t + 1, sc ^ 1, 1);
       // ---- phase 2: dP' = dO V^T - D (16 MFMAs) beside P = exp2(S' sc2) ----
 #pragma unroll
-      for (int i = 0; i < 4; ++i) mfma32v(dp, fa[i], vf[i]);
-      rd_row4(fa, dorow, 2, hi, sw);
-      mfma_result_ready(s);
+      for (int i = 0; i < 4; ++i) MMV(dp, fa[i], vf[i]);
+      if (ABL != 2 || first) rd_row4(fa, dorow, 2, hi, sw);
       // only the tiles that straddle this wave's keys (and the ragged last tile) need the mask
       if (q0 < my_first + 31 || q0 + 32 > S) {
 #pragma unroll
@@ -270,33 +292,33 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv32_kernel(
       MG_SCHED_FENCE();
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        mfma32v(dp, fb[i], vf[4 + i]);
+        MMV(dp, fb[i], vf[4 + i]);
         MG_SCHED_FENCE();
-        p[2 * i] = __builtin_amdgcn_exp2f(s[2 * i] * sc2);               // raw v_exp_f32; masked -> 0
-        p[2 * i + 1] = __builtin_amdgcn_exp2f(s[2 * i + 1] * sc2);
+        p[2 * i] = (ABL == 5 ? s[2 * i] : __builtin_amdgcn_exp2f(s[2 * i] * sc2));               // raw v_exp_f32; masked -> 0
+        p[2 * i + 1] = (ABL == 5 ? s[2 * i + 1] : __builtin_amdgcn_exp2f(s[2 * i + 1] * sc2));
         MG_SCHED_FENCE();
       }
-      rd_row4(fb, dorow, 3, hi, sw);
+      if (ABL != 2 || first) rd_row4(fb, dorow, 3, hi, sw);
       MG_SCHED_FENCE();
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        mfma32v(dp, fa[i], vf[8 + i]);
+        MMV(dp, fa[i], vf[8 + i]);
         MG_SCHED_FENCE();
-        p[8 + 2 * i] = __builtin_amdgcn_exp2f(s[8 + 2 * i] * sc2);
-        p[9 + 2 * i] = __builtin_amdgcn_exp2f(s[9 + 2 * i] * sc2);
+        p[8 + 2 * i] = (ABL == 5 ? s[8 + 2 * i] : __builtin_amdgcn_exp2f(s[8 + 2 * i] * sc2));
+        p[9 + 2 * i] = (ABL == 5 ? s[9 + 2 * i] : __builtin_amdgcn_exp2f(s[9 + 2 * i] * sc2));
         MG_SCHED_FENCE();
       }
-      rd_t4(fa, dotp, 0, tx);
+      if (ABL != 2 || first) rd_t4(fa, dotp, 0, tx);
       MG_SCHED_FENCE();
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        mfma32v(dp, fb[i], vf[12 + i]);
+        if (i < 3) MMV(dp, fb[i], vf[12 + i]); else MMVL(dp, fb[3], vf[15]);
         MG_SCHED_FENCE();
         pw0[i] = pack2bf(p[2 * i], p[2 * i + 1]);
         pw1[i] = pack2bf(p[8 + 2 * i], p[9 + 2 * i]);
         MG_SCHED_FENCE();
       }
-      rd_t4(fb, dotp, 1, tx);
+      if (ABL != 2 || first) rd_t4(fb, dotp, 1, tx);
       bf16x8 pf0 = __builtin_bit_cast(bf16x8, pw0), pf1 = __builtin_bit_cast(bf16x8, pw1);
       mfma_operand_ready(pf0, pf1);
       MG_SCHED_FENCE();
@@ -304,9 +326,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv32_kernel(
       // ---- phase 3: dV^T += dO^T P (16 MFMAs) beside 16 dS = P o dP' (the 1/16 is applied once, in the epilogue) ----
       // MFMA order 0, 2, 1, 3: the two d-blocks of a burst alternate, no back-to-back pair on one accumulator
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { const int j = ((i & 1) << 1) | (i >> 1); mfma32a(accv[j >> 1], fa[j], (j & 1) ? pf1 : pf0); }
-      rd_t4(fa, dotp, 2, tx);
-      mfma_result_ready(dp);
+      for (int i = 0; i < 4; ++i) { const int j = ((i & 1) << 1) | (i >> 1); MMA(accv[j >> 1], fa[j], (j & 1) ? pf1 : pf0); }
+      if (ABL != 2 || first) rd_t4(fa, dotp, 2, tx);
       // P re-read from its packed bf16 form (the value dV is multiplied with): 16 registers less across two phases
       const u32x4 q0w = __builtin_bit_cast(u32x4, pf0), q1w = __builtin_bit_cast(u32x4, pf1);
       float ds[16];
@@ -315,64 +336,71 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv32_kernel(
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int j = ((i & 1) << 1) | (i >> 1);
-        mfma32a(accv[2 + (j >> 1)], fb[j], (j & 1) ? pf1 : pf0);
+        MMA(accv[2 + (j >> 1)], fb[j], (j & 1) ? pf1 : pf0);
         MG_SCHED_FENCE();
         ds[2 * i] = bflo(q0w[i]) * dp[2 * i];
         ds[2 * i + 1] = bfhi(q0w[i]) * dp[2 * i + 1];
         MG_SCHED_FENCE();
       }
-      rd_t4(fb, dotp, 3, tx);
+      if (ABL != 2 || first) rd_t4(fb, dotp, 3, tx);
       MG_SCHED_FENCE();
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int j = ((i & 1) << 1) | (i >> 1);
-        mfma32a(accv[4 + (j >> 1)], fa[j], (j & 1) ? pf1 : pf0);
+        MMA(accv[4 + (j >> 1)], fa[j], (j & 1) ? pf1 : pf0);
         MG_SCHED_FENCE();
         ds[8 + 2 * i] = bflo(q1w[i]) * dp[8 + 2 * i];
         ds[9 + 2 * i] = bfhi(q1w[i]) * dp[9 + 2 * i];
         MG_SCHED_FENCE();
       }
-      rd_t4(fa, qtp, 0, tx);
+      if (ABL != 2 || first) rd_t4(fa, qtp, 0, tx);
       MG_SCHED_FENCE();
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int j = ((i & 1) << 1) | (i >> 1);
-        mfma32a(accv[6 + (j >> 1)], fb[j], (j & 1) ? pf1 : pf0);
+        if (i < 3) MMA(accv[6 + (j >> 1)], fb[j], (j & 1) ? pf1 : pf0); else MMAL(accv[7], fb[3], pf1);
         MG_SCHED_FENCE();
         dw0[i] = pack2bf(ds[2 * i], ds[2 * i + 1]);
         dw1[i] = pack2bf(ds[8 + 2 * i], ds[9 + 2 * i]);
         MG_SCHED_FENCE();
       }
-      rd_t4(fb, qtp, 1, tx);
+      if (ABL != 2 || first) rd_t4(fb, qtp, 1, tx);
       bf16x8 df0 = __builtin_bit_cast(bf16x8, dw0), df1 = __builtin_bit_cast(bf16x8, dw1);
       mfma_operand_ready(df0, df1);
       MG_SCHED_FENCE();
       if (SPREAD && more) issue_part(t + 1, sc ^ 1, 3);
       // ---- phase 4: 16 dK^T += Q^T (16 dS) (16 MFMAs) ----
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { const int j = ((i & 1) << 1) | (i >> 1); mfma32a(acck[j >> 1], fa[j], (j & 1) ? df1 : df0); }
-      rd_t4(fa, qtp, 2, tx);
+      for (int i = 0; i < 4; ++i) { const int j = ((i & 1) << 1) | (i >> 1); MMA(acck[j >> 1], fa[j], (j & 1) ? df1 : df0); }
+      if (ABL != 2 || first) rd_t4(fa, qtp, 2, tx);
       MG_SCHED_FENCE();
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { const int j = ((i & 1) << 1) | (i >> 1); mfma32a(acck[2 + (j >> 1)], fb[j], (j & 1) ? df1 : df0); }
-      rd_t4(fb, qtp, 3, tx);
+      for (int i = 0; i < 4; ++i) { const int j = ((i & 1) << 1) | (i >> 1); MMA(acck[2 + (j >> 1)], fb[j], (j & 1) ? df1 : df0); }
+      if (ABL != 2 || first) rd_t4(fb, qtp, 3, tx);
       MG_SCHED_FENCE();
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { const int j = ((i & 1) << 1) | (i >> 1); mfma32a(acck[4 + (j >> 1)], fa[j], (j & 1) ? df1 : df0); }
+      for (int i = 0; i < 4; ++i) { const int j = ((i & 1) << 1) | (i >> 1); MMA(acck[4 + (j >> 1)], fa[j], (j & 1) ? df1 : df0); }
       MG_SCHED_FENCE();
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { const int j = ((i & 1) << 1) | (i >> 1); mfma32a(acck[6 + (j >> 1)], fb[j], (j & 1) ? df1 : df0); }
+      for (int i = 0; i < 3; ++i) { const int j = ((i & 1) << 1) | (i >> 1); MMA(acck[6 + (j >> 1)], fb[j], (j & 1) ? df1 : df0); }
+      MMAL(acck[7], fb[3], df1);
     }
     sc ^= 1;
+    first = false;
   }
+  if constexpr (ABL == 1 || ABL == 4) MG_WAIT_VMCNT(0);
   // every wave is done with the ring (and no DMA is in flight: the last tile issues none) before it becomes staging space
   MG_BARRIER_KEEP_DMA();
-  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last asm MFMAs have left the pipe before hipcc reads their accumulators
   char* stage = smem + wave * (32 * EP_ROW);
   store_grad_tile32(gv, accv, 1.0f, stage, b, h, H, S, k0 + wave * 32, l31, hi);
   store_grad_tile32(gk, acck, 0.0625f, stage, b, h, H, S, k0 + wave * 32, l31, hi);
 }
 
+
+#undef MMV
+#undef MMVL
+#undef MMA
+#undef MMAL
 
 // first MFMA of a chain: C = 0 (no zero-fill of the accumulator registers)
 MG_DEV void mfma32v0(f32x16& c, const bf16x8 a, const bf16x8 b) {
@@ -488,7 +516,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq32_kernel(
       rd_row4(fa, vrow, 0, hi, sw);
       MG_SCHED_FENCE();
 #pragma unroll
-      for (int i = 0; i < 4; ++i) mfma32v(s, fb[i], qf[12 + i]);
+      for (int i = 0; i < 3; ++i) mfma32v(s, fb[i], qf[12 + i]);
+      mfma32v_last(s, fb[3], qf[15]);
       rd_row4(fb, vrow, 1, hi, sw);
       MG_SCHED_FENCE();
       if (SPREAD) issue_part(t + 2, nb, 1);
@@ -497,7 +526,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dq32_kernel(
 #pragma unroll
       for (int i = 1; i < 4; ++i) mfma32v(dp, fa[i], dof[i]);
       rd_row4(fa, vrow, 2, hi, sw);
-      mfma_result_ready(s);
       // only this wave's diagonal tile (and the ragged last tile) needs the mask: -1e30 -> exp2(-huge) = 0
       if (kv0 + 31 > qt0 + wave * 32 || kv0 + 32 > S) {
 #pragma unroll
@@ -530,11 +558,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq32_kernel(
       rd_t4(fa, ktp, 0, tx);
       MG_SCHED_FENCE();
 #pragma unroll
-      for (int i = 0; i < 4; ++i) mfma32v(dp, fb[i], dof[12 + i]);
+      for (int i = 0; i < 3; ++i) mfma32v(dp, fb[i], dof[12 + i]);
+      mfma32v_last(dp, fb[3], dof[15]);
       rd_t4(fb, ktp, 1, tx);
       MG_SCHED_FENCE();
       if (SPREAD) issue_part(t + 2, nb, 2);
-      mfma_result_ready(dp);
       // 16 dS^T = P^T o (dP^T - D) (the 1/16 is applied once, in the epilogue)
       {
         float ds[16];
@@ -560,7 +588,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq32_kernel(
       for (int i = 0; i < 4; ++i) { const int j = ((i & 1) << 1) | (i >> 1); mfma32a(accq[4 + (j >> 1)], fa[j], (j & 1) ? df1 : df0); }
       MG_SCHED_FENCE();
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { const int j = ((i & 1) << 1) | (i >> 1); mfma32a(accq[6 + (j >> 1)], fb[j], (j & 1) ? df1 : df0); }
+      for (int i = 0; i < 3; ++i) { const int j = ((i & 1) << 1) | (i >> 1); mfma32a(accq[6 + (j >> 1)], fb[j], (j & 1) ? df1 : df0); }
+      mfma32a_last(accq[7], fb[3], df1);
     }
     sc = sc == Q_STAGES - 1 ? 0 : sc + 1;
   }
@@ -572,7 +601,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dq32_kernel(
   }
   MG_WAIT_VMCNT(0);                   // drain the ring's trailing loads before the ring becomes staging space
   MG_BARRIER_KEEP_DMA();
-  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
   store_grad_tile32(gq, accq, 0.0625f, smem + wave * (32 * EP_ROW), b, h, H, S, qt0 + wave * 32, l31, hi);
 }
 
@@ -583,6 +611,21 @@ int attn_bwd_dkdv32_launch(const mg_bf16* q, const mg_bf16* k, const mg_bf16* v,
                            int ld_t, int variant, hipStream_t s, const char* who) {
   const int lds = KV_STAGES * KV_STAGE;
   const dim3 grid((unsigned)(((S + 127) / 128) * B * H));
+#ifdef MG_GEMM_ABLATIONS
+  {
+    const char* e = getenv("MAGMA_ATTN_BWD32_ABL");
+    const int abl = e ? atoi(e) : 0;
+#define MG_ABL(N_)                                                                                                         \
+    if (abl == N_) {                                                                                                       \
+      if (int rc = mg_allow_dynamic_lds((const void*)attn_bwd_dkdv32_kernel<true, N_>, lds, who)) return rc;                 \
+      hipLaunchKernelGGL((attn_bwd_dkdv32_kernel<true, N_>), grid, dim3(256), lds, s, q, k, v, qt, dO, dOt, ld2, gk, gv, B, H, S, ld_t); \
+      MG_CHECK_LAUNCH();                                                                                                   \
+      return MG_OK;                                                                                                        \
+    }
+    MG_ABL(1) MG_ABL(2) MG_ABL(3) MG_ABL(4) MG_ABL(5)
+#undef MG_ABL
+  }
+#endif
   if (variant == 1) {
     if (int rc = mg_allow_dynamic_lds((const void*)attn_bwd_dkdv32_kernel<false>, lds, who)) return rc;
     hipLaunchKernelGGL(attn_bwd_dkdv32_kernel<false>, grid, dim3(256), lds, s, q, k, v, qt, dO, dOt, ld2, gk, gv, B, H, S, ld_t);

@@ -233,7 +233,10 @@ class Magma(nn.Module):
             raise RuntimeError("from_checkpoint needs the real GPT-2 tokenizer (set MAGMA_TOKENIZER_DIR to its files): the "
                                "byte-level stand-in would feed the wrong token ids to trained weights.  "
                                "MAGMA_ALLOW_BYTE_TOKENIZER=1 overrides (synthetic checkpoints / tests).")
-        sd = torch.load(checkpoint_path, map_location=torch.device("cpu"))
+        # a full unpickle, as the reference's call (magma.py:292, written for torch < 2.6): DeepSpeed's
+        # mp_rank_00_model_states.pt carries argparse Namespaces / numpy scalars next to "module", which torch 2.10's
+        # default weights_only=True refuses
+        sd = torch.load(checkpoint_path, map_location=torch.device("cpu"), weights_only=False)
         if "module" in sd.keys():
             sd = sd["module"]
         print_main(f"loading magma checkpoint from: {checkpoint_path}")

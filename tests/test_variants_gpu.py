@@ -204,7 +204,12 @@ def test_from_checkpoint_classmethod_and_logits(dev, tmp_path, monkeypatch):
     sd["lm.transformer.h.0.attn.attention.bias"] = torch.ones(1, 1, 8, 8)
     sd["lm.transformer.h.0.attn.attention.masked_bias"] = torch.tensor(-1e9)
     path = tmp_path / "mp_rank_00_model_states.pt"
-    torch.save({"module": sd, "global_steps": 3}, path)
+    # DeepSpeed's mp_rank_00_model_states.pt carries non-tensor objects next to "module" (an argparse Namespace, numpy
+    # scalars): the file needs the reference's full unpickle (magma.py:292), not torch 2.10's weights_only default
+    import argparse
+    import numpy as np
+    torch.save({"module": sd, "global_steps": 3, "args": argparse.Namespace(lr=8e-4, config="MAGMA_v1.yml"),
+                "skipped_steps": np.int64(0), "ds_version": "0.3.15"}, path)
     kw = dict(lm_config=GPTJConfig(vocab_size=1056, hidden_size=512, num_layers=2, num_heads=2, rotary_dim=64,
                                    intermediate_size=2048, max_position_embeddings=256),
               enc=ModifiedResNetTrunk((1, 1, 2, 1), 16, 64, device=dev, dtype=torch.bfloat16))
