@@ -15,8 +15,11 @@ sum over ranks / max-over-ranks time, scaling "weak".
 Extra objects on the JSON line:
   roofline      dominant kernel = the decode weight-streaming GEMM (HBM-bound):
                 algorithmic bytes = every LM + adapter + head weight byte once
-                per token step (12.16 GB at full size) / time of the decode
-                graph, measured live with HIP events on the launch stream;
+                per token step (12.16 GB at full size) / time of the CAPTURED
+                token step (the launches generate() replays: attention co-launches,
+                argmax, bookkeeping included), measured live with HIP events on the
+                launch stream; roofline.sweep_frac = the same weight streams as bare
+                GEMVs back to back (the kernel family in isolation);
                 roofline.train = the training half's dominant kernel (the 256x256
                 MFMA GEMM at the four block-projection shapes, M = 16 x 2048),
                 measured live the same way against 2.5 PF/s.
@@ -326,7 +329,7 @@ def bench_train(model, args, rank, world, dev):
     if args.fp8:
         out["forward_only_fp8"] = _forward_fp8(model, images, caps, args.fp8, sync, dtf, f_fwd)
     eng.train()
-    exposed_comm_ms = overlapped = None
+    exposed_comm_ms = overlapped = comm_busy_ms = train_per_rank = None
     for trunc in ([False, True] if args.train_truncate else [False]):
         eng.truncate = trunc
         for _ in range(args.train_warmup):
@@ -337,8 +340,12 @@ def bench_train(model, args, rank, world, dev):
         dt, spread, loss = timed_steps(step, args.train_steps, 0, sync)
         if not trunc:
             exposed_comm_ms, overlapped = eng.exposed_comm_ms(), getattr(eng, "last_overlapped_elems", None)
+        if not trunc:
+            comm_busy_ms = eng.comm_busy_ms() if hasattr(eng, "comm_busy_ms") else None
         eng.time_comm = False
         if world > 1:
+            if not trunc:
+                train_per_rank = per_rank_ms(dt, dev)
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             dt = float(t)
@@ -385,6 +392,12 @@ def bench_train(model, args, rank, world, dev):
                             "exchanged_elements": n_train if world > 1 else None,
                             "elements_handed_over_during_backward": overlapped if world > 1 else None,
                             "exposed_comm_ms_per_step": exposed_comm_ms,
+                            # the exchange stream's own busy time per step (HIP events around every bucket's all-reduce on it): with
+                            # exposed ~ 0 and busy >> the 9 ms a 0.77 GB ring needs, the buckets are waiting for CUs behind the GEMMs
+                            # (MAGMA_DP_RESERVE_CUS leaves some out of the compute stream's mask)
+                            "comm_stream_busy_ms_per_step": comm_busy_ms,
+                            "per_rank_step_ms": train_per_rank,      # this rank-0 line carries every rank's own step time
+                            "reserved_cus": int(os.environ.get("MAGMA_DP_RESERVE_CUS", "0")),
                             "global_batch": world * B}
     out["max_memory_allocated_GB"] = torch.cuda.max_memory_allocated() / 2 ** 30
     return out
@@ -548,6 +561,16 @@ def check_launch(args, world):
         sys.exit(f"bench.py: --gpus {world} but only {n_dev} GPU(s) visible; refusing to label a {n_dev}-GPU run n_gpus={world}")
 
 
+def per_rank_ms(dt_local, dev, div=1):
+    """Every rank's own wall time of the timed region (ms, per step), gathered to all ranks: the line then says which rank
+    was the slow one (the headline uses the MAX) -- the first thing to look at when the N-GPU number disappoints."""
+    import torch.distributed as dist
+    t = torch.tensor([dt_local * 1e3 / div], dtype=torch.float64, device=dev if dev is not None else "cpu")
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [round(float(x), 4) for x in out]
+
+
 def rendezvous_only(args, rank, world):
     """The multi-rank control flow of main() without the model: process group, barrier, MAX over ranks, rank-0 line."""
     import torch.distributed as dist
@@ -555,7 +578,9 @@ def rendezvous_only(args, rank, world):
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    per_rank = [dt * 1e3]
     if world > 1:
+        per_rank = per_rank_ms(dt, None)
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
@@ -565,7 +590,7 @@ def rendezvous_only(args, rank, world):
         assert int(ranks.sum()) == world
     if rank == 0:
         print(json.dumps({"metric": "launch check (no model)", "value": None, "unit": "tokens/s", "n_gpus": world, "steps": 0,
-                          "warmup": 0, "ms_per_step": dt * 1e3, "rendezvous_only": True,
+                          "warmup": 0, "ms_per_step": dt * 1e3, "per_rank_ms": per_rank, "rendezvous_only": True,
                           "backend": dist.get_backend() if world > 1 else None,
                           "launched_by": os.environ.get("MAGMA_BENCH_LAUNCHER", "external")}), flush=True)
     if world > 1:
@@ -631,7 +656,9 @@ def main():
         toks = one_step()
     sync()
     dt = time.perf_counter() - t0
+    gen_per_rank = [round(dt / args.steps * 1e3, 4)]
     if world > 1:
+        gen_per_rank = per_rank_ms(dt, dev, args.steps)
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
@@ -679,10 +706,13 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         ms_sweep = e0.elapsed_time(e1) / 10
-        achieved = wbytes / (ms_sweep * 1e-3) / 1e9
+        sweep_achieved = wbytes / (ms_sweep * 1e-3) / 1e9
+        achieved = wbytes / (ms_tok * 1e-3) / 1e9      # the launches the captured token step RUNS (attention co-launches, argmax, bookkeeping included)
         traffic, traffic_src = pmc_traffic_per_launch(shapes)
-        roof = {"bound": "hbm", "kernel": "skinny_kernel (decode weight-streaming GEMM, M=8)",
+        roof = {"bound": "hbm", "kernel": "skinny_kernel (decode weight-streaming GEMM, M=8): the captured token step",
                 "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                # the same weight streams as bare GEMVs back to back (fc_out as a plain GEMV instead of the attention co-launch)
+                "sweep_achieved": sweep_achieved, "sweep_frac": sweep_achieved / 8000.0,
                 # HBM bytes per launch from the PMC pass over this sweep (per GEMV shape), not measured in this run
                 "traffic": traffic, "traffic_source": traffic_src,
                 "bytes_per_launch": wbytes / len(jobs), "launches": len(jobs),
@@ -765,6 +795,7 @@ def main():
                                        f"{args.res}x{args.res} images + {args.prompt}-token prompt -> {gen} greedy tokens",
                            "parallelism": f"replicas x{world}", "layers": model.lm.config.num_layers,
                            "prefill_len": int(toks.shape[1] - gen)},
+                "per_rank_ms": gen_per_rank,          # each rank's own time per step (the headline divides by the MAX)
                 "roofline": roof}
         line["generate_sampled"] = gen_s
         line["generate_from_host"] = gen_h

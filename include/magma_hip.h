@@ -67,8 +67,10 @@ const char* mg_version(void);
  *   2  round 4: mg_decode_attn_gemv_bf16 gained ld_attn_out (5th argument), mg_attn_prefill_bf16 gained ld_out (5th), mg_attn_bwd_bf16 /
  *      mg_attn_bwd_merged_bf16 gained ld_o (before the stream); removed: mg_decode_attn_2gemv_bf16,
  *      mg_decode_ctx_counter_ints, the persistent decode step's four entry points mg_decode_plan_* / mg_decode_step_* (in-launch hand-off
- *      experiments, measured slower than the launch chain: DESIGN.md 8).                                                        */
-#define MG_ABI_VERSION 2
+ *      experiments, measured slower than the launch chain: DESIGN.md 8).
+ *   3  round 5: added mg_stream_create_cu_mask / mg_stream_destroy (nothing moved; a revision-2 binder keeps working, the loader
+ *      of this repo asks for 3 because it binds the new pair).                                                                    */
+#define MG_ABI_VERSION 3
 int32_t mg_abi_version(void);
 const char* mg_last_error(void);
 
@@ -500,6 +502,13 @@ int mg_sumsq_bf16(const mg_bf16* g, int64_t n, float* out, void* stream);
 int mg_adamw_gbf16_f32(float* p, float* m, float* v, const mg_bf16* g, mg_bf16* p_bf16, int64_t n, float lr,
                        float beta1, float beta2, float eps, float weight_decay, int32_t step, float max_norm,
                        const float* norm_sq, float grad_scale, void* stream);
+
+/* A HIP stream whose kernels never run on `reserve` of the device's CUs (spread evenly; hipExtStreamCreateWithCUMask): the
+ * training engine can run its compute on it so that the RCCL kernels of the gradient exchange (reference train_loop.py:18-19 /
+ * DeepSpeed's overlapped reduce) always find free CUs instead of waiting for tile-GEMM workgroup boundaries.  Off by default
+ * (MAGMA_DP_RESERVE_CUS).  The caller destroys the stream.                                                             */
+int mg_stream_create_cu_mask(void** stream_out, int32_t reserve);
+int mg_stream_destroy(void* stream);
 
 /* ---- image preprocessing (reference magma/transforms.py:121-134) ----------------
  * One pass of Pillow's 8-bit antialiased resampling (ImagingResample, the arithmetic behind torchvision's

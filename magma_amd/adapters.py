@@ -92,14 +92,15 @@ class Adapter(nn.Module):
             xin = x2
             if self.ln is not None:
                 xin = ops.layernorm(x2, self.ln.weight.detach().float().contiguous(), self.ln.bias.detach().float().contiguous(), self.ln.eps)
-            packs = self.__dict__.get("_packs")
-            key = (dn.weight._version, up.weight._version, dn.weight.data_ptr(), up.weight.data_ptr())
-            if packs is None or packs[0] != key:        # padded row-major operands, rebuilt only when the weights changed
-                packs = self.__dict__["_packs"] = (key,
-                    ops.RawWeight(ops.pad_k_rowmajor(dn.weight.detach().to(torch.bfloat16)), K=dn.weight.shape[1],
-                                  bias=dn.bias.detach().float().contiguous()),
-                    ops.RawWeight(ops.pad_k_rowmajor(up.weight.detach().to(torch.bfloat16)), K=up.weight.shape[1],
-                                  bias=up.bias.detach().float().contiguous()))
+            # padded row-major operands built per call from the live parameters: the engines' optimizer step writes the
+            # parameters through raw pointers (no _version bump, same data_ptr), and a bias changes independently of its
+            # weight -- a cache keyed on either would serve pre-step values.  This is the module-call convenience path
+            # (reference adapters.py:38-39); the engines keep their own packed operands.
+            packs = (None,
+                ops.RawWeight(ops.pad_k_rowmajor(dn.weight.detach().to(torch.bfloat16)), K=dn.weight.shape[1],
+                              bias=dn.bias.detach().float().contiguous()),
+                ops.RawWeight(ops.pad_k_rowmajor(up.weight.detach().to(torch.bfloat16)), K=up.weight.shape[1],
+                              bias=up.bias.detach().float().contiguous()))
             erf = code == ops.MG_ACT_GELU_ERF
             t = ops.gemm(xin, packs[1], act=ops.MG_ACT_NONE if erf else code, layout="rm")
             if erf:

@@ -120,3 +120,25 @@ def allreduce_grads(flat: List[torch.Tensor], async_op: bool = False, exchange=N
     for w in works:
         w.wait()
     return []
+
+
+class ReservedCUStream:
+    """A compute stream that never dispatches to ``reserve`` of the device's CUs (mg_stream_create_cu_mask), as a
+    torch.cuda.ExternalStream.  The training engine runs forward / backward / step on it when MAGMA_DP_RESERVE_CUS=k, so the
+    RCCL kernels of the gradient buckets -- enqueued on the exchange stream while the tile GEMMs occupy every CU -- always find
+    k CUs to start on.  Off by default: the first multi-GPU hardware run can A/B it."""
+
+    def __init__(self, device: torch.device, reserve: int):
+        import ctypes as C
+        from . import lib as L
+        self.reserve, self._h = int(reserve), C.c_void_p()
+        with torch.cuda.device(device):
+            L.check(L.load().mg_stream_create_cu_mask(C.byref(self._h), self.reserve), "mg_stream_create_cu_mask")
+        self.stream = torch.cuda.ExternalStream(self._h.value, device=device)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            from . import lib as L
+            self.stream.synchronize()
+            L.load().mg_stream_destroy(self._h)
+            self._h.value = None

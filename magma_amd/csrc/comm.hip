@@ -125,3 +125,39 @@ extern "C" int mg_comm_destroy(void* comm) {
   if (rc != 0) MG_FAIL(MG_ERR_COMM, "mg_comm_destroy: ncclCommDestroy failed with %d", rc);
   return MG_OK;
 }
+
+// ---- a compute stream that leaves CUs to the exchange -------------------------------------------------------------------
+// The tile GEMMs fill every CU (one 512-thread workgroup with 128 KiB of LDS and the whole register file each), so an RCCL
+// kernel enqueued on the exchange stream can only start on a CU at a GEMM workgroup boundary (~100 us), and keeps losing it.
+// A stream created with a CU mask never dispatches to the masked-out CUs: run the training step's compute on it and the
+// exchange always finds `reserve` free CUs (spread evenly over the XCDs).  Default off (MAGMA_DP_RESERVE_CUS, train_engine.py).
+extern "C" int mg_stream_create_cu_mask(void** stream_out, int32_t reserve) {
+  if (!stream_out || reserve < 0) MG_FAIL(MG_ERR_SHAPE, "mg_stream_create_cu_mask: need a non-null pointer and reserve >= 0");
+  int dev = 0;
+  hipDeviceProp_t prop;
+  hipError_t e = hipGetDevice(&dev);
+  if (e == hipSuccess) e = hipGetDeviceProperties(&prop, dev);
+  if (e != hipSuccess) MG_FAIL(MG_ERR_HIP, "mg_stream_create_cu_mask: %s", hipGetErrorString(e));
+  const int ncu = prop.multiProcessorCount;
+  if (reserve >= ncu) MG_FAIL(MG_ERR_SHAPE, "mg_stream_create_cu_mask: cannot reserve %d of %d CUs", reserve, ncu);
+  const int words = (ncu + 31) / 32;
+  uint32_t mask[64] = {0};
+  if (words > 64) MG_FAIL(MG_ERR_UNSUPPORTED, "mg_stream_create_cu_mask: %d CUs", ncu);
+  for (int i = 0; i < ncu; ++i) mask[i >> 5] |= 1u << (i & 31);
+  for (int j = 0; j < reserve; ++j) {            // every (ncu / reserve)-th CU
+    const int i = (int)(((int64_t)j * ncu) / reserve);
+    mask[i >> 5] &= ~(1u << (i & 31));
+  }
+  hipStream_t st = nullptr;
+  e = hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask);
+  if (e != hipSuccess) MG_FAIL(MG_ERR_HIP, "mg_stream_create_cu_mask: hipExtStreamCreateWithCUMask: %s", hipGetErrorString(e));
+  *stream_out = (void*)st;
+  return MG_OK;
+}
+
+extern "C" int mg_stream_destroy(void* stream) {
+  if (!stream) return MG_OK;
+  const hipError_t e = hipStreamDestroy((hipStream_t)stream);
+  if (e != hipSuccess) MG_FAIL(MG_ERR_HIP, "mg_stream_destroy: %s", hipGetErrorString(e));
+  return MG_OK;
+}

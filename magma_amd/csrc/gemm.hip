@@ -1133,8 +1133,10 @@ int fill_skinny(const mg_skinny_desc* d, SkinnyParams& sp, const char* who) {
   sp.ln_colsum = d->ln_colsum; sp.ln_inv_d = d->ln_inv_d; sp.ln_eps = d->ln_eps;
   sp.split_n = d->split_n; sp.ep_b = d->ep_b;
   sp.w_scale = d->w_scale;
+#ifdef MG_GEMM_ABLATIONS
   static const int dbg = [] { const char* e = getenv("MAGMA_SKINNY_DBG"); return e ? atoi(e) : 0; }();
   sp.dbg = dbg;
+#endif
   if (d->w_scale && (!MG_ALIGNED16(d->w_scale) || (d->Kp & 1023))) MG_FAIL(MG_ERR_SHAPE, "%s: fp8 weights need a 16-byte aligned w_scale and Kp %% 1024 == 0", who);
   if (d->split_n != 0) {
     if (d->split_n < 0 || d->split_n >= d->N || (d->split_n & 15)) MG_FAIL(MG_ERR_SHAPE, "%s: split_n must be a multiple of 16 inside (0, N)", who);

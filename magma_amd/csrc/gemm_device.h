@@ -525,6 +525,11 @@ MG_DEV void epilogue_rows(const mg_epilogue& ep, const char* lds, int rows, int 
 // ---------------------------------------------------------------------------
 // skinny (decode) kernel
 // ---------------------------------------------------------------------------
+#ifdef MG_GEMM_ABLATIONS
+#define MG_SKINNY_DBG_NOSTATS(p_) (((p_).dbg & 1) != 0)
+#else
+#define MG_SKINNY_DBG_NOSTATS(p_) false      // the product library has no switch that produces wrong results
+#endif
 struct SkinnyParams {
   const mg_bf16* X; int64_t ldx;
   const mg_bf16* W;
@@ -541,7 +546,9 @@ struct SkinnyParams {
   // (lane = kq*16 + n: bytes 0-7 = W[n][32*(2j) + 8kq ..], bytes 8-15 = the same columns of k-step 2j+1) and
   // w_scale[n] the per-output-channel scale; the weights are widened to bf16 in registers, so the stream is half as long.
   const float* w_scale;
-  int dbg;   // tuning experiments only (MAGMA_SKINNY_DBG): bit 0 = skip the LayerNorm-fold row statistics (WRONG results)
+#ifdef MG_GEMM_ABLATIONS
+  int dbg;   // ablation library only (`make ABL=1`, MAGMA_SKINNY_DBG): bit 0 = skip the LayerNorm-fold row statistics (WRONG results)
+#endif
 };
 
 // Device body: `block` is the workgroup's index inside THIS problem's grid, `lds` a caller-provided
@@ -627,7 +634,7 @@ MG_DEV void skinny_body(const SkinnyParams& p, int block, char* lds, Wait wait =
       }
       if constexpr (decltype(has_next)::value) load_into(nxt, kc + KC);
       __builtin_amdgcn_sched_barrier(0);
-      if (p.ln_colsum && !(p.dbg & 1)) {
+      if (p.ln_colsum && !MG_SKINNY_DBG_NOSTATS(p)) {
 #pragma unroll
         for (int i = 0; i < KC; ++i) {
           const u32x4 raw = __builtin_bit_cast(u32x4, xf[i]);
@@ -681,7 +688,7 @@ MG_DEV void skinny_body(const SkinnyParams& p, int block, char* lds, Wait wait =
         xf[i] = __builtin_bit_cast(bf16x8, raw);
       }
     }
-    if (p.ln_colsum && !(p.dbg & 1)) {
+    if (p.ln_colsum && !MG_SKINNY_DBG_NOSTATS(p)) {
 #pragma unroll
       for (int i = 0; i < KC; ++i) {
         const u32x4 raw = __builtin_bit_cast(u32x4, xf[i]);

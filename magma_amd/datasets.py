@@ -82,6 +82,35 @@ class SyntheticImgCptDataset(torch.utils.data.Dataset):
         return img, cap
 
 
+def host_side_view(ds):
+    """The same dataset with every ImgCptDataset's transform replaced by its host-only twin (``transforms.host``: same pixels,
+    tensors stay on the CPU) -- what DataLoader worker processes iterate: a forked worker must not touch the GPU, and
+    pinned-memory batches need CPU tensors.  Subset / ConcatDataset wrappers (random_split, lists of directories) are
+    walked; datasets without a device-side transform are returned as they are."""
+    import copy
+    if isinstance(ds, torch.utils.data.Subset):
+        inner = host_side_view(ds.dataset)
+        return ds if inner is ds.dataset else torch.utils.data.Subset(inner, ds.indices)
+    if isinstance(ds, torch.utils.data.ConcatDataset):
+        inner = [host_side_view(d) for d in ds.datasets]
+        return ds if all(a is b for a, b in zip(inner, ds.datasets)) else torch.utils.data.ConcatDataset(inner)
+    host = getattr(getattr(ds, "transforms", None), "host", None)
+    if host is None or host is ds.transforms:
+        return ds
+    view = copy.copy(ds)
+    view.transforms = host
+    return view
+
+
+def on_disk(ds) -> bool:
+    """True when ``ds`` (through Subset / ConcatDataset wrappers) reads image files: the case loader workers exist for."""
+    if isinstance(ds, torch.utils.data.Subset):
+        return on_disk(ds.dataset)
+    if isinstance(ds, torch.utils.data.ConcatDataset):
+        return any(on_disk(d) for d in ds.datasets)
+    return isinstance(ds, ImgCptDataset)
+
+
 def load_img_cpt_datasets(dataset_dir, tokenizer, transforms, seq_len: int = 2048, synthetic=None):
     """reference train.py:34-42 ``_load_img_cpt_datasets``: a list / tuple of directories -> ConcatDataset of their
     datasets, a str -> ImgCptDataset (a missing directory RAISES -- a typo must not train on noise), anything else ->

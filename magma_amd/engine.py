@@ -374,6 +374,8 @@ class LMEngine:
                 # generate() only ever sends one, sampling.py:86-90): the causal mask makes this exactly T single-token steps in
                 # order, each appending its K / V -- run as such, logits (B, T, V) stacked
                 T = input_ids.shape[1]
+                if T == 0:
+                    raise ValueError("cached decoding needs at least one new token")
                 rows = []
                 for i in range(T):
                     lg, tok = self.decode(input_ids[:, i:i + 1], past_key_values, sampling=sampling if i == T - 1 else None)
@@ -624,6 +626,9 @@ class LMEngine:
                 ops.gemm_skinny(st.ctx_t[:, : self.d + r], ly.out_up, out=xn, residuals=(st.m, x))
                 x, xn = xn, x
                 continue
+            if grouped and w8_on and (src.mlp_adapter is None or src.mlp_adapter[0] is None or src.mlp_adapter[1] is None):
+                # an adapter projection whose K is not a multiple of 1024 has no e4m3 operand (_ensure_decode_packs_w8)
+                raise NotImplementedError("W8A16 decode needs adapter projections with K % 1024 == 0 (downsample_factor 4 at d = 4096)")
             if grouped:
                 # launch 2: attention workgroups + fc_out GEMV workgroups in one grid (they are independent
                 # branches of the parallel block; the latency-bound attention hides under the weight stream)

@@ -19,7 +19,7 @@ MG_A_DENSE, MG_A_CONV3X3 = 0, 1
 MG_AUX_NONE, MG_AUX_RELU_GATE, MG_AUX_GELU_GRAD, MG_AUX_MUL, MG_AUX_QUICK_GELU_GRAD = 0, 1, 2, 3, 4
 
 
-ABI_VERSION = 2      # include/magma_hip.h MG_ABI_VERSION
+ABI_VERSION = 3      # include/magma_hip.h MG_ABI_VERSION
 
 
 class MagmaHipError(RuntimeError):
@@ -84,6 +84,8 @@ SYMBOLS = {
     "mg_comm_allreduce_sum": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
     "mg_comm_broadcast": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
     "mg_comm_destroy": (C.c_int, [_vp]),
+    "mg_stream_create_cu_mask": (C.c_int, [C.POINTER(C.c_void_p), _i32]),
+    "mg_stream_destroy": (C.c_int, [_vp]),
     "mg_layernorm_bf16": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp]),
     "mg_embedding_bf16": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _i64, _i32, _vp]),
     "mg_rotary_split_bf16": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp]),

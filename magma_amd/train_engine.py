@@ -16,6 +16,7 @@ recomputed -- "no recompute" policy for every reported number.
 """
 from __future__ import annotations
 
+import contextlib
 import math
 import os
 from pathlib import Path
@@ -182,6 +183,12 @@ class MagmaEngine:
         self._norm_sq = torch.zeros(1, dtype=F32, device=self.device)
         self._dist = dist.is_initialized()            # a 1-rank process group still exercises the overlap path
         self._comm_stream = torch.cuda.Stream(device=self.device) if self._dist else None
+        # MAGMA_DP_RESERVE_CUS=k: compute on a stream that leaves k CUs to the exchange's RCCL kernels (default 0 = off)
+        self._compute_stream = None
+        k_res = int(os.environ.get("MAGMA_DP_RESERVE_CUS", "0"))
+        if self._dist and k_res > 0:
+            from .comm import ReservedCUStream
+            self._compute_stream = ReservedCUStream(self.device, k_res)
         if self._dist:
             from .comm import make_exchange
             self._exchange = make_exchange(self.device)       # torch.distributed (default) or the C-ABI mg_comm_* (RCCL)
@@ -194,6 +201,7 @@ class MagmaEngine:
         self._reduced = [[] for _ in self.groups]     # per group: (lo, hi) ranges already handed to RCCL this step
         self._works = []
         self.time_comm, self._comm_events = False, []
+        self._busy_events, self._busy_steps = [], 0
         self.overlapped_elems = 0                     # gradient elements handed over DURING backward in the last step
         if self._dist and self.world > 1:
             # every replica starts from rank 0's model: trainable masters, FROZEN parameters (a random-init GPT-J differs
@@ -244,9 +252,18 @@ class MagmaEngine:
         for (gi, lo, hi), buf in zip(todo, bufs):
             with torch.cuda.stream(self._comm_stream):
                 self._comm_stream.wait_event(ev)
+                if self.time_comm:       # busy time of the exchange stream itself (bench.py: train.data_parallel)
+                    e0 = torch.cuda.Event(enable_timing=True)
+                    e0.record(self._comm_stream)
                 w = self._exchange.all_reduce(buf)
                 if w is not None:
                     self._works.append(w)
+                if self.time_comm:
+                    if w is not None:
+                        w.wait()         # stream-side: the event below lands behind the collective
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e1.record(self._comm_stream)
+                    self._busy_events.append((e0, e1))
             self._reduced[gi].append((lo, hi))
             self.overlapped_elems += hi - lo
 
@@ -259,6 +276,18 @@ class MagmaEngine:
         ms = sum(a.elapsed_time(b) for a, b in self._comm_events) / len(self._comm_events)
         if reset:
             self._comm_events = []
+        return ms
+
+    def comm_busy_ms(self, reset: bool = True) -> Optional[float]:
+        """Mean time per optimizer step the exchange stream was busy with the buckets handed over DURING backward (sum of the
+        per-bucket spans on that stream), over the steps since the last call; needs time_comm = True and a device
+        synchronisation by the caller.  Together with exposed_comm_ms it tells a starved exchange (busy long, nothing
+        exposed: fine; busy long AND exposed: the buckets wait for CUs) from a slow link."""
+        if not self._busy_events:
+            return None
+        ms = sum(a.elapsed_time(b) for a, b in self._busy_events) / max(1, self._busy_steps)
+        if reset:
+            self._busy_events, self._busy_steps = [], 0
         return ms
 
     def _exchange_view(self, gi, lo, hi):
@@ -297,6 +326,10 @@ class MagmaEngine:
         ex = getattr(self, "_exchange", None)
         if ex is not None:
             ex.close()
+        cs = getattr(self, "_compute_stream", None)
+        if cs is not None:
+            cs.close()
+            self._compute_stream = None
 
     def __del__(self):
         try:
@@ -343,7 +376,33 @@ class MagmaEngine:
         return self.train(False)
 
     # ---- forward ---------------------------------------------------------------
+    @contextlib.contextmanager
+    def _on_compute_stream(self):
+        """MAGMA_DP_RESERVE_CUS=k (multi-rank runs): the step's kernels go to a stream that leaves k CUs to the exchange
+        (comm.ReservedCUStream); the caller's stream waits on both sides, so nothing outside sees the difference."""
+        cs = self._compute_stream
+        if cs is None:
+            yield
+            return
+        cur = torch.cuda.current_stream(self.device)
+        cs.stream.wait_stream(cur)
+        with torch.cuda.stream(cs.stream):
+            yield
+        cur.wait_stream(cs.stream)
+
     def __call__(self, images, captions, dropout_mask=None, captions_host=None) -> LMOutput:
+        with self._on_compute_stream():
+            return self._forward_impl(images, captions, dropout_mask, captions_host)
+
+    def backward(self, loss=None):
+        with self._on_compute_stream():
+            return self._backward_impl(loss)
+
+    def step(self):
+        with self._on_compute_stream():
+            return self._step_impl()
+
+    def _forward_impl(self, images, captions, dropout_mask=None, captions_host=None) -> LMOutput:
         torch.cuda.set_device(self.device)
         if not self.training:
             with torch.no_grad():
@@ -582,7 +641,7 @@ class MagmaEngine:
         return loss
 
     # ---- backward ----------------------------------------------------------------
-    def backward(self, loss=None):
+    def _backward_impl(self, loss=None):
         tape = self._tape
         assert tape is not None, "backward() without a training forward"
         scale_note = 1.0 / self.gas     # applied at step() through grad_scale (DeepSpeed divides the loss by gas)
@@ -1232,7 +1291,7 @@ class MagmaEngine:
                                    for p in m.parameters() if self.is_trainable(p)])
 
     # ---- optimizer step ----------------------------------------------------------------
-    def step(self):
+    def _step_impl(self):
         if self.micro_steps % self.gas != 0:
             return
         self.global_steps += 1
@@ -1248,6 +1307,7 @@ class MagmaEngine:
             if self.time_comm:
                 ev[1].record()
                 self._comm_events.append(ev)
+                self._busy_steps += 1
             grad_scale /= self.world
         self._norm_sq.zero_()
         grads = [g.comm if self.exchange_bf16 else g.grad for g in self.groups]    # what came back from the exchange
@@ -1269,15 +1329,30 @@ class MagmaEngine:
         return float(torch.sqrt(self._norm_sq)) / self.gas / self.world
 
     # ---- DeepSpeed-protocol odds and ends -------------------------------------------------
-    def deepspeed_io(self, dataset, batch_size=None, collate_fn=None):
+    def deepspeed_io(self, dataset, batch_size=None, collate_fn=None, num_workers=None, pin_memory=True):
+        """The loader DeepSpeed's engine hands out (reference train.py:103-112).  For a dataset that reads image files, worker
+        processes decode / resize on the host while the step runs (MAGMA_LOADER_WORKERS, default min(8, host cores / ranks);
+        they iterate the dataset's host-side view -- same pixels, no GPU in a forked worker), batches arrive in pinned memory
+        (the engine's non-blocking copies overlap the step) from one persistent worker pool.  Without workers (synthetic data,
+        MAGMA_LOADER_WORKERS=0) the items are produced on the launch thread, RGB images through the device-side resampler.
+        DistributedSampler shards per rank."""
         from torch.utils.data import DataLoader
         from torch.utils.data.distributed import DistributedSampler
         bs = batch_size or max(1, self.config.batch_size // (self.gas * self.world))
         sampler = DistributedSampler(dataset) if self.world > 1 else None
-        from .datasets import collate_fn as default_collate
+        from .datasets import collate_fn as default_collate, host_side_view, on_disk
         from functools import partial
+        if num_workers is None:
+            env = os.environ.get("MAGMA_LOADER_WORKERS")
+            num_workers = int(env) if env is not None else (min(8, max(1, (os.cpu_count() or 2) // max(1, self.world)))
+                                                           if on_disk(dataset) else 0)
+        kw = {}
+        if num_workers > 0:
+            dataset = host_side_view(dataset)
+            kw = dict(num_workers=num_workers, persistent_workers=True, prefetch_factor=2,
+                      pin_memory=bool(pin_memory) and torch.cuda.is_available())
         return DataLoader(dataset, batch_size=bs, sampler=sampler, shuffle=False,
-                          collate_fn=collate_fn or partial(default_collate, seq_len=self.module.seq_len))
+                          collate_fn=collate_fn or partial(default_collate, seq_len=self.module.seq_len), **kw)
 
     def _param_names(self) -> Dict[int, str]:
         return {id(p): n for n, p in self.module.named_parameters()}

@@ -124,6 +124,9 @@ def clip_preprocess(n_px, use_pad=False, device=None):
         # ones do, or collate_fn's torch.cat over a mixed batch raises (reference dataset.py:155-160)
         return out.to(device) if on_gpu else out
 
+    # the same transform with the tensors left on the host (bit-identical pixels): what a DataLoader worker process
+    # runs (train_engine.deepspeed_io with workers; a forked worker must not touch the GPU)
+    fn.host = clip_preprocess(n_px, use_pad, device=None) if on_gpu else fn
     return fn
 
 
@@ -234,6 +237,7 @@ def base_transforms(image_size, use_extra_transforms=False, device=None):
         t = maybe_add_batch_dim(t)
         return t.to(device) if on_gpu else t
 
+    fn.host = base_transforms(image_size, use_extra_transforms, device=None) if on_gpu else fn
     return fn
 
 

@@ -95,6 +95,15 @@ def test_bench_gpus_n_launches_n_ranks_by_itself():
     assert line["n_gpus"] == 2 and line["launched_by"] == "self" and line["backend"] == "gloo"
 
 
+def test_bench_gpus_8_launches_the_node_sized_job():
+    """The driver's scaling run: `python bench.py --gpus 8` -- 8 ranks (one per GPU of a node, reference README.md:121) join,
+    run the barrier / MAX-over-ranks path and rank 0 alone prints the line, n_gpus = 8, with each rank's time in it."""
+    rc, line, err = _run_bench(["--gpus", "8", "--rendezvous-only"], {"MAGMA_BENCH_BACKEND": "gloo"})
+    assert rc == 0, err[-2000:]
+    assert line["n_gpus"] == 8 and line["launched_by"] == "self" and line["backend"] == "gloo"
+    assert len(line["per_rank_ms"]) == 8 and abs(line["ms_per_step"] - max(line["per_rank_ms"])) < 1e-3
+
+
 def test_bench_refuses_a_mislabelled_launch():
     """--gpus must equal the number of ranks: a 1-rank run asked for 2 GPUs exits non-zero instead of printing n_gpus = 1."""
     rc, line, err = _run_bench(["--gpus", "2", "--rendezvous-only"], {"WORLD_SIZE": "1", "RANK": "0"})

@@ -58,6 +58,36 @@ def test_overlapped_allreduce_single_rank(dev, backend, monkeypatch):
         assert float((a - b).norm() / (a.norm() + 1e-20)) < 1e-5
 
 
+def test_compute_stream_with_reserved_cus(dev, monkeypatch):
+    """MAGMA_DP_RESERVE_CUS=8: forward / backward / step run on a stream whose CU mask leaves 8 CUs to the exchange
+    (mg_stream_create_cu_mask, hipExtStreamCreateWithCUMask); gradients and masters equal the run without a group, the
+    engine's kernels really went to that stream, and timing the exchange stream (bench.py: comm_stream_busy_ms) works."""
+    g0, m0 = _grads(dev, False)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    monkeypatch.setenv("MAGMA_DP_RESERVE_CUS", "8")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        from magma_amd.train_engine import MagmaEngine
+        seen = {}
+        orig = MagmaEngine._forward_impl
+
+        def spy(self, *a, **k):
+            seen["stream"] = torch.cuda.current_stream(self.device).cuda_stream
+            seen["masked"] = self._compute_stream.stream.cuda_stream
+            self.time_comm = True
+            return orig(self, *a, **k)
+        monkeypatch.setattr(MagmaEngine, "_forward_impl", spy)
+        g1, m1 = _grads(dev, True)
+    finally:
+        dist.destroy_process_group()
+    assert seen["stream"] == seen["masked"] != torch.cuda.default_stream(dev).cuda_stream
+    for a, b in zip(g0, g1):
+        assert float((a - b).norm() / (a.norm() + 1e-20)) < 1e-5
+    for a, b in zip(m0, m1):
+        assert float((a - b).norm() / (a.norm() + 1e-20)) < 1e-5
+
+
 def test_mg_comm_collectives_single_rank(dev):
     """The comm entry points on their own: a 1-rank communicator (SUM over one rank = identity, broadcast from rank 0 = identity),
     fp32 and bf16, then destroy; a bad dtype / root is refused with MG_ERR_SHAPE."""

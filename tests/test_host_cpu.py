@@ -180,6 +180,42 @@ def test_img_cpt_dataset_reads_the_reference_layout(tmp_path):
     assert images.shape == (3, 3, 32, 32) and caps.shape == (3, 64)
 
 
+def test_loader_workers_iterate_a_host_side_view(tmp_path):
+    """train_engine.deepspeed_io with worker processes (reference train.py:103-112: DeepSpeed's loader runs workers): the
+    workers iterate datasets.host_side_view -- every ImgCptDataset under Subset / ConcatDataset wrappers with its transform
+    replaced by the host-only twin (same pixels, CPU tensors) -- and a real DataLoader with 2 worker processes + the
+    default collate yields the batches of the in-process loader."""
+    from functools import partial
+    from magma_amd.datasets import ImgCptDataset, collate_fn, host_side_view, on_disk, SyntheticImgCptDataset
+    from magma_amd.tokenizer import ByteTokenizer
+    from magma_amd.transforms import clip_preprocess
+    _write_dataset(tmp_path, 6, modes=("RGB", "L"))
+    calls = []
+    host = clip_preprocess(32)
+    assert host.host is host                          # a host transform is its own host-side twin
+
+    def device_like(img):                             # stands in for the device pipeline: must never run in a worker
+        calls.append(1)
+        return host(img)
+    device_like.host = host
+    ds = ImgCptDataset(tmp_path, ByteTokenizer(64), device_like, seq_len=64)
+    sub = torch.utils.data.Subset(ds, [4, 2, 0, 1])
+    cat = torch.utils.data.ConcatDataset([sub, ds])
+    view = host_side_view(cat)
+    assert on_disk(cat) and not on_disk(SyntheticImgCptDataset(4, 32, 64))
+    assert isinstance(view, torch.utils.data.ConcatDataset) and isinstance(view.datasets[0], torch.utils.data.Subset)
+    assert view.datasets[0].indices == [4, 2, 0, 1] and view.datasets[0].dataset.transforms is host and view.datasets[1].transforms is host
+    assert ds.transforms is device_like               # the original keeps its transform
+    assert host_side_view(SyntheticImgCptDataset(4, 32, 64)).__class__ is SyntheticImgCptDataset
+    ref = [b for b in torch.utils.data.DataLoader(host_side_view(sub), batch_size=2, collate_fn=partial(collate_fn, seq_len=64))]
+    assert not calls
+    got = [b for b in torch.utils.data.DataLoader(host_side_view(sub), batch_size=2, num_workers=2,
+                                                  collate_fn=partial(collate_fn, seq_len=64))]
+    assert len(got) == len(ref) == 2
+    for (gi, gc), (ri, rc) in zip(got, ref):
+        assert gi.shape == (2, 3, 32, 32) and torch.equal(gi, ri) and torch.equal(gc, rc)
+
+
 def _write_dataset(root, n, modes=("RGB",)):
     import json
     import numpy as np

@@ -162,6 +162,15 @@ def test_adapter_as_a_module(dev):
     ref = adapter_fwd(p, "a.", x.float().cpu())
     assert y.shape == x.shape and rel(y, ref) < 4e-3
     assert rel(y - x, ref - x.float().cpu()) < 2e-2          # the adapter branch itself, not just the residual
+    # parameters rewritten behind autograd's back -- what the engines' raw-pointer AdamW does (no _version bump, same
+    # data_ptr) -- and a bias changed on its own: the next call computes with the NEW values
+    with torch.no_grad():
+        ad.adapter[0].weight.data.mul_(0.5)
+        ad.adapter[2].bias.data.add_(0.25)
+    y2 = ad(x)
+    p2 = {"a." + k.replace("adapter.", ""): v.float().cpu() for k, v in ad.state_dict().items()}
+    ref2 = adapter_fwd(p2, "a.", x.float().cpu())
+    assert rel(y2, ref2) < 4e-3 and rel(y2, ref) > 1e-2
 
 
 def test_rn50x4_trunk(dev):
