@@ -202,6 +202,7 @@ class MagmaEngine:
         self._works = []
         self.time_comm, self._comm_events = False, []
         self._busy_events, self._busy_steps = [], 0
+        self.recompute = os.environ.get("MAGMA_TRAIN_RECOMPUTE", "0") == "1" or bool(getattr(self.module.lm.config, "gradient_checkpointing", False))
         self.overlapped_elems = 0                     # gradient elements handed over DURING backward in the last step
         if self._dist and self.world > 1:
             # every replica starts from rank 0's model: trainable masters, FROZEN parameters (a random-init GPT-J differs
@@ -561,8 +562,9 @@ class MagmaEngine:
         x = emb.view(M, d)
         vt_ld = ops.ceil_to(S, 32)
         vt = torch.empty(B, H, vt_ld // 32, 256, 32, dtype=BF16, device=dev)   # V^T in 32-key tiles
-        saved = []
-        for li, (ly, blk) in enumerate(zip(eng.layers, self.module.lm.transformer.h)):
+        def block(li, ly, blk, x):
+            """One GPT-J block forward: (x', what its backward needs).  Called by the loop below and -- under per-block
+            recompute (self.recompute) -- once more per block from _lm_backward, on the saved block input."""
             sv = {"x": x}
             ln = ops.layernorm(x, ly.ln_g, ly.ln_b, eng.eps)
             lnq = ops.quantize_rows_fp8(ln) if self.fp8 else None     # shared by qkv and fc_in
@@ -620,8 +622,19 @@ class MagmaEngine:
                 sv.update(m=m)
             else:
                 x = self._fgemm((li, "fc_out"), h, ly.fc_out, residuals=(a, x))
-            del h, qkv, ln
-            saved.append(sv)
+            return x, sv
+
+        # Per-block recompute (reference language_model.py:23-37: gradient checkpointing is ON by default there): only each
+        # block's input is kept, its activations are rebuilt in the backward pass right before they are used (deterministic
+        # kernels, no dropout inside the blocks: the same bits).  Off by default -- 288 GB hold the 176 GB of a B = 16 step,
+        # and every reported number is taken without it; MAGMA_TRAIN_RECOMPUTE=1 / engine.recompute for larger
+        # per-GPU batches or 384-pixel prefixes.
+        saved = []
+        for li, (ly, blk) in enumerate(zip(eng.layers, self.module.lm.transformer.h)):
+            xin = x
+            x, sv = block(li, ly, blk, x)
+            saved.append({"x": xin} if self.recompute else sv)
+        tape["block_fn"] = block if self.recompute else None
         tape["layers"] = saved
         # ---- head + loss on rows that carry a target ----
         rows, tgt = tape["rows"], tape["tgt"]             # built on the host (target_index): no device sync here
@@ -749,6 +762,9 @@ class MagmaEngine:
         g.index_copy_(0, tape["rows"], dxr)
         for li in range(len(eng.layers) - 1, -1, -1):
             ly, blk, pk, sv = eng.layers[li], self.module.lm.transformer.h[li], packs[li], tape["layers"][li]
+            if tape.get("block_fn") is not None:       # per-block recompute: rebuild this block's activations from its input
+                _, sv = tape["block_fn"](li, ly, blk, sv["x"])
+                tape["layers"][li] = None
             # ---- MLP branch ----
             par = ly.mlp_par is not None or ly.attn_par is not None
             ln = ops.layernorm(sv["x"], ly.ln_g, ly.ln_b, eng.eps) if par else None   # the parallel adapters' input, recomputed

@@ -248,6 +248,40 @@ def test_truncation_is_exact(dev):
     assert rel(res[1][1], res[0][1]) < 2e-2
 
 
+@pytest.mark.parametrize("variant", ["v1", "v2"])
+def test_per_block_recompute_is_exact(dev, variant):
+    """reference language_model.py:23-37 (gradient checkpointing, on by default there): with engine.recompute only the block
+    inputs are kept and every block is run forward once more inside the backward pass.  Deterministic kernels, no dropout
+    inside the blocks: the loss is the same number and the gradients agree to the run-to-run noise of the atomically
+    accumulated column sums."""
+    from magma_amd.testing import build_reduced_magma
+    from magma_amd.train_engine import MagmaEngine
+    torch.manual_seed(0)
+    model = build_reduced_magma(dev, n_positions=128, **({} if variant == "v1" else {"mlp_factor": 8, "attn_factor": 8}))
+    model.config.gradient_accumulation_steps = 1
+    model.config.image_embed_dropout_prob = 0.0
+    model.image_prefix.dropout.p = 0.0
+    g = torch.Generator().manual_seed(6)
+    images = torch.randn(2, 3, 64, 64, generator=g).to(dev)
+    caps = torch.full((2, 128), model.eos_token, dtype=torch.int64)
+    caps[0, :30] = torch.randint(0, 1000, (30,), generator=g)
+    caps[1, :12] = torch.randint(0, 1000, (12,), generator=g)
+    eng = MagmaEngine(model)
+    eng.train()
+    res = []
+    for rc in (False, True):
+        eng.recompute = rc
+        for grp in eng.groups:
+            grp.grad.zero_()
+        out = eng(images, caps.to(dev))
+        kept = eng._tape["layers"][0].keys()
+        assert (set(kept) == {"x"}) == rc
+        eng.backward(out.loss)
+        res.append((float(out.loss), torch.cat([grp.grad.clone() for grp in eng.groups])))
+    assert res[0][0] == res[1][0]
+    assert rel(res[1][1], res[0][1]) < 1e-5
+
+
 def test_train_loop_and_checkpoint_roundtrip(dev, tmp_path):
     """train_step / eval_step / inference_step through the engine shim, then
     save_checkpoint -> load_checkpoint (DeepSpeed directory layout) reproduces the
