@@ -14,6 +14,7 @@
 #include <stdlib.h>
 #include "attn_tile_device.h"
 #include "attn_decode_device.h"
+#include "attn32_device.h"
 
 namespace {
 
@@ -360,12 +361,17 @@ extern "C" int mg_attn_prefill_bf16(const mg_bf16* q, const mg_bf16* kcache, con
   if ((vt_ld & 31) || vt_ld < ((S + 31) & ~31)) MG_FAIL(MG_ERR_SHAPE, "mg_attn_prefill_bf16: vt_ld must be a multiple of 32 and >= S");
   if (!q || !kcache || !vt || !out) MG_FAIL(MG_ERR_SHAPE, "mg_attn_prefill_bf16: null pointer");
   if (!MG_ALIGNED16(q) || !MG_ALIGNED16(kcache) || !MG_ALIGNED16(vt) || !MG_ALIGNED16(out)) MG_FAIL(MG_ERR_ALIGN, "mg_attn_prefill_bf16: pointers must be 16-byte aligned");
-  // 16-query waves x 8 (two per SIMD), deferred running max: 0.90 ms per layer at B = 16, S = 2048.  MAGMA_ATTN_FWD=0 keeps the
-  // plain running max (1.00 ms).  The 32-query-wave structure on the 32x32x16 MFMA measured slower (1.10 ms,
-  // profiles/r02_attention_variants.txt) and is gone from the library (git history: attn_prefill32_kernel).
+  // MAGMA_ATTN_FWD=4: 16-query waves x 8 (two per SIMD), deferred running max: 0.90-0.97 ms per layer at B = 16, S = 2048 (=0 keeps
+  // the plain running max: 1.00 ms).  Default since round 5: the 32-query-wave kernel with O^T and Q pinned to AGPRs
+  // (attention_fwd32.hip: 0.86-0.88 ms same-box, faster at every shape tried).  The round-2 attempt at 32-query waves left
+  // the register allocation to hipcc and measured 1.10 ms (profiles/r02_attention_variants.txt).
   // MAGMA_ATTN_FWD=0: plain running max instead of the deferred one (guide T13; 1.00 vs 0.95 ms in round 2)
-  static const int variant = [] { const char* e = getenv("MAGMA_ATTN_FWD"); return e ? atoi(e) : 4; }();
+  // MAGMA_ATTN_FWD=5: 32-query waves on the 32x32x16 MFMA, one wave per SIMD, O^T pinned to AGPRs (attention_fwd32.hip, round 5)
+  const char* env_v = getenv("MAGMA_ATTN_FWD");          // read per call: tests and A/B scripts switch it in-process
+  const int variant = env_v ? atoi(env_v) : 5;
   const float defer = variant == 0 ? 0.0f : FA2_DEFER;
+  if (variant == 5 && !(ld_out & 7))
+    return attn_prefill32_launch(q, kcache, vt, out, ld_out, lse, B, H, S, Smax, vt_ld, defer, (hipStream_t)stream, "mg_attn_prefill_bf16");
   const int lds = FA_STAGES * FA_STAGE;
   if (int rc = mg_allow_dynamic_lds((const void*)attn_prefill_sp_kernel<0>, lds, "mg_attn_prefill_bf16")) return rc;
   dim3 grid((unsigned)(((S + 127) / 128) * B * H));

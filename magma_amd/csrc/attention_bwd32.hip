@@ -24,40 +24,10 @@
 // supplies as the k-operand of the two 16-deep MFMA steps of the next product -- no cross-lane movement (the 16x16 kernels
 // use (li >> 2) 8 + (li & 3) for the same purpose).
 #include "attn_bwd_device.h"
+#include "attn32_device.h"
 #include <stdlib.h>
 
 namespace {
-
-MG_DEV f32x16 mfma32(const bf16x8 a, const bf16x8 b, const f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
-// the same with the accumulator pinned to the AGPR half of the register file: left to itself hipcc (ROCm 7.2) mixes the 256
-// accumulator registers of the two gradient tiles with the operand fragments across both halves and spills ~750 registers per
-// lane.  As an asm statement the MFMA is opaque to the hazard recogniser: an accumulate chain on the same registers needs no
-// wait states, the operands are never written by the instruction in front (ds_read results arrive behind hipcc's own lgkmcnt
-// wait, the packed P / dS operands are produced a phase earlier), and the epilogue reads the accumulators behind s_nop pads.
-MG_DEV void mfma32a(f32x16& c, const bf16x8 a, const bf16x8 b) {
-  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-}
-// ... and with the accumulator pinned to the VGPR half (S, dP: read by the softmax arithmetic).  hipcc gives a builtin MFMA's
-// result AGPRs of its own choice under this register pressure -- on top of the 256 pinned ones, which it then shuffles through
-// VGPRs every step.
-MG_DEV void mfma32v(f32x16& c, const bf16x8 a, const bf16x8 b) {
-  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
-}
-// ... between VALU writes of a packed operand and the asm MFMA that reads it
-MG_DEV void mfma_operand_ready(bf16x8& a, bf16x8& b) { asm volatile("s_nop 3" : "+v"(a), "+v"(b)); }
-// The LAST MFMA of an accumulate chain carries its wait states itself (8-pass XDL op -> any other reader or writer of the
-// result: 12+): whatever hipcc schedules behind the statement -- the softmax arithmetic, but also register copies of its own
-// around a loop exit (seen: one accumulator register read right behind the loop, two gradient columns wrong) -- finds the
-// result written.  The pad is issue time of THIS wave only; the matrix pipe is busy with the MFMA meanwhile.
-MG_DEV void mfma32v_last(f32x16& c, const bf16x8 a, const bf16x8 b) {
-  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n\ts_nop 15\n\ts_nop 3" : "+v"(c) : "v"(a), "v"(b));
-}
-MG_DEV void mfma32a_last(f32x16& c, const bf16x8 a, const bf16x8 b) {
-  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n\ts_nop 15\n\ts_nop 3" : "+a"(c) : "v"(a), "v"(b));
-}
-MG_DEV int perm32(int i) { return (i & 19) | ((i & 4) << 1) | ((i & 8) >> 1); }
-
-constexpr int EP_ROW = 528;   // epilogue staging image: 512-B rows padded to 132 dwords (a lane group's 16 rows hit 16 bank quads)
 
 // A wave's 32 x 256 gradient tile (acc[db] = d-rows db*32.. x 32 sequence positions) -> bf16, through a wave-private LDS
 // image, out as whole 512-byte rows: 16 dwordx4 stores of 1 KiB per wave instead of 64 dwordx2 at a row stride.
@@ -98,18 +68,8 @@ MG_DEV void store_grad_tile32(const GradOut& g, const f32x16 (&acc)[8], float sc
   __builtin_amdgcn_wave_barrier();
 }
 
-// fragment bursts of four: chunk ((ks << 1) | hi) of tile row R (swizzled), ks = g*4 .. g*4+3
-MG_DEV void rd_row4(bf16x8 (&f)[4], const char* row, int g, int hi, int sw) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) f[i] = *(const bf16x8*)(row + (((((g * 4 + i) << 1) | hi) ^ sw) << 4));
-}
-// T image: rows d = db*32 + l31 (64-byte rows), chunk ((ks2 << 1) | hi) ^ tsw; batch g = d-blocks 2g, 2g+1 x both k-steps
-MG_DEV void rd_t4(bf16x8 (&f)[4], const char* tp, int g, int x) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) f[i] = *(const bf16x8*)(tp + (g * 2 + (i >> 1)) * 2048 + ((((i & 1) << 1) ^ x) << 4));
-}
-
-constexpr int KV_STAGE = 2 * ROW_TILE + 2 * T_TILE + LD_TILE;   // Q rows | dO rows | Q^T | dO^T | {lse2 x 32, D x 32}
+constexpr int KV_STAGE = 2 * ROW_TILE + 2 * T_TILE + 2 * LD_TILE;   // Q rows | dO rows | Q^T | dO^T | {-16 lse x 32, -D x 32} | pad: a multiple of 512 (rd_row4x)
+static_assert(KV_STAGE % 512 == 0, "rd_row4x: the stage offset must not reach into the chunk bits");
 constexpr int KV_STAGES = 2;
 constexpr int KV_LD_OFF = 2 * ROW_TILE + 2 * T_TILE;
 
@@ -192,6 +152,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv32_kernel(
   const int my_first = k0 + wave * 32;         // query tiles that end before this wave's first key are fully masked
   const int R = perm32(l31);                   // tile row that feeds this lane's MFMA row
   const int sw = row_swz(R);
+  const uint32_t rb = row_base32(R, sw, hi);
   const int tx = hi ^ t_swz(l31);
   const uint32_t ls_addr = smem_u + (uint32_t)(KV_LD_OFF + hi * 32);   // + g*64 (+128 for D): 8 consecutive queries = 32 bytes
 
@@ -226,8 +187,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv32_kernel(
     const int q0 = t * 32;
     {
       const char* st = smem + sc * KV_STAGE;
-      const char* qrow = st + R * 512;
-      const char* dorow = qrow + ROW_TILE;
+      const uint32_t qrow = (uint32_t)(sc * KV_STAGE) + rb;
+      const uint32_t dorow = qrow + ROW_TILE;
       const char* qtp = st + 2 * ROW_TILE + l31 * 64;
       const char* dotp = qtp + T_TILE;
       const uint32_t lsa = ls_addr + (uint32_t)(sc * KV_STAGE);
@@ -246,16 +207,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv32_kernel(
                                          __builtin_shufflevector(i2, i3, 0, 1, 2, 3, 4, 5, 6, 7),
                                          0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
       // ---- phase 1: S' = Q K^T - 16 lse (16 MFMAs), fragment bursts of four one burst ahead ----
-      if (ABL != 2 || first) rd_row4(fa, qrow, 0, hi, sw);
-      if (ABL != 2 || first) rd_row4(fb, qrow, 1, hi, sw);
+      if (ABL != 2 || first) rd_row4x(fa, smem, qrow, 0);
+      if (ABL != 2 || first) rd_row4x(fb, smem, qrow, 1);
       MG_SCHED_FENCE();
 #pragma unroll
       for (int i = 0; i < 4; ++i) MMV(s, fa[i], kf[i]);
-      if (ABL != 2 || first) rd_row4(fa, qrow, 2, hi, sw);
+      if (ABL != 2 || first) rd_row4x(fa, smem, qrow, 2);
       MG_SCHED_FENCE();
 #pragma unroll
       for (int i = 0; i < 4; ++i) MMV(s, fb[i], kf[4 + i]);
-      if (ABL != 2 || first) rd_row4(fb, qrow, 3, hi, sw);
+      if (ABL != 2 || first) rd_row4x(fb, smem, qrow, 3);
       MG_SCHED_FENCE();
 #pragma unroll
       for (int i = 0; i < 4; ++i) MMV(s, fa[i], kf[8 + i]);
@@ -265,18 +226,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv32_kernel(
       f32x16 dp = __builtin_shufflevector(__builtin_shufflevector(i0, i1, 0, 1, 2, 3, 4, 5, 6, 7),
                                           __builtin_shufflevector(i2, i3, 0, 1, 2, 3, 4, 5, 6, 7),
                                           0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
-      if (ABL != 2 || first) rd_row4(fa, dorow, 0, hi, sw);
+      if (ABL != 2 || first) rd_row4x(fa, smem, dorow, 0);
       MG_SCHED_FENCE();
 #pragma unroll
       for (int i = 0; i < 3; ++i) MMV(s, fb[i], kf[12 + i]);
       MMVL(s, fb[3], kf[15]);
-      if (ABL != 2 || first) rd_row4(fb, dorow, 1, hi, sw);
+      if (ABL != 2 || first) rd_row4x(fb, smem, dorow, 1);
       MG_SCHED_FENCE();
       if (SPREAD && more) issue_part(t + 1, sc ^ 1, 1);
       // ---- phase 2: dP' = dO V^T - D (16 MFMAs) beside P = exp2(S' sc2) ----
 #pragma unroll
       for (int i = 0; i < 4; ++i) MMV(dp, fa[i], vf[i]);
-      if (ABL != 2 || first) rd_row4(fa, dorow, 2, hi, sw);
+      if (ABL != 2 || first) rd_row4x(fa, smem, dorow, 2);
       // only the tiles that straddle this wave's keys (and the ragged last tile) need the mask
       if (q0 < my_first + 31 || q0 + 32 > S) {
 #pragma unroll
@@ -298,7 +259,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv32_kernel(
         p[2 * i + 1] = (ABL == 5 ? s[2 * i + 1] : __builtin_amdgcn_exp2f(s[2 * i + 1] * sc2));
         MG_SCHED_FENCE();
       }
-      if (ABL != 2 || first) rd_row4(fb, dorow, 3, hi, sw);
+      if (ABL != 2 || first) rd_row4x(fb, smem, dorow, 3);
       MG_SCHED_FENCE();
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -402,11 +363,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv32_kernel(
 #undef MMA
 #undef MMAL
 
-// first MFMA of a chain: C = 0 (no zero-fill of the accumulator registers)
-MG_DEV void mfma32v0(f32x16& c, const bf16x8 a, const bf16x8 b) {
-  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
-}
-
 constexpr int Q_STAGE = 2 * ROW_TILE + T_TILE;   // K rows | V rows | K^T
 constexpr int Q_STAGES = 3;
 
@@ -472,6 +428,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq32_kernel(
   }
   const int R = perm32(l31);
   const int sw = row_swz(R);
+  const uint32_t rb = row_base32(R, sw, hi);
   const int tx = hi ^ t_swz(l31);
   // this wave's tiles: 0 .. n_act-1 (key tiles past its last query are fully masked for it)
   const int n_act = min(ntiles, ((qt0 + wave * 32 + 31) >> 5) + 1);
@@ -493,39 +450,39 @@ __global__ __launch_bounds__(256) void attn_bwd_dq32_kernel(
     const int kv0 = t * 32;
     {
       const char* st = smem + sc * Q_STAGE;
-      const char* krow = st + R * 512;
-      const char* vrow = krow + ROW_TILE;
+      const uint32_t krow = (uint32_t)(sc * Q_STAGE) + rb;
+      const uint32_t vrow = krow + ROW_TILE;
       const char* ktp = st + 2 * ROW_TILE + l31 * 64;
       bf16x8 fa[4], fb[4];
       f32x16 s, dp;
       // ---- phase 1: S^T = K Q^T ----
-      rd_row4(fa, krow, 0, hi, sw);
-      rd_row4(fb, krow, 1, hi, sw);
+      rd_row4x(fa, smem, krow, 0);
+      rd_row4x(fb, smem, krow, 1);
       MG_SCHED_FENCE();
       mfma32v0(s, fa[0], qf[0]);
 #pragma unroll
       for (int i = 1; i < 4; ++i) mfma32v(s, fa[i], qf[i]);
-      rd_row4(fa, krow, 2, hi, sw);
+      rd_row4x(fa, smem, krow, 2);
       MG_SCHED_FENCE();
 #pragma unroll
       for (int i = 0; i < 4; ++i) mfma32v(s, fb[i], qf[4 + i]);
-      rd_row4(fb, krow, 3, hi, sw);
+      rd_row4x(fb, smem, krow, 3);
       MG_SCHED_FENCE();
 #pragma unroll
       for (int i = 0; i < 4; ++i) mfma32v(s, fa[i], qf[8 + i]);
-      rd_row4(fa, vrow, 0, hi, sw);
+      rd_row4x(fa, smem, vrow, 0);
       MG_SCHED_FENCE();
 #pragma unroll
       for (int i = 0; i < 3; ++i) mfma32v(s, fb[i], qf[12 + i]);
       mfma32v_last(s, fb[3], qf[15]);
-      rd_row4(fb, vrow, 1, hi, sw);
+      rd_row4x(fb, smem, vrow, 1);
       MG_SCHED_FENCE();
       if (SPREAD) issue_part(t + 2, nb, 1);
       // ---- phase 2: dP^T = V dO^T beside P^T = exp2(S^T sc2 - lse2) ----
       mfma32v0(dp, fa[0], dof[0]);
 #pragma unroll
       for (int i = 1; i < 4; ++i) mfma32v(dp, fa[i], dof[i]);
-      rd_row4(fa, vrow, 2, hi, sw);
+      rd_row4x(fa, smem, vrow, 2);
       // only this wave's diagonal tile (and the ragged last tile) needs the mask: -1e30 -> exp2(-huge) = 0
       if (kv0 + 31 > qt0 + wave * 32 || kv0 + 32 > S) {
 #pragma unroll
@@ -545,7 +502,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq32_kernel(
         p[2 * i + 1] = __builtin_amdgcn_exp2f(fmaf(s[2 * i + 1], sc2, nl2));
         MG_SCHED_FENCE();
       }
-      rd_row4(fb, vrow, 3, hi, sw);
+      rd_row4x(fb, smem, vrow, 3);
       MG_SCHED_FENCE();
 #pragma unroll
       for (int i = 0; i < 4; ++i) {

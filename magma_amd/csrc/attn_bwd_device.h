@@ -4,8 +4,6 @@
 #include "common.h"
 #include "attn_tile_device.h"
 
-typedef __attribute__((ext_vector_type(16))) float f32x16;   // 32x32 MFMA accumulator
-
 constexpr int LD_TILE = 256;              // 32 x {lse*log2e, D}
 
 // Where a gradient row goes.  merged == nullptr: out[(bh*S + s)*256 + d] (dq / dk / dv as [B,H,S,256]).  Otherwise the

@@ -244,6 +244,34 @@ def test_rotary_split_and_prefill_attention(dev, B, S, H):
     assert_close(lse, torch.logsumexp(sc, -1), 1e-4, "lse")
 
 
+@pytest.mark.parametrize("variant", [4, 5])
+@pytest.mark.parametrize("B,H,S", [(1, 1, 1), (2, 2, 57), (1, 2, 300), (2, 1, 385), (1, 1, 1024)])
+def test_attention_forward_kernel_variants(dev, monkeypatch, variant, B, H, S):
+    """MAGMA_ATTN_FWD = 4 (16-query waves, two per SIMD) / 5 (32-query waves on the 32x32x16 MFMA, one per SIMD, O^T in AGPRs):
+    output and lse against fp32 softmax(QK^T/16)V, the output also at the row stride of a wider buffer, and a late dominant
+    key that forces the deferred-maximum rescale (guide rule 26)."""
+    from magma_amd import ops
+    monkeypatch.setenv("MAGMA_ATTN_FWD", str(variant))
+    d = H * 256
+    q = rnd(B, H, S, 256, dev=dev, seed=81, scale=0.5).to(BF16)
+    k = rnd(B, H, S, 256, dev=dev, seed=82, scale=0.5).to(BF16)
+    v = rnd(B, H, S, 256, dev=dev, seed=83).to(BF16)
+    if S > 100:                      # one late key dominates a late query block: the running maximum jumps by far more than 2^8
+        k[:, :, S - 40] = (q[:, :, S - 5] * 6).to(BF16)
+    vt = ops.head_transpose(v, B, H, S, sb=H * S * 256, ss=256, sh=S * 256)
+    out = torch.empty(B * S, d, dtype=BF16, device=dev)
+    lse = torch.empty(B, H, S, dtype=torch.float32, device=dev)
+    ops.attn_prefill(q, k, vt, out, B, H, S, lse=lse)
+    sc = q.float() @ k.float().transpose(-1, -2) / 16.0
+    sc = sc.masked_fill(~torch.ones(S, S, dtype=torch.bool, device=dev).tril(), float("-inf"))
+    ref = (torch.softmax(sc, -1) @ v.float()).permute(0, 2, 1, 3).reshape(B * S, d)
+    assert_close(out, ref, 8e-3, "flash attention")
+    assert_close(lse, torch.logsumexp(sc, -1), 1e-4, "lse")
+    wide = torch.full((B * S, d + 136), float("nan"), dtype=BF16, device=dev)
+    ops.attn_prefill(q, k, vt, wide[:, :d], B, H, S, lse=lse)
+    assert torch.equal(wide[:, :d], out)
+
+
 def test_attention_online_softmax_rescale(dev):
     """Force the running-max rescale branch: one late key dominates (guide rule 26)."""
     from magma_amd import ops

@@ -24,12 +24,18 @@ def t(fn, n=5):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
 
-fwd = t(lambda: ops.attn_prefill(q, k, vt, out, B, H, S, lse=lse))
+fwds = {}
+for var in os.environ.get("AFWD", "4,5").split(","):       # MAGMA_ATTN_FWD variants (attention.hip: 4 = 16-query waves, 5 = 32-query waves)
+    os.environ["MAGMA_ATTN_FWD"] = var
+    fwds[var] = t(lambda: ops.attn_prefill(q, k, vt, out, B, H, S, lse=lse))
+fwd = fwds[min(fwds)]
 qt = ops.head_transpose(q, B, H, S, sb=hs, ss=256, sh=S * 256)
 kt = ops.head_transpose(k, B, H, S, sb=hs, ss=256, sh=S * 256)
 dOt = ops.head_transpose(dO, B, H, S, sb=S * d, ss=d, sh=256)
 fl = B * H * 4 * S * S * 256 / 2
 res = {"B": B, "S": S, "fwd_ms": round(fwd, 4), "fwd_tflops_causal": round(fl / fwd / 1e9, 1)}
+for var, ms in fwds.items():
+    res["fwd_ms_v" + var] = round(ms, 4)
 # MAGMA_ATTN_BWD variants (attention_bwd.hip: 0 = three 16-row-wave kernels, 1/2 = merged dK+dV on 32-key waves, 3/4 = + 32-query dQ)
 for var in os.environ.get("ABWD", "0,1,2,3,4").split(","):
     os.environ["MAGMA_ATTN_BWD"] = var
