@@ -27,6 +27,16 @@
 #include "attn32_device.h"
 #include <stdlib.h>
 
+#ifdef MG_GEMM_ABLATIONS
+// ABL 6 of attn_bwd_dkdv32_kernel: per-wave s_memtime totals of the five segments of a tile step + the step count
+__device__ unsigned long long g_attn_stamps[4096 * 4 * 8];
+extern "C" int mg_debug_attn_stamps(void* host_dst, int64_t bytes) {
+  const hipError_t e = hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_attn_stamps), (size_t)bytes);
+  if (e != hipSuccess) MG_FAIL(MG_ERR_HIP, "mg_debug_attn_stamps: %s", hipGetErrorString(e));
+  return MG_OK;
+}
+#endif
+
 namespace {
 
 // A wave's 32 x 256 gradient tile (acc[db] = d-rows db*32.. x 32 sequence positions) -> bf16, through a wave-private LDS
@@ -179,10 +189,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv32_kernel(
     sc ^= 1;
   }
   bool first = true;
+  unsigned long long tsum[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+#define MG_STAMP(i_) do { if constexpr (ABL == 6) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); tsum[i_] += n_ - tprev; tprev = n_; } } while (0)
+  if constexpr (ABL == 6) tprev = __builtin_amdgcn_s_memtime();
   for (; t < t_end; ++t) {
     if constexpr (ABL != 1 && ABL != 4) MG_WAIT_VMCNT(0);   // this wave's pieces of tile t have landed (issued one step ago)
     if constexpr (ABL != 4) MG_BARRIER_KEEP_DMA();          // tile t complete; everyone is done with tile t-1
     const bool more = (ABL == 1 || ABL == 4) ? false : t + 1 < t_end;
+    MG_STAMP(0);                      // wait + barrier
     if (more) { if (SPREAD) issue_part(t + 1, sc ^ 1, 0); else issue(t + 1, sc ^ 1); }
     const int q0 = t * 32;
     {
@@ -210,14 +224,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv32_kernel(
       if (ABL != 2 || first) rd_row4x(fa, smem, qrow, 0);
       if (ABL != 2 || first) rd_row4x(fb, smem, qrow, 1);
       MG_SCHED_FENCE();
+      MG_LGKM4();
 #pragma unroll
       for (int i = 0; i < 4; ++i) MMV(s, fa[i], kf[i]);
       if (ABL != 2 || first) rd_row4x(fa, smem, qrow, 2);
       MG_SCHED_FENCE();
+      MG_LGKM4();
 #pragma unroll
       for (int i = 0; i < 4; ++i) MMV(s, fb[i], kf[4 + i]);
       if (ABL != 2 || first) rd_row4x(fb, smem, qrow, 3);
       MG_SCHED_FENCE();
+      MG_LGKM4();
 #pragma unroll
       for (int i = 0; i < 4; ++i) MMV(s, fa[i], kf[8 + i]);
       asm volatile("ds_read_b128 %0, %4 offset:128\n\tds_read_b128 %1, %4 offset:144\n\tds_read_b128 %2, %4 offset:192\n\t"
@@ -228,13 +245,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv32_kernel(
                                           0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
       if (ABL != 2 || first) rd_row4x(fa, smem, dorow, 0);
       MG_SCHED_FENCE();
+      MG_LGKM4();
 #pragma unroll
       for (int i = 0; i < 3; ++i) MMV(s, fb[i], kf[12 + i]);
       MMVL(s, fb[3], kf[15]);
       if (ABL != 2 || first) rd_row4x(fb, smem, dorow, 1);
       MG_SCHED_FENCE();
+      MG_STAMP(1);                    // DMA group 0 + phase 1
       if (SPREAD && more) issue_part(t + 1, sc ^ 1, 1);
       // ---- phase 2: dP' = dO V^T - D (16 MFMAs) beside P = exp2(S' sc2) ----
+      MG_LGKM4();
 #pragma unroll
       for (int i = 0; i < 4; ++i) MMV(dp, fa[i], vf[i]);
       if (ABL != 2 || first) rd_row4x(fa, smem, dorow, 2);
@@ -251,6 +271,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv32_kernel(
       float p[16];
       u32x4 pw0, pw1;
       MG_SCHED_FENCE();
+      MG_LGKM4();
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         MMV(dp, fb[i], vf[4 + i]);
@@ -261,6 +282,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv32_kernel(
       }
       if (ABL != 2 || first) rd_row4x(fb, smem, dorow, 3);
       MG_SCHED_FENCE();
+      MG_LGKM4();
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         MMV(dp, fa[i], vf[8 + i]);
@@ -271,6 +293,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv32_kernel(
       }
       if (ABL != 2 || first) rd_t4(fa, dotp, 0, tx);
       MG_SCHED_FENCE();
+      MG_LGKM4();
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         if (i < 3) MMV(dp, fb[i], vf[12 + i]); else MMVL(dp, fb[3], vf[15]);
@@ -283,9 +306,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv32_kernel(
       bf16x8 pf0 = __builtin_bit_cast(bf16x8, pw0), pf1 = __builtin_bit_cast(bf16x8, pw1);
       mfma_operand_ready(pf0, pf1);
       MG_SCHED_FENCE();
+      MG_STAMP(2);                    // DMA group 1 + phase 2
       if (SPREAD && more) issue_part(t + 1, sc ^ 1, 2);
       // ---- phase 3: dV^T += dO^T P (16 MFMAs) beside 16 dS = P o dP' (the 1/16 is applied once, in the epilogue) ----
       // MFMA order 0, 2, 1, 3: the two d-blocks of a burst alternate, no back-to-back pair on one accumulator
+      MG_LGKM4();
 #pragma unroll
       for (int i = 0; i < 4; ++i) { const int j = ((i & 1) << 1) | (i >> 1); MMA(accv[j >> 1], fa[j], (j & 1) ? pf1 : pf0); }
       if (ABL != 2 || first) rd_t4(fa, dotp, 2, tx);
@@ -294,6 +319,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv32_kernel(
       float ds[16];
       u32x4 dw0, dw1;
       MG_SCHED_FENCE();
+      MG_LGKM4();
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int j = ((i & 1) << 1) | (i >> 1);
@@ -305,6 +331,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv32_kernel(
       }
       if (ABL != 2 || first) rd_t4(fb, dotp, 3, tx);
       MG_SCHED_FENCE();
+      MG_LGKM4();
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int j = ((i & 1) << 1) | (i >> 1);
@@ -316,6 +343,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv32_kernel(
       }
       if (ABL != 2 || first) rd_t4(fa, qtp, 0, tx);
       MG_SCHED_FENCE();
+      MG_LGKM4();
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int j = ((i & 1) << 1) | (i >> 1);
@@ -329,26 +357,42 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv32_kernel(
       bf16x8 df0 = __builtin_bit_cast(bf16x8, dw0), df1 = __builtin_bit_cast(bf16x8, dw1);
       mfma_operand_ready(df0, df1);
       MG_SCHED_FENCE();
+      MG_STAMP(3);                    // DMA group 2 + phase 3
       if (SPREAD && more) issue_part(t + 1, sc ^ 1, 3);
       // ---- phase 4: 16 dK^T += Q^T (16 dS) (16 MFMAs) ----
+      MG_LGKM4();
 #pragma unroll
       for (int i = 0; i < 4; ++i) { const int j = ((i & 1) << 1) | (i >> 1); MMA(acck[j >> 1], fa[j], (j & 1) ? df1 : df0); }
       if (ABL != 2 || first) rd_t4(fa, qtp, 2, tx);
       MG_SCHED_FENCE();
+      MG_LGKM4();
 #pragma unroll
       for (int i = 0; i < 4; ++i) { const int j = ((i & 1) << 1) | (i >> 1); MMA(acck[2 + (j >> 1)], fb[j], (j & 1) ? df1 : df0); }
       if (ABL != 2 || first) rd_t4(fb, qtp, 3, tx);
       MG_SCHED_FENCE();
+      MG_LGKM4();
 #pragma unroll
       for (int i = 0; i < 4; ++i) { const int j = ((i & 1) << 1) | (i >> 1); MMA(acck[4 + (j >> 1)], fa[j], (j & 1) ? df1 : df0); }
       MG_SCHED_FENCE();
+      MG_LGKM4();
 #pragma unroll
       for (int i = 0; i < 3; ++i) { const int j = ((i & 1) << 1) | (i >> 1); MMA(acck[6 + (j >> 1)], fb[j], (j & 1) ? df1 : df0); }
       MMAL(acck[7], fb[3], df1);
     }
+    MG_STAMP(4);                      // DMA group 3 + phase 4
+    if constexpr (ABL == 6) tsum[5] += 1;
     sc ^= 1;
     first = false;
   }
+#undef MG_STAMP
+#ifdef MG_GEMM_ABLATIONS
+  if constexpr (ABL == 6) {
+    if (lane == 0 && blockIdx.x < 4096) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) g_attn_stamps[((size_t)blockIdx.x * 4 + wave) * 8 + i] = tsum[i];
+    }
+  }
+#endif
   if constexpr (ABL == 1 || ABL == 4) MG_WAIT_VMCNT(0);
   // every wave is done with the ring (and no DMA is in flight: the last tile issues none) before it becomes staging space
   MG_BARRIER_KEEP_DMA();
@@ -464,14 +508,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq32_kernel(
       for (int i = 1; i < 4; ++i) mfma32v(s, fa[i], qf[i]);
       rd_row4x(fa, smem, krow, 2);
       MG_SCHED_FENCE();
+      MG_LGKM4();
 #pragma unroll
       for (int i = 0; i < 4; ++i) mfma32v(s, fb[i], qf[4 + i]);
       rd_row4x(fb, smem, krow, 3);
       MG_SCHED_FENCE();
+      MG_LGKM4();
 #pragma unroll
       for (int i = 0; i < 4; ++i) mfma32v(s, fa[i], qf[8 + i]);
       rd_row4x(fa, smem, vrow, 0);
       MG_SCHED_FENCE();
+      MG_LGKM4();
 #pragma unroll
       for (int i = 0; i < 3; ++i) mfma32v(s, fb[i], qf[12 + i]);
       mfma32v_last(s, fb[3], qf[15]);
@@ -494,6 +541,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq32_kernel(
       float p[16];
       u32x4 pw0, pw1;
       MG_SCHED_FENCE();
+      MG_LGKM4();
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         mfma32v(dp, fb[i], dof[4 + i]);
@@ -504,6 +552,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq32_kernel(
       }
       rd_row4x(fb, smem, vrow, 3);
       MG_SCHED_FENCE();
+      MG_LGKM4();
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         mfma32v(dp, fa[i], dof[8 + i]);
@@ -514,6 +563,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq32_kernel(
       }
       rd_t4(fa, ktp, 0, tx);
       MG_SCHED_FENCE();
+      MG_LGKM4();
 #pragma unroll
       for (int i = 0; i < 3; ++i) mfma32v(dp, fb[i], dof[12 + i]);
       mfma32v_last(dp, fb[3], dof[15]);
@@ -532,18 +582,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dq32_kernel(
       mfma_operand_ready(df0, df1);
       MG_SCHED_FENCE();
       // ---- phase 3: 16 dQ^T += K^T (16 dS^T) ----
+      MG_LGKM4();
 #pragma unroll
       for (int i = 0; i < 4; ++i) { const int j = ((i & 1) << 1) | (i >> 1); mfma32a(accq[j >> 1], fa[j], (j & 1) ? df1 : df0); }
       rd_t4(fa, ktp, 2, tx);
       MG_SCHED_FENCE();
+      MG_LGKM4();
 #pragma unroll
       for (int i = 0; i < 4; ++i) { const int j = ((i & 1) << 1) | (i >> 1); mfma32a(accq[2 + (j >> 1)], fb[j], (j & 1) ? df1 : df0); }
       rd_t4(fb, ktp, 3, tx);
       MG_SCHED_FENCE();
       if (SPREAD) issue_part(t + 2, nb, 3);
+      MG_LGKM4();
 #pragma unroll
       for (int i = 0; i < 4; ++i) { const int j = ((i & 1) << 1) | (i >> 1); mfma32a(accq[4 + (j >> 1)], fa[j], (j & 1) ? df1 : df0); }
       MG_SCHED_FENCE();
+      MG_LGKM4();
 #pragma unroll
       for (int i = 0; i < 3; ++i) { const int j = ((i & 1) << 1) | (i >> 1); mfma32a(accq[6 + (j >> 1)], fb[j], (j & 1) ? df1 : df0); }
       mfma32a_last(accq[7], fb[3], df1);
@@ -579,7 +633,7 @@ int attn_bwd_dkdv32_launch(const mg_bf16* q, const mg_bf16* k, const mg_bf16* v,
       MG_CHECK_LAUNCH();                                                                                                   \
       return MG_OK;                                                                                                        \
     }
-    MG_ABL(1) MG_ABL(2) MG_ABL(3) MG_ABL(4) MG_ABL(5)
+    MG_ABL(1) MG_ABL(2) MG_ABL(3) MG_ABL(4) MG_ABL(5) MG_ABL(6)
 #undef MG_ABL
   }
 #endif

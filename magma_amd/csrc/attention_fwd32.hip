@@ -131,13 +131,16 @@ __global__ __launch_bounds__(256) void attn_prefill32_kernel(
     for (int i = 1; i < 4; ++i) mfma32v_ba(sA, fa[i], qa[i]);
     rd_row4x(fa, smem, krow, 2);
     MG_SCHED_FENCE();
+    MG_LGKM4();
 #pragma unroll
     for (int i = 0; i < 4; ++i) mfma32v_ba(sA, fb[i], qa[4 + i]);
     rd_row4x(fb, smem, krow, 3);
     MG_SCHED_FENCE();
+    MG_LGKM4();
 #pragma unroll
     for (int i = 0; i < 4; ++i) mfma32v_ba(sA, fa[i], qa[8 + i]);
     MG_SCHED_FENCE();
+    MG_LGKM4();
 #pragma unroll
     for (int i = 0; i < 3; ++i) mfma32v_ba(sA, fb[i], qa[12 + i]);
     mfma32v_ba_last(sA, fb[3], qa[15]);
@@ -167,6 +170,7 @@ __global__ __launch_bounds__(256) void attn_prefill32_kernel(
     rd_row4x(fa, smem, krow, 0);
     rd_row4x(fb, smem, krow, 1);
     MG_SCHED_FENCE();
+    MG_LGKM4();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if (i == 0) mfma32v0_ba(nxt, fa[0], qa[0]); else mfma32v_ba(nxt, fa[i], qa[i]);
@@ -176,6 +180,7 @@ __global__ __launch_bounds__(256) void attn_prefill32_kernel(
     }
     rd_row4x(fa, smem, krow, 2);
     MG_SCHED_FENCE();
+    MG_LGKM4();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       mfma32v_ba(nxt, fb[i], qa[4 + i]);
@@ -185,6 +190,7 @@ __global__ __launch_bounds__(256) void attn_prefill32_kernel(
     }
     rd_row4x(fb, smem, krow, 3);
     MG_SCHED_FENCE();
+    MG_LGKM4();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       mfma32v_ba(nxt, fa[i], qa[8 + i]);
@@ -194,6 +200,7 @@ __global__ __launch_bounds__(256) void attn_prefill32_kernel(
     }
     rd_t4(fa, vtp, 0, tx);
     MG_SCHED_FENCE();
+    MG_LGKM4();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if (i < 3) mfma32v_ba(nxt, fb[i], qa[12 + i]); else mfma32v_ba_last(nxt, fb[3], qa[15]);
@@ -225,19 +232,23 @@ __global__ __launch_bounds__(256) void attn_prefill32_kernel(
     }
     MG_SCHED_FENCE();
     // ---- block B: O^T += V^T(t) P^T(t), 16 MFMAs; part 1 of softmax(t+1) behind the first burst ----
+    MG_LGKM4();
 #pragma unroll
     for (int i = 0; i < 4; ++i) { const int j = ((i & 1) << 1) | (i >> 1); mfma32a(o[j >> 1], fa[j], (j & 1) ? pf1 : pf0); }
     rd_t4(fa, vtp, 2, tx);
     MG_SCHED_FENCE();
     part1(nxt, (t + 1) * 32);
     MG_SCHED_FENCE();
+    MG_LGKM4();
 #pragma unroll
     for (int i = 0; i < 4; ++i) { const int j = ((i & 1) << 1) | (i >> 1); mfma32a(o[2 + (j >> 1)], fb[j], (j & 1) ? pf1 : pf0); }
     rd_t4(fb, vtp, 3, tx);
     MG_SCHED_FENCE();
+    MG_LGKM4();
 #pragma unroll
     for (int i = 0; i < 4; ++i) { const int j = ((i & 1) << 1) | (i >> 1); mfma32a(o[4 + (j >> 1)], fa[j], (j & 1) ? pf1 : pf0); }
     MG_SCHED_FENCE();
+    MG_LGKM4();
 #pragma unroll
     for (int i = 0; i < 3; ++i) { const int j = ((i & 1) << 1) | (i >> 1); mfma32a(o[6 + (j >> 1)], fb[j], (j & 1) ? pf1 : pf0); }
     mfma32a_last(o[7], fb[3], pf1);

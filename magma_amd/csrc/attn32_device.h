@@ -46,6 +46,12 @@ MG_DEV void mfma32v_ba_last(f32x16& c, const bf16x8 a, const bf16x8 b) {
 MG_DEV void mfma32v0_ba(f32x16& c, const bf16x8 a, const bf16x8 b) {
   asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "a"(b));
 }
+// ONE wait for a whole fragment burst (the four oldest of eight outstanding reads) in front of its four MFMAs: left alone hipcc
+// emits a ladder lgkmcnt(7) .. (4), one s_waitcnt per MFMA -- 48 instructions per tile step of a wave that is bound by its
+// instruction stream.  The builtin (not asm) so that hipcc's scoreboard sees it and drops its own.  gfx9 encoding: vmcnt 63,
+// expcnt 7, lgkmcnt 4.
+#define MG_LGKM4() __builtin_amdgcn_s_waitcnt(0xC47F)
+#define MG_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)
 MG_DEV int perm32(int i) { return (i & 19) | ((i & 4) << 1) | ((i & 8) >> 1); }
 
 constexpr int EP_ROW = 528;   // epilogue staging image: 512-B rows padded to 132 dwords (a lane group's 16 rows hit 16 bank quads)

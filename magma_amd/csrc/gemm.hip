@@ -393,6 +393,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   static_assert(!(FP8 && MFMA32), "the 32x32 form is the bf16 path");
   bool abl_on = true;           // ABL 2 / 4: false once the pipeline is primed
   const unsigned long long t_start = ABL == 11 ? __builtin_amdgcn_s_memrealtime() : 0ull;
+  const unsigned long long c_start = ABL == 11 ? __builtin_amdgcn_s_memtime() : 0ull;     // shader-clock cycles (the 100-MHz counter above is wall time)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -828,7 +829,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
     if (ABL == 11) {
       MG_WAIT_VM(0);
       MG_STAMP(6);
-      if (tid == 0) stamps[7] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4);   // XCC_ID, HW_ID
+      // shader cycles of this workgroup's life: / its wall time (stamps[6] - stamps[0], 100 MHz) = the clock the kernel ran at
+      if (tid == 0) stamps[7] = __builtin_amdgcn_s_memtime() - c_start;
     }
   };
   const bool interior = nb + 256 <= p.N;

@@ -312,7 +312,9 @@ def main():
             else:
                 emit(kind="tilecost", epilogue=name, **pts)
     if which == "stamps":   # (make ABL=1) in-kernel 100-MHz time stamps of the 256x256 kernel: where does a tile's time go?
-        for (M, N, K, tag) in [(8192, 8192, 4096, "square_k4096"), (32768, 4096, 4096, "out_proj"), (8192, 8192, 1024, "square_k1024")]:
+        for (M, N, K, tag) in [(8192, 8192, 4096, "square_k4096"), (32768, 12288, 4096, "qkv"), (32768, 4096, 4096, "out_proj"), (32768, 16384, 4096, "fc_in"),
+                               (32768, 4096, 16384, "fc_out"),
+                               (8192, 8192, 1024, "square_k1024")]:
             a = torch.randn(M, K, device=dev).to(BF16)
             lin = ops.PackedLinear((torch.randn(N, K, device=dev) * 0.05).to(BF16))
             out = torch.empty(M, N, dtype=BF16, device=dev)
@@ -339,6 +341,10 @@ def main():
             r["first_wave"] = first_wave
             r["slot_turnaround_us"] = {"mean": round(float(gaps.mean()), 2), "p10": round(float(gaps.quantile(0.1)), 2), "p50": round(float(gaps.quantile(0.5)), 2), "p90": round(float(gaps.quantile(0.9)), 2)}
             r["first_wave_start_spread_us"] = round(float(starts[first_wave - 1] - starts[0]), 2)
+            # effective shader clock under this kernel's load: s_memtime cycles of a workgroup's life / its wall time
+            clk = st[:, 7].double() / (t[:, 6] - t[:, 0])        # cycles per us = MHz
+            r["shader_clock_MHz"] = {"mean": round(float(clk.mean()), 1), "p10": round(float(clk.quantile(0.1)), 1), "p90": round(float(clk.quantile(0.9)), 1)}
+            r["peak_at_this_clock_TF"] = round(2500.0 * float(clk.mean()) / 2400.0, 1)
             emit(**r)
     if which == "shortk":   # adapter up-projection (K = 1024) with three residual reads: epilogue-bound; 128x128 vs 256x256 kernel
         M, N, K = 32768, 4096, 1024
