@@ -68,8 +68,9 @@ const char* mg_version(void);
  *      mg_attn_bwd_merged_bf16 gained ld_o (before the stream); removed: mg_decode_attn_2gemv_bf16,
  *      mg_decode_ctx_counter_ints, the persistent decode step's four entry points mg_decode_plan_* / mg_decode_step_* (in-launch hand-off
  *      experiments, measured slower than the launch chain: DESIGN.md 8).
- *   3  round 5: added mg_stream_create_cu_mask / mg_stream_destroy (nothing moved; a revision-2 binder keeps working, the loader
- *      of this repo asks for 3 because it binds the new pair).                                                                    */
+ *   3  round 5: added mg_stream_create_cu_mask / mg_stream_destroy, mg_rotary_split_fp8 / mg_attn_prefill_fp8 /
+ *      mg_attn_fp8_scale_stride (nothing moved; a revision-2 binder keeps working, the loader of this repo asks for 3 because it
+ *      binds the new ones).                                                                    */
 #define MG_ABI_VERSION 3
 int32_t mg_abi_version(void);
 const char* mg_last_error(void);
@@ -502,6 +503,22 @@ int mg_sumsq_bf16(const mg_bf16* g, int64_t n, float* out, void* stream);
 int mg_adamw_gbf16_f32(float* p, float* m, float* v, const mg_bf16* g, mg_bf16* p_bf16, int64_t n, float lr,
                        float beta1, float beta2, float eps, float weight_decay, int32_t step, float max_norm,
                        const float* norm_sq, float grad_scale, void* stream);
+
+/* ---- fp8 attention forward (BASELINE config[4]: "fp8 MFMA path for GPT-J attention"; reference call site magma/magma.py:270-274) ----
+ * mg_rotary_split_fp8: the training form of the rotary split (everything mg_rotary_split_train_bf16 writes except V^T: the backward
+ * stays bf16) plus OCP MX e4m3 copies for the forward: q8 / k8 [B,H,S,256] with ONE power-of-two (E8M0) scale per token in
+ * eq / ek [B,H,Sp] bytes, Sp = mg_attn_fp8_scale_stride(S); v8t [B,H,ceil(S/64),256,64] = V^T in 64-key tiles with one E8M0 per
+ * (d, 32 keys) in sv8 [B,H,ceil(S/64),512] (layout [key block][d % 32][d / 32]); inside a tile the keys are stored in the order
+ * the attention kernel's accumulators hold them (attention.hip: rotary_split_fp8_kernel).  qt / kt may be NULL (no backward).
+ * mg_attn_prefill_fp8: causal flash attention on v_mfma_scale_f32_32x32x64_f8f6f4 with those operands, fp32 softmax, P as
+ * e4m3(16 p) with scale 2^-4; outputs as mg_attn_prefill_bf16 (out bf16 [B*S, >= H*256] at row stride ld_out % 8 == 0, lse fp32). */
+int32_t mg_attn_fp8_scale_stride(int32_t S);
+int mg_rotary_split_fp8(const mg_bf16* qkv, int32_t B, int32_t S, int32_t H, int32_t rot_dim, const float* sin_t,
+                        const float* cos_t, mg_bf16* q, mg_bf16* k, mg_bf16* v, mg_bf16* qt, mg_bf16* kt, int32_t ld_t,
+                        uint8_t* q8, uint8_t* k8, uint8_t* v8t, uint8_t* eq, uint8_t* ek, uint8_t* sv8, void* stream);
+int mg_attn_prefill_fp8(const uint8_t* q8, const uint8_t* k8, const uint8_t* v8t, const uint8_t* eq, const uint8_t* ek,
+                        const uint8_t* sv8, mg_bf16* out, int64_t ld_out, float* lse, int32_t B, int32_t H, int32_t S,
+                        void* stream);
 
 /* A HIP stream whose kernels never run on `reserve` of the device's CUs (spread evenly; hipExtStreamCreateWithCUMask): the
  * training engine can run its compute on it so that the RCCL kernels of the gradient exchange (reference train_loop.py:18-19 /

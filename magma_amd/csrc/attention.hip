@@ -99,6 +99,149 @@ __global__ __launch_bounds__(256) void rotary_split_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// rotary + split with OCP MX e4m3 copies for the fp8 attention forward (BASELINE config[4]: "fp8 MFMA path for GPT-J attention";
+// attention_fwd32_fp8.hip).  Same tile as rotary_split_kernel<true>; besides the rotated bf16 q / k / v [B,H,S,256] and q^T / k^T
+// (the backward stays bf16) it writes what v_mfma_scale_f32_32x32x64_f8f6f4 multiplies:
+//   q8, k8 [B,H,S,256]   e4m3 elements, ONE E8M0 scale per token (eq, ek [B,H,Sp] bytes, Sp = 64-key tiles + 256): the power of
+//                        two 2^e >= amax / 448 (no element saturates).  Every 32-element block of a row carries the same scale, so
+//                        nothing depends on which operand bytes the hardware calls a block.
+//   v8t [B,H,ceil(S/64),256,64]  e4m3 V^T in 64-key tiles with OCP MX scales along the KEYS: one E8M0 per (d, 32 keys), sv8
+//                        [B,H,tile,2,32,8] bytes = [key block][d % 32][d / 32] (a lane's eight scale bytes are one 8-byte read).
+//                        Inside a tile the keys are stored in the order the S^T accumulators of a lane hold them, so that a lane's
+//                        32 P values ARE its 32 operand bytes of the PV product: byte 32 hi + 16 b + r of row d <-> key
+//                        32 b + (r & 3) + 8 (r >> 2) + 4 hi.  Measured (tools/probes/mx32_probe.hip): the instruction's block b =
+//                        bytes 16 b .. 16 b + 15 of both half-wave lanes of a row = key block b here, its scale comes from lane
+//                        row + 32 b.
+// Blocks past the sequence (the second half of a ragged last tile) write zero elements / unit scales.
+// ---------------------------------------------------------------------------
+MG_DEV u32x2 quant8_e4m3(const float (&x)[8], float inv) {
+  int lo = 0, hi = 0;
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(x[0] * inv, x[1] * inv, lo, false);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(x[2] * inv, x[3] * inv, lo, true);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(x[4] * inv, x[5] * inv, hi, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(x[6] * inv, x[7] * inv, hi, true);
+  return (u32x2){(uint32_t)lo, (uint32_t)hi};
+}
+// smallest e with 2^e >= amax / 448 (amax > 0), as the biased E8M0 byte; 127 (2^0) for an all-zero block
+MG_DEV int e8m0_cover(float amax) {
+  if (!(amax > 0.f)) return 127;
+  const float t = amax * (1.0f / 448.0f);
+  int e = (int)((__float_as_uint(t) >> 23) & 0xff) - 127;              // floor(log2 t) for a normal t
+  if (__uint_as_float((uint32_t)(e + 127) << 23) < t) ++e;
+  return min(max(e + 127, 1), 254);
+}
+MG_DEV float e8m0_inv(int byte) { return __uint_as_float((uint32_t)(254 - byte) << 23); }    // 2^-(byte - 127)
+MG_DEV float row_amax32(const float (&x)[8]) {       // maximum |x| over the 32 lanes (8 values each) that hold one 256-wide row
+  float a = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a = fmaxf(a, fabsf(x[i]));
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) a = fmaxf(a, __shfl_xor(a, o, 32));
+  return a;
+}
+__global__ __launch_bounds__(256) void rotary_split_fp8_kernel(
+    const mg_bf16* __restrict__ qkv, int B, int S, int H, int rot_dim, const float* __restrict__ sin_t, const float* __restrict__ cos_t,
+    mg_bf16* __restrict__ q_out, mg_bf16* __restrict__ k_out, mg_bf16* __restrict__ v_out, mg_bf16* __restrict__ qt, mg_bf16* __restrict__ kt,
+    int ld_t, uint8_t* __restrict__ q8, uint8_t* __restrict__ k8, uint8_t* __restrict__ v8t, uint8_t* __restrict__ eq, uint8_t* __restrict__ ek,
+    uint8_t* __restrict__ sv8, int Sp) {
+  __shared__ __attribute__((aligned(16))) mg_bf16 tile[3 * 32 * DH];        // rotated q, k rows (transposes) and v rows
+  const int tid = threadIdx.x;
+  const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+  const int s0 = blockIdx.x * 32;
+  const int dmodel = H * DH, half_rot = rot_dim >> 1;
+  const int nt64 = (S + 63) >> 6;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int ci = tid + it * 256;
+    const int row = ci >> 5, c = ci & 31;
+    const int s = s0 + row, d0 = c * 8;
+    u32x4 qz = (u32x4){0u, 0u, 0u, 0u}, kz = qz, vv = qz;
+    float qf[8], kf[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { qf[i] = 0.f; kf[i] = 0.f; }
+    if (s < S) {
+      const mg_bf16* base = qkv + (int64_t)(b * S + s) * (3 * dmodel) + h * DH + d0;
+      u32x4 qv = *(const u32x4*)base;
+      u32x4 kv = *(const u32x4*)(base + dmodel);
+      vv = *(const u32x4*)(base + 2 * dmodel);
+      if (d0 < rot_dim) {
+        const float* sp = sin_t + (int64_t)s * half_rot + (d0 >> 1);
+        const float* cp = cos_t + (int64_t)s * half_rot + (d0 >> 1);
+#pragma unroll
+        for (int pi = 0; pi < 4; ++pi) {
+          const float sn = sp[pi], cs = cp[pi];
+          const float q0 = bflo(qv[pi]), q1 = bfhi(qv[pi]);
+          const float k0 = bflo(kv[pi]), k1 = bfhi(kv[pi]);
+          qv[pi] = pack2bf(q0 * cs - q1 * sn, q1 * cs + q0 * sn);
+          kv[pi] = pack2bf(k0 * cs - k1 * sn, k1 * cs + k0 * sn);
+        }
+      }
+      *(u32x4*)(q_out + ((int64_t)bh * S + s) * DH + d0) = qv;
+      *(u32x4*)(k_out + ((int64_t)bh * S + s) * DH + d0) = kv;
+      *(u32x4*)(v_out + ((int64_t)bh * S + s) * DH + d0) = vv;
+      qz = qv; kz = kv;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {       // the e4m3 copies are taken from the bf16-ROUNDED rotated values (what the bf16 path multiplies)
+        qf[2 * i] = bflo(qv[i]); qf[2 * i + 1] = bfhi(qv[i]);
+        kf[2 * i] = bflo(kv[i]); kf[2 * i + 1] = bfhi(kv[i]);
+      }
+    }
+    // per-token power-of-two scales: the 32 lanes of a row agree on them (rows past S: all zero, 2^0)
+    const int bq = e8m0_cover(row_amax32(qf)), bk = e8m0_cover(row_amax32(kf));
+    if (s < S) {
+      *(u32x2*)(q8 + ((int64_t)bh * S + s) * DH + d0) = quant8_e4m3(qf, e8m0_inv(bq));
+      *(u32x2*)(k8 + ((int64_t)bh * S + s) * DH + d0) = quant8_e4m3(kf, e8m0_inv(bk));
+    }
+    if (c == 0) { eq[(int64_t)bh * Sp + s] = (uint8_t)bq; ek[(int64_t)bh * Sp + s] = (uint8_t)bk; }    // s < nt64 * 64 <= Sp
+    *(u32x4*)(tile + 2 * 32 * DH + row * DH + d0) = vv;                  // zero rows beyond S
+    if (qt) {
+      *(u32x4*)(tile + row * DH + d0) = qz;
+      *(u32x4*)(tile + 32 * DH + row * DH + d0) = kz;
+    }
+  }
+  __syncthreads();
+  const int dd = tid;               // thread = one d
+  if (qt && s0 < ((S + 31) & ~31)) {
+    const int64_t toff = (((int64_t)bh * (ld_t >> 5) + blockIdx.x) * DH + dd) * 32;   // column-tiled: [b,h][tile][256][32]
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+      mg_bf16* dst = (which == 0 ? qt : kt) + toff;
+      const mg_bf16* tl = tile + which * 32 * DH;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u32x4 o;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) o[w] = (uint32_t)tl[(g * 8 + w * 2) * DH + dd] | ((uint32_t)tl[(g * 8 + w * 2 + 1) * DH + dd] << 16);
+        *(u32x4*)(dst + g * 8) = o;
+      }
+    }
+  }
+  {
+    // V^T of this 32-key block for column d: one MX block (32 keys of one d), its E8M0, its 32 elements in the kernel's key order
+    const mg_bf16* vt_ = tile + 2 * 32 * DH;
+    float x[32], amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) { x[i] = bf2f(vt_[i * DH + dd]); amax = fmaxf(amax, fabsf(x[i])); }
+    const int bv = e8m0_cover(amax);
+    const float inv = e8m0_inv(bv);
+    const int t64 = s0 >> 6, bb = (s0 >> 5) & 1;
+    sv8[(((int64_t)bh * nt64 + t64) * 2 + bb) * 256 + (dd & 31) * 8 + (dd >> 5)] = (uint8_t)bv;
+    uint8_t* dst = v8t + (((int64_t)bh * nt64 + t64) * DH + dd) * 64 + 16 * bb;
+#pragma unroll
+    for (int hi = 0; hi < 2; ++hi) {
+      int w[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const int k0 = (r & 3) + 8 * (r >> 2) + 4 * hi;          // keys of registers r, r + 1 (consecutive: r even)
+        if (r & 2) w[r >> 2] = __builtin_amdgcn_cvt_pk_fp8_f32(x[k0] * inv, x[k0 + 1] * inv, w[r >> 2], true);
+        else w[r >> 2] = __builtin_amdgcn_cvt_pk_fp8_f32(x[k0] * inv, x[k0 + 1] * inv, w[r >> 2], false);
+      }
+      *(u32x4*)(dst + 32 * hi) = (u32x4){(uint32_t)w[0], (uint32_t)w[1], (uint32_t)w[2], (uint32_t)w[3]};
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // flash attention forward, causal, dh = 256.
 // One workgroup = 128 queries = 8 waves x 16 query rows.  Per KV tile of 32 keys and per wave:
 //   S^T[key][q] = K . Q^T   (2 key-subtiles x 8 k-steps  = 16 MFMA)
@@ -348,6 +491,28 @@ extern "C" int mg_rotary_split_train_bf16(const mg_bf16* qkv, int32_t B, int32_t
   dim3 grid((S + 31) / 32, B * H);
   hipLaunchKernelGGL(rotary_split_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, qkv, (int64_t)3 * H * DH, B, S, H, rot_dim, sin_t,
                      cos_t, 0, nullptr, q, k, v, S, vt, ld_t, qt, kt);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
+// training form for the fp8 attention forward: everything mg_rotary_split_train_bf16 writes except V^T, plus the OCP MX e4m3 copies
+// (rotary_split_fp8_kernel): q8 / k8 [B,H,S,256] with one E8M0 per token in eq / ek [B,H,Sp] (bytes; Sp = mg_attn_fp8_scale_stride(S)),
+// v8t [B,H,ceil(S/64),256,64] with one E8M0 per (d, 32 keys) in sv8 [B,H,ceil(S/64),512].  qt / kt may be NULL (forward only).
+extern "C" int32_t mg_attn_fp8_scale_stride(int32_t S) { return ((S + 63) / 64) * 64 + 256; }
+extern "C" int mg_rotary_split_fp8(const mg_bf16* qkv, int32_t B, int32_t S, int32_t H, int32_t rot_dim, const float* sin_t,
+                                   const float* cos_t, mg_bf16* q, mg_bf16* k, mg_bf16* v, mg_bf16* qt, mg_bf16* kt, int32_t ld_t,
+                                   uint8_t* q8, uint8_t* k8, uint8_t* v8t, uint8_t* eq, uint8_t* ek, uint8_t* sv8, void* stream) {
+  if (B <= 0 || S <= 0 || H <= 0) MG_FAIL(MG_ERR_SHAPE, "mg_rotary_split_fp8: B,S,H must be positive");
+  if (rot_dim < 0 || rot_dim > DH || (rot_dim & 7)) MG_FAIL(MG_ERR_SHAPE, "mg_rotary_split_fp8: rot_dim must be a multiple of 8 in [0,256]");
+  if (!qkv || !q || !k || !v || !q8 || !k8 || !v8t || !eq || !ek || !sv8 || (rot_dim && (!sin_t || !cos_t)) || (!qt != !kt))
+    MG_FAIL(MG_ERR_SHAPE, "mg_rotary_split_fp8: null pointer");
+  if (!MG_ALIGNED16(qkv) || !MG_ALIGNED16(q) || !MG_ALIGNED16(k) || !MG_ALIGNED16(v) || !MG_ALIGNED16(qt) || !MG_ALIGNED16(kt) ||
+      !MG_ALIGNED16(q8) || !MG_ALIGNED16(k8) || !MG_ALIGNED16(v8t) || !MG_ALIGNED16(sv8) || ((uintptr_t)eq & 3) || ((uintptr_t)ek & 3))
+    MG_FAIL(MG_ERR_ALIGN, "mg_rotary_split_fp8: pointers must be 16-byte aligned (eq / ek: 4)");
+  if (qt && ((ld_t & 31) || ld_t < ((S + 31) & ~31))) MG_FAIL(MG_ERR_SHAPE, "mg_rotary_split_fp8: ld_t must be a multiple of 32 and >= S");
+  dim3 grid(((S + 63) / 64) * 2, B * H);      // both 32-key halves of every 64-key V^T tile
+  hipLaunchKernelGGL(rotary_split_fp8_kernel, grid, dim3(256), 0, (hipStream_t)stream, qkv, B, S, H, rot_dim, sin_t, cos_t, q, k, v, qt, kt,
+                     ld_t, q8, k8, v8t, eq, ek, sv8, mg_attn_fp8_scale_stride(S));
   MG_CHECK_LAUNCH();
   return MG_OK;
 }

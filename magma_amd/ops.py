@@ -361,6 +361,67 @@ def rotary_split_train(qkv, B, S, H, rot_dim, sin_t, cos_t, q, k, v, vt, qt, kt)
                                               kt.data_ptr(), vt.shape[2] * 32, _stream()), "mg_rotary_split_train_bf16")
 
 
+class AttnFP8Operands:
+    """What mg_rotary_split_fp8 writes for the fp8 attention forward (include/magma_hip.h): OCP MX e4m3 copies of the rotated q, k
+    and of v^T with their E8M0 scales."""
+
+    def __init__(self, B, H, S, device):
+        self.B, self.H, self.S = B, H, S
+        self.Sp = int(L.load().mg_attn_fp8_scale_stride(S))
+        nt = (S + 63) // 64
+        u8 = dict(dtype=torch.uint8, device=device)
+        self.q8, self.k8 = torch.empty(B, H, S, 256, **u8), torch.empty(B, H, S, 256, **u8)
+        self.v8t = torch.empty(B, H, nt, 256, 64, **u8)
+        self.eq, self.ek = torch.full((B, H, self.Sp), 127, **u8), torch.full((B, H, self.Sp), 127, **u8)
+        self.sv8 = torch.empty(B, H, nt, 512, **u8)
+
+    def dequant(self):
+        """(q, k, v) [B,H,S,256] fp32: the values the fp8 attention kernel multiplies (tests / oracles)."""
+        B, H, S = self.B, self.H, self.S
+        f8 = torch.float8_e4m3fn
+        sq = torch.exp2(self.eq[:, :, :S].float() - 127.0)[..., None]
+        sk = torch.exp2(self.ek[:, :, :S].float() - 127.0)[..., None]
+        q = self.q8.view(f8).float() * sq
+        k = self.k8.view(f8).float() * sk
+        nt = self.v8t.shape[2]
+        vt = self.v8t.view(f8).float()                                     # [B,H,nt,256 d,64 bytes]
+        sv = torch.exp2(self.sv8.view(B, H, nt, 2, 32, 8).float() - 127.0)  # [key block][d % 32][d / 32]
+        sv = sv.permute(0, 1, 2, 3, 5, 4).reshape(B, H, nt, 2, 256)        # -> [key block][d]
+        # byte 32 hi + 16 b + r  <->  key 32 b + (r & 3) + 8 (r >> 2) + 4 hi
+        idx = torch.empty(64, dtype=torch.long)
+        blk = torch.empty(64, dtype=torch.long)
+        for hi in range(2):
+            for b in range(2):
+                for r in range(16):
+                    idx[32 * b + (r & 3) + 8 * (r >> 2) + 4 * hi] = 32 * hi + 16 * b + r
+                    blk[32 * b + (r & 3) + 8 * (r >> 2) + 4 * hi] = b
+        idx, blk = idx.to(vt.device), blk.to(vt.device)
+        v_keys = vt[..., idx]                                              # [B,H,nt,256,64 keys in natural order]
+        v_keys = v_keys * sv[:, :, :, blk, :].permute(0, 1, 2, 4, 3)        # scale of (key block, d)
+        v = v_keys.permute(0, 1, 2, 4, 3).reshape(B, H, nt * 64, 256)[:, :, :S]
+        return q, k, v
+
+
+def rotary_split_fp8(qkv, B, S, H, rot_dim, sin_t, cos_t, q, k, v, qt=None, kt=None) -> AttnFP8Operands:
+    """rotary_split_train without V^T + the OCP MX e4m3 operands of the fp8 attention forward (-> AttnFP8Operands)."""
+    _need_gpu(qkv)
+    op = AttnFP8Operands(B, H, S, qkv.device)
+    check(L.load().mg_rotary_split_fp8(qkv.data_ptr(), B, S, H, rot_dim, sin_t.data_ptr(), cos_t.data_ptr(), q.data_ptr(), k.data_ptr(),
+                                       v.data_ptr(), _p(qt), _p(kt), (qt.shape[2] * 32) if qt is not None else 0,
+                                       op.q8.data_ptr(), op.k8.data_ptr(), op.v8t.data_ptr(), op.eq.data_ptr(), op.ek.data_ptr(),
+                                       op.sv8.data_ptr(), _stream()), "mg_rotary_split_fp8")
+    return op
+
+
+def attn_prefill_fp8(op: AttnFP8Operands, out, lse: Optional[torch.Tensor] = None):
+    """Causal flash attention on the fp8 MFMA (mg_attn_prefill_fp8): out [B*S, >= H*256] bf16 (a column range of a wider row is fine)."""
+    assert out.ndim == 2 and out.stride(1) == 1 and out.shape[1] == op.H * 256 and out.stride(0) % 8 == 0
+    check(L.load().mg_attn_prefill_fp8(op.q8.data_ptr(), op.k8.data_ptr(), op.v8t.data_ptr(), op.eq.data_ptr(), op.ek.data_ptr(),
+                                       op.sv8.data_ptr(), out.data_ptr(), out.stride(0), _p(lse), op.B, op.H, op.S, _stream()),
+          "mg_attn_prefill_fp8")
+    return out
+
+
 def attn_prefill(q, kcache, vt, out, B, H, S, lse: Optional[torch.Tensor] = None):
     _need_gpu(q)
     assert out.ndim == 2 and out.stride(1) == 1 and out.shape[1] == H * 256      # a column range of a wider row is fine

@@ -13,6 +13,11 @@ def rel(a, b):
     return float((a - b).norm() / (b.norm() + 1e-12))
 
 
+def rnd(*shape, dev, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dev)
+
+
 def ref_quant(x):
     amax = x.float().abs().amax(1)
     scale = torch.where(amax > 0, amax * (1.0 / 448.0), torch.ones_like(amax))
@@ -314,3 +319,61 @@ def test_gemm_mx_fp8(dev, layout, M, N, K):
     e_mx, e_row = rel(plain, full), rel(rowscaled, full)
     print(f"{M}x{N}x{K}: MX block scales {e_mx:.3e}, per-row / per-channel scales {e_row:.3e}")
     assert e_mx < 0.07, e_mx
+
+
+@pytest.mark.parametrize("B,H,S", [(1, 1, 1), (2, 2, 57), (1, 2, 300), (2, 1, 385), (1, 1, 1024)])
+def test_fp8_attention_forward(dev, B, H, S):
+    """BASELINE config[4] "fp8 MFMA path for GPT-J attention": mg_rotary_split_fp8 + mg_attn_prefill_fp8
+    (v_mfma_scale_f32_32x32x64_f8f6f4, OCP MX e4m3 operands, fp32 softmax).
+    (1) The producer: the bf16 outputs equal mg_rotary_split_train_bf16's bit for bit; every e4m3 copy dequantises to its bf16
+        source within e4m3's half-ulp (2^-4 relative to the block maximum's binade), its scale is the smallest power of two
+        that avoids saturation.
+    (2) The attention kernel against fp32 softmax(QK^T/16)V evaluated on the DEQUANTISED operands (what the kernel multiplies):
+        what is left is the rounding of P to e4m3 (3 mantissa bits), 2^-4 relative per probability -- stated bound 3e-2 rel-L2
+        on the output (measured 1.3-1.9e-2), lse to 2e-3 absolute (no P rounding in it).  A late dominant key forces the
+        deferred-maximum rescale."""
+    from magma_amd import ops
+    d = H * 256
+    rot = 64
+    qkv = (rnd(B * S, 3 * d, dev=dev, seed=91) * 0.7).to(BF16)
+    if S > 100:
+        x = qkv.view(B, S, 3, H, 256)
+        x[:, S - 40, 1] = x[:, S - 5, 0] * 5          # k[S-40] ~ q[S-5] (before rotary: still a strong late key)
+    inv = 1.0 / (10000 ** (torch.arange(0, rot, 2, dtype=torch.float32, device=dev) / rot))
+    ang = torch.arange(S + 3, dtype=torch.float32, device=dev)[:, None] * inv[None, :]
+    sin_t, cos_t = ang.sin().contiguous(), ang.cos().contiguous()
+    ld = ops.ceil_to(S, 32)
+    mk = lambda: torch.empty(B, H, S, 256, dtype=BF16, device=dev)
+    mt = lambda: torch.full((B, H, ld // 32, 256, 32), 7.0, dtype=BF16, device=dev)
+    q0, k0, v0, vt0, qt0, kt0 = mk(), mk(), mk(), mt(), mt(), mt()
+    ops.rotary_split_train(qkv, B, S, H, rot, sin_t, cos_t, q0, k0, v0, vt0, qt0, kt0)
+    q1, k1, v1, qt1, kt1 = mk(), mk(), mk(), mt(), mt()
+    op = ops.rotary_split_fp8(qkv, B, S, H, rot, sin_t, cos_t, q1, k1, v1, qt1, kt1)
+    for a, b_, name in ((q1, q0, "q"), (k1, k0, "k"), (v1, v0, "v"), (qt1, qt0, "qt"), (kt1, kt0, "kt")):
+        assert torch.equal(a, b_), name
+    qd, kd, vd = op.dequant()
+    for deq, src, name in ((qd, q0, "q8"), (kd, k0, "k8"), (vd, v0, "v8")):
+        err = (deq - src.float()).abs()
+        assert float(err.max()) <= float(src.float().abs().max()) * 2 ** -3.9, name      # half an ulp of the top binade: 2^-4 x amax (x 2: scale rounding)
+        assert rel(deq, src.float()) < 4e-2, (name, rel(deq, src.float()))
+    # per-token scales: 2^e >= amax / 448 > 2^(e - 1)
+    aq = q0.float().abs().amax(-1)
+    sq = torch.exp2(op.eq[:, :, :S].float() - 127)
+    nz = aq > 0
+    assert bool((sq[nz] * 448 >= aq[nz] * (1 - 1e-6)).all()) and bool((sq[nz] * 224 < aq[nz] * (1 + 1e-6)).all())
+    out = torch.empty(B * S, d, dtype=BF16, device=dev)
+    lse = torch.empty(B, H, S, dtype=torch.float32, device=dev)
+    ops.attn_prefill_fp8(op, out, lse=lse)
+    sc = qd @ kd.transpose(-1, -2) / 16.0
+    sc = sc.masked_fill(~torch.ones(S, S, dtype=torch.bool, device=dev).tril(), float("-inf"))
+    ref = (torch.softmax(sc, -1) @ vd).permute(0, 2, 1, 3).reshape(B * S, d)
+    e = rel(out, ref)
+    assert e < 3e-2, e
+    assert float((lse - torch.logsumexp(sc, -1)).abs().max()) < 2e-3
+    # against the bf16 path on the unquantised operands: the whole cost of e4m3 operands + e4m3 P (reported, loosely bounded)
+    out16 = torch.empty(B * S, d, dtype=BF16, device=dev)
+    ops.attn_prefill(q0, k0, vt0, out16, B, H, S)
+    assert rel(out, out16) < 0.12
+    wide = torch.full((B * S, d + 136), float("nan"), dtype=BF16, device=dev)
+    ops.attn_prefill_fp8(op, wide[:, :d])
+    assert torch.equal(wide[:, :d], out)
