@@ -372,7 +372,8 @@ def bench_train(model, args, rank, world, dev):
                 dt8 = float(t)
             out["full_S2048_fp8"] = {"images_per_s": world * B / dt8, "ms_per_step": dt8 * 1e3, "loss": float(loss8), "spread": spread8,
                                      "note": "qkv / out_proj / fc_in / fc_out forward and dgrad GEMMs in e4m3 (per-row / per-channel "
-                                             "scales, fp32 accumulate); adapters, attention, wgrads, trunk stay bf16",
+                                             "scales, fp32 accumulate) and the attention forward (QK^T / PV on the MX-scaled fp8 MFMA, OCP e4m3 operands); "
+                                             "adapters, attention backward, wgrads, trunk stay bf16",
                                      "loss_note": "this leg runs AFTER the optimizer steps of the bf16 legs (same model, same batch), so its "
                                                   "loss is further down the training curve, not comparable with full_S2048.loss; the same-weights "
                                                   "comparison is train.forward_only_fp8 (loss_bf16 / loss_fp8)"}

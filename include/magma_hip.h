@@ -509,7 +509,8 @@ int mg_adamw_gbf16_f32(float* p, float* m, float* v, const mg_bf16* g, mg_bf16* 
  * stays bf16) plus OCP MX e4m3 copies for the forward: q8 / k8 [B,H,S,256] with ONE power-of-two (E8M0) scale per token in
  * eq / ek [B,H,Sp] bytes, Sp = mg_attn_fp8_scale_stride(S); v8t [B,H,ceil(S/64),256,64] = V^T in 64-key tiles with one E8M0 per
  * (d, 32 keys) in sv8 [B,H,ceil(S/64),512] (layout [key block][d % 32][d / 32]); inside a tile the keys are stored in the order
- * the attention kernel's accumulators hold them (attention.hip: rotary_split_fp8_kernel).  qt / kt may be NULL (no backward).
+ * the attention kernel's accumulators hold them (attention.hip: rotary_split_fp8_kernel).  qt / kt may be NULL (no backward);
+ * q / k / v may be NULL together (forward only).
  * mg_attn_prefill_fp8: causal flash attention on v_mfma_scale_f32_32x32x64_f8f6f4 with those operands, fp32 softmax, P as
  * e4m3(16 p) with scale 2^-4; outputs as mg_attn_prefill_bf16 (out bf16 [B*S, >= H*256] at row stride ld_out % 8 == 0, lse fp32). */
 int32_t mg_attn_fp8_scale_stride(int32_t S);

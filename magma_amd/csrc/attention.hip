@@ -176,9 +176,11 @@ __global__ __launch_bounds__(256) void rotary_split_fp8_kernel(
           kv[pi] = pack2bf(k0 * cs - k1 * sn, k1 * cs + k0 * sn);
         }
       }
-      *(u32x4*)(q_out + ((int64_t)bh * S + s) * DH + d0) = qv;
-      *(u32x4*)(k_out + ((int64_t)bh * S + s) * DH + d0) = kv;
-      *(u32x4*)(v_out + ((int64_t)bh * S + s) * DH + d0) = vv;
+      if (q_out) {                        // (NULL: forward only -- nobody reads the bf16 copies)
+        *(u32x4*)(q_out + ((int64_t)bh * S + s) * DH + d0) = qv;
+        *(u32x4*)(k_out + ((int64_t)bh * S + s) * DH + d0) = kv;
+        *(u32x4*)(v_out + ((int64_t)bh * S + s) * DH + d0) = vv;
+      }
       qz = qv; kz = kv;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {       // the e4m3 copies are taken from the bf16-ROUNDED rotated values (what the bf16 path multiplies)
@@ -497,15 +499,16 @@ extern "C" int mg_rotary_split_train_bf16(const mg_bf16* qkv, int32_t B, int32_t
 
 // training form for the fp8 attention forward: everything mg_rotary_split_train_bf16 writes except V^T, plus the OCP MX e4m3 copies
 // (rotary_split_fp8_kernel): q8 / k8 [B,H,S,256] with one E8M0 per token in eq / ek [B,H,Sp] (bytes; Sp = mg_attn_fp8_scale_stride(S)),
-// v8t [B,H,ceil(S/64),256,64] with one E8M0 per (d, 32 keys) in sv8 [B,H,ceil(S/64),512].  qt / kt may be NULL (forward only).
+// v8t [B,H,ceil(S/64),256,64] with one E8M0 per (d, 32 keys) in sv8 [B,H,ceil(S/64),512].  qt / kt may be NULL (no backward), and
+// so may q / k / v together (forward only: just the e4m3 operands).
 extern "C" int32_t mg_attn_fp8_scale_stride(int32_t S) { return ((S + 63) / 64) * 64 + 256; }
 extern "C" int mg_rotary_split_fp8(const mg_bf16* qkv, int32_t B, int32_t S, int32_t H, int32_t rot_dim, const float* sin_t,
                                    const float* cos_t, mg_bf16* q, mg_bf16* k, mg_bf16* v, mg_bf16* qt, mg_bf16* kt, int32_t ld_t,
                                    uint8_t* q8, uint8_t* k8, uint8_t* v8t, uint8_t* eq, uint8_t* ek, uint8_t* sv8, void* stream) {
   if (B <= 0 || S <= 0 || H <= 0) MG_FAIL(MG_ERR_SHAPE, "mg_rotary_split_fp8: B,S,H must be positive");
   if (rot_dim < 0 || rot_dim > DH || (rot_dim & 7)) MG_FAIL(MG_ERR_SHAPE, "mg_rotary_split_fp8: rot_dim must be a multiple of 8 in [0,256]");
-  if (!qkv || !q || !k || !v || !q8 || !k8 || !v8t || !eq || !ek || !sv8 || (rot_dim && (!sin_t || !cos_t)) || (!qt != !kt))
-    MG_FAIL(MG_ERR_SHAPE, "mg_rotary_split_fp8: null pointer");
+  if (!qkv || !q8 || !k8 || !v8t || !eq || !ek || !sv8 || (rot_dim && (!sin_t || !cos_t)) || (!qt != !kt) || (!q != !k) || (!q != !v) || (qt && !q))
+    MG_FAIL(MG_ERR_SHAPE, "mg_rotary_split_fp8: null pointer (q / k / v together or not at all; qt / kt only with them)");
   if (!MG_ALIGNED16(qkv) || !MG_ALIGNED16(q) || !MG_ALIGNED16(k) || !MG_ALIGNED16(v) || !MG_ALIGNED16(qt) || !MG_ALIGNED16(kt) ||
       !MG_ALIGNED16(q8) || !MG_ALIGNED16(k8) || !MG_ALIGNED16(v8t) || !MG_ALIGNED16(sv8) || ((uintptr_t)eq & 3) || ((uintptr_t)ek & 3))
     MG_FAIL(MG_ERR_ALIGN, "mg_rotary_split_fp8: pointers must be 16-byte aligned (eq / ek: 4)");

@@ -137,6 +137,7 @@ class LMEngine:
         # fp8 operands for the prefill / forward GEMMs (BASELINE config 5): None | "attn" (QKV, out_proj, adapters)
         # | "all" (+ fc_in, fc_out).  bf16 stays the default: it is what the parity tests and the headline use.
         self.fp8_mode = os.environ.get("MAGMA_FP8") or None
+        self.fp8_attn = os.environ.get("MAGMA_FP8_ATTN", "1") == "1"     # with fp8_mode: QK^T / PV of the cache-less forward in e4m3 too
         # scaling of the fp8 operands: "row" = one fp32 scale per activation row / weight output channel (any tile kernel), "mx" =
         # OCP MX, one E8M0 scale per 32 K-elements of both operands, applied by the MFMA itself (128x128 kernel)
         self.fp8_scaling = os.environ.get("MAGMA_FP8_SCALING", "row")
@@ -454,8 +455,13 @@ class LMEngine:
             else:
                 qkv = self._linear(ly, "qkv", ly.qkv, ln, lnq)
             kc, vc = (cache.k[li], cache.v[li]) if cache is not None else (kscr, vscr)
-            ops.rotary_split(qkv, B, S, self.H, self.rot, self.sin_t, self.cos_t, q, kc, vc, pos0=0, vt=vt)
-            ops.attn_prefill(q, kc, vt, ctx, B, self.H, S, lse=None if lse_out is None else lse_out[li])
+            if self.fp8_mode and self.fp8_attn and cache is None and qkv.is_contiguous():
+                # BASELINE config[4]: the attention core on the fp8 MFMA as well (no KV cache to fill: cached decoding reads bf16)
+                a8 = ops.rotary_split_fp8(qkv, B, S, self.H, self.rot, self.sin_t, self.cos_t)
+                ops.attn_prefill_fp8(a8, ctx, lse=None if lse_out is None else lse_out[li])
+            else:
+                ops.rotary_split(qkv, B, S, self.H, self.rot, self.sin_t, self.cos_t, q, kc, vc, pos0=0, vt=vt)
+                ops.attn_prefill(q, kc, vt, ctx, B, self.H, S, lse=None if lse_out is None else lse_out[li])
             if r_cat and ly.__dict__.get("out_up") is not None and ly.mlp_adapter[0].N == r_cat:
                 h = h_fused if h_fused is not None else self._linear(ly, "fc_in", ly.fc_in, ln, lnq, act=ops.MG_ACT_GELU_NEW)
                 m = ops.gemm(h, ly.fc_out)

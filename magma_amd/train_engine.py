@@ -145,6 +145,9 @@ class MagmaEngine:
         # BASELINE config[4]: the frozen-weight block GEMMs (qkv, out_proj, fc_in, fc_out; forward and dgrad) on the fp8
         # MFMA -- activations / gradients quantised per row to e4m3, weights per output channel.  Off by default.
         self.fp8 = os.environ.get("MAGMA_TRAIN_FP8", "0") == "1"
+        # with self.fp8: the attention FORWARD on the fp8 MFMA as well (BASELINE config[4]: "fp8 MFMA path for GPT-J attention";
+        # mg_rotary_split_fp8 + mg_attn_prefill_fp8; the backward stays bf16).  MAGMA_FP8_ATTN=0 keeps the bf16 attention.
+        self.fp8_attn = os.environ.get("MAGMA_FP8_ATTN", "1") == "1"
         if self.fp8 and self.lm_trainable:
             raise NotImplementedError("MAGMA_TRAIN_FP8 quantises the FROZEN block weights once; with freeze_lm: false they change every step")
         self._fp8_packs = {}
@@ -575,7 +578,11 @@ class MagmaEngine:
             # q^T / k^T (the s-contraction operands of the attention backward) come out of the same pass as q, k, v, V^T
             qt = torch.empty(B, H, vt_ld // 32, 256, 32, dtype=BF16, device=dev)
             kt = torch.empty(B, H, vt_ld // 32, 256, 32, dtype=BF16, device=dev)
-            ops.rotary_split_train(qkv, B, S, H, eng.rot, eng.sin_t, eng.cos_t, q, k, v, vt, qt, kt)
+            a8 = None
+            if self.fp8 and self.fp8_attn:     # e4m3 copies of q, k, v^T for the forward; q, k, v, q^T, k^T in bf16 for the backward
+                a8 = ops.rotary_split_fp8(qkv, B, S, H, eng.rot, eng.sin_t, eng.cos_t, q, k, v, qt, kt)
+            else:
+                ops.rotary_split_train(qkv, B, S, H, eng.rot, eng.sin_t, eng.cos_t, q, k, v, vt, qt, kt)
             out_up = self._cat_out_up(li, ly, blk)
             if out_up is not None:
                 ctx_t = torch.empty(M, out_up.K, dtype=BF16, device=dev)        # [ctx | t]: one saved buffer, one GEMM operand
@@ -583,7 +590,10 @@ class MagmaEngine:
             else:
                 ctx = torch.empty(M, d, dtype=BF16, device=dev)
             lse = torch.empty(B, H, S, dtype=F32, device=dev)
-            ops.attn_prefill(q, k, vt, ctx, B, H, S, lse=lse)
+            if a8 is not None:
+                ops.attn_prefill_fp8(a8, ctx, lse=lse)
+            else:
+                ops.attn_prefill(q, k, vt, ctx, B, H, S, lse=lse)
             sv.update(q=q, k=k, v=v, qt=qt, kt=kt, ctx=ctx, lse=lse)
             a = None if out_up is not None else self._fgemm((li, "out"), ctx, ly.out)
             if ly.attn_adapter is not None and ly.attn_par is not None:

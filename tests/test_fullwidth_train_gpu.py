@@ -167,7 +167,8 @@ def test_gradients_four_blocks_deep_full_width_s2048(dev):
     assert 1 - cos_hip <= 2 * (1 - cos_bf) + 1e-3, (cos_hip, cos_bf)
 
 
-def test_fp8_training_step_vs_oracle_on_dequantised_weights(dev):
+@pytest.mark.parametrize("fp8_attn", [False, True])
+def test_fp8_training_step_vs_oracle_on_dequantised_weights(dev, fp8_attn):
     """BASELINE config[4], training side, at full width (d 4096, ff 16384, V 50258, S = 2048, one block, tiny trunk): the engine with
     eng.fp8 = True runs qkv / out_proj / fc_in / fc_out forward AND their dgrads on the fp8 MFMA (e4m3, per-row activation scales,
     per-output-channel weight scales).  Oracle: torch.autograd through the fp32 restatement evaluated on the DEQUANTISED e4m3
@@ -192,6 +193,7 @@ def test_fp8_training_step_vs_oracle_on_dequantised_weights(dev):
     model.config.gradient_accumulation_steps = 1
     eng = MagmaEngine(model)
     eng.fp8 = True
+    eng.fp8_attn = fp8_attn       # round 5: QK^T / PV of the attention forward on the fp8 MFMA as well (the oracle does not model it either)
     eng.train()
     B, S, P = 2, 2048, 4
     g = torch.Generator().manual_seed(9)
@@ -250,5 +252,7 @@ def test_fp8_training_step_vs_oracle_on_dequantised_weights(dev):
           [(n, f"{a:.2e}", f"{b:.2e}") for _, n, a, b in rows[:5]])
     assert len(seen) == len(g_deq), (len(seen), len(g_deq))
     assert abs(loss_hip - loss_deq) <= 5e-3 * abs(loss_deq), (loss_hip, loss_deq, loss_unq)
+    # fp8_attn: e4m3 q / k / v^T / P in the attention forward on top (operands the oracle keeps exact) -- the same bounds hold.
+    # Measured (MI355X, round 5): loss 11.63929 (11.63592 with the bf16 attention), global error 0.1164 (0.1151), cosine 0.99323 (0.99338).
     assert not bad, bad[:8]
     assert cos >= 0.99 and e_glob <= 1.5 * ew_glob + 1e-2, (cos, e_glob, ew_glob)
