@@ -1171,6 +1171,13 @@ extern "C" int mg_gemm_skinny_bf16(const mg_skinny_desc* d, void* stream) {
   // nt_hint = nt | waves<<4 | kc<<8 (bench/tuning sweeps use this).
   int nt = d->nt_hint & 15, waves = (d->nt_hint >> 4) & 15, kc = (d->nt_hint >> 8) & 255;
   const bool pipe = (d->nt_hint >> 16) & 1;        // double-buffered weight bursts (skinny_body<..., PIPE>)
+#ifdef MG_GEMM_ABLATIONS
+  // round-5 experiment, ablation library only (4-11 % slower than the register-direct stream in every form:
+  // profiles/r05_gemv_lds_dma_experiment.txt): bit 18 = non-temporal DMA, 19..21 = form, 22..30 = workgroups
+  if ((d->nt_hint >> 17) & 1) return skinny_dma_launch(sp, d->nt_hint >> 18, s);
+#else
+  if ((d->nt_hint >> 17) & 1) MG_FAIL(MG_ERR_UNSUPPORTED, "mg_gemm_skinny_bf16: the LDS-DMA GEMV exists only in the ablation library (make ABL=1)");
+#endif
   if (pipe) {
     if (sp.w_scale || nt != 1 || sp.ksteps % (waves * kc) != 0) MG_FAIL(MG_ERR_UNSUPPORTED, "mg_gemm_skinny_bf16: pipelined variants are bf16, one n-tile");
 #define MG_SKP(W_, K_) if (waves == W_ && kc == K_) return launch_skinny<W_, K_, 1, false, true>(sp, s)

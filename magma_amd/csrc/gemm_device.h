@@ -566,6 +566,9 @@ MG_DEV bf16x8 fp8x8_to_bf16(uint32_t w0, uint32_t w1) {
   return __builtin_bit_cast(bf16x8, o);
 }
 
+// gemv_dma.hip: the same GEMV with an LDS-DMA loader wave and one persistent workgroup per CU (nt_hint bit 17)
+int skinny_dma_launch(const SkinnyParams& sp, int variant, hipStream_t s);
+
 struct NoWait { MG_DEV void operator()() const {} };
 
 // COH: activations in / out go through the coherent 8-byte accessors (persistent decode step); `wait` is called once,

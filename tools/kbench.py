@@ -91,6 +91,37 @@ def bench_skinny(M, N, K, variants, tag=""):
     del lins
 
 
+def bench_skinny_dma(M, N, K, tag=""):
+    """the LDS-DMA loader-wave GEMV (nt_hint bit 17; bit 18 = non-temporal DMA) against the default register-direct GEMV"""
+    nbytes = N * K * 2
+    ncopy = max(2, int(600e6 // nbytes) + 1)
+    lins = []
+    for c in range(ncopy):
+        w = (torch.randn(N, K, device=dev) * 0.05).to(BF16)
+        lins.append(ops.PackedLinear(w))
+        del w
+    x = torch.randn(M, K, device=dev).to(BF16)
+    ref = torch.empty(M, N, dtype=BF16, device=dev)
+    out = torch.empty(M, N, dtype=BF16, device=dev)
+    ops.gemm_skinny(x, lins[0], out=ref, variant=0)
+    # nt_hint: bit 17 = LDS-DMA GEMV, 18 = non-temporal DMA, 19..21 = form (gemv_dma.hip), 22..30 = workgroups (0 = 256)
+    D, NT = 1 << 17, 1 << 18
+    for name, v in (("default", 0), ("dma", D), ("dma_nt", D | NT), ("dma2_xl2", D | 1 << 19), ("dma2_xl2_nt", D | NT | 1 << 19),
+                    ("dma_nt_ring5", D | NT | 2 << 19), ("dma2_nt_ring5", D | NT | 3 << 19)):
+        try:
+            out.zero_()
+            ops.gemm_skinny(x, lins[0], out=out, variant=v)
+            torch.cuda.synchronize()
+            err = float((out.float() - ref.float()).abs().max())
+            ms = timeit(lambda i: ops.gemm_skinny(x, lins[i % ncopy], out=out, variant=v), 4 * ncopy, warmup=ncopy)
+        except Exception as e:  # noqa: BLE001
+            emit(kind="skinny_dma", tag=tag, variant=name, error=str(e)[:200])
+            continue
+        emit(kind="skinny_dma", tag=tag, M=M, N=N, K=K, variant=name, ms=ms, gbps=nbytes / ms / 1e6, max_abs_vs_default=err,
+             ref_absmax=float(ref.float().abs().max()))
+    del lins
+
+
 def main():
     t0 = time.time()
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
@@ -374,6 +405,10 @@ def main():
         for (N, K, tag) in [(12288, 4096, "qkv"), (16384, 4096, "fc_in"), (4096, 4096, "out_proj"),
                             (4096, 16384, "fc_out"), (1024, 4096, "adapter_dn"), (4096, 1024, "adapter_up")]:
             bench_prefill(456, N, K, tag)
+    if which == "dma":
+        for (N, K, tag) in [(28672, 4096, "qkv|fc_in"), (16384, 4096, "fc_in"), (4096, 4096, "out_proj"),
+                            (1024, 4096, "adapter_dn"), (50272, 4096, "lm_head")]:
+            bench_skinny_dma(8, N, K, tag=tag)
     if which in ("all", "skinny"):
         variants = [(1, 8, 16), (2, 8, 16), (1, 4, 16), (2, 4, 16), (1, 8, 8), (2, 8, 8), (4, 8, 8), (2, 4, 8),
                     (4, 4, 8), (1, 8, 4), (2, 8, 4), (4, 8, 4), (1, 16, 8), (1, 16, 4), (1, 16, 2), (2, 16, 4)]
