@@ -256,7 +256,8 @@ def _forward_fp8(model, images, caps, mode, sync, dtf, f_fwd):
         return {"mode": mode, "ms": dt8 * 1e3, "speedup_vs_bf16": dtf / dt8, "loss_bf16": ref_loss, "loss_fp8": l8,
                 "algorithmic_tflops": f_fwd / dt8 / 1e12,
                 "note": "e4m3 operands with per-row / per-channel fp32 scales on v_mfma_scale_f32_16x16x128_f8f6f4 "
-                        "(unit block scales), fp32 accumulate, bf16 I/O; attention itself stays bf16"}
+                        "(unit block scales), fp32 accumulate, bf16 I/O; attention forward on v_mfma_scale_f32_32x32x64_f8f6f4 "
+                        "(MX e4m3 q / k / v^T, P as e4m3, fp32 softmax) unless MAGMA_FP8_ATTN=0"}
     except Exception as e:  # noqa: BLE001  (the bf16 numbers must survive a failure of the extra leg)
         return {"error": repr(e)[:300]}
     finally:
