@@ -160,8 +160,9 @@ int mg_gemm_fp8(const mg_gemm_desc* d, const float* row_scale, void* stream);
  *                       what it supplies for four 16-row fragments of a 64-row slab (rows >= M of the last slab: unwritten).
  *   mg_gemm_mx_fp8      descriptor as for mg_gemm_fp8 (K / lda / ldw count fp8 elements; rows padded to whole 128-element chunks;
  *                       row-major or fragment-tiled W: the bf16 tiling applied to the byte pairs of the row-major image), the scale
- *                       arrays of the two operands from the quantiser (4-byte aligned).  128x128 tile kernel (split-K as for
- *                       bf16; the 256x256 fp8 kernel has no register left for the scale operands); the usual epilogue.
+ *                       arrays of the two operands from the quantiser (4-byte aligned).  tile_hint 0 / 128 / 256: the 128x128
+ *                       kernel (scales in registers a K-tile ahead; split-K as for bf16) or the 256x256 one (scales staged
+ *                       through LDS with their K-tile; bit-identical un-split); the usual epilogue.
  *   mg_debug_mx_mfma    test probe: ONE wave-level MFMA on caller-supplied operand registers (a, b: [64 lanes][8] dwords) and
  *                       per-lane scale dwords -> out [64][4]; pins the instruction's lane / block / scale-byte semantics.            */
 int64_t mg_mx_scale_bytes(int32_t rows, int32_t K);

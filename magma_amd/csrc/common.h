@@ -92,6 +92,11 @@ MG_DEV void glds16au(const void* g, uint32_t lds_addr) {
 MG_DEV void glds16su(const void* base_uniform, uint32_t byte_off, uint32_t lds_addr) {
   asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(byte_off), "s"(base_uniform), "s"(lds_addr) : "memory");
 }
+MG_DEV void glds4s(const void* base_uniform, uint32_t byte_off, char* lds_wave_base) {   // 64 lanes x 4 B, SGPR base + lane offset
+  asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dword %0, %1"
+               :: "v"(byte_off), "s"(base_uniform),
+                  "s"(__builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(mg_lptr_t)lds_wave_base)) : "memory");
+}
 MG_DEV void glds4su(const void* base_uniform, uint32_t byte_off, uint32_t lds_addr) {
   asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dword %0, %1" :: "v"(byte_off), "s"(base_uniform), "s"(lds_addr) : "memory");
 }

@@ -388,9 +388,10 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 // 1 = every K-tile's DMA reads K-tile (t & 1) (operands always L2-hot: isolates memory latency), 2 = no fragment reads after
 // the first two K-tiles (isolates the LDS read segments), 3 = no MFMA, 4 = no DMA after the prologue, 6 = the first DMA
 // schedule (correct results), 7 = no epilogue, 8 = epilogue staging only, 10 = every tile stores to tile (0, 0).
-template <int WLAYOUT, bool LATE_LGKM, bool FP8 = false, bool MFMA32 = false, int ABL = 0, bool SPLITK = false>
+template <int WLAYOUT, bool LATE_LGKM, bool FP8 = false, bool MFMA32 = false, int ABL = 0, bool SPLITK = false, bool MX = false>
 __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   static_assert(!(FP8 && MFMA32), "the 32x32 form is the bf16 path");
+  static_assert(!MX || (FP8 && !SPLITK && ABL == 0), "block scales: fp8 path, un-split");
   bool abl_on = true;           // ABL 2 / 4: false once the pipeline is primed
   const unsigned long long t_start = ABL == 11 ? __builtin_amdgcn_s_memrealtime() : 0ull;
   const unsigned long long c_start = ABL == 11 ? __builtin_amdgcn_s_memtime() : 0ull;     // shader-clock cycles (the 100-MHz counter above is wall time)
@@ -504,6 +505,28 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
       glds16s(src_, (uint32_t)b2_off[u][1] * 2u, d_ + 1024);                                             \
     }                                                                                                    \
   }
+
+  // ---- MX block scales (mg_gemm_mx_fp8) ----
+  // The K loop of the fp8 form lives in exactly 256 VGPRs: scale registers loaded a tile ahead (as in gemm128_kernel) made hipcc
+  // spill accumulators inside the loop (round 3).  Here the scales of a K-tile travel with the tile instead: 2 KiB per tile --
+  // [operand][k-quarter lq][slab of 64 rows][row % 16] dwords, byte (row % 64) / 16, i.e. mg_quantize_mx_fp8's layout cut to
+  // the workgroup's four A slabs and four W slabs -- staged behind the tile buffers by ONE 256-byte LDS-DMA per wave and
+  // K-tile (wave = operand * 4 + lq; part of DMA unit A_0, whose waits count one more), read with a ds_read_b32 in the
+  // phase that needs them (W and A slab 0 in q0, A slab 1 in q2): two short-lived registers.
+  constexpr int MX_OFF = G256_LDS;          // behind the epilogue image
+  uint32_t mx_sw = 0x7f7f7f7fu, mx_sa = 0x7f7f7f7fu;
+  const int mx_op = wave >> 2, mx_lq = wave & 3;
+  const int mx_rg = mx_op ? p.rg_w : p.rg_a;
+  const uint32_t mx_src_off = (uint32_t)((mx_lq * mx_rg + min(((mx_op ? n0 : m0) >> 6) + (lane >> 4), mx_rg - 1)) * 64 + (lane & 15) * 4);
+  const int mx_rd_w = MX_OFF + 1024 + lq * 256 + wc * 64 + li * 4;
+  const int mx_rd_a = MX_OFF + lq * 256 + wr * 128 + li * 4;              // slab 1 of the wave's rows: + 64
+#define MG_DMA_S(kt)                                                                                     \
+  if constexpr (MX) {                                                                                    \
+    const char* src_ = (const char*)(mx_op ? p.mx_w : p.mx_a) + (int64_t)(kt0 + (kt)) * mx_rg * 256;     \
+    glds4s(src_, mx_src_off, smem + MX_OFF + ((kt) & 1) * 2048 + wave * 256);                           \
+  }
+#define MG_READ_SW(par) if constexpr (MX) mx_sw = *(const uint32_t*)(smem + mx_rd_w + (par) * 2048)
+#define MG_READ_SA(par, s) if constexpr (MX) mx_sa = *(const uint32_t*)(smem + mx_rd_a + (par) * 2048 + (s) * 64)
 
   // ---- fragment readers (single register set) ----
   const int fsw = (li >> 1) & 7;
@@ -665,7 +688,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
     __builtin_amdgcn_s_setprio(1);                                                                       \
     _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                                     \
       _Pragma("unroll") for (int n_ = 0; n_ < 4; ++n_)                                                   \
-        acc[(mq) * 2 + i_][n_] = mfma_fp8_k128(bw[n_ >> 1][n_ & 1], af[i_], acc[(mq) * 2 + i_][n_]);     \
+        if constexpr (MX) acc[(mq) * 2 + i_][n_] = mfma_mx_k128(bw[n_ >> 1][n_ & 1], n_, mx_sw, af[i_], ((mq) * 2 + i_) & 3, mx_sa, acc[(mq) * 2 + i_][n_]); \
+        else acc[(mq) * 2 + i_][n_] = mfma_fp8_k128(bw[n_ >> 1][n_ & 1], af[i_], acc[(mq) * 2 + i_][n_]); \
     __builtin_amdgcn_s_setprio(0);                                                                       \
   }
 #define MG_PHASEQ(READS, DMA, MQ)                                                                        \
@@ -681,10 +705,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
 #define MG_G256_TILE(t, PAR, NXT, NXT2)                                                                  \
   if constexpr (FP8) {                                                                                   \
     /* all of W is read in q0, the A quarters in q0..q3: A_0 (quarters 0, 1) is free from q2, A_1 from q0 of the next tile */ \
-    MG_PHASEQ({ MG_READ_AQ(PAR, 0); MG_READ_B(PAR, 0); MG_READ_B(PAR, 1); }, { if (NXT) MG_DMA_A2((t) + 1, 1); }, 0); \
+    MG_PHASEQ({ MG_READ_AQ(PAR, 0); MG_READ_B(PAR, 0); MG_READ_B(PAR, 1); MG_READ_SW(PAR); MG_READ_SA(PAR, 0); }, { if (NXT) MG_DMA_A2((t) + 1, 1); }, 0); \
     MG_PHASEQ({ MG_READ_AQ(PAR, 1); }, { if (NXT2) MG_DMA_B2((t) + 2, 0); }, 1);                          \
-    MG_PHASEQ({ MG_READ_AQ(PAR, 2); }, { if (NXT2) MG_DMA_B2((t) + 2, 1); }, 2);                          \
-    MG_PHASEQ({ MG_READ_AQ(PAR, 3); }, { if (NXT2) { MG_DMA_A2((t) + 2, 0); MG_WAIT_VM(6); } else { MG_WAIT_VM(0); } }, 3); \
+    MG_PHASEQ({ MG_READ_AQ(PAR, 2); MG_READ_SA(PAR, 1); }, { if (NXT2) MG_DMA_B2((t) + 2, 1); }, 2);      \
+    MG_PHASEQ({ MG_READ_AQ(PAR, 3); }, { if (NXT2) { MG_DMA_A2((t) + 2, 0); MG_DMA_S((t) + 2); if constexpr (MX) MG_WAIT_VM(7); else MG_WAIT_VM(6); } else { MG_WAIT_VM(0); } }, 3); \
   } else if constexpr (MFMA32) {                                                                         \
     MG_PHASE32({ MG_READ_A32(PAR, 0); MG_READ_B32(PAR, 0); }, { if (NXT) MG_DMA_A2((t) + 1, 1); }, 0, 0); \
     MG_PHASE32({ MG_READ_B32(PAR, 1); }, { if (NXT2) MG_DMA_A2((t) + 2, 0); }, 0, 1);                     \
@@ -713,9 +737,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
 
   // ---- prologue: tile 0 complete, W_lo(1) in flight; group 1 starts one barrier late ----
   if constexpr (EARLY) {     // tile 0 complete; A_0, W_0, W_1 of tile 1 in flight (A_1(1) follows in q0 of tile 0; every path)
-    MG_DMA_B2(0, 0); MG_DMA_B2(0, 1); MG_DMA_A2(0, 0); MG_DMA_A2(0, 1);
-    MG_DMA_A2(1, 0); MG_DMA_B2(1, 0); MG_DMA_B2(1, 1);
-    MG_WAIT_VM(6);
+    MG_DMA_B2(0, 0); MG_DMA_B2(0, 1); MG_DMA_A2(0, 0); MG_DMA_S(0); MG_DMA_A2(0, 1);
+    MG_DMA_A2(1, 0); MG_DMA_S(1); MG_DMA_B2(1, 0); MG_DMA_B2(1, 1);
+    if constexpr (MX) MG_WAIT_VM(7); else MG_WAIT_VM(6);
   } else {
     MG_DMA_B(0, 0); MG_DMA_B(0, 1); MG_DMA_A(0, 0); MG_DMA_A(0, 1);
     MG_DMA_B(1, 0);
@@ -735,6 +759,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   MG_G256_TILE(t + 1, 1, false, false)
   if (wr == 0) MG_BAR();
 #undef MG_G256_TILE
+#undef MG_DMA_S
+#undef MG_READ_SW
+#undef MG_READ_SA
 #undef MG_PHASE32
 #undef MG_PHASES
 #undef MG_MMAS
@@ -900,9 +927,10 @@ int group_m_256(int tiles_m, int tiles_n, int K) {
 // the automatic rule for the un-split 256x256 kernel (enough tiles to fill the chip)
 inline bool want256_noforce(int tile_hint, int64_t wgs256, int M, int N) { return tile_hint == 0 && wgs256 >= 192 && M >= 1024 && N >= 512; }
 
-template <int WLAYOUT, bool LATE_LGKM, bool FP8 = false, bool MFMA32 = false, int ABL = 0, bool SPLITK = false>
+template <int WLAYOUT, bool LATE_LGKM, bool FP8 = false, bool MFMA32 = false, int ABL = 0, bool SPLITK = false, bool MX = false>
 int launch_gemm256(GemmParams gp, hipStream_t s) {
-  if (int rc = mg_allow_dynamic_lds((const void*)gemm256_kernel<WLAYOUT, LATE_LGKM, FP8, MFMA32, ABL, SPLITK>, G256_LDS, "mg_gemm")) return rc;
+  constexpr int LDS = G256_LDS + (MX ? 4096 : 0);        // + the block scales of two K-tiles
+  if (int rc = mg_allow_dynamic_lds((const void*)gemm256_kernel<WLAYOUT, LATE_LGKM, FP8, MFMA32, ABL, SPLITK, MX>, LDS, "mg_gemm")) return rc;
   if (SPLITK != (gp.splits > 1)) MG_FAIL(MG_ERR_SHAPE, "mg_gemm: internal: split-K form of the 256x256 kernel selected inconsistently");
   gp.tiles_m = (gp.M + 255) / 256; gp.tiles_n = (gp.N + 255) / 256;
   gp.group_m = group_m_256(gp.tiles_m, gp.tiles_n, gp.K);
@@ -915,7 +943,7 @@ int launch_gemm256(GemmParams gp, hipStream_t s) {
     gp.ep = slab;
     gp.nt = 0;
   }
-  hipLaunchKernelGGL((gemm256_kernel<WLAYOUT, LATE_LGKM, FP8, MFMA32, ABL, SPLITK>), dim3(gp.tiles_m * gp.tiles_n * gp.splits), dim3(512), G256_LDS, s, gp);
+  hipLaunchKernelGGL((gemm256_kernel<WLAYOUT, LATE_LGKM, FP8, MFMA32, ABL, SPLITK, MX>), dim3(gp.tiles_m * gp.tiles_n * gp.splits), dim3(512), LDS, s, gp);
   MG_CHECK_LAUNCH();
   if (gp.splits > 1) {
     const int64_t quads = (int64_t)gp.M * ((gp.N + 3) >> 2);
@@ -1043,6 +1071,8 @@ int gemm_dispatch(const mg_gemm_desc* d, bool fp8, const float* row_scale, hipSt
     if (mfma32 || (d->tile_hint == 257 && !fp8))
       MG_FAIL(MG_ERR_UNSUPPORTED, "%s: tile_hint %d / MAGMA_GEMM256_MFMA=32 select an A/B variant of the 256x256 kernel that exists only in the ablation library (`make ABL=1`)", who, d->tile_hint);
 #endif
+    if (fp8 && gp.mx_a) return rm ? launch_gemm256<MG_W_ROWMAJOR, false, true, false, 0, false, true>(gp, s)
+                                  : launch_gemm256<MG_W_FRAGTILED, false, true, false, 0, false, true>(gp, s);
     if (fp8) return rm ? launch_gemm256<MG_W_ROWMAJOR, false, true>(gp, s) : launch_gemm256<MG_W_FRAGTILED, false, true>(gp, s);
     return rm ? launch_gemm256<MG_W_ROWMAJOR, false>(gp, s) : launch_gemm256<MG_W_FRAGTILED, false>(gp, s);
   }
@@ -1106,13 +1136,11 @@ extern "C" int mg_gemm_mx_fp8(const mg_gemm_desc* d, const uint8_t* a_scales, co
   const int64_t chunks = ((int64_t)d->K + 127) / 128;
   if (!a_scales || !w_scales || ((uintptr_t)a_scales & 3) || ((uintptr_t)w_scales & 3)) MG_FAIL(MG_ERR_SHAPE, "mg_gemm_mx_fp8: block scales missing or not 4-byte aligned");
   if (d->lda < chunks * 128 || d->ldw < chunks * 128) MG_FAIL(MG_ERR_SHAPE, "mg_gemm_mx_fp8: operand rows must be padded to whole 128-element chunks (mg_quantize_mx_fp8)");
-  // The block scales are wired into the 128x128 kernel.  The 256x256 fp8 kernel has no register left for them: its K loop
-  // lives in exactly 256 VGPRs, and the six scale registers (two A slabs + one W slab, double-buffered) made hipcc spill
-  // accumulators INSIDE the loop (scratch 72 -> 272 bytes per lane) -- measured, removed again.
-  if (d->tile_hint == 256) MG_FAIL(MG_ERR_UNSUPPORTED, "mg_gemm_mx_fp8: block scales are wired into the 128x128 kernel only");
+  // Both tile kernels take block scales: the 128x128 one loads them into registers a tile ahead, the 256x256 one (whose K loop
+  // has no register to spare) stages them through LDS with the tile they belong to.  tile_hint 0 = the usual automatic choice.
+  if (d->tile_hint != 0 && d->tile_hint != 128 && d->tile_hint != 256) MG_FAIL(MG_ERR_UNSUPPORTED, "mg_gemm_mx_fp8: tile_hint must be 0, 128 or 256");
   const MxScales mx{(const uint32_t*)a_scales, (const uint32_t*)w_scales};
   mg_gemm_desc dd = *d;
-  dd.tile_hint = 128;
   return gemm_dispatch(&dd, true, nullptr, (hipStream_t)stream, "mg_gemm_mx_fp8", &mx);
 }
 

@@ -139,7 +139,7 @@ class LMEngine:
         self.fp8_mode = os.environ.get("MAGMA_FP8") or None
         self.fp8_attn = os.environ.get("MAGMA_FP8_ATTN", "1") == "1"     # with fp8_mode: QK^T / PV of the cache-less forward in e4m3 too
         # scaling of the fp8 operands: "row" = one fp32 scale per activation row / weight output channel (any tile kernel), "mx" =
-        # OCP MX, one E8M0 scale per 32 K-elements of both operands, applied by the MFMA itself (128x128 kernel)
+        # OCP MX, one E8M0 scale per 32 K-elements of both operands, applied by the MFMA itself (both tile kernels)
         self.fp8_scaling = os.environ.get("MAGMA_FP8_SCALING", "row")
         if self.fp8_scaling not in ("row", "mx"):
             raise ValueError("MAGMA_FP8_SCALING must be 'row' or 'mx'")

@@ -321,6 +321,30 @@ def test_gemm_mx_fp8(dev, layout, M, N, K):
     assert e_mx < 0.07, e_mx
 
 
+@pytest.mark.parametrize("layout", ["rm", "ft"])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 256), (300, 520, 512), (456, 4096, 4096), (2048, 1024, 4096), (1000, 264, 1280)])
+def test_gemm_mx_fp8_tile256(dev, layout, M, N, K):
+    """The block scales in the 256x256 kernel (round 5: staged through LDS with the K-tile they belong to): same restatement as
+    test_gemm_mx_fp8, and the same bits as the 128x128 kernel (same products, same K order per accumulator)."""
+    from magma_amd import ops
+    g = torch.Generator(device=dev).manual_seed(M + N + K + 11)
+    a = (torch.randn(M, K, device=dev, generator=g) * (1 + 30 * (torch.rand(1, K, device=dev, generator=g) < 0.02))).to(BF16)
+    w = (torch.randn(N, K, device=dev, generator=g) * 0.05).to(BF16)
+    bias = torch.randn(N, device=dev, generator=g)
+    res = torch.randn(M, ops.ceil_to(N, 8), device=dev, generator=g).to(BF16)
+    lin = ops.PackedLinearMX(w, bias=bias, tiled=True, rowmajor=True)
+    aq, asc = ops.quantize_mx_fp8(a)
+    ad, wd = ops.mx_dequant(aq, asc, K), lin.dequant()
+    ref = F.gelu(ad.double() @ wd.double().t() + bias.double(), approximate="tanh").float() + res[:, :N].float()
+    kw = dict(layout=layout, act=ops.MG_ACT_GELU_NEW, residuals=(res,), out_dtype=torch.float32)
+    o256 = ops.gemm_mx_fp8(aq, asc, lin, tile=256, split_k=1, **kw)
+    o128 = ops.gemm_mx_fp8(aq, asc, lin, tile=128, split_k=1, **kw)      # un-split: one accumulator walks K in both kernels
+    assert rel(o256, ref) < 1e-4, rel(o256, ref)
+    assert torch.equal(o256, o128)
+    b256 = ops.gemm_mx_fp8(aq, asc, lin, tile=256, layout=layout)          # bf16 output, bias only
+    assert rel(b256.float(), (ad.double() @ wd.double().t() + bias.double()).float()) < 5e-3
+
+
 @pytest.mark.parametrize("B,H,S", [(1, 1, 1), (2, 2, 57), (1, 2, 300), (2, 1, 385), (1, 1, 1024)])
 def test_fp8_attention_forward(dev, B, H, S):
     """BASELINE config[4] "fp8 MFMA path for GPT-J attention": mg_rotary_split_fp8 + mg_attn_prefill_fp8

@@ -203,7 +203,7 @@ def main():
             r.update(mfma16_ms=best[259], mfma32_ms=best[258], mfma16_tflops=fl / best[259] / 1e9, mfma32_tflops=fl / best[258] / 1e9,
                      speedup=best[259] / best[258])
             emit(**r)
-    if which == "mx":   # fp8 GEMM at 5 PF dense peak: MX block-scaled (128x128 kernel) vs per-row scaled (128x128, 256x256) + the quantisers
+    if which == "mx":   # fp8 GEMM at 5 PF dense peak: MX block-scaled vs per-row scaled (128x128, 256x256 kernels) + the quantisers
         for M in (456, 32768):
             for (N, K, tag) in [(12288, 4096, "qkv"), (4096, 4096, "out_proj"), (16384, 4096, "fc_in"), (4096, 16384, "fc_out")]:
                 a = torch.randn(M, K, device=dev).to(BF16)
@@ -217,7 +217,8 @@ def main():
                 r = {"kind": "mx", "tag": tag, "M": M, "N": N, "K": K}
                 for name, fn in (("row_128", lambda i: ops.gemm_fp8(aq, asc, lin8, out=out, tile=128)),
                                  ("row_256", lambda i: ops.gemm_fp8(aq, asc, lin8, out=out, tile=256 if M >= 256 else 128)),
-                                 ("mx_128", lambda i: ops.gemm_mx_fp8(xq, xsc, linx, out=out)),
+                                 ("mx_128", lambda i: ops.gemm_mx_fp8(xq, xsc, linx, out=out, tile=128)),
+                                 ("mx_256", lambda i: ops.gemm_mx_fp8(xq, xsc, linx, out=out, tile=256 if M >= 256 else 128)),
                                  ("quant_row", lambda i: ops.quantize_rows_fp8(a)), ("quant_mx", lambda i: ops.quantize_mx_fp8(a))):
                     ms = timeit(fn, it)
                     r[name + "_ms"] = ms
