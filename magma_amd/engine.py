@@ -209,6 +209,8 @@ class LMEngine:
             ly.dec_in = lin
             del w, w2
             self._fold_adapter_down(ly)
+            if self.fold_dn in (1, 2):
+                self._ensure_out_up(ly)          # built HERE, never inside a token step (no allocation under hipGraph capture)
         w2, b2, cs = ops.fold_layernorm(self._lm_head.weight, self._lm_head.bias, self.lnf_g, self.lnf_b)
         self.head_dec = ops.PackedLinear(w2, bias=b2)
         self.head_dec.colsum = cs
@@ -225,7 +227,10 @@ class LMEngine:
     def _ensure_out_up(self, ly):
         """[W_out | W_up] (d rows over K = d + r, bias b_up) of a MAGMA_v1 block -- the operand of the ONE GEMM / GEMV that
         replaces out_proj and the adapter's up-projection (prefill / forward blocks and the decode step) -- or None where a
-        block does not have that shape.  Built on first use, dropped by repack_adapters (it contains W_up)."""
+        block does not have that shape.  Built with the decode operands (_ensure_decode_packs / repack_adapters) or on the first
+        prefill that wants it; dropped by repack_adapters (it contains W_up).  It is a SECOND copy of W_out (42 MB per block,
+        1.2 GB at 28 blocks): ly.out stays for the paths that still read it (fp8 modes, MAGMA_PREFILL_CAT=0 / MAGMA_DECODE_FOLD=0,
+        attention adapters)."""
         if "out_up" not in ly.__dict__:
             ly.out_up = None
             if self._v1_block(ly):
@@ -300,8 +305,10 @@ class LMEngine:
             ly.__dict__.pop("up_cat", None)
             ly.__dict__.pop("out_up", None)        # [W_out | W_up] contains the adapter weights: rebuilt on next use
             ly.__dict__.pop("fc_dn", None)
-            if self.head_dec is not None:          # decode operands exist: rebuild the folded ones now
+            if self.head_dec is not None:          # decode operands exist: rebuild the folded ones now, not inside the next token step
                 self._fold_adapter_down(ly)
+                if self.fold_dn in (1, 2):
+                    self._ensure_out_up(ly)
 
     @staticmethod
     def _par_up(up, par):
@@ -378,8 +385,8 @@ class LMEngine:
                 if T == 0:
                     raise ValueError("cached decoding needs at least one new token")
                 rows = []
-                for i in range(T):
-                    lg, tok = self.decode(input_ids[:, i:i + 1], past_key_values, sampling=sampling if i == T - 1 else None)
+                for i in range(T):      # only the LAST position selects a token (history / RNG step / eos latch untouched before)
+                    lg, tok = self.decode(input_ids[:, i:i + 1], past_key_values, sampling=sampling, select=i == T - 1)
                     rows.append(lg.clone())
                 return LMOutput(logits=torch.stack(rows, 1), past_key_values=past_key_values, next_token=tok, loss=None,
                                 eos_state=past_key_values.sample_state)
@@ -706,7 +713,10 @@ class LMEngine:
         else:
             head = self.head_w8 if w8_on else self.head_dec
             ops.gemm_skinny(x, head, out=st.logits, ln_fold=(head.colsum, self.d, self.eps))
-        self.select_token(st.logits[:, : self.V], cache, mode, out=st.token, advance=True)
+        if mode == "noselect":
+            ops.advance_pos(cache.d_pos)          # teacher-forced position: nothing selected, nothing recorded
+        else:
+            self.select_token(st.logits[:, : self.V], cache, mode, out=st.token, advance=True)
 
     def _ensure_decode_state(self, cache: KVCache):
         st = cache.decode_state
@@ -718,10 +728,12 @@ class LMEngine:
             st = cache.decode_state = self._alloc_decode_state(cache)
         return st
 
-    def decode(self, input_ids: Optional[torch.Tensor], cache: KVCache, use_graph: bool = True, sampling=None):
+    def decode(self, input_ids: Optional[torch.Tensor], cache: KVCache, use_graph: bool = True, sampling=None, select: bool = True):
         """One cached step.  Returns (fp32 logits (B,V) view, selected token (B,) view: greedy, or sampled when
         ``sampling = (temperature, top_k, top_p)``); both are overwritten by the next step.  ``input_ids=None`` feeds the
-        previously selected tokens back without leaving the device."""
+        previously selected tokens back without leaving the device.  ``select=False`` (teacher-forced positions of a
+        multi-token call): no token is selected -- the history, the RNG step counter and the all-eos latch are left alone,
+        only the KV write position advances; the returned token view is stale."""
         if cache.pos >= cache.Smax:
             raise ValueError(f"KV cache full (Smax={cache.Smax}); pass a larger cache_hint / max_steps")
         if cache.B > 16:
@@ -738,6 +750,10 @@ class LMEngine:
         if not feed_back:
             st.ids.copy_(input_ids.reshape(cache.B, 1))
         mode = None if sampling is None else (float(sampling[0]), int(sampling[1]), float(sampling[2]))
+        if not select:
+            if feed_back:
+                raise ValueError("decode(select=False) needs input_ids: there is no selected token to feed back")
+            mode = "noselect"
         key = (mode, feed_back)
         if not use_graph:
             self._decode_step(cache, st, mode, feed_back)

@@ -87,6 +87,34 @@ class LMOutput(dict):
         except KeyError as e:
             raise AttributeError(k) from e
 
+    def is_lazy(self, k) -> bool:
+        """True while ``k`` has not been computed: ``out.is_lazy("logits")`` does not launch the (B*S x V) head GEMM that
+        ``out.logits is not None`` would."""
+        return isinstance(dict.get(self, k), LMOutput.lazy)
+
+    def resolve(self) -> "LMOutput":
+        """Compute every lazy value (afterwards the object is a plain dict of tensors and releases what the closures held)."""
+        for k in list(self.keys()):
+            self[k]
+        return self
+
+    # conversions that take dict's C fast path (dict(out), {**out}, out.copy(), pickle / torch.save) would hand out the raw
+    # lazy object -- an unpicklable closure: resolve first
+    def copy(self):
+        return LMOutput(self.resolve())
+
+    def __iter__(self):
+        return dict.__iter__(self)
+
+    def keys(self):
+        return dict.keys(self)
+
+    def __reduce__(self):
+        return (LMOutput, (dict(self.items()),))
+
+    def to_dict(self) -> dict:
+        return dict(self.items())
+
 
 class _AttnParams(nn.Module):
     def __init__(self, d, **kw):

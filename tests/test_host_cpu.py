@@ -610,3 +610,24 @@ def test_checkpoint_helpers_equal_the_reference_functions_run_in_place(tmp_path)
         elif stage == 1:
             (save / "global_step500").mkdir()
             (save / "global_step500" / "mp_rank_00_model_states.pt").write_bytes(b"x")
+
+
+def test_lm_output_lazy_values_resolve_on_every_conversion():
+    """dict(out), {**out}, out.copy() and pickling must not hand out the raw lazy closure; is_lazy() asks
+    without computing."""
+    import pickle
+    from magma_amd.language_model import LMOutput
+    calls = []
+
+    def make():
+        return LMOutput(loss=torch.tensor(1.0), logits=LMOutput.lazy(lambda: (calls.append(1), torch.ones(2))[1]))
+
+    o = make()
+    assert o.is_lazy("logits") and not o.is_lazy("loss") and not calls
+    assert isinstance(dict(make())["logits"], torch.Tensor)
+    assert isinstance({**make()}["logits"], torch.Tensor)
+    assert isinstance(make().copy()["logits"], torch.Tensor)
+    back = pickle.loads(pickle.dumps(make()))
+    assert isinstance(back, LMOutput) and torch.equal(back.logits, torch.ones(2))
+    n = len(calls)
+    assert o.logits is o.logits and len(calls) == n + 1 and not o.is_lazy("logits")      # computed once, then stored

@@ -221,3 +221,13 @@ def test_multi_token_cached_step(setup):
     assert o.logits.shape == ref.shape == (2, 3, cfg.vocab_out)
     check(rel(o.logits, ref), eb, "3-token cached step logits")
     assert o.past_key_values.pos == emb_ref.shape[1] + 3
+    # only the LAST position selects a token: one step on the loop's counter, one history entry, and that token is the argmax of
+    # the last row (the teacher-forced positions leave the generate()-loop bookkeeping alone)
+    cache = o.past_key_values
+    torch.cuda.synchronize()
+    assert int(cache.sample_state[0]) == 1, cache.sample_state
+    assert torch.equal(o.next_token.cpu(), o.logits[:, -1].argmax(-1).cpu())
+    assert torch.equal(cache.history[:, 0].cpu(), o.next_token.cpu()) and int(cache.history[:, 1:].abs().sum()) == 0
+    assert int(cache.d_pos) == cache.pos
+    with pytest.raises(ValueError):
+        model.lm(input_ids=new[:, :0].cuda(), use_cache=True, past_key_values=cache)
