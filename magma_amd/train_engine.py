@@ -554,7 +554,12 @@ class MagmaEngine:
         self._tape = tape
         # rows are b * S + position within the (possibly truncated) sequence of this step
         xf = tape.pop("x_final")
+        # .logits is LAZY (language_model.LMOutput): reading it -- even `out.logits is not None` -- runs the (B*S x V) head GEMM,
+        # and the closure keeps x_final [B*S, d] alive until the output is dropped; ask with out.is_lazy("logits").  With
+        # truncate=True the tensor covers the positions this step ran, (B, logits_seq_len, V) with logits_seq_len <= seq_len (the
+        # reference always returns (B, seq_len, V)); the rows cut off carry no target and were never computed.
         return LMOutput(loss=loss, labels=labels, target_rows=tape["rows"], target_logits=tape.pop("target_logits"),
+                        logits_seq_len=S,
                         logits=LMOutput.lazy(lambda: eng._full_logits(xf, xf.shape[0]).view(B, S, eng.V)))
 
     def _lm_forward(self, emb, labels, tape):
