@@ -147,6 +147,8 @@ class LMEngine:
         # GEMVs -> half the bytes per token step.  Changes the numerics (weight quantisation), so it is opt-in.
         self.decode_w8 = os.environ.get("MAGMA_DECODE_W8", "0") == "1"
         self._dec_in_variant = int(os.environ.get("MAGMA_DEC_IN_VARIANT", "0"))   # tuning knob: nt | waves<<4 | kc<<8
+        self._dec_dn_variant = int(os.environ.get("MAGMA_DEC_DN_VARIANT", "0"))   # the same for the adapter-down and the
+        self._dec_cat_variant = int(os.environ.get("MAGMA_DEC_CAT_VARIANT", "0"))  # [W_out | W_up] launches of the v1 block
         self._side_stream = torch.cuda.Stream(device=dev)
         self.group_launches = os.environ.get("MAGMA_DECODE_GROUPED", "1") == "1"
         # MAGMA_DECODE_FOLD -- how the adapter of a MAGMA_v1 block is laid over the block's launches (round 4):
@@ -624,8 +626,8 @@ class LMEngine:
                 ctx, t = st.ctx_t[:, : self.d], st.ctx_t[:, self.d: self.d + r]
                 ops.decode_attn_gemv(st.qkv, cache.k[li], cache.v[li], ctx, B, self.H, cache.d_pos, self.rot, self.sin_t, self.cos_t,
                                      (st.h, ly.fc_out, st.m, {}))
-                ops.gemm_skinny(st.m, ly.mlp_adapter[0], out=t, act=ops.MG_ACT_RELU)
-                ops.gemm_skinny(st.ctx_t[:, : self.d + r], ly.out_up, out=xn, residuals=(st.m, x))
+                ops.gemm_skinny(st.m, ly.mlp_adapter[0], out=t, act=ops.MG_ACT_RELU, variant=self._dec_dn_variant)
+                ops.gemm_skinny(st.ctx_t[:, : self.d + r], ly.out_up, out=xn, residuals=(st.m, x), variant=self._dec_cat_variant)
                 x, xn = xn, x
                 continue
             if out_up is not None and self.fold_dn == 1 and getattr(ly, "fc_dn", None) is not None:

@@ -57,6 +57,8 @@ for v in [int(x) for x in os.environ.get("DEC_IN_VARIANTS", "").split(",") if x]
 for setting in [x for x in os.environ.get("DEC_ENV_SWEEP", "").split(";") if x]:
     kv = dict(item.split("=") for item in setting.split(",")) if setting != "-" else {}
     eng._dec_in_variant = int(kv.pop("DEC_IN", 0))      # nt | waves << 4 | kc << 8 | pipelined << 16 of the ln_1+qkv+fc_in GEMV
+    eng._dec_dn_variant = int(kv.pop("DEC_DN", 0))      # the same for the adapter-down GEMV
+    eng._dec_cat_variant = int(kv.pop("DEC_CAT", 0))    # and for the [W_out | W_up] GEMV
     kv_env = dict(kv)
     for k, v in kv_env.items():
         os.environ[k] = v
@@ -73,7 +75,7 @@ for setting in [x for x in os.environ.get("DEC_ENV_SWEEP", "").split(";") if x]:
                 eng.decode(tok, cache)
             e1.record(); torch.cuda.synchronize()
             best = min(best, e0.elapsed_time(e1) / 40)
-        print(json.dumps({"env": kv_env, "dec_in": eng._dec_in_variant, "token_step_ms": best}))
+        print(json.dumps({"env": kv_env, "dec_in": eng._dec_in_variant, "dec_dn": eng._dec_dn_variant, "dec_cat": eng._dec_cat_variant, "token_step_ms": best}))
     except Exception as e:  # noqa: BLE001
         print(json.dumps({"env": kv_env, "dec_in": eng._dec_in_variant, "error": str(e)[:200]}))
     for k in kv_env:

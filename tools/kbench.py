@@ -410,6 +410,10 @@ def main():
         for (N, K, tag) in [(28672, 4096, "qkv|fc_in"), (16384, 4096, "fc_in"), (4096, 4096, "out_proj"),
                             (1024, 4096, "adapter_dn"), (50272, 4096, "lm_head")]:
             bench_skinny_dma(8, N, K, tag=tag)
+    if which == "skinny_cat":      # the [W_out | W_up] launch of the MAGMA_v1 decode block (K = 5120) and the adapter's down-projection
+        variants = [(1, 8, 4), (1, 8, 2), (1, 8, 1), (1, 16, 2), (1, 16, 1), (1, 8, 5), (1, 8, 10), (1, 4, 8), (1, 4, 4), (2, 8, 4), (1, 16, 5), (1, 16, 10)]
+        for (N, K, tag) in [(4096, 5120, "out|up"), (1024, 4096, "adapter_dn"), (4096, 4096, "out_proj")]:
+            bench_skinny(8, N, K, variants, tag=tag)
     if which in ("all", "skinny"):
         variants = [(1, 8, 16), (2, 8, 16), (1, 4, 16), (2, 4, 16), (1, 8, 8), (2, 8, 8), (4, 8, 8), (2, 4, 8),
                     (4, 4, 8), (1, 8, 4), (2, 8, 4), (4, 8, 4), (1, 16, 8), (1, 16, 4), (1, 16, 2), (2, 16, 4)]
