@@ -70,8 +70,10 @@ const char* mg_version(void);
  *      experiments, measured slower than the launch chain: DESIGN.md 8).
  *   3  round 5: added mg_stream_create_cu_mask / mg_stream_destroy, mg_rotary_split_fp8 / mg_attn_prefill_fp8 /
  *      mg_attn_fp8_scale_stride (nothing moved; a revision-2 binder keeps working, the loader of this repo asks for 3 because it
- *      binds the new ones).                                                                    */
-#define MG_ABI_VERSION 3
+ *      binds the new ones).
+ *   4  round 5: mg_epilogue grew by C8 / ldc8 / c8_scales / c8_rgroups (the MX e4m3 copy of a tile GEMM's output): every
+ *      descriptor that embeds an epilogue changed size.                                         */
+#define MG_ABI_VERSION 4
 int32_t mg_abi_version(void);
 const char* mg_last_error(void);
 
@@ -104,6 +106,16 @@ typedef struct mg_epilogue {
                        * [q|k|v | fc_in] with gelu_new on the fc_in columns; multiple of 8 */
   mg_bf16* C2;        /* optional second output (value before `act`), bf16 */
   int64_t ldc2;
+  /* optional OCP MX copy of the final value (what C receives, rounded to bf16 first: the same bytes mg_quantize_mx_fp8 makes
+   * of the bf16 output): e4m3 elements C8[m * ldc8 + n] with one E8M0 scale per 32 consecutive n in that quantiser's layout
+   * (c8_rgroups = ceil(M / 64)) -- the A operand of a following mg_gemm_mx_fp8 without a quantisation pass in between.
+   * Tile GEMMs only (mg_gemm_bf16 / mg_gemm_fp8 / mg_gemm_mx_fp8), un-split, N % 32 == 0, ldc8 == ceil(N / 128) * 128,
+   * bf16 C (or C == NULL: only the fp8 copy is written).  ABI revision 4.                                              */
+  uint8_t* C8;
+  int64_t ldc8;
+  uint8_t* c8_scales;
+  int32_t c8_rgroups;
+  int32_t reserved0;
 } mg_epilogue;
 
 /* K9/K11/K12/K13/K14/K18 (GPT-J + adapter GEMMs, prefill/training shapes),
@@ -154,7 +166,9 @@ int mg_gemm_fp8(const mg_gemm_desc* d, const float* row_scale, void* stream);
  * K-elements of every operand row, multiplied by v_mfma_scale_f32_16x16x128_f8f6f4 with those block scales (no per-row / per-column
  * scale, fp32 accumulate).
  *   mg_quantize_mx_fp8  x [M, K] bf16 -> q [M, ldq] e4m3 in K order (ldq == ceil(K / 128) * 128, zero padded) + the E8M0 block
- *                       scales (shared exponent floor(log2 max|x|) - 8, biased by 127; elements saturate at +-448) as
+ *                       scales (shared exponent floor(log2 max|x|) - 8, biased by 127, and ONE HIGHER when the block maximum
+ *                       would otherwise exceed 448 -- the v1.0 formula alone saturates maxima in (448, 512) 2^e by up to 12.5 %,
+ *                       which the gradient operands of the training path do not tolerate; revision 4) as
  *                       mg_mx_scale_bytes(M, K) bytes: with R = ceil(M / 64), byte ((((k / 128) * 4 + (k / 32) % 4) * R + m / 64) * 16
  *                       + m % 16) * 4 + (m % 64) / 16 is the scale of (row m, block k / 32) -- one dword load hands an MFMA lane
  *                       what it supplies for four 16-row fragments of a 64-row slab (rows >= M of the last slab: unwritten).

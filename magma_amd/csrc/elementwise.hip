@@ -702,9 +702,13 @@ __global__ __launch_bounds__(256) void quantize_mx_fp8_kernel(const mg_bf16* __r
     const int ef = (int)((__float_as_uint(amax) >> 23) & 0xff);
     int e8 = amax > 0.f ? ef - 8 : 127;                          // E8M0 byte = floor(log2 amax) - 8 + 127 = ef - 127 - 8 + 127
     e8 = max(0, min(254, e8));
-    const float inv = __uint_as_float((uint32_t)(254 - e8) << 23);   // 2^-(e8 - 127)  (e8 in [0, 254] -> exponent field 254 - e8)
+    float inv = __uint_as_float((uint32_t)(254 - e8) << 23);   // 2^-(e8 - 127)
+    if (amax * inv > 448.f) {    // the block maximum lies in (448, 512) 2^e: one exponent up instead of saturating it (header: MX scale rule)
+      e8 = min(254, e8 + 1);
+      inv = __uint_as_float((uint32_t)(254 - e8) << 23);
+    }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) f[i] = fminf(fmaxf(f[i] * inv, -448.f), 448.f);
+    for (int i = 0; i < 8; ++i) f[i] = __builtin_amdgcn_fmed3f(f[i] * inv, -448.f, 448.f);
     int lo = 0, hi = 0;
     lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
     lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);

@@ -388,8 +388,9 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 // 1 = every K-tile's DMA reads K-tile (t & 1) (operands always L2-hot: isolates memory latency), 2 = no fragment reads after
 // the first two K-tiles (isolates the LDS read segments), 3 = no MFMA, 4 = no DMA after the prologue, 6 = the first DMA
 // schedule (correct results), 7 = no epilogue, 8 = epilogue staging only, 10 = every tile stores to tile (0, 0).
-template <int WLAYOUT, bool LATE_LGKM, bool FP8 = false, bool MFMA32 = false, int ABL = 0, bool SPLITK = false, bool MX = false>
+template <int WLAYOUT, bool LATE_LGKM, bool FP8 = false, bool MFMA32 = false, int ABL = 0, bool SPLITK = false, bool MX = false, bool Q8 = false>
 __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
+  static_assert(!Q8 || (FP8 && !SPLITK && ABL == 0), "the MX output copy: fp8 path, un-split");
   static_assert(!(FP8 && MFMA32), "the 32x32 form is the bf16 path");
   static_assert(!MX || (FP8 && !SPLITK && ABL == 0), "block scales: fp8 path, un-split");
   bool abl_on = true;           // ABL 2 / 4: false once the pipeline is primed
@@ -843,15 +844,15 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
     const bool loads = ep.aux_mode != MG_AUX_NONE || ep.res0 || ep.res1 || ep.res2;
     stage(std::integral_constant<int, 0>{});
     MG_STAMP(2);
-    if (FULL && W == 8 && !loads) epilogue_rows_c<256, EPI256_ROWB, W, NT, FULL, false>(ep, c, smem, 128, 8, wave, lane, mb0, 128, nb, mlim, p.N, p.row_scale);
-    else epilogue_rows_c<256, EPI256_ROWB, W, NT, FULL>(ep, c, smem, 128, 8, wave, lane, mb0, 128, nb, mlim, p.N, p.row_scale);
+    if (FULL && W == 8 && !loads) epilogue_rows_c<256, EPI256_ROWB, W, NT, FULL, false, Q8>(ep, c, smem, 128, 8, wave, lane, mb0, 128, nb, mlim, p.N, p.row_scale);
+    else epilogue_rows_c<256, EPI256_ROWB, W, NT, FULL, true, Q8>(ep, c, smem, 128, 8, wave, lane, mb0, 128, nb, mlim, p.N, p.row_scale);
     MG_WAIT_LGKM0();
     MG_BAR();                                 // pass 0 has been read
     MG_STAMP(3);
     stage(std::integral_constant<int, 1>{});
     MG_STAMP(4);
-    if (FULL && W == 8 && !loads) epilogue_rows_c<256, EPI256_ROWB, W, NT, FULL, false>(ep, c, smem, 128, 8, wave, lane, mb0 + 64, 128, nb, mlim, p.N, p.row_scale);
-    else epilogue_rows_c<256, EPI256_ROWB, W, NT, FULL>(ep, c, smem, 128, 8, wave, lane, mb0 + 64, 128, nb, mlim, p.N, p.row_scale);
+    if (FULL && W == 8 && !loads) epilogue_rows_c<256, EPI256_ROWB, W, NT, FULL, false, Q8>(ep, c, smem, 128, 8, wave, lane, mb0 + 64, 128, nb, mlim, p.N, p.row_scale);
+    else epilogue_rows_c<256, EPI256_ROWB, W, NT, FULL, true, Q8>(ep, c, smem, 128, 8, wave, lane, mb0 + 64, 128, nb, mlim, p.N, p.row_scale);
     MG_STAMP(5);
     if (ABL == 11) {
       MG_WAIT_VM(0);
@@ -884,8 +885,15 @@ __global__ __launch_bounds__(WAVES * 64) void skinny2_kernel(const SkinnyParams 
   else skinny_body<WAVES, KC, NT, W8, false, NoWait, PIPE>(p1, blockIdx.x - g0, lds);
 }
 
-int check_epilogue(const mg_epilogue& ep, const char* who) {
-  if (!ep.C) MG_FAIL(MG_ERR_SHAPE, "%s: null output", who);
+int check_epilogue(const mg_epilogue& ep, const char* who, bool tile_gemm = false, int N = 0) {
+  if (!ep.C && !(tile_gemm && ep.C8)) MG_FAIL(MG_ERR_SHAPE, "%s: null output", who);
+  if (ep.C8) {
+    if (!tile_gemm) MG_FAIL(MG_ERR_UNSUPPORTED, "%s: the MX e4m3 output copy (mg_epilogue.C8) exists for the tile GEMMs only", who);
+    if (!ep.c8_scales || ep.c8_rgroups <= 0 || (N & 31) || ep.ldc8 != ((N + 127) / 128) * 128 || ((uintptr_t)ep.C8 & 7) || ep.out_f32)
+      MG_FAIL(MG_ERR_SHAPE, "%s: C8 needs c8_scales, c8_rgroups = ceil(M / 64), N %% 32 == 0, ldc8 == ceil(N / 128) * 128, an 8-byte aligned C8 and a bf16 (or no) C", who);
+    if ((ep.ldc & 7) || (ep.C2 && (ep.ldc2 & 7)) || (ep.aux_mode != MG_AUX_NONE && (ep.ldaux & 7)) || ((ep.res0 || ep.res1 || ep.res2) && (ep.ldr & 7)))
+      MG_FAIL(MG_ERR_ALIGN, "%s: C8 needs the 8-column epilogue walk: every leading dimension a multiple of 8", who);
+  }
   if ((ep.ldc & 3) != 0) MG_FAIL(MG_ERR_ALIGN, "%s: ldc must be a multiple of 4", who);
   if ((ep.res0 || ep.res1 || ep.res2) && (ep.ldr & 3) != 0) MG_FAIL(MG_ERR_ALIGN, "%s: ldr must be a multiple of 4", who);
   if (!MG_ALIGNED16(ep.C) || !MG_ALIGNED16(ep.scale) || !MG_ALIGNED16(ep.bias) || !MG_ALIGNED16(ep.res0) ||
@@ -927,10 +935,10 @@ int group_m_256(int tiles_m, int tiles_n, int K) {
 // the automatic rule for the un-split 256x256 kernel (enough tiles to fill the chip)
 inline bool want256_noforce(int tile_hint, int64_t wgs256, int M, int N) { return tile_hint == 0 && wgs256 >= 192 && M >= 1024 && N >= 512; }
 
-template <int WLAYOUT, bool LATE_LGKM, bool FP8 = false, bool MFMA32 = false, int ABL = 0, bool SPLITK = false, bool MX = false>
+template <int WLAYOUT, bool LATE_LGKM, bool FP8 = false, bool MFMA32 = false, int ABL = 0, bool SPLITK = false, bool MX = false, bool Q8 = false>
 int launch_gemm256(GemmParams gp, hipStream_t s) {
   constexpr int LDS = G256_LDS + (MX ? 4096 : 0);        // + the block scales of two K-tiles
-  if (int rc = mg_allow_dynamic_lds((const void*)gemm256_kernel<WLAYOUT, LATE_LGKM, FP8, MFMA32, ABL, SPLITK, MX>, LDS, "mg_gemm")) return rc;
+  if (int rc = mg_allow_dynamic_lds((const void*)gemm256_kernel<WLAYOUT, LATE_LGKM, FP8, MFMA32, ABL, SPLITK, MX, Q8>, LDS, "mg_gemm")) return rc;
   if (SPLITK != (gp.splits > 1)) MG_FAIL(MG_ERR_SHAPE, "mg_gemm: internal: split-K form of the 256x256 kernel selected inconsistently");
   gp.tiles_m = (gp.M + 255) / 256; gp.tiles_n = (gp.N + 255) / 256;
   gp.group_m = group_m_256(gp.tiles_m, gp.tiles_n, gp.K);
@@ -943,7 +951,7 @@ int launch_gemm256(GemmParams gp, hipStream_t s) {
     gp.ep = slab;
     gp.nt = 0;
   }
-  hipLaunchKernelGGL((gemm256_kernel<WLAYOUT, LATE_LGKM, FP8, MFMA32, ABL, SPLITK, MX>), dim3(gp.tiles_m * gp.tiles_n * gp.splits), dim3(512), LDS, s, gp);
+  hipLaunchKernelGGL((gemm256_kernel<WLAYOUT, LATE_LGKM, FP8, MFMA32, ABL, SPLITK, MX, Q8>), dim3(gp.tiles_m * gp.tiles_n * gp.splits), dim3(512), LDS, s, gp);
   MG_CHECK_LAUNCH();
   if (gp.splits > 1) {
     const int64_t quads = (int64_t)gp.M * ((gp.N + 3) >> 2);
@@ -974,7 +982,11 @@ int gemm_dispatch(const mg_gemm_desc* d, bool fp8, const float* row_scale, hipSt
   if (d->K & (8 * epb - 1)) MG_FAIL(MG_ERR_SHAPE, "%s: K=%d must be a multiple of %d", who, d->K, 8 * epb);
   if (!d->A || !d->W || !d->zero_page) MG_FAIL(MG_ERR_SHAPE, "%s: null A/W/zero_page", who);
   if (!MG_ALIGNED16(d->A) || !MG_ALIGNED16(d->W) || !MG_ALIGNED16(d->zero_page)) MG_FAIL(MG_ERR_ALIGN, "%s: A/W/zero_page must be 16-byte aligned", who);
-  if (int rc = check_epilogue(d->ep, who)) return rc;
+  if (int rc = check_epilogue(d->ep, who, true, d->N)) return rc;
+  if (d->ep.C8 && d->ep.c8_rgroups != (d->M + 63) / 64) MG_FAIL(MG_ERR_SHAPE, "%s: c8_rgroups must be ceil(M / 64)", who);
+  if (d->ep.C8 && d->split_k > 1) MG_FAIL(MG_ERR_UNSUPPORTED, "%s: the MX output copy is written by the un-split kernels", who);
+  mg_gemm_desc unsplit;
+  if (d->ep.C8 && d->split_k != 1) { unsplit = *d; unsplit.split_k = 1; d = &unsplit; }      // no automatic split-K either
   if (fp8 && d->a_mode != MG_A_DENSE) MG_FAIL(MG_ERR_UNSUPPORTED, "%s: fp8 operands need a dense A", who);
   GemmParams gp;
   gp.A = d->A; gp.lda = d->lda / epb; gp.W = d->W; gp.ldw = d->ldw / epb;
@@ -1071,12 +1083,18 @@ int gemm_dispatch(const mg_gemm_desc* d, bool fp8, const float* row_scale, hipSt
     if (mfma32 || (d->tile_hint == 257 && !fp8))
       MG_FAIL(MG_ERR_UNSUPPORTED, "%s: tile_hint %d / MAGMA_GEMM256_MFMA=32 select an A/B variant of the 256x256 kernel that exists only in the ablation library (`make ABL=1`)", who, d->tile_hint);
 #endif
+    if (d->ep.C8) {      // the build of the fp8 kernels whose epilogue also writes the MX e4m3 copy (fragment-tiled weights)
+      if (!fp8 || rm) MG_FAIL(MG_ERR_UNSUPPORTED, "%s: the MX output copy is built for the fp8 GEMMs on fragment-tiled weights", who);
+      return gp.mx_a ? launch_gemm256<MG_W_FRAGTILED, false, true, false, 0, false, true, true>(gp, s)
+                     : launch_gemm256<MG_W_FRAGTILED, false, true, false, 0, false, false, true>(gp, s);
+    }
     if (fp8 && gp.mx_a) return rm ? launch_gemm256<MG_W_ROWMAJOR, false, true, false, 0, false, true>(gp, s)
                                   : launch_gemm256<MG_W_FRAGTILED, false, true, false, 0, false, true>(gp, s);
     if (fp8) return rm ? launch_gemm256<MG_W_ROWMAJOR, false, true>(gp, s) : launch_gemm256<MG_W_FRAGTILED, false, true>(gp, s);
     return rm ? launch_gemm256<MG_W_ROWMAJOR, false>(gp, s) : launch_gemm256<MG_W_FRAGTILED, false>(gp, s);
   }
   if (d->tile_hint == 256 && !can256) MG_FAIL(MG_ERR_UNSUPPORTED, "%s: the 256x256 kernel needs dense A and K %% %d == 0", who, 128 * epb);
+  if (d->ep.C8) MG_FAIL(MG_ERR_UNSUPPORTED, "%s: the MX output copy is written by the 256x256 fp8 kernel (K %% 256 == 0; tile_hint 0 with >= 192 tiles, or 256)", who);
   // split-K: a grid that leaves most of the 256 CUs idle and has a long K loop is cut along K
   // until ~2 workgroups per CU exist (>= 4 K-tiles each); needs the caller's fp32 workspace.
   if (d->workspace && d->split_k != 1) {

@@ -324,7 +324,9 @@ MG_DEV bool epilogue_wide_ok(const mg_epilogue& ep) {
 // chip that also waits for the acknowledgement of every store of the pass before.
 // LOADS = false (caller's promise: no aux operand, no residual, and rows <= 8 * step): the walk is compiled without a single
 // global load -- see `iteration` below.
-template <int NCOLS, int ROWB, int W, bool NT, bool FULL = false, bool LOADS = true>
+// Q8: the build that can also write the MX e4m3 copy (mg_epilogue.C8) -- its own instantiation, so that the kernels that never
+// write one keep their register allocation (the extra live values cost the bf16 256x256 kernel four spilled registers).
+template <int NCOLS, int ROWB, int W, bool NT, bool FULL = false, bool LOADS = true, bool Q8 = false>
 MG_DEV void epilogue_rows_c(const mg_epilogue& ep, const EpiColsW<W>& c, const char* lds, int rows, int nwaves, int wave, int lane,
                             int m_base, int hi_stride, int n0, int M, int N, const float* row_scale = nullptr) {
   constexpr int LPR = NCOLS / W, RPI = 64 / LPR;     // lanes per row, rows per wave-iteration
@@ -455,7 +457,51 @@ MG_DEV void epilogue_rows_c(const mg_epilogue& ep, const EpiColsW<W>& c, const c
 #pragma unroll
           for (int g = 0; g < W; ++g) o[k][g] = o[k][g] > 0.f ? o[k][g] : 0.f;
       }
-      if (ep.out_f32) {
+      if constexpr (W == 8 && Q8) {
+        if (ep.C8) {   // OCP MX copy (mg_epilogue.C8): the arithmetic of quantize_mx_fp8_kernel on the bf16-rounded values
+#pragma unroll
+          for (int k = 0; k < R; ++k) {
+            float f[8];
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+              const uint32_t pk = pack2bf(o[k][2 * h], o[k][2 * h + 1]);
+              f[2 * h] = bflo(pk); f[2 * h + 1] = bfhi(pk);
+            }
+            float amax = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(f[i]));
+            // four consecutive lanes = 32 consecutive columns of one row: the maximum over a quad with two DPP moves
+            // (quad_perm [1,0,3,2] and [2,3,0,1]); __shfl_xor would go through ds_bpermute, an LDS round trip per step
+            amax = fmaxf(amax, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(amax), 0xB1, 0xf, 0xf, true)));
+            amax = fmaxf(amax, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(amax), 0x4E, 0xf, 0xf, true)));
+            const int ef = (int)((__float_as_uint(amax) >> 23) & 0xff);
+            int e8 = amax > 0.f ? ef - 8 : 127;
+            e8 = max(0, min(254, e8));
+            float inv = __uint_as_float((uint32_t)(254 - e8) << 23);   // 2^-(e8 - 127)
+            if (amax * inv > 448.f) {    // the block maximum lies in (448, 512) 2^e: one exponent up instead of saturating it (header: MX scale rule)
+              e8 = min(254, e8 + 1);
+              inv = __uint_as_float((uint32_t)(254 - e8) << 23);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) f[i] = __builtin_amdgcn_fmed3f(f[i] * inv, -448.f, 448.f);
+            int lo = 0, hi = 0;
+            lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
+            lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+            hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
+            hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+            if (ok[k]) {
+              const u32x2 w8 = {(uint32_t)lo, (uint32_t)hi};
+              *(u32x2*)(ep.C8 + (int64_t)m[k] * ep.ldc8 + n) = w8;
+              // (collecting a pass's scale bytes in LDS and storing them as whole dwords after its barrier was measured: no gain)
+              if ((cl & 3) == 0)
+                ep.c8_scales[((((int64_t)(n >> 7) * 4 + ((n & 127) >> 5)) * ep.c8_rgroups + (m[k] >> 6)) * 16 + (m[k] & 15)) * 4 +
+                             ((m[k] & 63) >> 4)] = (uint8_t)e8;
+            }
+          }
+        }
+      }
+      if (Q8 && !ep.C) {
+      } else if (ep.out_f32) {
 #pragma unroll
         for (int k = 0; k < R; ++k)
           if (ok[k]) {

@@ -19,7 +19,7 @@ MG_A_DENSE, MG_A_CONV3X3 = 0, 1
 MG_AUX_NONE, MG_AUX_RELU_GATE, MG_AUX_GELU_GRAD, MG_AUX_MUL, MG_AUX_QUICK_GELU_GRAD = 0, 1, 2, 3, 4
 
 
-ABI_VERSION = 3      # include/magma_hip.h MG_ABI_VERSION
+ABI_VERSION = 4      # include/magma_hip.h MG_ABI_VERSION
 
 
 class MagmaHipError(RuntimeError):
@@ -37,6 +37,7 @@ class Epilogue(C.Structure):
         ("aux", C.c_void_p), ("ldaux", C.c_int64),
         ("aux_after", C.c_int32), ("act_n0", C.c_int32),
         ("C2", C.c_void_p), ("ldc2", C.c_int64),
+        ("C8", C.c_void_p), ("ldc8", C.c_int64), ("c8_scales", C.c_void_p), ("c8_rgroups", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 

@@ -110,8 +110,10 @@ class PackedLinear:
         return ft.view(nt, ks, 4, 16, 8).permute(0, 3, 1, 2, 4).reshape(nt * 16, ks * 32)
 
 
-def _epilogue(out: torch.Tensor, N: int, bias, scale, act, residuals, act_after, aux=None, aux_mode=MG_AUX_NONE,
-              aux_after=False, out2=None) -> Epilogue:
+def _epilogue(out: Optional[torch.Tensor], N: int, bias, scale, act, residuals, act_after, aux=None, aux_mode=MG_AUX_NONE,
+              aux_after=False, out2=None, mx_out=None, M: int = 0) -> Epilogue:
+    """``mx_out`` = (q [M, ceil(N / 128) * 128] uint8, scales uint8 [mg_mx_scale_bytes(M, N)]) from ``mx_empty``: the epilogue also
+    writes the OCP MX e4m3 copy of its final value (mg_epilogue.C8); ``out`` may then be None (no bf16 output at all)."""
     ep = Epilogue()
     ep.scale = _p(scale)
     ep.bias = _p(bias)
@@ -126,9 +128,16 @@ def _epilogue(out: torch.Tensor, N: int, bias, scale, act, residuals, act_after,
         assert r.stride(0) == ldr, "all residuals must share a row stride"
     ep.res0, ep.res1, ep.res2 = _p(res[0]), _p(res[1]), _p(res[2])
     ep.ldr = ldr
-    ep.C = out.data_ptr()
-    ep.ldc = out.stride(0)
-    ep.out_f32 = 1 if out.dtype == torch.float32 else 0
+    if out is not None:
+        ep.C = out.data_ptr()
+        ep.ldc = out.stride(0)
+        ep.out_f32 = 1 if out.dtype == torch.float32 else 0
+    if mx_out is not None:
+        q8, sc8 = mx_out
+        _need_gpu(q8, sc8)
+        assert q8.dtype == torch.uint8 and q8.ndim == 2 and q8.stride(1) == 1 and q8.shape[0] >= M and q8.stride(0) == ceil_to(N, 128)
+        assert sc8.dtype == torch.uint8 and sc8.numel() == int(L.load().mg_mx_scale_bytes(M, N))
+        ep.C8, ep.ldc8, ep.c8_scales, ep.c8_rgroups = q8.data_ptr(), q8.stride(0), sc8.data_ptr(), (M + 63) // 64
     if aux is not None and aux_mode != MG_AUX_NONE:
         _need_gpu(aux)
         assert aux.dtype == BF16 and aux.ndim == 2 and aux.stride(1) == 1 and aux.shape[1] >= N
@@ -1009,13 +1018,16 @@ def gemm_fp8(aq: torch.Tensor, a_scale: torch.Tensor, w: PackedLinearFP8, out: O
              act: int = MG_ACT_NONE, residuals: Sequence[torch.Tensor] = (), act_after: int = MG_ACT_NONE,
              use_bias: bool = True, out_dtype=BF16, layout: Optional[str] = None, split_k: int = 0,
              aux=None, aux_mode: int = MG_AUX_NONE, aux_after: bool = False, out2: Optional[torch.Tensor] = None,
-             tile: int = 0) -> torch.Tensor:
+             tile: int = 0, mx_out=None, no_out: bool = False):
     """out[M,N] = epilogue((aq @ wq^T) * a_scale[m] * w.scale[n]) on the fp8 MFMA (fp32 accumulate).
-    ``tile``: 0 lets the library choose between the 128x128 and the 256x256 kernel, 128 / 256 force one."""
+    ``tile``: 0 lets the library choose between the 128x128 and the 256x256 kernel, 128 / 256 force one.
+    ``mx_out`` (from mx_empty): the epilogue also writes the MX e4m3 copy of the result; with ``no_out`` only that copy
+    (returns None)."""
     _need_gpu(aq)
     assert aq.dtype == torch.uint8 and aq.ndim == 2 and aq.stride(1) == 1 and aq.shape[1] >= w.K
     M = aq.shape[0]
-    if out is None:
+    assert not no_out or (mx_out is not None and out is None)
+    if out is None and not no_out:
         out = torch.empty(M, ceil_to(w.N, 8), dtype=out_dtype, device=aq.device)[:, : w.N]
     d = GemmDesc()
     d.A, d.lda = aq.data_ptr(), aq.stride(0)
@@ -1033,7 +1045,8 @@ def gemm_fp8(aq: torch.Tensor, a_scale: torch.Tensor, w: PackedLinearFP8, out: O
     if split_k != 1:
         ws = splitk_workspace(aq.device)
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
-    d.ep = _epilogue(out, w.N, w.bias if use_bias else None, w.scale, act, residuals, act_after, aux, aux_mode, aux_after, out2)
+    d.ep = _epilogue(out, w.N, w.bias if use_bias else None, w.scale, act, residuals, act_after, aux, aux_mode, aux_after, out2,
+                     mx_out=mx_out, M=M)
     check(L.load().mg_gemm_fp8(C.byref(d), a_scale.data_ptr(), _stream()), "mg_gemm_fp8")
     return out
 
@@ -1045,6 +1058,16 @@ def mx_scales_rowmajor(scales: torch.Tensor, rows: int, K: int) -> torch.Tensor:
     chunks, rg = (K + 127) // 128, (rows + 63) // 64
     v = scales.view(chunks, 4, rg, 16, 4).permute(2, 4, 3, 0, 1).reshape(rg * 64, chunks * 4)
     return v[:rows]
+
+
+def mx_empty(M: int, N: int, device):
+    """Uninitialised (q, scales) of an [M, N] MX operand: what quantize_mx_fp8 returns, for a GEMM epilogue to fill (``mx_out``).
+    Columns N .. ceil(N / 128) * 128 of q are zeroed (the consumer's K loop reads whole 128-element chunks)."""
+    Kp = ceil_to(N, 128)
+    q = torch.empty(M, Kp, dtype=torch.uint8, device=device)
+    if Kp != N:
+        q[:, N:].zero_()
+    return q, torch.empty(int(L.load().mg_mx_scale_bytes(M, N)), dtype=torch.uint8, device=device)
 
 
 def quantize_mx_fp8(x: torch.Tensor):
@@ -1097,13 +1120,17 @@ class PackedLinearMX:
 
 def gemm_mx_fp8(aq: torch.Tensor, a_scales: torch.Tensor, w: PackedLinearMX, out: Optional[torch.Tensor] = None, *,
                 act: int = MG_ACT_NONE, residuals: Sequence[torch.Tensor] = (), act_after: int = MG_ACT_NONE, use_bias: bool = True,
-                out_dtype=BF16, layout: Optional[str] = None, split_k: int = 0, act_n0: int = 0, tile: int = 0) -> torch.Tensor:
-    """out[M,N] = epilogue(sum over 32-blocks of 2^(ea + ew) * (qa . qw)) on the block-scaled fp8 MFMA (fp32 accumulate)."""
+                out_dtype=BF16, layout: Optional[str] = None, split_k: int = 0, act_n0: int = 0, tile: int = 0,
+                aux=None, aux_mode: int = MG_AUX_NONE, aux_after: bool = False, out2: Optional[torch.Tensor] = None,
+                mx_out=None, no_out: bool = False):
+    """out[M,N] = epilogue(sum over 32-blocks of 2^(ea + ew) * (qa . qw)) on the block-scaled fp8 MFMA (fp32 accumulate).
+    ``mx_out`` / ``no_out`` as for gemm_fp8."""
     _need_gpu(aq, a_scales)
     assert aq.dtype == torch.uint8 and aq.ndim == 2 and aq.stride(1) == 1 and aq.shape[1] == w.Kp
     M = aq.shape[0]
     assert a_scales.dtype == torch.uint8 and a_scales.numel() == int(L.load().mg_mx_scale_bytes(M, w.Kp))
-    if out is None:
+    assert not no_out or (mx_out is not None and out is None)
+    if out is None and not no_out:
         out = torch.empty(M, ceil_to(w.N, 8), dtype=out_dtype, device=aq.device)[:, : w.N]
     d = GemmDesc()
     d.A, d.lda = aq.data_ptr(), aq.stride(0)
@@ -1121,7 +1148,8 @@ def gemm_mx_fp8(aq: torch.Tensor, a_scales: torch.Tensor, w: PackedLinearMX, out
     if split_k != 1:
         ws = splitk_workspace(aq.device)
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
-    d.ep = _epilogue(out, w.N, w.bias if use_bias else None, None, act, residuals, act_after)
+    d.ep = _epilogue(out, w.N, w.bias if use_bias else None, None, act, residuals, act_after, aux, aux_mode, aux_after, out2,
+                     mx_out=mx_out, M=M)
     d.ep.act_n0 = act_n0
     check(L.load().mg_gemm_mx_fp8(C.byref(d), a_scales.data_ptr(), w.scales.data_ptr(), _stream()), "mg_gemm_mx_fp8")
     return out

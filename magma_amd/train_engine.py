@@ -148,6 +148,12 @@ class MagmaEngine:
         # with self.fp8: the attention FORWARD on the fp8 MFMA as well (BASELINE config[4]: "fp8 MFMA path for GPT-J attention";
         # mg_rotary_split_fp8 + mg_attn_prefill_fp8; the backward stays bf16).  MAGMA_FP8_ATTN=0 keeps the bf16 attention.
         self.fp8_attn = os.environ.get("MAGMA_FP8_ATTN", "1") == "1"
+        # with self.fp8: the two widest activations of a block never exist in bf16 -- gelu(fc_in) and its gradient leave the
+        # epilogues of the fc_in GEMM / the fc_out dgrad as OCP MX e4m3 (mg_epilogue.C8: one E8M0 scale per 32 elements, local to
+        # the tile that produces them) and feed fc_out / the fc_in dgrad through mg_gemm_mx_fp8 (MX-quantised weights there).
+        # Removes two of the seven quantisation passes per block -- the two over [B*S, 16384] -- and the bf16 round trip of
+        # both tensors.  MAGMA_TRAIN_FP8_MX=0: every fp8 GEMM on per-row scales with a quantisation pass in front (round 4).
+        self.fp8_mx = os.environ.get("MAGMA_TRAIN_FP8_MX", "1") == "1"
         if self.fp8 and self.lm_trainable:
             raise NotImplementedError("MAGMA_TRAIN_FP8 quantises the FROZEN block weights once; with freeze_lm: false they change every step")
         self._fp8_packs = {}
@@ -513,15 +519,29 @@ class MagmaEngine:
             sv[key + "_pre"] = pre
         return t
 
-    def _fgemm(self, key, x, lin, xq=None, **kw):
-        """GEMM against a FROZEN packed weight: bf16 tile GEMM, or (self.fp8) the fp8 MFMA on a per-row quantised x."""
+    def _fgemm(self, key, x, lin, xq=None, mx_out=False, **kw):
+        """GEMM against a FROZEN packed weight: bf16 tile GEMM, or (self.fp8) the fp8 MFMA on a per-row quantised x.
+        fp8 only: ``mx_out`` -> the result exists only as an MX e4m3 operand ("mx", q, scales), written by the epilogue;
+        an ``x`` of that form is multiplied by the MX-quantised weight (mg_gemm_mx_fp8), no quantisation pass."""
         if not self.fp8:
             return ops.gemm(x, lin, **kw)
+        mx_in = isinstance(x, tuple)
         w8 = self._fp8_packs.get(key)
-        if w8 is None:
-            w8 = self._fp8_packs[key] = ops.PackedLinearFP8(ops.PackedLinear.untile(lin.ft)[: lin.N, : lin.K], lin.bias)
-        q, sc = xq if xq is not None else ops.quantize_rows_fp8(x)
-        return ops.gemm_fp8(q, sc, w8, **kw)
+        if w8 is None or isinstance(w8, ops.PackedLinearMX) != mx_in:
+            cls = ops.PackedLinearMX if mx_in else ops.PackedLinearFP8
+            w8 = self._fp8_packs[key] = cls(ops.PackedLinear.untile(lin.ft)[: lin.N, : lin.K], lin.bias)
+        # the MX copy is written by the 256x256 fp8 kernel (K % 256 == 0 in fp8 elements) for whole 32-column blocks; other
+        # shapes (reduced test models) keep the bf16 output and the quantisation pass of the consumer
+        mx_out = mx_out and lin.K % 256 == 0 and lin.N % 32 == 0
+        if mx_out:
+            M = x[1].shape[0] if mx_in else (xq[0] if xq is not None else x).shape[0]
+            kw.update(mx_out=ops.mx_empty(M, lin.N, self.device), no_out=True, tile=256)
+        if mx_in:
+            y = ops.gemm_mx_fp8(x[1], x[2], w8, **kw)
+        else:
+            q, sc = xq if xq is not None else ops.quantize_rows_fp8(x)
+            y = ops.gemm_fp8(q, sc, w8, **kw)
+        return ("mx", *kw["mx_out"]) if mx_out else y
 
     def forward_train(self, images, captions, dropout_mask=None, captions_host=None) -> LMOutput:
         model = self.module
@@ -613,7 +633,7 @@ class MagmaEngine:
                 sv.update(a=a)
                 a = a2
             hpre = torch.empty(M, ly.fc_in.N, dtype=BF16, device=dev)
-            h = self._fgemm((li, "fc_in"), ln, ly.fc_in, lnq, act=ops.MG_ACT_GELU_NEW, out2=hpre)
+            h = self._fgemm((li, "fc_in"), ln, ly.fc_in, lnq, act=ops.MG_ACT_GELU_NEW, out2=hpre, mx_out=self.fp8 and self.fp8_mx)
             sv["hpre"] = hpre
             if self.lm_trainable:
                 sv["h"] = h                    # operand of the fc_out weight gradient
@@ -793,7 +813,8 @@ class MagmaEngine:
                 dm = self._adapter_dx(blk.mlp[1], dt, dn_t, sv["m"], res=g)
             else:
                 dm = g
-            dhpre = self._fgemm((li, "fc_out_t"), dm, pk["fc_out_t"], aux=sv["hpre"], aux_mode=ops.MG_AUX_GELU_GRAD)
+            dhpre = self._fgemm((li, "fc_out_t"), dm, pk["fc_out_t"], aux=sv["hpre"], aux_mode=ops.MG_AUX_GELU_GRAD,
+                                mx_out=self.fp8 and self.fp8_mx)
             dln_mlp = self._fgemm((li, "fc_in_t"), dhpre, pk["fc_in_t"])
             if self.lm_trainable:
                 a_mod, mlp_mod = ly._src

@@ -225,8 +225,9 @@ def test_w8a16_generate_tracks_bf16(dev, config):
 
 # ---------------------------------------------------------------------------------------------------- OCP MX block scaling
 def _mx_ref_quant(x):
-    """OCP MX v1.0 restated in torch: per 32 consecutive elements, shared exponent floor(log2 max|x|) - 8 (E8M0, bias 127),
-    elements = saturating e4m3 cast of x * 2^-shared.  Returns (e4m3 values as fp32 [M, Kp], E8M0 bytes [M, Kp/32])."""
+    """OCP MX restated in torch: per 32 consecutive elements, shared exponent floor(log2 max|x|) - 8 (E8M0, bias 127) -- raised
+    by one when the block maximum would land above 448 (round 5: the v1.0 formula saturates such maxima by up to 12.5 %; see
+    include/magma_hip.h) --, elements = e4m3 cast of x * 2^-shared.  Returns (e4m3 values as fp32 [M, Kp], E8M0 bytes [M, Kp/32])."""
     M, K = x.shape
     Kp = (K + 127) // 128 * 128
     xf = torch.zeros(M, Kp, device=x.device)
@@ -234,6 +235,7 @@ def _mx_ref_quant(x):
     blk = xf.view(M, Kp // 32, 32)
     amax = blk.abs().amax(-1)
     e = torch.where(amax > 0, torch.floor(torch.log2(amax)) - 8 + 127, torch.full_like(amax, 127.0)).clamp(0, 254)
+    e = torch.where(amax * torch.exp2(127.0 - e) > 448, (e + 1).clamp(max=254), e)
     q = (blk * torch.exp2(127.0 - e)[:, :, None]).clamp(-448, 448).to(torch.float8_e4m3fn).float()
     return q.view(M, Kp), e
 
@@ -401,3 +403,48 @@ def test_fp8_attention_forward(dev, B, H, S):
     wide = torch.full((B * S, d + 136), float("nan"), dtype=BF16, device=dev)
     ops.attn_prefill_fp8(op, wide[:, :d])
     assert torch.equal(wide[:, :d], out)
+
+
+@pytest.mark.parametrize("producer", ["row", "mx"])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 256), (300, 512, 512), (456, 1024, 1280), (1000, 4096, 1024)])
+def test_gemm_epilogue_writes_the_mx_copy(dev, producer, M, N, K):
+    """mg_epilogue.C8 (ABI 4): the 256x256 fp8 kernels write the OCP MX e4m3 copy of their output from the epilogue -- the
+    operand of the next mg_gemm_mx_fp8 without a quantisation pass.  The copy is bit for bit what mg_quantize_mx_fp8 makes of
+    the bf16 output (elements AND block scales), with every epilogue option in play (bias, GELU with the pre-activation copy,
+    a GELU-gradient aux operand, residuals); C == NULL writes the copy alone; and it feeds the MX GEMM like the quantiser's."""
+    from magma_amd import ops
+    g = torch.Generator(device=dev).manual_seed(M + N + K + 3)
+    a = torch.randn(M, K, device=dev, generator=g).to(BF16)
+    w = (torch.randn(N, K, device=dev, generator=g) * 0.05).to(BF16)
+    bias = torch.randn(N, device=dev, generator=g)
+    res = torch.randn(M, N, device=dev, generator=g).to(BF16)
+    aux = torch.randn(M, N, device=dev, generator=g).to(BF16)
+    if producer == "row":
+        lin = ops.PackedLinearFP8(w, bias=bias)
+        aq, asc = ops.quantize_rows_fp8(a)
+        run = lambda **kw: ops.gemm_fp8(aq, asc, lin, tile=256, **kw)
+    else:
+        lin = ops.PackedLinearMX(w, bias=bias)
+        aq, asc = ops.quantize_mx_fp8(a)
+        run = lambda **kw: ops.gemm_mx_fp8(aq, asc, lin, tile=256, **kw)
+    for kw in (dict(act=ops.MG_ACT_GELU_NEW, out2=torch.empty(M, N, dtype=BF16, device=dev)),
+               dict(aux=aux, aux_mode=ops.MG_AUX_GELU_GRAD),
+               dict(residuals=(res,)), dict()):
+        ref = run(**kw)                                   # bf16 output, no copy
+        rq, rs = ops.quantize_mx_fp8(ref.contiguous())
+        q, sc = ops.mx_empty(M, N, dev)
+        out = run(mx_out=(q, sc), **kw)
+        assert torch.equal(out, ref)
+        assert torch.equal(q[:, :N], rq[:, :N]), sorted(kw)
+        assert torch.equal(ops.mx_scales_rowmajor(sc, M, N), ops.mx_scales_rowmajor(rs, M, N)), sorted(kw)
+        q2, sc2 = ops.mx_empty(M, N, dev)
+        assert run(mx_out=(q2, sc2), no_out=True, **kw) is None
+        assert torch.equal(q2[:, :N], rq[:, :N]) and torch.equal(ops.mx_scales_rowmajor(sc2, M, N), ops.mx_scales_rowmajor(rs, M, N))
+    # consumer: the copy as the A operand of the MX GEMM
+    w2 = (torch.randn(256, N, device=dev, generator=g) * 0.05).to(BF16)
+    lin2 = ops.PackedLinearMX(w2)
+    y_fused = ops.gemm_mx_fp8(q, sc, lin2, out_dtype=torch.float32)
+    y_two = ops.gemm_mx_fp8(rq, rs, lin2, out_dtype=torch.float32)
+    assert torch.equal(y_fused, y_two)
+    with pytest.raises(Exception):
+        ops.gemm_fp8(*ops.quantize_rows_fp8(a), ops.PackedLinearFP8(w), tile=128, mx_out=ops.mx_empty(M, N, dev))

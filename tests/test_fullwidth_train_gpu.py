@@ -167,8 +167,8 @@ def test_gradients_four_blocks_deep_full_width_s2048(dev):
     assert 1 - cos_hip <= 2 * (1 - cos_bf) + 1e-3, (cos_hip, cos_bf)
 
 
-@pytest.mark.parametrize("fp8_attn", [False, True])
-def test_fp8_training_step_vs_oracle_on_dequantised_weights(dev, fp8_attn):
+@pytest.mark.parametrize("fp8_attn,fp8_mx", [(False, False), (True, False), (True, True)])
+def test_fp8_training_step_vs_oracle_on_dequantised_weights(dev, fp8_attn, fp8_mx):
     """BASELINE config[4], training side, at full width (d 4096, ff 16384, V 50258, S = 2048, one block, tiny trunk): the engine with
     eng.fp8 = True runs qkv / out_proj / fc_in / fc_out forward AND their dgrads on the fp8 MFMA (e4m3, per-row activation scales,
     per-output-channel weight scales).  Oracle: torch.autograd through the fp32 restatement evaluated on the DEQUANTISED e4m3
@@ -194,6 +194,8 @@ def test_fp8_training_step_vs_oracle_on_dequantised_weights(dev, fp8_attn):
     eng = MagmaEngine(model)
     eng.fp8 = True
     eng.fp8_attn = fp8_attn       # round 5: QK^T / PV of the attention forward on the fp8 MFMA as well (the oracle does not model it either)
+    eng.fp8_mx = fp8_mx           # round 5: gelu(fc_in) and its gradient exist only as OCP MX e4m3, written by the GEMM epilogues; fc_out
+                                  # and the fc_in dgrad multiply them by MX-quantised weights (whose dequantisation the oracle gets below)
     eng.train()
     B, S, P = 2, 2048, 4
     g = torch.Generator().manual_seed(9)
@@ -227,6 +229,17 @@ def test_fp8_training_step_vs_oracle_on_dequantised_weights(dev, fp8_attn):
 
     loss_deq, g_deq = oracle(deq)
     loss_unq, g_unq = oracle(params)
+    g_cal = g_deq
+    if fp8_mx:
+        # The yardstick e_w stays the one of the other two modes -- how far per-row / per-channel e4m3 weights move each gradient --:
+        # it stands for "an fp8 quantisation effect of this size", and the activation / gradient quantisation it is a proxy for
+        # did not shrink because two of the eight weight copies are now MX (whose own e_w is smaller: 0.025 against 0.039 on
+        # the trunk's BatchNorm gains).  The ORACLE the HIP step is compared with still runs on the weights the kernels multiply by.
+        from magma_amd import ops
+        cal = dict(deq)
+        for key, name in (((0, "fc_out"), mp + "c_proj.weight"),):
+            cal[name] = ops.PackedLinearFP8(params[name].to(dev).to(torch.bfloat16)).dequant().cpu()
+        _, g_cal = oracle(cal)
     name_of = {id(p): n for n, p in model.named_parameters()}
     seen, bad, rows = set(), [], []
     dot = nh = nr = dw = nu = 0.0
@@ -238,12 +251,12 @@ def test_fp8_training_step_vs_oracle_on_dequantised_weights(dev, fp8_attn):
                 continue
             seen.add(n)
             got, ref, unq = eng.grad_of(p).float().cpu().reshape(-1), g_deq[n].reshape(-1), g_unq[n].reshape(-1)
-            e_hip, e_w = rel(got, ref), rel(ref, unq)
+            e_hip, e_w = rel(got, ref), rel(g_cal[n].reshape(-1), unq)
             rows.append((e_hip - 2.5 * e_w, n, e_hip, e_w))
             if e_hip > 2.5 * e_w + 3e-2:
                 bad.append((n, e_hip, e_w))
             dot += float((got * ref).sum()); nh += float((got * got).sum()); nr += float((ref * ref).sum())
-            dw += float(((ref - unq) ** 2).sum()); nu += float(((got - ref) ** 2).sum())
+            dw += float(((g_cal[n].reshape(-1) - unq) ** 2).sum()); nu += float(((got - ref) ** 2).sum())
     rows.sort(reverse=True)
     cos = dot / (nh ** 0.5 * nr ** 0.5)
     e_glob, ew_glob = (nu / nr) ** 0.5, (dw / nr) ** 0.5

@@ -226,6 +226,27 @@ def main():
                         r[name + "_tflops"] = fl / ms / 1e9
                         r[name + "_frac_of_5PF"] = fl / ms / 1e9 / 5000.0
                 emit(**r)
+    if which == "q8":   # the fp8 256x256 GEMM with and without the MX e4m3 copy written by its epilogue (mg_epilogue.C8)
+        M, N, K = 32768, 16384, 4096
+        a = torch.randn(M, K, device=dev).to(BF16)
+        w = (torch.randn(N, K, device=dev) * 0.05).to(BF16)
+        lin8 = ops.PackedLinearFP8(w)
+        aq, asc = ops.quantize_rows_fp8(a)
+        out = torch.empty(M, N, dtype=BF16, device=dev)
+        pre = torch.empty(M, N, dtype=BF16, device=dev)
+        aux = torch.randn(M, N, device=dev).to(BF16)
+        q, sc = ops.mx_empty(M, N, dev)
+        fl = 2.0 * M * N * K
+        for name, fn in (("fwd_bf16_out", lambda i: ops.gemm_fp8(aq, asc, lin8, out=out, act=1, out2=pre)),
+                         ("fwd_mx_only", lambda i: ops.gemm_fp8(aq, asc, lin8, act=1, out2=pre, mx_out=(q, sc), no_out=True)),
+                         ("fwd_mx_and_bf16", lambda i: ops.gemm_fp8(aq, asc, lin8, out=out, act=1, out2=pre, mx_out=(q, sc))),
+                         ("dgrad_bf16_out", lambda i: ops.gemm_fp8(aq, asc, lin8, out=out, aux=aux, aux_mode=ops.MG_AUX_GELU_GRAD)),
+                         ("dgrad_mx_only", lambda i: ops.gemm_fp8(aq, asc, lin8, aux=aux, aux_mode=ops.MG_AUX_GELU_GRAD, mx_out=(q, sc), no_out=True)),
+                         ("plain_bf16_out", lambda i: ops.gemm_fp8(aq, asc, lin8, out=out)),
+                         ("plain_mx_only", lambda i: ops.gemm_fp8(aq, asc, lin8, mx_out=(q, sc), no_out=True)),
+                         ("quantize_mx_pass", lambda i: ops.quantize_mx_fp8(out)), ("quantize_rows_pass", lambda i: ops.quantize_rows_fp8(out))):
+            ms = timeit(fn, 5)
+            emit(kind="q8", case=name, M=M, N=N, K=K, ms=ms, tflops=fl / ms / 1e9 if "quantize" not in name else None)
     if which == "lib":   # calibration: the vendor libraries on the same shapes (torch.matmul -> hipBLASLt / rocBLAS, SDPA)
         for (M, N, K, tag) in [(32768, 12288, 4096, "qkv"), (32768, 4096, 4096, "out_proj"), (32768, 16384, 4096, "fc_in"),
                                (32768, 4096, 16384, "fc_out"), (8192, 8192, 8192, "square8k"), (456, 28672, 4096, "prefill_qkv_fc_in")]:
