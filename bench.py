@@ -893,10 +893,32 @@ def main():
                     line["magma_v2"] = variant_v2(args, dev)
                 except Exception as e:  # noqa: BLE001
                     line["magma_v2"] = {"error": repr(e)[:300]}
+    if world == 1:
+        _flush_c_stdio()
         print(json.dumps(line), flush=True)
-    if world > 1:
-        torch.distributed.barrier()          # rank 0 measured the roofline objects alone: leave together
-        torch.distributed.destroy_process_group()
+        return
+    # N ranks share one stdout.  The line has to be the LAST thing on it: RCCL (and gloo) write banners through C stdio, which is
+    # block-buffered on a pipe and would otherwise drain at interpreter exit, behind the line.  So: leave the group together, every
+    # rank pushes out what its C runtime still holds, ranks > 0 exit without running exit handlers, rank 0 prints last.
+    torch.distributed.barrier()          # rank 0 measured the roofline objects alone: leave together
+    torch.distributed.destroy_process_group()
+    _flush_c_stdio()
+    if rank != 0:
+        os._exit(0)
+    time.sleep(1.0)                      # the other ranks' last bytes reach the shared pipe first
+    print(json.dumps(line), flush=True)
+    sys.stderr.flush()
+    os._exit(0)
+
+
+def _flush_c_stdio():
+    sys.stdout.flush()
+    sys.stderr.flush()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001
+        pass
 
 
 if __name__ == "__main__":
