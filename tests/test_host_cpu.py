@@ -631,3 +631,38 @@ def test_lm_output_lazy_values_resolve_on_every_conversion():
     assert isinstance(back, LMOutput) and torch.equal(back.logits, torch.ones(2))
     n = len(calls)
     assert o.logits is o.logits and len(calls) == n + 1 and not o.is_lazy("logits")      # computed once, then stored
+
+
+def test_ctypes_structs_have_the_layout_of_the_header(tmp_path):
+    """The descriptors cross the C ABI by value-in-memory: every ctypes mirror in magma_amd/lib.py (and with it the stub in
+    INTEGRATION.md) must have the size and the field offsets the C compiler gives include/magma_hip.h.  gcc compiles a probe
+    that prints offsetof() of every field; compared field by field."""
+    import ctypes as C
+    import subprocess
+    from magma_amd import lib as L
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    structs = {"mg_epilogue": L.Epilogue, "mg_gemm_desc": L.GemmDesc, "mg_skinny_desc": L.SkinnyDesc}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "magma_hip.h"', 'int main(void) {']
+    for cname, cls in structs.items():
+        lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  printf("abi %d\\n", MG_ABI_VERSION);', '  return 0;', '}']
+    src = tmp_path / "probe.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "probe"
+    subprocess.run(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], check=True)
+    got = {}
+    for ln in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines():
+        parts = ln.split()
+        got[tuple(parts[:-1])] = int(parts[-1])
+    assert got[("abi",)] == L.ABI_VERSION
+    for cname, cls in structs.items():
+        assert got[(cname, "size")] == C.sizeof(cls), (cname, got[(cname, "size")], C.sizeof(cls))
+        for fname, _ in cls._fields_:
+            assert got[(cname, fname)] == getattr(cls, fname).offset, (cname, fname)
+    # the stub in INTEGRATION.md names the same epilogue fields in the same order
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    stub = text[text.index("class mg_epilogue(C.Structure)"):text.index("class mg_gemm_desc(C.Structure)")]
+    import re
+    assert re.findall(r'\("(\w+)",', stub) == [f for f, _ in L.Epilogue._fields_]
