@@ -68,12 +68,19 @@ def parse():
                     help="launch check: N ranks are started exactly as for a real run (self-launch or torch.distributed.run), join "
                          "the process group, run the bench's barrier / MAX-over-ranks collectives and rank 0 prints a line with "
                          "n_gpus = N and value = null; no model, no GPU needed with MAGMA_BENCH_BACKEND=gloo")
+    ap.add_argument("--train-only", action="store_true",
+                    help="only the training leg (BASELINE's 'train images/sec, whole node'): metric / value / ms_per_step / roofline "
+                         "of the line are the training step's; the generate legs, variants and config1 are skipped -- a multi-GPU "
+                         "record that fits a short lease")
     ap.add_argument("--variants", action=argparse.BooleanOptionalAction, default=True,
                     help="N = 1 only: also time BASELINE config[3] (MAGMA_v2: attention + MLP adapters) and the model-native 384^2 "
                          "images as extra objects ('magma_v2', 'generate_res384'); never in 'value'")
     args = ap.parse_args()
     if args.fp8 == "off":
         args.fp8 = None
+    if args.train_only:
+        args.variants = False
+        args.train_steps = max(1, args.train_steps)
     return args
 
 
@@ -571,6 +578,44 @@ def variant_v2(args, dev):
     return out
 
 
+def config1_leg(model, dev):
+    """BASELINE config[0] at its stated shape on the model of this run (reference README.md:84, magma/magma.py:176-212): one
+    224 x 224 image FILE + an 8-token prompt -> preprocess_inputs (resize to the model-native resolution, prefix tokens) ->
+    (1, P + 8, 4096) -> LM forward.  Pass = shapes as stated + finite logits + the caller's list mutated as the reference does;
+    wall seconds of the second call (the first pays one-time packing).  The reference runs this on device='cpu'; parity of the
+    same path against the oracle is tests/test_config1_gpu.py."""
+    import tempfile
+    import numpy as np
+    import PIL.Image as I
+    from magma_amd import ImageInput
+    rng = np.random.RandomState(3)
+    arr = (rng.rand(224, 224, 3) * 255).astype(np.uint8)
+    prompt = "Describe"          # 8 tokens under the byte-level stand-in tokenizer (no GPT-2 files offline); preprocess_inputs takes str / ImageInput only
+    n_tok = int(model.tokenizer.encode(prompt, return_tensors="pt").shape[1])
+    P = model.image_prefix_seq_len
+    d = model.lm.config.hidden_size
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "image.png")
+        I.fromarray(arr).save(path)
+        wall = None
+        for _ in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            inputs = [ImageInput(path), prompt]
+            with torch.no_grad():
+                emb = model.preprocess_inputs(inputs)
+                logits = model.lm(inputs_embeds=emb).logits
+            finite = bool(torch.isfinite(logits.float()).all())
+            torch.cuda.synchronize()
+            wall = time.perf_counter() - t0
+    res = model.image_prefix.enc.input_resolution
+    ok = (tuple(emb.shape) == (1, P + n_tok, d) and tuple(logits.shape)[:2] == (1, P + n_tok) and finite
+          and tuple(inputs[0].shape) == (1, 3, res, res) and tuple(inputs[1].shape) == (1, n_tok))
+    return {"pass": bool(ok), "wall_s": wall, "embeddings_shape": list(emb.shape), "logits_shape": list(logits.shape),
+            "layers": model.lm.config.num_layers, "image": "224x224 RGB file", "prompt_tokens": n_tok, "device": str(dev),
+            "note": "BASELINE config[0] (plumbing) on the GPU: this build has no CPU execution path; parity vs the oracle in tests/test_config1_gpu.py"}
+
+
 def _free_port():
     import socket
     with socket.socket() as s:
@@ -681,169 +726,184 @@ def main():
     images = torch.randn(B, 3, args.res, args.res, device=dev, generator=g).to(torch.bfloat16)
     prompt = torch.randint(0, 50256, (B, args.prompt), device=dev, generator=g)
 
-    def one_step():
-        emb = model.embed([images, prompt])
-        return model.generate(emb, max_steps=gen, temperature=0.0, decode=False, stop_on_eos=False)
-
-    def sync():
-        torch.cuda.synchronize()
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        one_step()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        toks = one_step()
-    sync()
-    dt = time.perf_counter() - t0
-    gen_per_rank = [round(dt / args.steps * 1e3, 4)]
-    if world > 1:
-        gen_per_rank = per_rank_ms(dt, dev, args.steps)
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t)
-    ms_step = dt / args.steps * 1e3
-    value = world * B * gen / (dt / args.steps)
-
-    # ---- roofline of the dominant kernel (decode weight streaming), measured live ----
-    roof = None
-    if rank == 0:
-        emb = model.embed([images, prompt])
-        out = model.lm(inputs_embeds=emb, use_cache=True, cache_hint=gen + 40)
-        cache = out.past_key_values
-        tok = out.logits[:, -1].argmax(-1, keepdim=True)
-        for _ in range(3):                                       # eager, capture, first replay
-            eng.decode(tok, cache)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        n_rep = 20
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(n_rep):
-            eng.decode(tok, cache)
-        e1.record()
-        torch.cuda.synchronize()
-        ms_tok = e0.elapsed_time(e1) / n_rep
-        # dominant kernel in isolation: every decode GEMV of the model (all layers + head) launched
-        # back to back on the real weights (12.16 GB, far beyond the 256 MiB Infinity Cache), HIP events
-        # on the launch stream.  achieved = algorithmic bytes per launch / average launch duration.
-        st = cache.decode_state
-        jobs, wbytes, shapes = decode_gemv_jobs(eng, st)
-
-        def sweep():
-            for fn in jobs:
-                fn()
-
-        gk = torch.cuda.CUDAGraph()
-        sweep()
-        torch.cuda.synchronize()
-        with torch.cuda.graph(gk):
-            sweep()
-        gk.replay()
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(10):
-            gk.replay()
-        e1.record()
-        torch.cuda.synchronize()
-        ms_sweep = e0.elapsed_time(e1) / 10
-        sweep_achieved = wbytes / (ms_sweep * 1e-3) / 1e9
-        achieved = wbytes / (ms_tok * 1e-3) / 1e9      # the launches the captured token step RUNS (attention co-launches, argmax, bookkeeping included)
-        traffic, traffic_src = pmc_traffic_per_launch(shapes)
-        roof = {"bound": "hbm", "kernel": "skinny_kernel (decode weight-streaming GEMM, M=8): the captured token step",
-                "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                # the same weight streams as bare GEMVs back to back (fc_out as a plain GEMV instead of the attention co-launch)
-                "sweep_achieved": sweep_achieved, "sweep_frac": sweep_achieved / 8000.0,
-                # HBM bytes per launch from the PMC pass over this sweep (per GEMV shape), not measured in this run
-                "traffic": traffic, "traffic_source": traffic_src,
-                "bytes_per_launch": wbytes / len(jobs), "launches": len(jobs),
-                "streamed_bytes": sum(n * k * 2 for n, k in shapes), "algorithmic_bytes": wbytes,
-                "block": {0: "4 launches", 1: "3 launches (adapter-down folded through fc_out)", 2: "4 launches, [W_out | W_up] K-concatenated"}.get(eng.fold_dn, "?"),
-                "avg_launch_us": ms_sweep * 1e3 / len(jobs),
-                "token_step": {"ms": ms_tok, "decode_tokens_per_s": B / (ms_tok * 1e-3),
-                               "hbm_frac_whole_step": wbytes / (ms_tok * 1e-3) / 8e12}}
-
-    # the reference's DEFAULT generate() settings (temperature 0.7, top_p 0.9, magma.py:214-221): the sampled branch -- top-p
-    # rule, softmax, multinomial -- runs inside the same captured token step (csrc/sampling.hip); never the headline
-    gen_s = None
-    try:
-        def sampled_step():
+    value = ms_step = roof = gen_s = gen_h = gen8 = gen_per_rank = toks = None
+    if not args.train_only:
+        def one_step():
             emb = model.embed([images, prompt])
-            return model.generate(emb, max_steps=gen, temperature=0.7, top_k=0, top_p=0.9, decode=False, stop_on_eos=False, seed=1)
-        sampled_step()
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            sampled_step()
-        sync()
-        dts = (time.perf_counter() - t0) / args.steps
-        gen_s = {"mode": "temperature 0.7, top_p 0.9 (reference defaults), device-side sampling in the decode graph",
-                 "tokens_per_s": world * B * gen / dts, "ms_per_call": dts * 1e3, "vs_greedy": (dt / args.steps) / dts}
-    except Exception as e:  # noqa: BLE001
-        gen_s = {"error": repr(e)[:300]}
-
-    # the reference's callers hand over HOST tensors (preprocess_inputs -> CPU float images); `value` above starts with the
-    # inputs resident in HBM, this leg adds the H2D copy + cast of the batch (pinned fp32 images, int64 prompt) to every call
-    gen_h = None
-    try:
-        images_h, prompt_h = images.float().cpu().pin_memory(), prompt.cpu().pin_memory()
-
-        def host_step():
-            emb = model.embed([images_h.to(dev, non_blocking=True).to(torch.bfloat16), prompt_h.to(dev, non_blocking=True)])
             return model.generate(emb, max_steps=gen, temperature=0.0, decode=False, stop_on_eos=False)
-        host_step()
+
+        def sync():
+            torch.cuda.synchronize()
+            if world > 1:
+                torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+        for _ in range(args.warmup):
+            one_step()
         sync()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            host_step()
+            toks = one_step()
         sync()
-        dth = (time.perf_counter() - t0) / args.steps
-        gen_h = {"mode": "inputs start in pinned host memory (fp32 images, int64 prompt): PCIe copy + cast inside the timed region",
-                 "tokens_per_s": world * B * gen / dth, "ms_per_call": dth * 1e3, "h2d_bytes_per_call": int(images_h.numel() * 4 + prompt_h.numel() * 8)}
-    except Exception as e:  # noqa: BLE001
-        gen_h = {"error": repr(e)[:300]}
+        dt = time.perf_counter() - t0
+        gen_per_rank = [round(dt / args.steps * 1e3, 4)]
+        if world > 1:
+            gen_per_rank = per_rank_ms(dt, dev, args.steps)
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t)
+        ms_step = dt / args.steps * 1e3
+        value = world * B * gen / (dt / args.steps)
 
-    gen8 = None
-    if args.fp8:
-        # BASELINE config[4] on the inference side: e4m3 weights in every decode GEMV (W8A16: bf16 activations, weights
-        # widened in registers -> half the bytes per token step) + fp8 MFMA projections in the prefill.  Different
-        # numerics (weight quantisation), so this is a separate object and never the headline `value`.
-        eng.decode_w8, eng.fp8_mode = True, args.fp8
-        eng._cache_pool.clear()
+        # ---- roofline of the dominant kernel (decode weight streaming), measured live ----
+        roof = None
+        if rank == 0:
+            emb = model.embed([images, prompt])
+            out = model.lm(inputs_embeds=emb, use_cache=True, cache_hint=gen + 40)
+            cache = out.past_key_values
+            tok = out.logits[:, -1].argmax(-1, keepdim=True)
+            for _ in range(3):                                       # eager, capture, first replay
+                eng.decode(tok, cache)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n_rep = 20
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(n_rep):
+                eng.decode(tok, cache)
+            e1.record()
+            torch.cuda.synchronize()
+            ms_tok = e0.elapsed_time(e1) / n_rep
+            # dominant kernel in isolation: every decode GEMV of the model (all layers + head) launched
+            # back to back on the real weights (12.16 GB, far beyond the 256 MiB Infinity Cache), HIP events
+            # on the launch stream.  achieved = algorithmic bytes per launch / average launch duration.
+            st = cache.decode_state
+            jobs, wbytes, shapes = decode_gemv_jobs(eng, st)
+
+            def sweep():
+                for fn in jobs:
+                    fn()
+
+            gk = torch.cuda.CUDAGraph()
+            sweep()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(gk):
+                sweep()
+            gk.replay()
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(10):
+                gk.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            ms_sweep = e0.elapsed_time(e1) / 10
+            sweep_achieved = wbytes / (ms_sweep * 1e-3) / 1e9
+            achieved = wbytes / (ms_tok * 1e-3) / 1e9      # the launches the captured token step RUNS (attention co-launches, argmax, bookkeeping included)
+            traffic, traffic_src = pmc_traffic_per_launch(shapes)
+            roof = {"bound": "hbm", "kernel": "skinny_kernel (decode weight-streaming GEMM, M=8): the captured token step",
+                    "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                    # the same weight streams as bare GEMVs back to back (fc_out as a plain GEMV instead of the attention co-launch)
+                    "sweep_achieved": sweep_achieved, "sweep_frac": sweep_achieved / 8000.0,
+                    # HBM bytes per launch from the PMC pass over this sweep (per GEMV shape), not measured in this run
+                    "traffic": traffic, "traffic_source": traffic_src,
+                    "bytes_per_launch": wbytes / len(jobs), "launches": len(jobs),
+                    "streamed_bytes": sum(n * k * 2 for n, k in shapes), "algorithmic_bytes": wbytes,
+                    "block": {0: "4 launches", 1: "3 launches (adapter-down folded through fc_out)", 2: "4 launches, [W_out | W_up] K-concatenated"}.get(eng.fold_dn, "?"),
+                    "avg_launch_us": ms_sweep * 1e3 / len(jobs),
+                    "token_step": {"ms": ms_tok, "decode_tokens_per_s": B / (ms_tok * 1e-3),
+                                   "hbm_frac_whole_step": wbytes / (ms_tok * 1e-3) / 8e12}}
+
+        # the reference's DEFAULT generate() settings (temperature 0.7, top_p 0.9, magma.py:214-221): the sampled branch -- top-p
+        # rule, softmax, multinomial -- runs inside the same captured token step (csrc/sampling.hip); never the headline
+        gen_s = None
         try:
-            one_step()
+            def sampled_step():
+                emb = model.embed([images, prompt])
+                return model.generate(emb, max_steps=gen, temperature=0.7, top_k=0, top_p=0.9, decode=False, stop_on_eos=False, seed=1)
+            sampled_step()
             sync()
             t0 = time.perf_counter()
             for _ in range(args.steps):
-                one_step()
+                sampled_step()
             sync()
-            dt8 = (time.perf_counter() - t0) / args.steps
-            gen8 = {"mode": f"decode W8A16 + prefill fp8 '{args.fp8}'", "tokens_per_s": world * B * gen / dt8, "ms_per_call": dt8 * 1e3,
-                    "speedup_vs_bf16": (dt / args.steps) / dt8}
-        except Exception as e:  # noqa: BLE001  (the bf16 line must survive a failure of the extra leg)
-            gen8 = {"error": repr(e)[:300]}
-        finally:
-            eng.decode_w8, eng.fp8_mode = False, None
+            dts = (time.perf_counter() - t0) / args.steps
+            gen_s = {"mode": "temperature 0.7, top_p 0.9 (reference defaults), device-side sampling in the decode graph",
+                     "tokens_per_s": world * B * gen / dts, "ms_per_call": dts * 1e3, "vs_greedy": (dt / args.steps) / dts}
+        except Exception as e:  # noqa: BLE001
+            gen_s = {"error": repr(e)[:300]}
+
+        # the reference's callers hand over HOST tensors (preprocess_inputs -> CPU float images); `value` above starts with the
+        # inputs resident in HBM, this leg adds the H2D copy + cast of the batch (pinned fp32 images, int64 prompt) to every call
+        gen_h = None
+        try:
+            images_h, prompt_h = images.float().cpu().pin_memory(), prompt.cpu().pin_memory()
+
+            def host_step():
+                emb = model.embed([images_h.to(dev, non_blocking=True).to(torch.bfloat16), prompt_h.to(dev, non_blocking=True)])
+                return model.generate(emb, max_steps=gen, temperature=0.0, decode=False, stop_on_eos=False)
+            host_step()
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                host_step()
+            sync()
+            dth = (time.perf_counter() - t0) / args.steps
+            gen_h = {"mode": "inputs start in pinned host memory (fp32 images, int64 prompt): PCIe copy + cast inside the timed region",
+                     "tokens_per_s": world * B * gen / dth, "ms_per_call": dth * 1e3, "h2d_bytes_per_call": int(images_h.numel() * 4 + prompt_h.numel() * 8)}
+        except Exception as e:  # noqa: BLE001
+            gen_h = {"error": repr(e)[:300]}
+
+        gen8 = None
+        if args.fp8:
+            # BASELINE config[4] on the inference side: e4m3 weights in every decode GEMV (W8A16: bf16 activations, weights
+            # widened in registers -> half the bytes per token step) + fp8 MFMA projections in the prefill.  Different
+            # numerics (weight quantisation), so this is a separate object and never the headline `value`.
+            eng.decode_w8, eng.fp8_mode = True, args.fp8
             eng._cache_pool.clear()
+            try:
+                one_step()
+                sync()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    one_step()
+                sync()
+                dt8 = (time.perf_counter() - t0) / args.steps
+                gen8 = {"mode": f"decode W8A16 + prefill fp8 '{args.fp8}'", "tokens_per_s": world * B * gen / dt8, "ms_per_call": dt8 * 1e3,
+                        "speedup_vs_bf16": (dt / args.steps) / dt8}
+            except Exception as e:  # noqa: BLE001  (the bf16 line must survive a failure of the extra leg)
+                gen8 = {"error": repr(e)[:300]}
+            finally:
+                eng.decode_w8, eng.fp8_mode = False, None
+                eng._cache_pool.clear()
     if rank == 0:
         cname = os.path.splitext(os.path.basename(str(args.config)))[0]
         adapters = "MLP adapters" if cname == "MAGMA_v1" else ("attention + MLP adapters" if cname == "MAGMA_v2" else "adapters per config")
-        line = {"metric": f"generate tokens/sec ({cname}, batch-{B} images, {gen} new tokens, greedy)",
-                "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "bf16", "data": "synthetic",
-                "config": {"workload": f"{cname} (CLIP RN50x16 + GPT-J-6B + {adapters}) bf16 inference: batch {B} "
-                                       f"{args.res}x{args.res} images + {args.prompt}-token prompt -> {gen} greedy tokens",
-                           "parallelism": f"replicas x{world}", "layers": model.lm.config.num_layers,
-                           "prefill_len": int(toks.shape[1] - gen)},
-                "per_rank_ms": gen_per_rank,          # each rank's own time per step (the headline divides by the MAX)
-                "roofline": roof}
-        line["generate_sampled"] = gen_s
-        line["generate_from_host"] = gen_h
-        if gen8 is not None:
-            line["generate_fp8"] = gen8
+        if args.train_only:
+            # a short-lease multi-GPU record: BASELINE's first metric half alone ("train images/sec, whole node"); value / ms_per_step /
+            # roofline are filled from the training leg below
+            line = {"metric": f"train images/sec ({cname} training step, per-GPU batch {args.train_batch}, S = {model.seq_len}, whole job)",
+                    "value": None, "unit": "images/s", "n_gpus": world, "steps": args.train_steps, "warmup": args.train_warmup,
+                    "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                    "dtype": "bf16", "data": "synthetic",
+                    "config": {"workload": f"{cname} (CLIP RN50x16 + GPT-J-6B + {adapters}) bf16 training step: per-GPU batch "
+                                           f"{args.train_batch} synthetic {args.res}x{args.res} image-caption pairs, S = {model.seq_len}, "
+                                           f"adapters + image encoder + prefix trainable, clip + AdamW in the timed region",
+                               "parallelism": f"dp{world}", "layers": model.lm.config.num_layers},
+                    "train_only": True, "roofline": {"bound": "mfma"}}
+        else:
+            line = {"metric": f"generate tokens/sec ({cname}, batch-{B} images, {gen} new tokens, greedy)",
+                    "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                    "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                    "dtype": "bf16", "data": "synthetic",
+                    "config": {"workload": f"{cname} (CLIP RN50x16 + GPT-J-6B + {adapters}) bf16 inference: batch {B} "
+                                           f"{args.res}x{args.res} images + {args.prompt}-token prompt -> {gen} greedy tokens",
+                               "parallelism": f"replicas x{world}", "layers": model.lm.config.num_layers,
+                               "prefill_len": int(toks.shape[1] - gen)},
+                    "per_rank_ms": gen_per_rank,          # each rank's own time per step (the headline divides by the MAX)
+                    "roofline": roof}
+            line["generate_sampled"] = gen_s
+            line["generate_from_host"] = gen_h
+            if gen8 is not None:
+                line["generate_fp8"] = gen8
         line["train"] = None
     train = None
     if args.train_steps > 0:
@@ -870,11 +930,32 @@ def main():
                         line["roofline"]["train_fp8"] = {"error": repr(e)[:200]}
             except Exception as e:  # noqa: BLE001
                 line["roofline"]["train"] = {"error": repr(e)[:200]}
-        # data-parallel training throughput of the whole job (BASELINE metric, first half), next to the headline
+        # data-parallel training throughput of the whole job (BASELINE metric, first half), next to the headline -- and, at the top
+        # level where a flat parser keeps them, what a scaling curve is computed from: every rank's own step time, the gradient
+        # exchange's exposed time and the exchange stream's busy time per step
         full = (train or {}).get("full_S2048") or {}
+        dpo = (train or {}).get("data_parallel") or {}
         line["train_images_per_s"] = full.get("images_per_s")
+        line["train_ms_per_step"] = full.get("ms_per_step")
         line["train_ranks"] = world
-        if not args.no_cpu_baseline and world == 1:   # reported on rank 0 at N=1 only
+        line["train_per_gpu_batch"] = args.train_batch
+        line["train_per_rank_step_ms"] = dpo.get("per_rank_step_ms") or ([round(full["ms_per_step"], 4)] if full.get("ms_per_step") else None)
+        line["train_exposed_comm_ms"] = dpo.get("exposed_comm_ms_per_step")
+        line["train_comm_stream_busy_ms"] = dpo.get("comm_stream_busy_ms_per_step")
+        if args.train_only:
+            line["value"], line["ms_per_step"] = full.get("images_per_s"), full.get("ms_per_step")
+            mf = (line.get("roofline") or {}).get("train")
+            if isinstance(mf, dict) and "achieved" in mf:      # the dominant kernel of THIS workload in the contract's own keys
+                line["roofline"].update({"bound": "mfma", "kernel": mf["kernel"], "achieved": mf["achieved"], "peak": mf["peak"],
+                                         "unit": mf["unit"], "frac": mf["frac"], "traffic": None})
+        elif world == 1 and args.layers is None:
+            try:
+                line["config1"] = config1_leg(model, dev)
+            except Exception as e:  # noqa: BLE001
+                line["config1"] = {"pass": False, "error": repr(e)[:300]}
+        if not args.no_cpu_baseline:
+            # rank 0 only, AFTER the last timed region; at N > 1 the other ranks are parked at the final barrier meanwhile (the
+            # process group's timeout is 30 min), so the first multi-GPU record carries its CPU baseline too
             try:
                 line["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
             except Exception as e:  # noqa: BLE001

@@ -17,6 +17,18 @@ import torch
 import torch.nn as nn
 
 
+# Raw-pointer writers of adapter parameters (the engines' fused AdamW, checkpoint loads through the flat groups) do not bump a
+# tensor's _version and keep its data_ptr: they bump THIS counter instead, and Adapter.adapter_branch keys its packed operands
+# on it next to (_version, data_ptr) of weight and bias -- stale packs are dropped without repacking on every call.
+_WEIGHTS_EPOCH = 0
+
+
+def bump_weights_epoch() -> int:
+    global _WEIGHTS_EPOCH
+    _WEIGHTS_EPOCH += 1
+    return _WEIGHTS_EPOCH
+
+
 def activation_codes(act: nn.Module):
     """(epilogue activation, epilogue gradient mode, gradient needs the PRE-activation) of an adapter activation module.
     reference adapters.py:11,20 takes any nn.Module class; the fused epilogues cover ReLU (the default), torch.nn.GELU() (erf) and
@@ -92,15 +104,20 @@ class Adapter(nn.Module):
             xin = x2
             if self.ln is not None:
                 xin = ops.layernorm(x2, self.ln.weight.detach().float().contiguous(), self.ln.bias.detach().float().contiguous(), self.ln.eps)
-            # padded row-major operands built per call from the live parameters: the engines' optimizer step writes the
-            # parameters through raw pointers (no _version bump, same data_ptr), and a bias changes independently of its
-            # weight -- a cache keyed on either would serve pre-step values.  This is the module-call convenience path
+            # padded row-major operands of the live parameters, cached on (epoch, _version, data_ptr) of each weight AND bias:
+            # in-place torch updates bump _version, a re-assigned .data changes data_ptr, and the engines' raw-pointer
+            # optimizer step bumps the module-level epoch (bump_weights_epoch).  This is the module-call convenience path
             # (reference adapters.py:38-39); the engines keep their own packed operands.
-            packs = (None,
-                ops.RawWeight(ops.pad_k_rowmajor(dn.weight.detach().to(torch.bfloat16)), K=dn.weight.shape[1],
-                              bias=dn.bias.detach().float().contiguous()),
-                ops.RawWeight(ops.pad_k_rowmajor(up.weight.detach().to(torch.bfloat16)), K=up.weight.shape[1],
-                              bias=up.bias.detach().float().contiguous()))
+            key = (_WEIGHTS_EPOCH,) + tuple((t._version, t.data_ptr(), t.device) for t in (dn.weight, dn.bias, up.weight, up.bias))
+            cached = self.__dict__.get("_pack_cache")
+            if cached is None or cached[0] != key:
+                cached = (key,
+                    ops.RawWeight(ops.pad_k_rowmajor(dn.weight.detach().to(torch.bfloat16)), K=dn.weight.shape[1],
+                                  bias=dn.bias.detach().float().contiguous()),
+                    ops.RawWeight(ops.pad_k_rowmajor(up.weight.detach().to(torch.bfloat16)), K=up.weight.shape[1],
+                                  bias=up.bias.detach().float().contiguous()))
+                self.__dict__["_pack_cache"] = cached
+            packs = cached
             erf = code == ops.MG_ACT_GELU_ERF
             t = ops.gemm(xin, packs[1], act=ops.MG_ACT_NONE if erf else code, layout="rm")
             if erf:

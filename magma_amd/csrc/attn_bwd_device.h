@@ -4,7 +4,7 @@
 #include "common.h"
 #include "attn_tile_device.h"
 
-constexpr int LD_TILE = 256;              // 32 x {lse*log2e, D}
+constexpr int LD_TILE = 256;              // the statistics of 32 queries, {-16 lse, -D} (fp32): 8 B each, interleaved or as two arrays of 32
 
 // Where a gradient row goes.  merged == nullptr: out[(bh*S + s)*256 + d] (dq / dk / dv as [B,H,S,256]).  Otherwise the
 // row lands in the gradient of the fused qkv projection, merged[(b*S + s)*3*H*256 + which*H*256 + h*256 + d], with the

@@ -101,8 +101,9 @@ class ModifiedResNetTrunk(nn.Module):
         if self._packed is not None:
             return self._packed
         if self.training:
-            raise NotImplementedError("batch-statistics BatchNorm is not implemented; the reference runs the tower "
-                                      "in eval mode until its first eval phase (SURVEY Q5)")
+            raise RuntimeError("the packed (BatchNorm-folded) operands of the trunk are inference operands: in training mode the "
+                               "tower runs through magma_amd.train_engine (batch-statistics BatchNorm, running-stat updates) -- "
+                               "call .eval() for the module-call path (SURVEY Q5)")
         pk = {"conv1": self._pack_conv(self.conv1, self.bn1), "conv2": self._pack_conv(self.conv2, self.bn2),
               "conv3": self._pack_conv(self.conv3, self.bn3)}
         for li in range(1, 5):

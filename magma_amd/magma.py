@@ -30,6 +30,38 @@ from .transforms import get_transforms
 from .utils import build_labels, get_tokenizer, print_main
 
 
+def _load_checkpoint_file(path):
+    """torch.load to host memory: the safe unpickler first, the reference's full unpickle (magma.py:292) only on opt-in."""
+    import argparse
+    import pickle
+    safe = [argparse.Namespace]
+    try:      # numpy scalars (DeepSpeed's step counters): the reconstructor, numpy.dtype and the dtype classes it is called with
+        import numpy as np
+        safe += [np.dtype, np.ndarray]
+        safe += [c for c in vars(getattr(np, "dtypes", None) or object()).values() if isinstance(c, type)]
+        for mod in ("numpy._core.multiarray", "numpy.core.multiarray"):
+            try:
+                m = __import__(mod, fromlist=["scalar"])
+                safe += [m.scalar, m._reconstruct]
+                break
+            except Exception:
+                continue
+    except Exception:
+        pass
+    try:
+        with torch.serialization.safe_globals(safe):
+            return torch.load(path, map_location=torch.device("cpu"), weights_only=True)
+    except pickle.UnpicklingError as e:
+        if os.environ.get("MAGMA_UNSAFE_UNPICKLE") != "1":
+            raise RuntimeError(
+                f"checkpoint {path} needs a full (code-executing) unpickle: {str(e).splitlines()[0]}  Set "
+                "MAGMA_UNSAFE_UNPICKLE=1 to load it the way the reference does (torch.load without weights_only) -- only "
+                "for files you trust.") from e
+        import warnings
+        warnings.warn(f"MAGMA_UNSAFE_UNPICKLE=1: loading {path} with a full unpickle", RuntimeWarning)
+        return torch.load(path, map_location=torch.device("cpu"), weights_only=False)
+
+
 class Magma(nn.Module):
     def __init__(self, config, device=None, lm_config: Optional[GPTJConfig] = None, enc: nn.Module = None,
                  dtype=torch.bfloat16, init_seed: Optional[int] = None):
@@ -42,7 +74,8 @@ class Magma(nn.Module):
             "cuda" if torch.cuda.is_available() else "cpu")
         if self.device.type != "cuda":
             from .lib import MagmaHipError
-            raise MagmaHipError("magma_amd.Magma runs on MI355X only (device=%s requested); there is no CPU "
+            raise MagmaHipError("magma_amd.Magma runs on MI355X only (device=%s requested): pass device='cuda:0' (the "
+                                "reference README's own call, Magma.from_checkpoint(..., device='cuda:0')); there is no CPU "
                                 "execution path -- the CPU restatement lives in oracle/ and is test-only" % self.device)
         # every kernel launches on the CURRENT HIP device / stream (ops._need_gpu refuses operands that live elsewhere):
         # the model's device becomes current here and again in the entry points below
@@ -125,6 +158,8 @@ class Magma(nn.Module):
         self.lm.invalidate_packed()
 
     def invalidate_packed(self):
+        from .adapters import bump_weights_epoch
+        bump_weights_epoch()
         self.lm.invalidate_packed()
         self.image_prefix.invalidate_packed()
 
@@ -221,10 +256,19 @@ class Magma(nn.Module):
 
     # ---------------------------------------------------------- checkpoints
     @classmethod
-    def from_checkpoint(cls, config_path, checkpoint_path, device="cuda", **model_kwargs):
+    def from_checkpoint(cls, config_path, checkpoint_path, device="cpu", **model_kwargs):
         """Load a (DeepSpeed-layout) MAGMA checkpoint: a torch-saved dict, optionally
-        wrapped in "module" (reference magma.py:292-297).  The download fallback of
-        the reference needs the network and is not reproduced."""
+        wrapped in "module" (reference magma.py:278-301).  The download fallback of
+        the reference needs the network and is not reproduced.
+
+        The signature is the reference's, default ``device='cpu'`` included (magma.py:279).  This build has no CPU
+        execution path, so the default RAISES ``MagmaHipError`` naming the fix: pass ``device='cuda:0'`` as the
+        reference's README does.  (The checkpoint itself is always read to host memory first, as in the reference.)
+
+        The file is read with ``weights_only=True`` first (argparse.Namespace allow-listed: DeepSpeed's
+        mp_rank_00_model_states.pt carries one next to "module").  A file that still needs a full unpickle -- which can
+        execute arbitrary code -- is only loaded that way with ``MAGMA_UNSAFE_UNPICKLE=1`` (what the reference's call,
+        written for torch < 2.6, always did)."""
         if not exists(checkpoint_path):
             raise FileNotFoundError(f"checkpoint {checkpoint_path} does not exist (no network download in this build)")
         model = cls(config=config_path, device=device, **model_kwargs)     # model_kwargs: reduced lm_config / enc (tests)
@@ -233,10 +277,7 @@ class Magma(nn.Module):
             raise RuntimeError("from_checkpoint needs the real GPT-2 tokenizer (set MAGMA_TOKENIZER_DIR to its files): the "
                                "byte-level stand-in would feed the wrong token ids to trained weights.  "
                                "MAGMA_ALLOW_BYTE_TOKENIZER=1 overrides (synthetic checkpoints / tests).")
-        # a full unpickle, as the reference's call (magma.py:292, written for torch < 2.6): DeepSpeed's
-        # mp_rank_00_model_states.pt carries argparse Namespaces / numpy scalars next to "module", which torch 2.10's
-        # default weights_only=True refuses
-        sd = torch.load(checkpoint_path, map_location=torch.device("cpu"), weights_only=False)
+        sd = _load_checkpoint_file(checkpoint_path)
         if "module" in sd.keys():
             sd = sd["module"]
         print_main(f"loading magma checkpoint from: {checkpoint_path}")

@@ -1061,13 +1061,16 @@ def mx_scales_rowmajor(scales: torch.Tensor, rows: int, K: int) -> torch.Tensor:
 
 
 def mx_empty(M: int, N: int, device):
-    """Uninitialised (q, scales) of an [M, N] MX operand: what quantize_mx_fp8 returns, for a GEMM epilogue to fill (``mx_out``).
-    Columns N .. ceil(N / 128) * 128 of q are zeroed (the consumer's K loop reads whole 128-element chunks)."""
+    """(q, scales) of an [M, N] MX operand for a GEMM epilogue to fill (``mx_out``): what quantize_mx_fp8 returns.  Columns
+    N .. ceil(N / 128) * 128 of q are zeroed (the consumer's K loop reads whole 128-element chunks) and every scale byte is
+    2^0 until written."""
     Kp = ceil_to(N, 128)
     q = torch.empty(M, Kp, dtype=torch.uint8, device=device)
     if Kp != N:
         q[:, N:].zero_()
-    return q, torch.empty(int(L.load().mg_mx_scale_bytes(M, N)), dtype=torch.uint8, device=device)
+    # scale bytes start at 127 (2^0), as the quantiser writes them for the zero blocks past N: the C8 epilogue only writes the
+    # blocks with n < N, and the consuming GEMM walks whole 128-element chunks -- a leftover 0xFF byte is NaN in E8M0
+    return q, torch.full((int(L.load().mg_mx_scale_bytes(M, N)),), 127, dtype=torch.uint8, device=device)
 
 
 def quantize_mx_fp8(x: torch.Tensor):

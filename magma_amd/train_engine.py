@@ -1370,6 +1370,8 @@ class MagmaEngine:
                       self.global_steps, max_norm=self.clip, norm_sq=self._norm_sq, grad_scale=grad_scale)
             g.grad.zero_()
         self.lr_scheduler.step()
+        from .adapters import bump_weights_epoch
+        bump_weights_epoch()        # the AdamW above wrote the parameters through raw pointers: Adapter.forward's packs are stale
         self.module.image_prefix.invalidate_packed()
         self._adapters_dirty = True
         if self.lm_trainable:       # the forward / dgrad operands are packed COPIES of the LM weights: rebuild them from the new values

@@ -612,6 +612,43 @@ def test_checkpoint_helpers_equal_the_reference_functions_run_in_place(tmp_path)
             (save / "global_step500" / "mp_rank_00_model_states.pt").write_bytes(b"x")
 
 
+def test_from_checkpoint_signature_and_safe_unpickle(tmp_path, monkeypatch):
+    """reference magma.py:278-279: from_checkpoint(config_path, checkpoint_path, device='cpu') -- the signature is kept, and since
+    there is no CPU execution path the default fails loudly NAMING the fix.  The file itself is read with the safe unpickler
+    (DeepSpeed's Namespace / numpy scalars allow-listed); a payload that needs code execution is refused unless
+    MAGMA_UNSAFE_UNPICKLE=1."""
+    import argparse
+    import inspect
+    import numpy as np
+    from magma_amd import Magma
+    from magma_amd.lib import MagmaHipError
+    from magma_amd.magma import _load_checkpoint_file
+    sig = inspect.signature(Magma.from_checkpoint)
+    assert list(sig.parameters)[:3] == ["config_path", "checkpoint_path", "device"] and sig.parameters["device"].default == "cpu"
+    path = tmp_path / "mp_rank_00_model_states.pt"
+    torch.save({"module": {"w": torch.ones(2)}, "global_steps": 3, "args": argparse.Namespace(lr=8e-4), "skipped_steps": np.int64(0),
+                "scale": np.float32(2.5), "ds_version": "0.3.15"}, path)
+    with pytest.raises(MagmaHipError, match="device='cuda:0'"):
+        Magma.from_checkpoint("MAGMA_v1", str(path))
+    sd = _load_checkpoint_file(str(path))
+    assert sd["args"].lr == 8e-4 and int(sd["skipped_steps"]) == 0 and torch.equal(sd["module"]["w"], torch.ones(2))
+
+    class Payload:
+        def __reduce__(self):
+            return (exec, ("import os; os.environ['MAGMA_TEST_PAYLOAD_RAN'] = '1'",))
+
+    torch.save({"module": {"w": torch.ones(2)}, "x": Payload()}, path)
+    monkeypatch.delenv("MAGMA_UNSAFE_UNPICKLE", raising=False)
+    monkeypatch.delenv("MAGMA_TEST_PAYLOAD_RAN", raising=False)
+    with pytest.raises(RuntimeError, match="MAGMA_UNSAFE_UNPICKLE"):
+        _load_checkpoint_file(str(path))
+    assert "MAGMA_TEST_PAYLOAD_RAN" not in os.environ
+    monkeypatch.setenv("MAGMA_UNSAFE_UNPICKLE", "1")
+    with pytest.warns(RuntimeWarning, match="full unpickle"):
+        assert "module" in _load_checkpoint_file(str(path))
+    assert os.environ.pop("MAGMA_TEST_PAYLOAD_RAN", None) == "1"
+
+
 def test_lm_output_lazy_values_resolve_on_every_conversion():
     """dict(out), {**out}, out.copy() and pickling must not hand out the raw lazy closure; is_lazy() asks
     without computing."""
