@@ -68,6 +68,9 @@ def parse():
                     help="launch check: N ranks are started exactly as for a real run (self-launch or torch.distributed.run), join "
                          "the process group, run the bench's barrier / MAX-over-ranks collectives and rank 0 prints a line with "
                          "n_gpus = N and value = null; no model, no GPU needed with MAGMA_BENCH_BACKEND=gloo")
+    ap.add_argument("--with-cpu-baseline", action="store_true",
+                    help="--rendezvous-only: rank 0 also measures cpu_baseline where a real run does (after the last collective, the "
+                         "other ranks waiting at the final barrier) -- the N > 1 control flow of that leg without a GPU")
     ap.add_argument("--train-only", action="store_true",
                     help="only the training leg (BASELINE's 'train images/sec, whole node'): metric / value / ms_per_step / roofline "
                          "of the line are the training step's; the generate legs, variants and config1 are skipped -- a multi-GPU "
@@ -578,6 +581,19 @@ def variant_v2(args, dev):
     return out
 
 
+def flat_training_keys(train, world, args):
+    """What a scaling curve over N is computed from, at the TOP level of the line (a flat parser keeps these): whole-job training
+    throughput, every rank's own step time, the gradient exchange's exposed time and the exchange stream's busy time per step
+    (reference train.py:103-111, magma/utils.py:26-34: the step is one DP all-reduce wide)."""
+    full = (train or {}).get("full_S2048") or {}
+    dpo = (train or {}).get("data_parallel") or {}
+    return {"train_images_per_s": full.get("images_per_s"), "train_ms_per_step": full.get("ms_per_step"), "train_ranks": world,
+            "train_per_gpu_batch": args.train_batch,
+            "train_per_rank_step_ms": dpo.get("per_rank_step_ms") or ([round(full["ms_per_step"], 4)] if full.get("ms_per_step") else None),
+            "train_exposed_comm_ms": dpo.get("exposed_comm_ms_per_step"),
+            "train_comm_stream_busy_ms": dpo.get("comm_stream_busy_ms_per_step")}
+
+
 def config1_leg(model, dev):
     """BASELINE config[0] at its stated shape on the model of this run (reference README.md:84, magma/magma.py:176-212): one
     224 x 224 image FILE + an 8-token prompt -> preprocess_inputs (resize to the model-native resolution, prefix tokens) ->
@@ -677,10 +693,18 @@ def rendezvous_only(args, rank, world):
         dist.all_reduce(ranks)
         assert int(ranks.sum()) == world
     if rank == 0:
-        print(json.dumps({"metric": "launch check (no model)", "value": None, "unit": "tokens/s", "n_gpus": world, "steps": 0,
-                          "warmup": 0, "ms_per_step": dt * 1e3, "per_rank_ms": per_rank, "rendezvous_only": True,
-                          "backend": dist.get_backend() if world > 1 else None,
-                          "launched_by": os.environ.get("MAGMA_BENCH_LAUNCHER", "external")}), flush=True)
+        line = {"metric": "launch check (no model)", "value": None, "unit": "tokens/s", "n_gpus": world, "steps": 0,
+                "warmup": 0, "ms_per_step": dt * 1e3, "per_rank_ms": per_rank, "rendezvous_only": True,
+                "backend": dist.get_backend() if world > 1 else None,
+                "launched_by": os.environ.get("MAGMA_BENCH_LAUNCHER", "external")}
+        line.update(flat_training_keys(None, world, args))
+        if args.with_cpu_baseline:
+            # as in main(): rank 0 alone, after the last collective of the timed part, the other ranks parked at the final barrier
+            line["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
@@ -934,14 +958,7 @@ def main():
         # level where a flat parser keeps them, what a scaling curve is computed from: every rank's own step time, the gradient
         # exchange's exposed time and the exchange stream's busy time per step
         full = (train or {}).get("full_S2048") or {}
-        dpo = (train or {}).get("data_parallel") or {}
-        line["train_images_per_s"] = full.get("images_per_s")
-        line["train_ms_per_step"] = full.get("ms_per_step")
-        line["train_ranks"] = world
-        line["train_per_gpu_batch"] = args.train_batch
-        line["train_per_rank_step_ms"] = dpo.get("per_rank_step_ms") or ([round(full["ms_per_step"], 4)] if full.get("ms_per_step") else None)
-        line["train_exposed_comm_ms"] = dpo.get("exposed_comm_ms_per_step")
-        line["train_comm_stream_busy_ms"] = dpo.get("comm_stream_busy_ms_per_step")
+        line.update(flat_training_keys(train, world, args))
         if args.train_only:
             line["value"], line["ms_per_step"] = full.get("images_per_s"), full.get("ms_per_step")
             mf = (line.get("roofline") or {}).get("train")

@@ -45,6 +45,21 @@ def full_depth_params(cfg, seed: int = WEIGHT_SEED, adapter_gain: float = 20.0):
     return p
 
 
+def oracle_window(caps: torch.Tensor, P: int, eos: int, multiple: int = 64) -> torch.Tensor:
+    """The captions the ORACLE is evaluated on in the S = 2048 parity tests: the first T = ceil64(P + longest caption + 2)
+    positions.  The product path under test still runs all 2048 positions; for the oracle the rest is dead weight -- the
+    loss is masked behind the first eos (reference magma/utils.py:334-364), and under the causal mask a position cannot influence
+    an earlier one, so loss, target-row logits and every gradient are the SAME function values on the window (checked
+    against the full-length evaluation in tests/test_oracle_pins.py::test_oracle_window_is_exact).  Cuts each fp32 / bf16
+    autograd leg of the CPU oracle by ~S / T."""
+    longest = 0
+    for row in caps:
+        nz = (row != eos).nonzero()
+        longest = max(longest, int(nz.max()) + 1 if nz.numel() else 0)
+    T = min(caps.shape[1], -(-(P + longest + 2) // multiple) * multiple)
+    return caps[:, :T].contiguous()
+
+
 def lm_only(params):
     return {k: v for k, v in params.items() if k.startswith("lm.")}
 

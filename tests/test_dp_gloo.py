@@ -104,6 +104,23 @@ def test_bench_gpus_8_launches_the_node_sized_job():
     assert len(line["per_rank_ms"]) == 8 and abs(line["ms_per_step"] - max(line["per_rank_ms"])) < 1e-3
 
 
+def test_multi_rank_line_carries_cpu_baseline_and_the_flat_training_keys():
+    """The first multi-GPU record must be self-sufficient: at N > 1 rank 0 still measures cpu_baseline -- alone, after the last
+    collective of the timed part, the other ranks parked at the final barrier -- and the line carries the keys a scaling curve is
+    computed from at its top level.  (--rendezvous-only: that control flow without the model; the same tail of main() with the
+    model runs in tests/test_dp_engine_gpu.py::test_bench_two_ranks_self_launched and tools/gpu_bench_2rank_rehearsal.sh.)"""
+    rc, line, err = _run_bench(["--gpus", "2", "--rendezvous-only", "--with-cpu-baseline", "--cpu-seconds", "2", "--gen", "2"],
+                               {"MAGMA_BENCH_BACKEND": "gloo"}, timeout=600)
+    assert rc == 0, err[-2000:]
+    assert line["n_gpus"] == 2
+    cb = line["cpu_baseline"]
+    assert cb["value"] > 0 and cb["unit"] == "tokens/s" and cb["kind"] == "port" and cb["cores"] >= 1 and "sample" in cb
+    for k in ("train_images_per_s", "train_ms_per_step", "train_ranks", "train_per_gpu_batch", "train_per_rank_step_ms",
+              "train_exposed_comm_ms", "train_comm_stream_busy_ms"):
+        assert k in line, k
+    assert line["train_ranks"] == 2
+
+
 def test_bench_refuses_a_mislabelled_launch():
     """--gpus must equal the number of ranks: a 1-rank run asked for 2 GPUs exits non-zero instead of printing n_gpus = 1."""
     rc, line, err = _run_bench(["--gpus", "2", "--rendezvous-only"], {"WORLD_SIZE": "1", "RANK": "0"})

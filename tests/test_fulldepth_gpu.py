@@ -104,7 +104,8 @@ def test_training_engine_loss_at_28_blocks_s2048(v1_28, dev):
     """The TRAINING engine's forward (taped activations, the 256x256 GEMMs at M = 2048 rows, flash attention at S = 2048 with the
     LSE written for the backward, rotary split that also emits q^T / k^T, the loss head on the target rows) through all 28 blocks
     at the sequence length of BASELINE config[2], against the fp32 oracle forward (reference magma.py:238-276): the loss and the
-    fp32 logits of every row that carries a target, under the 2 x eager-bf16 criterion.  B = 1 keeps the CPU oracle at ~30 TF."""
+    fp32 logits of every row that carries a target, under the 2 x eager-bf16 criterion.  The engine runs all 2048 positions; the CPU oracle evaluates the
+    same loss / target-row logits on the window that carries them (fullwidth_common.oracle_window: causal mask + masked loss)."""
     from magma_amd.train_engine import MagmaEngine
     from oracle.model import magma_forward
     cfg, params, model = v1_28
@@ -120,9 +121,10 @@ def test_training_engine_loss_at_28_blocks_s2048(v1_28, dev):
     caps[0, :n_tok] = torch.randint(0, 50256, (n_tok,), generator=g)
     mask = (torch.rand(B, P, cfg.d_model, generator=g) < 0.9).float() / 0.9
     with torch.no_grad():
-        ref = magma_forward(params, cfg, images, caps, dropout_mask=mask)
+        win = F.oracle_window(caps, P, cfg.eos_token)       # the oracle's view: same loss / target-row logits (fullwidth_common.oracle_window)
+        ref = magma_forward(params, cfg, images, win, dropout_mask=mask)
         pb = bf16_params(params)
-        rb = magma_forward(pb, cfg, images.to(BF16), caps, dropout_mask=mask.to(BF16))
+        rb = magma_forward(pb, cfg, images.to(BF16), win, dropout_mask=mask.to(BF16))
         del pb
     labels = ref["labels"]
     rows = (labels[0, 1:] != -100).nonzero().squeeze(1)           # positions whose NEXT token carries a label
@@ -211,7 +213,7 @@ def test_magma_v2_gradients_s2048(v2, dev):
         p = {k: (v.detach().to(dtype).clone() if v.is_floating_point() else v) for k, v in params.items()}
         for k in names:
             p[k].requires_grad_(True)
-        out = magma_forward(p, cfg, images.to(dtype), caps, dropout_mask=mask.to(dtype))
+        out = magma_forward(p, cfg, images.to(dtype), F.oracle_window(caps, P, cfg.eos_token), dropout_mask=mask.to(dtype))
         out["loss"].backward()
         return float(out["loss"].detach()), {k: p[k].grad.float() for k in names}
 

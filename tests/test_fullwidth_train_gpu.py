@@ -52,7 +52,7 @@ def test_gradients_full_width_s2048(dev):
         p = {k: (v.detach().to(dtype).clone() if v.is_floating_point() else v) for k, v in params.items()}
         for k in names:
             p[k].requires_grad_(True)
-        out = magma_forward(p, cfg, images.to(dtype), caps, dropout_mask=mask.to(dtype))
+        out = magma_forward(p, cfg, images.to(dtype), F.oracle_window(caps, P, cfg.eos_token), dropout_mask=mask.to(dtype))
         out["loss"].backward()
         return float(out["loss"].detach()), {k: p[k].grad.float() for k in names}
 
@@ -126,7 +126,7 @@ def test_gradients_four_blocks_deep_full_width_s2048(dev):
         p = {k: (v.detach().to(dtype).clone() if v.is_floating_point() else v) for k, v in params.items()}
         for k in names:
             p[k].requires_grad_(True)
-        out = magma_forward(p, cfg, images.to(dtype), caps, dropout_mask=mask.to(dtype))
+        out = magma_forward(p, cfg, images.to(dtype), F.oracle_window(caps, P, cfg.eos_token), dropout_mask=mask.to(dtype))
         out["loss"].backward()
         return float(out["loss"].detach()), {k: p[k].grad.float() for k in names}
 
@@ -165,6 +165,9 @@ def test_gradients_four_blocks_deep_full_width_s2048(dev):
     cos_hip, cos_bf = dots / (n1 ** 0.5 * n2 ** 0.5), bdots / (bn1 ** 0.5 * n2 ** 0.5)
     print("cosine: hip", cos_hip, "bf16 oracle", cos_bf)
     assert 1 - cos_hip <= 2 * (1 - cos_bf) + 1e-3, (cos_hip, cos_bf)
+
+
+_FP8_ORACLE_MEMO = {}
 
 
 @pytest.mark.parametrize("fp8_attn,fp8_mx", [(False, False), (True, False), (True, True)])
@@ -220,10 +223,20 @@ def test_fp8_training_step_vs_oracle_on_dequantised_weights(dev, fp8_attn, fp8_m
     deq[mp + "c_proj.weight"] = packs[(0, "fc_out")].dequant().cpu()
 
     def oracle(src):
+        # the three parametrisations share inputs and most weight sets (unquantised: all three; per-row e4m3: the two non-MX modes
+        # and the MX mode's yardstick): each distinct weight set goes through the CPU autograd once per session
+        key = tuple((k, float(src[k].double().sum()), float(src[k].double().abs().sum()))
+                    for k in (ap + "q_proj.weight", ap + "out_proj.weight", mp + "c_fc.weight", mp + "c_proj.weight"))
+        if key in _FP8_ORACLE_MEMO:
+            return _FP8_ORACLE_MEMO[key]
+        _FP8_ORACLE_MEMO[key] = r = _oracle(src)
+        return r
+
+    def _oracle(src):
         p = {k: (v.detach().float().clone() if v.is_floating_point() else v) for k, v in src.items()}
         for k in names:
             p[k].requires_grad_(True)
-        o = magma_forward(p, cfg, images, caps, dropout_mask=mask)
+        o = magma_forward(p, cfg, images, F.oracle_window(caps, P, cfg.eos_token), dropout_mask=mask)
         o["loss"].backward()
         return float(o["loss"].detach()), {k: p[k].grad.float() for k in names}
 

@@ -384,3 +384,46 @@ def test_oracle_image_prefix_plumbing_equals_the_reference_method_run_in_place()
     with torch.no_grad():
         got2, want2 = ns["forward"](fake2, images), om.pooled_prefix_fwd(pp, d, S, feats)
     assert got2.shape == (2, S, d) and torch.allclose(got2, want2, atol=1e-6, rtol=1e-6)
+
+
+def test_oracle_window_is_exact():
+    """tests/fullwidth_common.oracle_window: the S = 2048 GPU parity tests evaluate the CPU oracle on the first
+    ceil64(P + longest caption + 2) positions only.  Loss, labels, target-row logits and every gradient must be the values of the
+    full-length evaluation (causal mask: no position influences an earlier one; build_labels masks everything behind the first
+    eos, reference magma/utils.py:334-364) -- checked here on the tiny configuration, full length 256 against the window."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import fullwidth_common as F
+    cfg = O.OracleConfig.tiny(n_positions=256)
+    params = O.init_params(cfg, seed=3)
+    for k in params:
+        if ".adapter." in k:
+            params[k] = params[k] * 20
+    g = torch.Generator().manual_seed(2)
+    B, S, P = 2, 256, 4
+    images = torch.randn(B, 3, 64, 64, generator=g)
+    caps = torch.full((B, S), cfg.eos_token, dtype=torch.int64)
+    caps[0, :37] = torch.randint(0, 1000, (37,), generator=g)
+    caps[1, :9] = torch.randint(0, 1000, (9,), generator=g)
+    mask = (torch.rand(B, P, cfg.d_model, generator=g) < 0.9).float() / 0.9
+    win = F.oracle_window(caps, P, cfg.eos_token)
+    assert win.shape == (B, 64) and torch.equal(win, caps[:, :64])
+    names = [k for k in params if (".adapter." in k or k.startswith("image_prefix.")) and "running_" not in k]
+
+    def run(c):
+        p = {k: (v.detach().clone() if v.is_floating_point() else v) for k, v in params.items()}
+        for k in names:
+            p[k].requires_grad_(True)
+        out = O.magma_forward(p, cfg, images, c, dropout_mask=mask)
+        out["loss"].backward()
+        return out, {k: p[k].grad for k in names}
+
+    full, g_full = run(caps)
+    part, g_part = run(win)
+    assert torch.equal(full["labels"][:, :64], part["labels"]) and bool((full["labels"][:, 64:] == -100).all())
+    assert abs(float(full["loss"]) - float(part["loss"])) <= 1e-6 * abs(float(full["loss"]))
+    rows = (part["labels"][0, 1:] != -100).nonzero().squeeze(1)
+    assert torch.allclose(full["logits"][0, rows], part["logits"][0, rows], rtol=1e-5, atol=1e-5)
+    for k in names:
+        a, b = g_full[k], g_part[k]
+        assert float((a - b).norm()) <= 1e-5 * float(a.norm()) + 1e-12, k

@@ -400,7 +400,7 @@ def test_batch_statistics_batchnorm(dev):
     assert torch.isfinite(eng(images.to(dev), caps).loss)
 
 
-def test_train_step_on_an_on_disk_dataset_with_mixed_image_modes(dev, tmp_path):
+def test_train_step_on_an_on_disk_dataset_with_mixed_image_modes(dev, tmp_path, monkeypatch):
     """reference train.py:34-66 + magma/datasets/dataset.py:92-160 end to end: a dataset directory in the reference's layout with
     RGB AND greyscale images, read by ImgCptDataset through the model's own transform (device pipeline for RGB, PIL for the rest --
     both must land on one device or collate_fn's torch.cat fails), split into train / eval by eval_dataset_pct, fed to train_step /
@@ -409,6 +409,9 @@ def test_train_step_on_an_on_disk_dataset_with_mixed_image_modes(dev, tmp_path):
     import numpy as np
     import PIL.Image as I
     from types import SimpleNamespace
+    # two worker processes per loader instead of min(8, host cores): the worker path is what is under test, not its width (the
+    # default pool of 2 x 8 persistent workers took most of this test's 88 s on the 256-thread host of the round-5 box)
+    monkeypatch.setenv("MAGMA_LOADER_WORKERS", "2")
     from magma_amd.datasets import get_pretraining_datasets
     from magma_amd.testing import build_reduced_magma
     from magma_amd.train_engine import initialize
