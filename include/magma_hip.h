@@ -72,8 +72,10 @@ const char* mg_version(void);
  *      mg_attn_fp8_scale_stride (nothing moved; a revision-2 binder keeps working, the loader of this repo asks for 3 because it
  *      binds the new ones).
  *   4  round 5: mg_epilogue grew by C8 / ldc8 / c8_scales / c8_rgroups (the MX e4m3 copy of a tile GEMM's output): every
- *      descriptor that embeds an epilogue changed size.                                         */
-#define MG_ABI_VERSION 4
+ *      descriptor that embeds an epilogue changed size.
+ *   5  round 6: added mg_rotary_qk_inplace_bf16 / mg_attn_fwd_rows_bf16 / mg_attn_bwd_rows_bf16 (attention without transposed operand
+ *      images, q / k / v taken as strided rows -- straight from the fused qkv activation); nothing moved.                            */
+#define MG_ABI_VERSION 5
 int32_t mg_abi_version(void);
 const char* mg_last_error(void);
 
@@ -463,6 +465,30 @@ int mg_attn_bwd_merged_bf16(const mg_bf16* q, const mg_bf16* k, const mg_bf16* v
                             const mg_bf16* kt, const mg_bf16* dO, mg_bf16* dOt, const mg_bf16* O,
                             const float* lse, float* D, mg_bf16* dqkv, int32_t rot_dim, const float* sin_t,
                             const float* cos_t, int32_t B, int32_t H, int32_t S, int32_t ld_t, int64_t ld_o, void* stream);
+
+/* ---- attention without transposed operand images (round 6, csrc/attention_tr.hip) -------------------------------------------------
+ * The path replaced: reference magma/magma.py:263-276 -> HF GPTJAttention (rotary on q / k, causal softmax(q k^T / 16) v) and its
+ * autograd.  The s-contraction operands (V^T in the forward; Q^T, dO^T, K^T in the backward) are read from the ROW images in LDS with
+ * ds_read_b64_tr_b16, so no transposed tensor exists in HBM, and q / k / v are taken as rows of 256 at arbitrary strides:
+ * position s of head (b, h) at  ptr + b stride_b + h stride_h + s ld_row  (elements; ld_row >= 256, all multiples of 8,
+ * S ld_row 2 < 2^31).  [B,H,S,256]: ld_row 256, stride_h S 256, stride_b H S 256.  The fused qkv activation [B*S, 3 H 256] ITSELF:
+ * q = qkv, k = qkv + H 256, v = qkv + 2 H 256, ld_row 3 H 256, stride_h 256, stride_b S 3 H 256 -- after mg_rotary_qk_inplace_bf16
+ * there is no split pass and no copy of q, k or v.                                                                                   */
+/* GPT-J rotary (interleaved pairs) applied in place to the first rot_dim columns of every q and k head of qkv [B*S, ld_qkv >= 3 H 256],
+ * angles of position s = row % S (tables sin_t / cos_t fp32 [>= S, rot_dim / 2]); v is not touched.                                  */
+int mg_rotary_qk_inplace_bf16(mg_bf16* qkv, int64_t ld_qkv, int32_t B, int32_t S, int32_t H, int32_t rot_dim,
+                              const float* sin_t, const float* cos_t, void* stream);
+/* causal flash-attention forward: out [B*S, >= H*256] bf16 at row stride ld_out (0 = H*256; % 8 == 0), lse [B,H,S] fp32 or NULL.
+ * Same arithmetic as mg_attn_prefill_bf16 (fp32 online softmax, 1/16 scale).                                                          */
+int mg_attn_fwd_rows_bf16(const mg_bf16* q, const mg_bf16* k, const mg_bf16* v, int64_t ld_row, int64_t stride_b,
+                          int64_t stride_h, mg_bf16* out, int64_t ld_out, float* lse, int32_t B, int32_t H, int32_t S, void* stream);
+/* backward: dO [B*S, H*256]; O [B*S, >= H*256] at row stride ld_o; lse [B,H,S]; D fp32 workspace of 2 B H S floats.  Output EITHER
+ * dq, dk, dv [B,H,S,256] (dqkv NULL) OR dqkv [B*S, 3 H 256] = the gradient of the fused qkv projection with the inverse rotary applied
+ * to the first rot_dim columns of every dq and dk head (dq, dk, dv NULL) -- as mg_attn_bwd_bf16 / mg_attn_bwd_merged_bf16.           */
+int mg_attn_bwd_rows_bf16(const mg_bf16* q, const mg_bf16* k, const mg_bf16* v, int64_t ld_row, int64_t stride_b,
+                          int64_t stride_h, const mg_bf16* dO, const mg_bf16* O, int64_t ld_o, const float* lse, float* D,
+                          mg_bf16* dq, mg_bf16* dk, mg_bf16* dv, mg_bf16* dqkv, int32_t rot_dim, const float* sin_t,
+                          const float* cos_t, int32_t B, int32_t H, int32_t S, void* stream);
 
 /* CLIP trunk backward helpers */
 int mg_avgpool2_bwd_nhwc_bf16(const mg_bf16* dy, const mg_bf16* gate, mg_bf16* dx, int32_t B, int32_t H, int32_t W, int32_t C, void* stream);

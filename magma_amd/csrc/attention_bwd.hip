@@ -436,7 +436,9 @@ int attn_bwd_launch(const mg_bf16* q, const mg_bf16* k, const mg_bf16* v, const 
   if (int rc = mg_allow_dynamic_lds((const void*)attn_bwd_dkdv_kernel<false>, DV_STAGES * DV_STAGE, who)) return rc;
   const int64_t rows = (int64_t)B * S * H;
   const dim3 grid((unsigned)(((S + 127) / 128) * B * H));
-  if (make_dOt)
+  const char* env_v = getenv("MAGMA_ATTN_BWD");        // read per call: tests and A/B scripts switch it in-process
+  const int variant = env_v ? atoi(env_v) : 4;
+  if (make_dOt && variant < 5)
     hipLaunchKernelGGL(attn_bwd_prep_t_kernel, dim3((S + 31) / 32, B * H), dim3(256), 0, s, dO, O, lse, D, (mg_bf16*)dOt, ld_t, B, H, S, ld_o);
   else
     hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, dO, O, lse, D, B, H, S, ld_o);
@@ -444,12 +446,20 @@ int attn_bwd_launch(const mg_bf16* q, const mg_bf16* k, const mg_bf16* v, const 
   // 1 / 2 = dQ as before + dK and dV in ONE 32-key-wave kernel (attention_bwd32.hip; 1: all LDS-DMA pieces of a tile at the
   // top of the step, 2: spread between the MFMA phases); 3 / 4 = the 32-query-wave dQ kernel as well (3: DMA at the top, 4: spread;
   // the dK/dV kernel then in its spread form).
-  const char* env_v = getenv("MAGMA_ATTN_BWD");        // read per call: tests and A/B scripts switch it in-process
-  const int variant = env_v ? atoi(env_v) : 4;
-  if (variant >= 3) {
+  // 5 / 6 = the dK/dV kernel WITHOUT transposed images (attention_bwd32_tr.hip: ds_read_b64_tr_b16 from the row images; 5: two LDS
+  // stages, 6: three); dO^T is then not made.
+  // 7 / 8 = the dQ kernel without K^T as well (7: three LDS stages, 8: four), dK/dV as in 6.
+  const AttnRows xr{q, k, v, (int64_t)H * S * DH, (int64_t)S * DH, DH};     // [B,H,S,256]
+  if (variant >= 7) {
+    if (int rc = attn_bwd_dq32_tr_launch(xr, dO, D, gq, B, H, S, variant == 8 ? 4 : 3, s, who)) return rc;
+  } else if (variant >= 3) {
     if (int rc = attn_bwd_dq32_launch(q, k, v, kt, dO, D, gq, B, H, S, ld_t, variant, s, who)) return rc;
   } else {
     hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(512), DQ_STAGES * DQ_STAGE, s, q, k, v, kt, dO, D, gq, B, H, S, ld_t);
+  }
+  if (variant >= 5) {
+    MG_CHECK_LAUNCH();
+    return attn_bwd_dkdv32_tr_launch(xr, dO, D, gk, gv, B, H, S, variant >= 6 ? 3 : 2, s, who);
   }
   if (variant >= 1) {
     MG_CHECK_LAUNCH();

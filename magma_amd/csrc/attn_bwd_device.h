@@ -31,3 +31,18 @@ int attn_bwd_dkdv32_launch(const mg_bf16* q, const mg_bf16* k, const mg_bf16* v,
 int attn_bwd_dq32_launch(const mg_bf16* q, const mg_bf16* k, const mg_bf16* v, const mg_bf16* kt, const mg_bf16* dO,
                          const float* ld2, const GradOut& gq, int B, int H, int S, int ld_t, int variant, hipStream_t s,
                          const char* who);
+// ---- attention_tr.hip: the attention kernels WITHOUT transposed operand images (ds_read_b64_tr_b16 from the row images) ----------
+// q / k / v of head (b, h) as rows of 256 at an arbitrary row stride: position s of the head is at ptr + b stride_b + h stride_h + s ld
+// (elements).  [B,H,S,256]: ld 256, stride_h S 256, stride_b H S 256.  The fused qkv activation [B*S, 3 H 256] itself: q = qkv,
+// k = qkv + H 256, v = qkv + 2 H 256, ld 3 H 256, stride_h 256, stride_b S 3 H 256 -- no split pass, no copies.
+struct AttnRows {
+  const mg_bf16 *q, *k, *v;
+  int64_t stride_b, stride_h;
+  int ld;
+};
+int attn_bwd_dkdv32_tr_launch(const AttnRows& x, const mg_bf16* dO, const float* ld2,
+                              const GradOut& gk, const GradOut& gv, int B, int H, int S, int stages, hipStream_t s, const char* who);
+int attn_bwd_dq32_tr_launch(const AttnRows& x, const mg_bf16* dO, const float* ld2,
+                            const GradOut& gq, int B, int H, int S, int stages, hipStream_t s, const char* who);
+int attn_fwd32_tr_launch(const AttnRows& x, mg_bf16* out, int64_t ld_out, float* lse, int B, int H, int S, float defer, hipStream_t s,
+                         const char* who);

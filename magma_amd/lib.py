@@ -19,7 +19,7 @@ MG_A_DENSE, MG_A_CONV3X3 = 0, 1
 MG_AUX_NONE, MG_AUX_RELU_GATE, MG_AUX_GELU_GRAD, MG_AUX_MUL, MG_AUX_QUICK_GELU_GRAD = 0, 1, 2, 3, 4
 
 
-ABI_VERSION = 4      # include/magma_hip.h MG_ABI_VERSION
+ABI_VERSION = 5      # include/magma_hip.h MG_ABI_VERSION
 
 
 class MagmaHipError(RuntimeError):
@@ -129,6 +129,10 @@ SYMBOLS = {
     "mg_rotary_merge_bwd_bf16": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "mg_attn_bwd_bf16": (C.c_int, [_vp] * 13 + [_i32, _i32, _i32, _i32, _i64, _vp]),
     "mg_attn_bwd_merged_bf16": (C.c_int, [_vp] * 11 + [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _i64, _vp]),
+    "mg_rotary_qk_inplace_bf16": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "mg_attn_fwd_rows_bf16": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _vp]),
+    "mg_attn_bwd_rows_bf16": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp,
+                                        _i32, _i32, _i32, _vp]),
     "mg_avgpool2_bwd_nhwc_bf16": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mg_mul_bf16": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "mg_gelu_erf_bf16": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _vp]),

@@ -826,6 +826,66 @@ def attn_bwd_merged(q, k, v, qt, kt, dO, O, lse, B, H, S, rot_dim, sin_t, cos_t)
     return dqkv
 
 
+class AttnRows:
+    """q / k / v of a batch of heads as strided rows of 256 (include/magma_hip.h, attention without transposed images): either three
+    [B,H,S,256] tensors or -- ``AttnRows.of_qkv`` -- column ranges of the fused qkv activation [B*S, 3 H 256] itself."""
+
+    def __init__(self, q, k, v, ld_row, stride_b, stride_h, B, H, S, keep=()):
+        self.q, self.k, self.v, self.ld_row, self.stride_b, self.stride_h = q, k, v, ld_row, stride_b, stride_h
+        self.B, self.H, self.S, self.keep = B, H, S, keep          # keep: the tensors the pointers live in
+
+    @classmethod
+    def of_bhsd(cls, q, k, v):
+        B, H, S, dh = q.shape
+        assert dh == 256 and q.is_contiguous() and k.is_contiguous() and v.is_contiguous() and k.shape == q.shape == v.shape
+        return cls(q.data_ptr(), k.data_ptr(), v.data_ptr(), 256, H * S * 256, S * 256, B, H, S, keep=(q, k, v))
+
+    @classmethod
+    def of_qkv(cls, qkv, B, S, H):
+        assert qkv.ndim == 2 and qkv.stride(1) == 1 and qkv.shape[0] == B * S and qkv.shape[1] >= 3 * H * 256
+        ld, p = qkv.stride(0), qkv.data_ptr()
+        return cls(p, p + H * 256 * 2, p + 2 * H * 256 * 2, ld, S * ld, 256, B, H, S, keep=(qkv,))
+
+
+def rotary_qk_inplace(qkv, B, S, H, rot_dim, sin_t, cos_t):
+    """GPT-J rotary on the q and k sections of qkv [B*S, >= 3 H 256], in place (v untouched)."""
+    _need_gpu(qkv)
+    assert qkv.ndim == 2 and qkv.stride(1) == 1 and qkv.shape[0] == B * S
+    check(L.load().mg_rotary_qk_inplace_bf16(qkv.data_ptr(), qkv.stride(0), B, S, H, rot_dim, sin_t.data_ptr(), cos_t.data_ptr(),
+                                             _stream()), "mg_rotary_qk_inplace_bf16")
+    return qkv
+
+
+def attn_fwd_rows(x: AttnRows, out, lse: Optional[torch.Tensor] = None):
+    """Causal flash attention reading q / k / v as strided rows (no V^T): out [B*S, >= H*256] (a column range of a wider row is fine)."""
+    _need_gpu(out)
+    assert out.ndim == 2 and out.stride(1) == 1 and out.shape[1] == x.H * 256
+    check(L.load().mg_attn_fwd_rows_bf16(x.q, x.k, x.v, x.ld_row, x.stride_b, x.stride_h, out.data_ptr(), out.stride(0), _p(lse),
+                                         x.B, x.H, x.S, _stream()), "mg_attn_fwd_rows_bf16")
+    return out
+
+
+def attn_bwd_rows(x: AttnRows, dO, O, lse, merged_rot=None):
+    """Attention backward without transposed operands.  merged_rot None -> (dq, dk, dv) [B,H,S,256]; merged_rot = (rot_dim, sin_t,
+    cos_t) -> dqkv [B*S, 3 H 256], the gradient of the fused qkv projection (inverse rotary applied)."""
+    _need_gpu(dO)
+    assert O.ndim == 2 and O.stride(1) == 1 and dO.is_contiguous()
+    B, H, S, dev = x.B, x.H, x.S, dO.device
+    D = torch.empty(B, H, S, 2, dtype=torch.float32, device=dev)
+    if merged_rot is None:
+        dq, dk, dv = (torch.empty(B, H, S, 256, dtype=BF16, device=dev) for _ in range(3))
+        check(L.load().mg_attn_bwd_rows_bf16(x.q, x.k, x.v, x.ld_row, x.stride_b, x.stride_h, dO.data_ptr(), O.data_ptr(), O.stride(0),
+                                             lse.data_ptr(), D.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), None, 0, None, None,
+                                             B, H, S, _stream()), "mg_attn_bwd_rows_bf16")
+        return dq, dk, dv
+    rot_dim, sin_t, cos_t = merged_rot
+    dqkv = torch.empty(B * S, 3 * H * 256, dtype=BF16, device=dev)
+    check(L.load().mg_attn_bwd_rows_bf16(x.q, x.k, x.v, x.ld_row, x.stride_b, x.stride_h, dO.data_ptr(), O.data_ptr(), O.stride(0),
+                                         lse.data_ptr(), D.data_ptr(), None, None, None, dqkv.data_ptr(), rot_dim, sin_t.data_ptr(),
+                                         cos_t.data_ptr(), B, H, S, _stream()), "mg_attn_bwd_rows_bf16")
+    return dqkv
+
+
 def avgpool2_bwd(dy: torch.Tensor, B, H, W, Cc, gate: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dy [B,H/2,W/2,C] -> dx [B,H,W,C] (zeroed where gate <= 0 when a gate is given)."""
     _need_gpu(dy)

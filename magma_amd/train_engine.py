@@ -588,8 +588,6 @@ class MagmaEngine:
         B, S, d = emb.shape
         M, H = B * S, eng.H
         x = emb.view(M, d)
-        vt_ld = ops.ceil_to(S, 32)
-        vt = torch.empty(B, H, vt_ld // 32, 256, 32, dtype=BF16, device=dev)   # V^T in 32-key tiles
         def block(li, ly, blk, x):
             """One GPT-J block forward: (x', what its backward needs).  Called by the loop below and -- under per-block
             recompute (self.recompute) -- once more per block from _lm_backward, on the saved block input."""
@@ -597,17 +595,27 @@ class MagmaEngine:
             ln = ops.layernorm(x, ly.ln_g, ly.ln_b, eng.eps)
             lnq = ops.quantize_rows_fp8(ln) if self.fp8 else None     # shared by qkv and fc_in
             qkv = self._fgemm((li, "qkv"), ln, ly.qkv, lnq)
-            q = torch.empty(B, H, S, 256, dtype=BF16, device=dev)
-            k = torch.empty(B, H, S, 256, dtype=BF16, device=dev)
-            v = torch.empty(B, H, S, 256, dtype=BF16, device=dev)
-            # q^T / k^T (the s-contraction operands of the attention backward) come out of the same pass as q, k, v, V^T
-            qt = torch.empty(B, H, vt_ld // 32, 256, 32, dtype=BF16, device=dev)
-            kt = torch.empty(B, H, vt_ld // 32, 256, 32, dtype=BF16, device=dev)
-            a8 = None
-            if self.fp8 and self.fp8_attn:     # e4m3 copies of q, k, v^T for the forward; q, k, v, q^T, k^T in bf16 for the backward
-                a8 = ops.rotary_split_fp8(qkv, B, S, H, eng.rot, eng.sin_t, eng.cos_t, q, k, v, qt, kt)
-            else:
+            a8 = rows = None
+            if self.fp8 and self.fp8_attn:     # e4m3 copies of q, k, v^T for the forward; q, k, v in bf16 for the backward
+                q = torch.empty(B, H, S, 256, dtype=BF16, device=dev)
+                k = torch.empty(B, H, S, 256, dtype=BF16, device=dev)
+                v = torch.empty(B, H, S, 256, dtype=BF16, device=dev)
+                a8 = ops.rotary_split_fp8(qkv, B, S, H, eng.rot, eng.sin_t, eng.cos_t, q, k, v)
+                rows = ops.AttnRows.of_bhsd(q, k, v)
+            elif os.environ.get("MAGMA_ATTN_TR", "1") == "0":
+                # A/B switch only (tools/gpu_r06_step_ab.sh): the round-5 path -- split pass with three transposes, kernels with
+                # transposed operand images
+                vt_ld = ops.ceil_to(S, 32)
+                q, k, v = (torch.empty(B, H, S, 256, dtype=BF16, device=dev) for _ in range(3))
+                vt, qt, kt = (torch.empty(B, H, vt_ld // 32, 256, 32, dtype=BF16, device=dev) for _ in range(3))
                 ops.rotary_split_train(qkv, B, S, H, eng.rot, eng.sin_t, eng.cos_t, q, k, v, vt, qt, kt)
+                sv.update(old=(q, k, v, qt, kt))
+            else:
+                # round 6: no split pass and no transposed copies.  The rotary is applied in place to the q / k sections of the GEMM
+                # output, and the attention kernels (csrc/attention_tr.hip) take q, k, v as strided rows of that buffer -- forward
+                # and backward; the s-contraction fragments (V^T; Q^T, dO^T, K^T) come from the row images by ds_read_b64_tr_b16.
+                ops.rotary_qk_inplace(qkv, B, S, H, eng.rot, eng.sin_t, eng.cos_t)
+                rows = ops.AttnRows.of_qkv(qkv, B, S, H)
             out_up = self._cat_out_up(li, ly, blk)
             if out_up is not None:
                 ctx_t = torch.empty(M, out_up.K, dtype=BF16, device=dev)        # [ctx | t]: one saved buffer, one GEMM operand
@@ -617,9 +625,11 @@ class MagmaEngine:
             lse = torch.empty(B, H, S, dtype=F32, device=dev)
             if a8 is not None:
                 ops.attn_prefill_fp8(a8, ctx, lse=lse)
-            else:
+            elif rows is None:
                 ops.attn_prefill(q, k, vt, ctx, B, H, S, lse=lse)
-            sv.update(q=q, k=k, v=v, qt=qt, kt=kt, ctx=ctx, lse=lse)
+            else:
+                ops.attn_fwd_rows(rows, ctx, lse=lse)
+            sv.update(rows=rows, ctx=ctx, lse=lse)
             a = None if out_up is not None else self._fgemm((li, "out"), ctx, ly.out)
             if ly.attn_adapter is not None and ly.attn_par is not None:
                 # parallel / scaled_parallel (reference adapters.py:42-92): the adapter reads the attention INPUT (ln_1 output)
@@ -836,8 +846,11 @@ class MagmaEngine:
             else:
                 da = g
             dctx = self._fgemm((li, "out_t"), da, pk["out_t"])
-            q, k, v = sv["q"], sv["k"], sv["v"]
-            dqkv = ops.attn_bwd_merged(q, k, v, sv["qt"], sv["kt"], dctx, sv["ctx"], sv["lse"], B, H, S, eng.rot, eng.sin_t, eng.cos_t)
+            if sv["rows"] is None:      # MAGMA_ATTN_TR=0 (A/B only)
+                q, k, v, qt, kt = sv["old"]
+                dqkv = ops.attn_bwd_merged(q, k, v, qt, kt, dctx, sv["ctx"], sv["lse"], B, H, S, eng.rot, eng.sin_t, eng.cos_t)
+            else:
+                dqkv = ops.attn_bwd_rows(sv["rows"], dctx, sv["ctx"], sv["lse"], merged_rot=(eng.rot, eng.sin_t, eng.cos_t))
             dln = self._fgemm((li, "qkv_t"), dqkv, pk["qkv_t"], residuals=(dln_mlp, *extra))
             if self.lm_trainable:
                 self._acc_wgrad(a_mod.out_proj.weight, _t(da), _t(sv["ctx"]))

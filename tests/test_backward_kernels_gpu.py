@@ -132,7 +132,7 @@ def test_attention_backward(dev, B, H, S):
             assert rel(got, ref) < 1.5e-2, (name, rel(got, ref))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("B,H,S", [(1, 1, 1), (2, 2, 57), (1, 2, 300), (2, 1, 385), (1, 1, 1024)])
 def test_attention_backward_kernel_variants(dev, monkeypatch, variant, B, H, S):
     """MAGMA_ATTN_BWD = 0 (three 16-row-wave kernels) / 1, 2 (dK and dV in one 32-key-wave kernel, S and dP computed once)
@@ -234,6 +234,83 @@ def test_rotary_split_train_emits_all_transposes(dev):
     ops.rotary_split_train(qkv, B, S, H, rot, sin_t, cos_t, q1, k1, v1, vt1, qt1, kt1)
     for a, b, name in ((q1, q0, "q"), (k1, k0, "k"), (v1, v0, "v"), (vt1, vt0, "vt"), (qt1, qt0, "qt"), (kt1, kt0, "kt")):
         assert torch.equal(a, b), name
+
+
+def test_rotary_qk_inplace_equals_the_split_pass(dev):
+    """mg_rotary_qk_inplace_bf16 leaves in the q / k sections of qkv exactly what mg_rotary_split_bf16 writes to q / kcache (same
+    fp32 arithmetic, one bf16 rounding), v untouched; also at a row stride wider than 3 H 256."""
+    from magma_amd import ops
+    B, H, S, rot = 2, 3, 75, 64
+    d = H * 256
+    wide = rnd(B * S, 3 * d + 40, dev=dev, seed=41).to(BF16)
+    qkv = wide[:, :3 * d]
+    inv = 1.0 / (10000 ** (torch.arange(0, rot, 2, dtype=torch.float32, device=dev) / rot))
+    ang = torch.arange(S + 5, dtype=torch.float32, device=dev)[:, None] * inv[None, :]
+    sin_t, cos_t = ang.sin().contiguous(), ang.cos().contiguous()
+    mk = lambda: torch.empty(B, H, S, 256, dtype=BF16, device=dev)
+    q0, k0, v0 = mk(), mk(), mk()
+    ops.rotary_split(qkv, B, S, H, rot, sin_t, cos_t, q0, k0, v0, pos0=0)
+    before = wide.clone()
+    ops.rotary_qk_inplace(qkv, B, S, H, rot, sin_t, cos_t)
+    got = qkv.reshape(B, S, 3, H, 256).permute(2, 0, 3, 1, 4)
+    assert torch.equal(got[0], q0) and torch.equal(got[1], k0) and torch.equal(got[2], v0)
+    assert torch.equal(wide[:, 3 * d:], before[:, 3 * d:]) and torch.equal(wide[:, 2 * d:3 * d], before[:, 2 * d:3 * d])
+
+
+@pytest.mark.parametrize("B,H,S", [(1, 1, 1), (2, 2, 57), (1, 2, 300), (2, 1, 385), (1, 1, 1024), (1, 3, 129)])
+def test_attention_without_transposed_images(dev, B, H, S):
+    """mg_attn_fwd_rows_bf16 / mg_attn_bwd_rows_bf16 (csrc/attention_tr.hip: V^T, Q^T, dO^T, K^T fragments read from the ROW images
+    with ds_read_b64_tr_b16): forward and all three gradients against fp32 autograd of the same attention; against the kernels with
+    transposed images (same MFMA order: the outputs agree to the last bit or nearly); and reading q / k / v straight from the fused qkv
+    activation [B*S, 3 H 256] gives the SAME bits as reading [B,H,S,256] tensors -- separate and merged (inverse rotary) outputs."""
+    from magma_amd import ops
+    d = H * 256
+    q = rnd(B, H, S, 256, dev=dev, seed=60, scale=0.5).to(BF16)
+    k = rnd(B, H, S, 256, dev=dev, seed=61, scale=0.5).to(BF16)
+    v = rnd(B, H, S, 256, dev=dev, seed=62).to(BF16)
+    dO = rnd(B * S, d, dev=dev, seed=63).to(BF16)
+    x = ops.AttnRows.of_bhsd(q, k, v)
+    out = torch.empty(B * S, d, dtype=BF16, device=dev)
+    lse = torch.empty(B, H, S, dtype=torch.float32, device=dev)
+    ops.attn_fwd_rows(x, out, lse=lse)
+    # the same operands as column ranges of one fused activation (what the training engine hands over), wider row stride
+    fused = torch.zeros(B * S, 3 * d + 24, dtype=BF16, device=dev)
+    fused[:, :3 * d] = torch.stack((q, k, v)).permute(1, 3, 0, 2, 4).reshape(B * S, 3 * d)
+    xf = ops.AttnRows.of_qkv(fused[:, :3 * d], B, S, H)
+    out_f = torch.full((B * S, d + 8), float("nan"), dtype=BF16, device=dev)
+    lse_f = torch.empty_like(lse)
+    ops.attn_fwd_rows(xf, out_f[:, :d], lse=lse_f)
+    assert torch.equal(out_f[:, :d], out) and torch.equal(lse_f, lse)
+    # the kernels with transposed images
+    vt = ops.head_transpose(v, B, H, S, sb=H * S * 256, ss=256, sh=S * 256)
+    out_old = torch.empty_like(out)
+    lse_old = torch.empty_like(lse)
+    ops.attn_prefill(q, k, vt, out_old, B, H, S, lse=lse_old)
+    assert rel(out, out_old) < 1e-3 and float((lse - lse_old).abs().max()) < 1e-4
+    qf, kf, vf = (t.float().requires_grad_(True) for t in (q, k, v))
+    sc = qf @ kf.transpose(-1, -2) / 16.0
+    sc = sc.masked_fill(~torch.ones(S, S, dtype=torch.bool, device=dev).tril(), float("-inf"))
+    o = (torch.softmax(sc, -1) @ vf).permute(0, 2, 1, 3).reshape(B * S, d)
+    assert rel(out, o.detach()) < 1e-2
+    o.backward(dO.float())
+    dq, dk, dv = ops.attn_bwd_rows(x, dO, out, lse)
+    for got, ref, name in ((dq, qf.grad, "dq"), (dk, kf.grad, "dk"), (dv, vf.grad, "dv")):
+        if float(ref.abs().max()) < 1e-6:      # S = 1: softmax over one key has zero gradient
+            assert float(got.float().abs().max()) < 1e-6, name
+        else:
+            assert rel(got, ref) < 1.5e-2, (name, rel(got, ref))
+    for a, b_ in zip(ops.attn_bwd_rows(xf, dO, out_f[:, :d], lse), (dq, dk, dv)):
+        assert torch.equal(a, b_)
+    rot = 64
+    inv = 1.0 / (10000 ** (torch.arange(0, rot, 2, dtype=torch.float32, device=dev) / rot))
+    ang = torch.arange(S + 3, dtype=torch.float32, device=dev)[:, None] * inv[None, :]
+    sin_t, cos_t = ang.sin().contiguous(), ang.cos().contiguous()
+    two_pass = ops.rotary_merge_bwd(dq, dk, dv, B, S, H, rot, sin_t, cos_t)
+    merged = ops.attn_bwd_rows(xf, dO, out, lse, merged_rot=(rot, sin_t, cos_t))
+    assert merged.shape == (B * S, 3 * d) and torch.equal(merged[:, 2 * d:], two_pass[:, 2 * d:])
+    if S > 1:
+        for sl in (slice(0, d), slice(d, 2 * d)):
+            assert rel(merged[:, sl], two_pass[:, sl]) < 6e-3
 
 
 def test_rotary_merge_bwd(dev):

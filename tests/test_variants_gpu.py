@@ -162,11 +162,21 @@ def test_adapter_as_a_module(dev):
     ref = adapter_fwd(p, "a.", x.float().cpu())
     assert y.shape == x.shape and rel(y, ref) < 4e-3
     assert rel(y - x, ref - x.float().cpu()) < 2e-2          # the adapter branch itself, not just the residual
-    # parameters rewritten behind autograd's back -- what the engines' raw-pointer AdamW does (no _version bump, same
-    # data_ptr) -- and a bias changed on its own: the next call computes with the NEW values
+    # the packed operands are cached: a second call with unchanged parameters re-uses them
+    packs = ad.__dict__["_pack_cache"]
+    ad(x)
+    assert ad.__dict__["_pack_cache"] is packs
+    # an ordinary in-place update (what torch optimizers do: _version moves) is seen by itself
     with torch.no_grad():
-        ad.adapter[0].weight.data.mul_(0.5)
-        ad.adapter[2].bias.data.add_(0.25)
+        ad.adapter[2].bias.add_(0.25)
+    y1 = ad(x)
+    assert ad.__dict__["_pack_cache"] is not packs and rel(y1, ref) > 1e-2
+    # parameters rewritten behind autograd's back -- what the engines' raw-pointer AdamW does (no _version bump, same data_ptr):
+    # such writers bump the weights epoch (train_engine._step_impl, Magma.invalidate_packed), and the next call computes with the
+    # NEW values
+    from magma_amd.adapters import bump_weights_epoch
+    ad.adapter[0].weight.data.mul_(0.5)
+    bump_weights_epoch()
     y2 = ad(x)
     p2 = {"a." + k.replace("adapter.", ""): v.float().cpu() for k, v in ad.state_dict().items()}
     ref2 = adapter_fwd(p2, "a.", x.float().cpu())
