@@ -5,7 +5,7 @@ cd /tmp
 i=0
 for grp in "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES" "TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_WAIT_INST_ANY" "SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES" "GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_SALU"; do
   i=$((i+1)); rm -rf $ROOT/gpurun_out/pmc_attn_$i
-  AB=16 timeout 200 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $ROOT/gpurun_out/pmc_attn_$i -o t -- python $ROOT/tools/attn_bench.py > $ROOT/gpurun_out/pmc_attn_$i.log 2>&1
+  AB=16 ABWD=${ABWD:-4} timeout 200 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $ROOT/gpurun_out/pmc_attn_$i -o t -- python $ROOT/tools/attn_bench.py > $ROOT/gpurun_out/pmc_attn_$i.log 2>&1
   tail -2 $ROOT/gpurun_out/pmc_attn_$i.log | cut -c1-300
 done
 python - <<'PY'
