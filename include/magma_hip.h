@@ -74,7 +74,8 @@ const char* mg_version(void);
  *   4  round 5: mg_epilogue grew by C8 / ldc8 / c8_scales / c8_rgroups (the MX e4m3 copy of a tile GEMM's output): every
  *      descriptor that embeds an epilogue changed size.
  *   5  round 6: added mg_rotary_qk_inplace_bf16 / mg_attn_fwd_rows_bf16 / mg_attn_bwd_rows_bf16 (attention without transposed operand
- *      images, q / k / v taken as strided rows -- straight from the fused qkv activation); nothing moved.                            */
+ *      images, q / k / v taken as strided rows -- straight from the fused qkv activation); mg_attn_prefill_fp8 gained
+ *      out8 / ld_out8 / out8_scales (the MX e4m3 copy of its output, before the stream).                                             */
 #define MG_ABI_VERSION 5
 int32_t mg_abi_version(void);
 const char* mg_last_error(void);
@@ -484,11 +485,14 @@ int mg_attn_fwd_rows_bf16(const mg_bf16* q, const mg_bf16* k, const mg_bf16* v, 
                           int64_t stride_h, mg_bf16* out, int64_t ld_out, float* lse, int32_t B, int32_t H, int32_t S, void* stream);
 /* backward: dO [B*S, H*256]; O [B*S, >= H*256] at row stride ld_o; lse [B,H,S]; D fp32 workspace of 2 B H S floats.  Output EITHER
  * dq, dk, dv [B,H,S,256] (dqkv NULL) OR dqkv [B*S, 3 H 256] = the gradient of the fused qkv projection with the inverse rotary applied
- * to the first rot_dim columns of every dq and dk head (dq, dk, dv NULL) -- as mg_attn_bwd_bf16 / mg_attn_bwd_merged_bf16.           */
+ * to the first rot_dim columns of every dq and dk head (dq, dk, dv NULL) -- as mg_attn_bwd_bf16 / mg_attn_bwd_merged_bf16.
+ * dqkv8 / dqkv8_scales (or NULL): also the OCP MX e4m3 copy of dqkv, [B*S, 3 H 256] bytes + E8M0 scales of mg_mx_scale_bytes(B*S, 3 H 256)
+ * bytes, bit for bit what mg_quantize_mx_fp8 makes of the bf16 dqkv -- the operand of the qkv dgrad's mg_gemm_mx_fp8 (BASELINE config[4]),
+ * written from the epilogue's row pieces; dqkv itself may then be NULL (no bf16 copy).                                               */
 int mg_attn_bwd_rows_bf16(const mg_bf16* q, const mg_bf16* k, const mg_bf16* v, int64_t ld_row, int64_t stride_b,
                           int64_t stride_h, const mg_bf16* dO, const mg_bf16* O, int64_t ld_o, const float* lse, float* D,
                           mg_bf16* dq, mg_bf16* dk, mg_bf16* dv, mg_bf16* dqkv, int32_t rot_dim, const float* sin_t,
-                          const float* cos_t, int32_t B, int32_t H, int32_t S, void* stream);
+                          const float* cos_t, int32_t B, int32_t H, int32_t S, uint8_t* dqkv8, uint8_t* dqkv8_scales, void* stream);
 
 /* CLIP trunk backward helpers */
 int mg_avgpool2_bwd_nhwc_bf16(const mg_bf16* dy, const mg_bf16* gate, mg_bf16* dx, int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
@@ -553,14 +557,16 @@ int mg_adamw_gbf16_f32(float* p, float* m, float* v, const mg_bf16* g, mg_bf16* 
  * the attention kernel's accumulators hold them (attention.hip: rotary_split_fp8_kernel).  qt / kt may be NULL (no backward);
  * q / k / v may be NULL together (forward only).
  * mg_attn_prefill_fp8: causal flash attention on v_mfma_scale_f32_32x32x64_f8f6f4 with those operands, fp32 softmax, P as
- * e4m3(16 p) with scale 2^-4; outputs as mg_attn_prefill_bf16 (out bf16 [B*S, >= H*256] at row stride ld_out % 8 == 0, lse fp32). */
+ * e4m3(16 p) with scale 2^-4; outputs as mg_attn_prefill_bf16 (out bf16 [B*S, >= H*256] at row stride ld_out % 8 == 0, lse fp32).
+ * ABI 5: out8 / out8_scales (or NULL) = also the OCP MX e4m3 copy of out ([B*S, ld_out8 = ceil(H*256 / 128) * 128] bytes + E8M0 scales
+ * of mg_mx_scale_bytes(B*S, H*256) bytes), bit for bit what mg_quantize_mx_fp8 makes of it: the operand of out_proj's MX GEMM.      */
 int32_t mg_attn_fp8_scale_stride(int32_t S);
 int mg_rotary_split_fp8(const mg_bf16* qkv, int32_t B, int32_t S, int32_t H, int32_t rot_dim, const float* sin_t,
                         const float* cos_t, mg_bf16* q, mg_bf16* k, mg_bf16* v, mg_bf16* qt, mg_bf16* kt, int32_t ld_t,
                         uint8_t* q8, uint8_t* k8, uint8_t* v8t, uint8_t* eq, uint8_t* ek, uint8_t* sv8, void* stream);
 int mg_attn_prefill_fp8(const uint8_t* q8, const uint8_t* k8, const uint8_t* v8t, const uint8_t* eq, const uint8_t* ek,
                         const uint8_t* sv8, mg_bf16* out, int64_t ld_out, float* lse, int32_t B, int32_t H, int32_t S,
-                        void* stream);
+                        uint8_t* out8, int64_t ld_out8, uint8_t* out8_scales, void* stream);
 
 /* A HIP stream whose kernels never run on `reserve` of the device's CUs (spread evenly; hipExtStreamCreateWithCUMask): the
  * training engine can run its compute on it so that the RCCL kernels of the gradient exchange (reference train_loop.py:18-19 /

@@ -65,7 +65,7 @@ MG_DEV i32x8 rd32(const char* lds, uint32_t a) {
 __global__ __launch_bounds__(256) void attn_prefill32_fp8_kernel(
     const uint8_t* __restrict__ q8, const uint8_t* __restrict__ k8, const uint8_t* __restrict__ v8t, const uint8_t* __restrict__ eq,
     const uint8_t* __restrict__ ek, const uint8_t* __restrict__ sv8, mg_bf16* __restrict__ out, int64_t ld_out, float* __restrict__ lse,
-    int B, int H, int S, int Sp) {
+    int B, int H, int S, int Sp, uint8_t* __restrict__ out8, int64_t ld_out8, uint8_t* __restrict__ out8_scales) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -290,7 +290,12 @@ __global__ __launch_bounds__(256) void attn_prefill32_fp8_kernel(
     const int row = it * 2 + hi;
     const u32x4 w = *(const u32x4*)(stage + row * EP_ROW + l31 * 16);
     const int s = qt0 + wave * 32 + row;
-    if (s < S) *(u32x4*)(out + (int64_t)(b * S + s) * ld_out + h * DH + l31 * 8) = w;
+    if (s < S) {
+      *(u32x4*)(out + (int64_t)(b * S + s) * ld_out + h * DH + l31 * 8) = w;
+      // the OCP MX e4m3 copy of the same row piece (the operand of the out_proj MX GEMM): the lane holds 8 consecutive columns, the
+      // four lanes of a 32-column block are consecutive -- mg_quantize_mx_fp8's result bit for bit, without its pass over ctx
+      if (out8) mx_emit8(w, out8 + (int64_t)(b * S + s) * ld_out8, out8_scales, (B * S + 63) >> 6, b * S + s, h * DH + l31 * 8);
+    }
   }
   if (lse && hi == 0 && qrow < S) lse[(int64_t)bh * S + qrow] = (m2 + log2f(lsum)) * 0.6931471805599453f;
 }
@@ -302,17 +307,19 @@ __global__ __launch_bounds__(256) void attn_prefill32_fp8_kernel(
 // a multiple of 8), lse [B,H,S] fp32 or NULL -- the outputs of mg_attn_prefill_bf16.
 extern "C" int mg_attn_prefill_fp8(const uint8_t* q8, const uint8_t* k8, const uint8_t* v8t, const uint8_t* eq, const uint8_t* ek,
                                    const uint8_t* sv8, mg_bf16* out, int64_t ld_out, float* lse, int32_t B, int32_t H, int32_t S,
-                                   void* stream) {
+                                   uint8_t* out8, int64_t ld_out8, uint8_t* out8_scales, void* stream) {
   if (ld_out == 0) ld_out = (int64_t)H * DH;
   if (ld_out < (int64_t)H * DH || (ld_out & 7)) MG_FAIL(MG_ERR_SHAPE, "mg_attn_prefill_fp8: ld_out must be 0 or a multiple of 8 >= H*256");
   if (B <= 0 || H <= 0 || S <= 0) MG_FAIL(MG_ERR_SHAPE, "mg_attn_prefill_fp8: bad B/H/S");
   if (!q8 || !k8 || !v8t || !eq || !ek || !sv8 || !out) MG_FAIL(MG_ERR_SHAPE, "mg_attn_prefill_fp8: null pointer");
   if (!MG_ALIGNED16(q8) || !MG_ALIGNED16(k8) || !MG_ALIGNED16(v8t) || !MG_ALIGNED16(sv8) || !MG_ALIGNED16(out) || ((uintptr_t)ek & 3))
     MG_FAIL(MG_ERR_ALIGN, "mg_attn_prefill_fp8: pointers must be 16-byte aligned (ek: 4)");
+  if (out8 && (!out8_scales || ((uintptr_t)out8 & 7) || ld_out8 != (((int64_t)H * DH + 127) / 128) * 128))
+    MG_FAIL(MG_ERR_SHAPE, "mg_attn_prefill_fp8: the MX output copy needs its scale array, 8-byte alignment and ld_out8 == ceil(H*256 / 128) * 128");
   const int lds = P_STAGES * P_STAGE;
   if (int rc = mg_allow_dynamic_lds((const void*)attn_prefill32_fp8_kernel, lds, "mg_attn_prefill_fp8")) return rc;
   hipLaunchKernelGGL(attn_prefill32_fp8_kernel, dim3((unsigned)(((S + 127) / 128) * B * H)), dim3(256), lds, (hipStream_t)stream, q8, k8,
-                     v8t, eq, ek, sv8, out, ld_out, lse, B, H, S, ((S + 63) / 64) * 64 + 256);
+                     v8t, eq, ek, sv8, out, ld_out, lse, B, H, S, ((S + 63) / 64) * 64 + 256, out8, ld_out8, out8_scales);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }

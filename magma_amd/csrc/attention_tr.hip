@@ -67,7 +67,8 @@ MG_DEV void rd_t_half(bf16x8& f0, bf16x8& f1, uint32_t tb) {
 // A wave's 32 x 256 gradient tile -> bf16 through a wave-private LDS image, out as whole 512-byte rows (as attention_bwd32.hip)
 MG_DEV void store_grad_tile32_tr(const GradOut& g, const f32x16 (&acc)[8], float scale, char* stage, int b, int h, int H, int S,
                                  int row0, int l31, int hi) {
-  const bool rot = g.merged && g.which < 2 && g.rot_dim > 0;
+  const bool mrg = g.merged || g.q8;
+  const bool rot = mrg && g.which < 2 && g.rot_dim > 0;
   const int half_rot = g.rot_dim >> 1;
   const int s_me = min(row0 + l31, S - 1);
   char* wr = stage + l31 * EP_ROW + hi * 8;
@@ -95,7 +96,13 @@ MG_DEV void store_grad_tile32_tr(const GradOut& g, const f32x16 (&acc)[8], float
     const int row = it * 2 + hi;
     const u32x4 w = *(const u32x4*)(stage + row * EP_ROW + l31 * 16);
     const int s = row0 + row;
-    if (s < S) *(u32x4*)(grad_row_ptr(g, b, h, H, S, s) + l31 * 8) = w;
+    if (s < S) {
+      if (g.merged || g.out) *(u32x4*)(grad_row_ptr(g, b, h, H, S, s) + l31 * 8) = w;
+      if (g.q8) {      // the MX e4m3 copy of this row piece of dqkv (GradOut): four consecutive lanes hold one 32-column block
+        const int64_t grow = (int64_t)b * S + s;
+        mx_emit8(w, g.q8 + grow * (3 * H * DH), g.q8_scales, (g.mx_rows + 63) >> 6, (int)grow, g.which * H * DH + h * DH + l31 * 8);
+      }
+    }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
@@ -1061,19 +1068,23 @@ extern "C" int mg_attn_fwd_rows_bf16(const mg_bf16* q, const mg_bf16* k, const m
 extern "C" int mg_attn_bwd_rows_bf16(const mg_bf16* q, const mg_bf16* k, const mg_bf16* v, int64_t ld_row, int64_t stride_b,
                                      int64_t stride_h, const mg_bf16* dO, const mg_bf16* O, int64_t ld_o, const float* lse, float* D,
                                      mg_bf16* dq, mg_bf16* dk, mg_bf16* dv, mg_bf16* dqkv, int32_t rot_dim, const float* sin_t,
-                                     const float* cos_t, int32_t B, int32_t H, int32_t S, void* stream) {
+                                     const float* cos_t, int32_t B, int32_t H, int32_t S, uint8_t* dqkv8, uint8_t* dqkv8_scales,
+                                     void* stream) {
   const char* who = "mg_attn_bwd_rows_bf16";
   if (int rc = check_rows(who, q, k, v, ld_row, stride_b, stride_h, B, H, S)) return rc;
   if (!dO || !O || !lse || !D) MG_FAIL(MG_ERR_SHAPE, "%s: null pointer", who);
   if (!MG_ALIGNED16(dO) || !MG_ALIGNED16(O)) MG_FAIL(MG_ERR_ALIGN, "%s: dO and O must be 16-byte aligned", who);
   if (ld_o < (int64_t)H * DH || (ld_o & 7)) MG_FAIL(MG_ERR_SHAPE, "%s: ld_o must be a multiple of 8 and >= H * 256", who);
   GradOut gq, gk, gv;
-  if (dqkv) {
-    if (dq || dk || dv) MG_FAIL(MG_ERR_SHAPE, "%s: either dqkv (merged) or dq / dk / dv", who);
-    if (!MG_ALIGNED16(dqkv)) MG_FAIL(MG_ERR_ALIGN, "%s: dqkv must be 16-byte aligned", who);
+  if (dqkv8 && (!dqkv8_scales || ((uintptr_t)dqkv8 & 7) || ((3 * H * DH) & 127)))
+    MG_FAIL(MG_ERR_SHAPE, "%s: the MX copy of dqkv needs its scale array, 8-byte alignment and 3 H 256 %% 128 == 0", who);
+  if (dqkv || dqkv8) {
+    if (dq || dk || dv) MG_FAIL(MG_ERR_SHAPE, "%s: either dqkv (merged; bf16 and / or its MX copy) or dq / dk / dv", who);
+    if (dqkv && !MG_ALIGNED16(dqkv)) MG_FAIL(MG_ERR_ALIGN, "%s: dqkv must be 16-byte aligned", who);
     if (rot_dim < 0 || rot_dim > DH || (rot_dim & 7)) MG_FAIL(MG_ERR_SHAPE, "%s: rot_dim must be a multiple of 8 in [0,256]", who);
     if (rot_dim && (!sin_t || !cos_t)) MG_FAIL(MG_ERR_SHAPE, "%s: rotary tables missing", who);
     gq = GradOut{nullptr, dqkv, sin_t, cos_t, 0, rot_dim}; gk = GradOut{nullptr, dqkv, sin_t, cos_t, 1, rot_dim}; gv = GradOut{nullptr, dqkv, sin_t, cos_t, 2, 0};
+    for (GradOut* g : {&gq, &gk, &gv}) { g->q8 = dqkv8; g->q8_scales = dqkv8_scales; g->mx_rows = B * S; }
   } else {
     if (!dq || !dk || !dv) MG_FAIL(MG_ERR_SHAPE, "%s: null gradient pointer", who);
     if (!MG_ALIGNED16(dq) || !MG_ALIGNED16(dk) || !MG_ALIGNED16(dv)) MG_FAIL(MG_ERR_ALIGN, "%s: dq, dk, dv must be 16-byte aligned", who);

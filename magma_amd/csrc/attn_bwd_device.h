@@ -16,9 +16,15 @@ struct GradOut {
   const float* sin_t;
   const float* cos_t;
   int which, rot_dim;
+  // round 6 (attention_tr.hip, merged form only): the OCP MX e4m3 copy of the merged gradient, q8 [B*S, 3 H 256] + E8M0 scales in the
+  // layout of mg_quantize_mx_fp8 -- the operand of the qkv dgrad's MX GEMM, written from the epilogue's row pieces (no quantisation
+  // pass over dqkv).  `merged` may then be null (no bf16 copy at all).
+  uint8_t* q8 = nullptr;
+  uint8_t* q8_scales = nullptr;
+  int mx_rows = 0;          // B * S: the row count the scale layout is built for
 };
 MG_DEV mg_bf16* grad_row_ptr(const GradOut& g, int b, int h, int H, int S, int s) {
-  return g.merged ? g.merged + ((int64_t)b * S + s) * (3 * H * DH) + (int64_t)g.which * H * DH + h * DH
+  return (g.merged || !g.out) ? g.merged + ((int64_t)b * S + s) * (3 * H * DH) + (int64_t)g.which * H * DH + h * DH
                   : g.out + (((int64_t)b * H + h) * S + s) * DH;
 }
 

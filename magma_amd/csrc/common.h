@@ -55,6 +55,46 @@ MG_DEV float apply_act(float v, int act) {
   return v;
 }
 
+// ---- OCP MX e4m3 copy of 8 consecutive bf16 values held by one lane ---------------------------------------------------------
+// The rule of mg_quantize_mx_fp8 (include/magma_hip.h): one E8M0 scale per 32 consecutive columns of a row = the smallest power of
+// two that keeps the block maximum <= 448, elements rounded to e4m3 by v_cvt_pk_fp8_f32.  `w` = columns c .. c+7 of row `row`
+// (c % 8 == 0); the FOUR lanes that hold one 32-column block must be consecutive lanes l, l^1, l^2, l^3 of the wave, all active.
+// Writes the 8 bytes at qrow + c (qrow = q + row * ldq) and -- the lane with c % 32 == 0 -- the block's scale byte into the
+// [chunk][block][row / 64][row % 16][(row % 64) / 16] layout the MX GEMM reads.  Used by the quantiser itself and by producer
+// epilogues that hold whole rows (attention forward / backward), so their copies are the quantiser's bit for bit.
+MG_DEV void mx_emit8(const u32x4 w, uint8_t* __restrict__ qrow, uint8_t* __restrict__ scales, int rgroups, int row, int c) {
+  float f[8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { f[2 * i] = bflo(w[i]); f[2 * i + 1] = bfhi(w[i]); }
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(f[i]));
+  amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+  amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+  // floor(log2(amax)) from the exponent field (amax is a bf16 value: normal or zero; bf16 subnormals -> exponent field 0)
+  const int ef = (int)((__float_as_uint(amax) >> 23) & 0xff);
+  int e8 = amax > 0.f ? ef - 8 : 127;                          // E8M0 byte = floor(log2 amax) - 8 + 127
+  e8 = max(0, min(254, e8));
+  float inv = __uint_as_float((uint32_t)(254 - e8) << 23);   // 2^-(e8 - 127)
+  if (amax * inv > 448.f) {    // the block maximum lies in (448, 512) 2^e: one exponent up instead of saturating it
+    e8 = min(254, e8 + 1);
+    inv = __uint_as_float((uint32_t)(254 - e8) << 23);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) f[i] = __builtin_amdgcn_fmed3f(f[i] * inv, -448.f, 448.f);
+  int lo = 0, hi = 0;
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+  const u32x2 o = {(uint32_t)lo, (uint32_t)hi};
+  *(u32x2*)(qrow + c) = o;
+  if ((c & 31) == 0) {
+    const int chunk = c >> 7, b = (c & 127) >> 5;
+    scales[((((int64_t)chunk * 4 + b) * rgroups + (row >> 6)) * 16 + (row & 15)) * 4 + ((row & 63) >> 4)] = (uint8_t)e8;
+  }
+}
+
 // ---- LDS-DMA: global -> LDS without a register round trip -----------------------
 typedef const __attribute__((address_space(1))) void* mg_gptr_t;
 typedef __attribute__((address_space(3))) void* mg_lptr_t;

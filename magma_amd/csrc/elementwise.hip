@@ -685,39 +685,9 @@ __global__ __launch_bounds__(256) void quantize_mx_fp8_kernel(const mg_bf16* __r
   const mg_bf16* xr = x + (int64_t)row * ldx;
   uint8_t* qr = q + (int64_t)row * ldq;
   for (int c = tid * 8; c < (int)ldq; c += 256 * 8) {          // ldq % 128 == 0: whole blocks, whole quads of lanes
-    float f[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) f[i] = 0.f;
-    if (c < K) {                                                // K % 8 == 0
-      const u32x4 w = *(const u32x4*)(xr + c);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { f[2 * i] = bflo(w[i]); f[2 * i + 1] = bfhi(w[i]); }
-    }
-    float amax = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(f[i]));
-    amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
-    amax = fmaxf(amax, __shfl_xor(amax, 2, 64));               // the 4 lanes of a block are consecutive
-    // floor(log2(amax)) from the exponent field (amax is a bf16 value: normal or zero; bf16 subnormals -> exponent field 0)
-    const int ef = (int)((__float_as_uint(amax) >> 23) & 0xff);
-    int e8 = amax > 0.f ? ef - 8 : 127;                          // E8M0 byte = floor(log2 amax) - 8 + 127 = ef - 127 - 8 + 127
-    e8 = max(0, min(254, e8));
-    float inv = __uint_as_float((uint32_t)(254 - e8) << 23);   // 2^-(e8 - 127)
-    if (amax * inv > 448.f) {    // the block maximum lies in (448, 512) 2^e: one exponent up instead of saturating it (header: MX scale rule)
-      e8 = min(254, e8 + 1);
-      inv = __uint_as_float((uint32_t)(254 - e8) << 23);
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) f[i] = __builtin_amdgcn_fmed3f(f[i] * inv, -448.f, 448.f);
-    int lo = 0, hi = 0;
-    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
-    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
-    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
-    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
-    const int chunk = c >> 7, e = c & 127, b = e >> 5, r = e & 31;               // r in {0, 8, 16, 24}
-    const u32x2 o = {(uint32_t)lo, (uint32_t)hi};
-    *(u32x2*)(qr + c) = o;
-    if (r == 0) scales[((((int64_t)chunk * 4 + b) * rgroups + (row >> 6)) * 16 + (row & 15)) * 4 + ((row & 63) >> 4)] = (uint8_t)e8;
+    u32x4 w = {0u, 0u, 0u, 0u};
+    if (c < K) w = *(const u32x4*)(xr + c);                     // K % 8 == 0
+    mx_emit8(w, qr, scales, rgroups, row, c);                   // common.h: the ONE statement of the MX rule (producer epilogues use it too)
   }
 }
 

@@ -424,11 +424,17 @@ def rotary_split_fp8(qkv, B, S, H, rot_dim, sin_t, cos_t, q=None, k=None, v=None
     return op
 
 
-def attn_prefill_fp8(op: AttnFP8Operands, out, lse: Optional[torch.Tensor] = None):
-    """Causal flash attention on the fp8 MFMA (mg_attn_prefill_fp8): out [B*S, >= H*256] bf16 (a column range of a wider row is fine)."""
+def attn_prefill_fp8(op: AttnFP8Operands, out, lse: Optional[torch.Tensor] = None, mx_out=None):
+    """Causal flash attention on the fp8 MFMA (mg_attn_prefill_fp8): out [B*S, >= H*256] bf16 (a column range of a wider row is fine).
+    ``mx_out`` = (q, scales) from mx_empty(B*S, H*256): the epilogue also writes the OCP MX e4m3 copy of out."""
     assert out.ndim == 2 and out.stride(1) == 1 and out.shape[1] == op.H * 256 and out.stride(0) % 8 == 0
+    q8, sc8 = mx_out if mx_out is not None else (None, None)
+    if q8 is not None:
+        assert q8.dtype == torch.uint8 and q8.shape[0] >= op.B * op.S and q8.stride(0) == ceil_to(op.H * 256, 128)
+        assert sc8.numel() == int(L.load().mg_mx_scale_bytes(op.B * op.S, op.H * 256))
     check(L.load().mg_attn_prefill_fp8(op.q8.data_ptr(), op.k8.data_ptr(), op.v8t.data_ptr(), op.eq.data_ptr(), op.ek.data_ptr(),
-                                       op.sv8.data_ptr(), out.data_ptr(), out.stride(0), _p(lse), op.B, op.H, op.S, _stream()),
+                                       op.sv8.data_ptr(), out.data_ptr(), out.stride(0), _p(lse), op.B, op.H, op.S,
+                                       _p(q8), 0 if q8 is None else q8.stride(0), _p(sc8), _stream()),
           "mg_attn_prefill_fp8")
     return out
 
@@ -865,9 +871,11 @@ def attn_fwd_rows(x: AttnRows, out, lse: Optional[torch.Tensor] = None):
     return out
 
 
-def attn_bwd_rows(x: AttnRows, dO, O, lse, merged_rot=None):
+def attn_bwd_rows(x: AttnRows, dO, O, lse, merged_rot=None, mx_out=None, no_out: bool = False):
     """Attention backward without transposed operands.  merged_rot None -> (dq, dk, dv) [B,H,S,256]; merged_rot = (rot_dim, sin_t,
-    cos_t) -> dqkv [B*S, 3 H 256], the gradient of the fused qkv projection (inverse rotary applied)."""
+    cos_t) -> dqkv [B*S, 3 H 256], the gradient of the fused qkv projection (inverse rotary applied).  Merged form only:
+    ``mx_out`` = (q, scales) from mx_empty(B*S, 3 H 256) -> the epilogue also writes the OCP MX e4m3 copy of dqkv; with ``no_out``
+    only that copy (returns None)."""
     _need_gpu(dO)
     assert O.ndim == 2 and O.stride(1) == 1 and dO.is_contiguous()
     B, H, S, dev = x.B, x.H, x.S, dO.device
@@ -876,13 +884,18 @@ def attn_bwd_rows(x: AttnRows, dO, O, lse, merged_rot=None):
         dq, dk, dv = (torch.empty(B, H, S, 256, dtype=BF16, device=dev) for _ in range(3))
         check(L.load().mg_attn_bwd_rows_bf16(x.q, x.k, x.v, x.ld_row, x.stride_b, x.stride_h, dO.data_ptr(), O.data_ptr(), O.stride(0),
                                              lse.data_ptr(), D.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), None, 0, None, None,
-                                             B, H, S, _stream()), "mg_attn_bwd_rows_bf16")
+                                             B, H, S, None, None, _stream()), "mg_attn_bwd_rows_bf16")
         return dq, dk, dv
     rot_dim, sin_t, cos_t = merged_rot
-    dqkv = torch.empty(B * S, 3 * H * 256, dtype=BF16, device=dev)
+    q8, sc8 = mx_out if mx_out is not None else (None, None)
+    assert not no_out or q8 is not None
+    if q8 is not None:
+        assert q8.dtype == torch.uint8 and q8.shape[0] >= B * S and q8.stride(0) == 3 * H * 256
+        assert sc8.numel() == int(L.load().mg_mx_scale_bytes(B * S, 3 * H * 256))
+    dqkv = None if no_out else torch.empty(B * S, 3 * H * 256, dtype=BF16, device=dev)
     check(L.load().mg_attn_bwd_rows_bf16(x.q, x.k, x.v, x.ld_row, x.stride_b, x.stride_h, dO.data_ptr(), O.data_ptr(), O.stride(0),
-                                         lse.data_ptr(), D.data_ptr(), None, None, None, dqkv.data_ptr(), rot_dim, sin_t.data_ptr(),
-                                         cos_t.data_ptr(), B, H, S, _stream()), "mg_attn_bwd_rows_bf16")
+                                         lse.data_ptr(), D.data_ptr(), None, None, None, _p(dqkv), rot_dim, sin_t.data_ptr(),
+                                         cos_t.data_ptr(), B, H, S, _p(q8), _p(sc8), _stream()), "mg_attn_bwd_rows_bf16")
     return dqkv
 
 
@@ -1073,6 +1086,19 @@ class PackedLinearFP8:
         q = self.rm if self.rm is not None else PackedLinear.untile(self.ft.view(torch.int16)).view(torch.uint8)[: self.N]
         return q[:, : self.K].view(torch.float8_e4m3fn).float() * self.scale[:, None]
 
+    @classmethod
+    def of_live(cls, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> "PackedLinearFP8":
+        """The fragment-tiled pack of a TRAINABLE [N, K] bf16 weight (N % 16 == 0, K % 128 == 0), rebuilt every optimizer step: two
+        launches (quantise, tile), no padding copies; ``bias`` is kept by reference (a live fp32 master view)."""
+        self = cls.__new__(cls)
+        self.N, self.K = weight.shape
+        assert weight.dtype == BF16 and weight.stride(1) == 1 and self.N % 16 == 0 and self.K % 128 == 0
+        self.Kp = self.K
+        q, self.scale = quantize_rows_fp8(weight, self.Kp)
+        self.bias, self.rm = bias, None
+        self.ft = PackedLinear.tile(q.view(torch.int16)).view(torch.uint8)
+        return self
+
 
 def gemm_fp8(aq: torch.Tensor, a_scale: torch.Tensor, w: PackedLinearFP8, out: Optional[torch.Tensor] = None, *,
              act: int = MG_ACT_NONE, residuals: Sequence[torch.Tensor] = (), act_after: int = MG_ACT_NONE,
@@ -1179,6 +1205,18 @@ class PackedLinearMX:
     def dequant(self) -> torch.Tensor:
         q = self.rm if self.rm is not None else PackedLinear.untile(self.ft.view(torch.int16)).view(torch.uint8)[: self.N]
         return mx_dequant(q.contiguous(), self.scales, self.K)
+
+    @classmethod
+    def of_live(cls, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> "PackedLinearMX":
+        """As PackedLinearFP8.of_live, with OCP MX block scales."""
+        self = cls.__new__(cls)
+        self.N, self.K = weight.shape
+        assert weight.dtype == BF16 and weight.stride(1) == 1 and self.N % 16 == 0 and self.K % 128 == 0
+        self.Kp, self._n16 = self.K, self.N
+        q, self.scales = quantize_mx_fp8(weight)
+        self.bias, self.rm = bias, None
+        self.ft = PackedLinear.tile(q.view(torch.int16)).view(torch.uint8)
+        return self
 
 
 def gemm_mx_fp8(aq: torch.Tensor, a_scales: torch.Tensor, w: PackedLinearMX, out: Optional[torch.Tensor] = None, *,

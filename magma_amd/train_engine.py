@@ -154,6 +154,15 @@ class MagmaEngine:
         # Removes two of the seven quantisation passes per block -- the two over [B*S, 16384] -- and the bf16 round trip of
         # both tensors.  MAGMA_TRAIN_FP8_MX=0: every fp8 GEMM on per-row scales with a quantisation pass in front (round 4).
         self.fp8_mx = os.environ.get("MAGMA_TRAIN_FP8_MX", "1") == "1"
+        # with self.fp8 and self.fp8_mx: the MLP adapter's four activation-side GEMMs (down, up, and their two dgrads) on the fp8 MFMA
+        # too (BASELINE config[4]: "fp8 MFMA path for GPT-J attention + adapter GEMMs"), fed through the MX output copies of the
+        # producing epilogues (no quantisation pass of their own): fc_out's epilogue emits the MX copy of m -> down as an MX GEMM
+        # whose ReLU epilogue emits MX t -> up consumes it; backward: the up-dgrad reads the row-quantised incoming gradient the
+        # out_proj dgrad quantises anyway, its ReLU-gate epilogue emits MX dt -> the down-dgrad (+ g) emits dm as MX only, which
+        # feeds the fc_out dgrad.  The adapter weights are re-quantised when they change (adapters.bump_weights_epoch).
+        # Weight gradients stay bf16.  Plain ReLU MLP adapters (the MAGMA_v1 shape); MAGMA_FP8_ADAPTERS=0: bf16 adapters.
+        self.fp8_adapters = os.environ.get("MAGMA_FP8_ADAPTERS", "1") == "1"
+        self._ad8_cache = {}
         if self.fp8 and self.lm_trainable:
             raise NotImplementedError("MAGMA_TRAIN_FP8 quantises the FROZEN block weights once; with freeze_lm: false they change every step")
         self._fp8_packs = {}
@@ -501,6 +510,30 @@ class MagmaEngine:
         sc = sval.reshape(1).to(F32).expand(up.weight.shape[0]).contiguous()
         return dnw, RawWeight(up.weight.data, bias=(self.master_of(up.bias) * sc).contiguous()), sc
 
+    def _ad8_ok(self, ly, mod) -> bool:
+        """fp8 adapter chain: plain ReLU MLP adapter (no LayerNorm, not parallel), shapes the 256x256 fp8 kernel's MX output covers."""
+        if not (self.fp8 and self.fp8_mx and self.fp8_adapters) or ly.mlp_adapter is None or ly.mlp_par is not None:
+            return False
+        if not getattr(mod, "plain", False):
+            return False
+        r, d = mod.down.weight.shape
+        return r % 256 == 0 and d % 256 == 0
+
+    def _ad8(self, li, mod):
+        """e4m3 operands of the adapter's four activation-side GEMMs, rebuilt when the weights epoch moved (every optimizer step)."""
+        from . import adapters
+        ep = adapters._WEIGHTS_EPOCH
+        c = self._ad8_cache.get(li)
+        if c is not None and c[0] == ep:
+            return c[1]
+        wd, wu = mod.down.weight.data, mod.up.weight.data                   # [r, d], [d, r]
+        packs = {"dn": ops.PackedLinearMX.of_live(wd, self.master_of(mod.down.bias)),
+                 "up": ops.PackedLinearMX.of_live(wu, self.master_of(mod.up.bias)),
+                 "up_t": ops.PackedLinearFP8.of_live(ops.transpose(wu)),        # dt = g W_up        (row-quantised g)
+                 "dn_t": ops.PackedLinearMX.of_live(ops.transpose(wd))}         # dm = g + dt W_dn   (MX dt)
+        self._ad8_cache[li] = (ep, packs)
+        return packs
+
     def _adapter_down(self, mod, x_in, dn, sv, key):
         """t = act(W_dn [LayerNorm] x_in + b_dn) for an Adapter-like module with any of the reference's options
         (reference adapters.py:11-24).  Saves what the backward needs under sv[key] (t) and sv[key + "_pre"] (the
@@ -532,8 +565,13 @@ class MagmaEngine:
             w8 = self._fp8_packs[key] = cls(ops.PackedLinear.untile(lin.ft)[: lin.N, : lin.K], lin.bias)
         # the MX copy is written by the 256x256 fp8 kernel (K % 256 == 0 in fp8 elements) for whole 32-column blocks; other
         # shapes (reduced test models) keep the bf16 output and the quantisation pass of the consumer
-        mx_out = mx_out and lin.K % 256 == 0 and lin.N % 32 == 0
-        if mx_out:
+        mx_both = mx_out if isinstance(mx_out, tuple) else None      # (q, scales) from ops.mx_empty: the MX copy NEXT TO the bf16 output
+        mx_ok = lin.K % 256 == 0 and lin.N % 32 == 0
+        mx_out = bool(mx_out) and mx_both is None and mx_ok
+        if mx_both is not None:
+            assert mx_ok, "the MX output copy needs K % 256 == 0 and N % 32 == 0"
+            kw.update(mx_out=mx_both, tile=256)
+        elif mx_out:
             M = x[1].shape[0] if mx_in else (xq[0] if xq is not None else x).shape[0]
             kw.update(mx_out=ops.mx_empty(M, lin.N, self.device), no_out=True, tile=256)
         if mx_in:
@@ -596,12 +634,12 @@ class MagmaEngine:
             lnq = ops.quantize_rows_fp8(ln) if self.fp8 else None     # shared by qkv and fc_in
             qkv = self._fgemm((li, "qkv"), ln, ly.qkv, lnq)
             a8 = rows = None
-            if self.fp8 and self.fp8_attn:     # e4m3 copies of q, k, v^T for the forward; q, k, v in bf16 for the backward
-                q = torch.empty(B, H, S, 256, dtype=BF16, device=dev)
-                k = torch.empty(B, H, S, 256, dtype=BF16, device=dev)
-                v = torch.empty(B, H, S, 256, dtype=BF16, device=dev)
-                a8 = ops.rotary_split_fp8(qkv, B, S, H, eng.rot, eng.sin_t, eng.cos_t, q, k, v)
-                rows = ops.AttnRows.of_bhsd(q, k, v)
+            if self.fp8 and self.fp8_attn:
+                # e4m3 copies of q, k, v^T for the fp8 forward, made from the qkv buffer AFTER the in-place rotary (rot_dim 0: the
+                # split pass only quantises); the bf16 backward reads q, k, v as rows of that same buffer -- no bf16 copies
+                ops.rotary_qk_inplace(qkv, B, S, H, eng.rot, eng.sin_t, eng.cos_t)
+                a8 = ops.rotary_split_fp8(qkv, B, S, H, 0, eng.sin_t, eng.cos_t)
+                rows = ops.AttnRows.of_qkv(qkv, B, S, H)
             elif os.environ.get("MAGMA_ATTN_TR", "1") == "0":
                 # A/B switch only (tools/gpu_r06_step_ab.sh): the round-5 path -- split pass with three transposes, kernels with
                 # transposed operand images
@@ -623,14 +661,19 @@ class MagmaEngine:
             else:
                 ctx = torch.empty(M, d, dtype=BF16, device=dev)
             lse = torch.empty(B, H, S, dtype=F32, device=dev)
+            ctx_mx = None
             if a8 is not None:
-                ops.attn_prefill_fp8(a8, ctx, lse=lse)
+                # fp8_mx: the attention epilogue also emits the OCP MX e4m3 copy of ctx (it holds whole rows): out_proj then runs as an
+                # MX GEMM without a quantisation pass over ctx
+                if self.fp8_mx and out_up is None and (H * 256) % 256 == 0:
+                    ctx_mx = ops.mx_empty(M, H * 256, dev)
+                ops.attn_prefill_fp8(a8, ctx, lse=lse, mx_out=ctx_mx)
             elif rows is None:
                 ops.attn_prefill(q, k, vt, ctx, B, H, S, lse=lse)
             else:
                 ops.attn_fwd_rows(rows, ctx, lse=lse)
             sv.update(rows=rows, ctx=ctx, lse=lse)
-            a = None if out_up is not None else self._fgemm((li, "out"), ctx, ly.out)
+            a = None if out_up is not None else self._fgemm((li, "out"), ctx if ctx_mx is None else ("mx", *ctx_mx), ly.out)
             if ly.attn_adapter is not None and ly.attn_par is not None:
                 # parallel / scaled_parallel (reference adapters.py:42-92): the adapter reads the attention INPUT (ln_1 output)
                 dn, up, sc = self._par_adapter_ops(blk.attn)
@@ -659,6 +702,15 @@ class MagmaEngine:
                 m = self._fgemm((li, "fc_out"), h, ly.fc_out)
                 t = self._adapter_down(blk.mlp, ln, dn, sv, "t")
                 x = ops.gemm(t, up, scale=sc, residuals=(m, a, x), layout="rm")
+            elif self._ad8_ok(ly, blk.mlp[1]):
+                # config[4]: the adapter GEMMs on the fp8 MFMA, operands from the producing epilogues (see __init__)
+                p8 = self._ad8(li, blk.mlp[1])
+                m_mx = ops.mx_empty(M, ly.fc_out.N, dev)
+                m = self._fgemm((li, "fc_out"), h, ly.fc_out, mx_out=m_mx)
+                t_mx = ops.mx_empty(M, p8["dn"].N, dev)
+                t = ops.gemm_mx_fp8(m_mx[0], m_mx[1], p8["dn"], act=ops.MG_ACT_RELU, mx_out=t_mx, tile=256)
+                x = ops.gemm_mx_fp8(t_mx[0], t_mx[1], p8["up"], residuals=(m, a, x))
+                sv.update(m=m, t=t)
             elif ly.mlp_adapter is not None:
                 dn, up = self._adapter_ops(blk.mlp[1])
                 m = self._fgemm((li, "fc_out"), h, ly.fc_out)
@@ -814,10 +866,22 @@ class MagmaEngine:
             par = ly.mlp_par is not None or ly.attn_par is not None
             ln = ops.layernorm(sv["x"], ly.ln_g, ly.ln_b, eng.eps) if par else None   # the parallel adapters' input, recomputed
             extra = []                                                                 # dL/d ln through the parallel adapters
+            gq = None                                                                  # row-quantised g, shared by its consumers
             if ly.mlp_adapter is not None and ly.mlp_par is not None:
                 dt, dn_t = self._par_adapter_backward(blk.mlp, g, ln, sv["t"], sv.get("t_pre"))
                 extra.append(self._adapter_dx(blk.mlp, dt, dn_t, ln))
                 dm = g
+            elif self._ad8_ok(ly, blk.mlp[1]):
+                mod, p8 = blk.mlp[1], self._ad8(li, blk.mlp[1])
+                gq = ops.quantize_rows_fp8(g)          # also the operand of the out_proj dgrad below (no attention adapter: da = g)
+                self._acc_wgrad(mod.up.weight, RawWeight(ops.transpose_colsum(g, self.grad_of(mod.up.bias))), _t(sv["t"]))
+                dt_mx = ops.mx_empty(M, p8["up_t"].N, dev)
+                dt = ops.gemm_fp8(gq[0], gq[1], p8["up_t"], aux=sv["t"], aux_mode=ops.MG_AUX_RELU_GATE, use_bias=False,
+                                  mx_out=dt_mx, tile=256)
+                self._acc_wgrad(mod.down.weight, RawWeight(ops.transpose_colsum(dt, self.grad_of(mod.down.bias))), _t(sv["m"]))
+                dm_mx = ops.mx_empty(M, p8["dn_t"].N, dev)
+                ops.gemm_mx_fp8(dt_mx[0], dt_mx[1], p8["dn_t"], residuals=(g,), use_bias=False, mx_out=dm_mx, no_out=True, tile=256)
+                dm = ("mx", *dm_mx)                    # dL/dm exists only as the MX operand of the fc_out dgrad
             elif ly.mlp_adapter is not None:
                 dt, dn_t = self._adapter_backward(blk.mlp[1], g, sv["m"], sv["t"], sv.get("t_pre"))
                 dm = self._adapter_dx(blk.mlp[1], dt, dn_t, sv["m"], res=g)
@@ -845,10 +909,16 @@ class MagmaEngine:
                 da = self._adapter_dx(blk.attn, dta, dn_t, sv["a"], res=g)
             else:
                 da = g
-            dctx = self._fgemm((li, "out_t"), da, pk["out_t"])
+            dctx = self._fgemm((li, "out_t"), da, pk["out_t"], xq=gq if da is g else None)
             if sv["rows"] is None:      # MAGMA_ATTN_TR=0 (A/B only)
                 q, k, v, qt, kt = sv["old"]
                 dqkv = ops.attn_bwd_merged(q, k, v, qt, kt, dctx, sv["ctx"], sv["lse"], B, H, S, eng.rot, eng.sin_t, eng.cos_t)
+            elif self.fp8 and self.fp8_mx and (3 * H * 256) % 256 == 0:
+                # fp8_mx: the gradient of the fused qkv projection leaves the attention backward's epilogues ONLY as the OCP MX e4m3
+                # operand of the qkv dgrad (the LM is frozen in fp8 mode: nothing else reads dqkv) -- no bf16 dqkv, no quantisation pass
+                dq_mx = ops.mx_empty(M, 3 * H * 256, dev)
+                ops.attn_bwd_rows(sv["rows"], dctx, sv["ctx"], sv["lse"], merged_rot=(eng.rot, eng.sin_t, eng.cos_t), mx_out=dq_mx, no_out=True)
+                dqkv = ("mx", *dq_mx)
             else:
                 dqkv = ops.attn_bwd_rows(sv["rows"], dctx, sv["ctx"], sv["lse"], merged_rot=(eng.rot, eng.sin_t, eng.cos_t))
             dln = self._fgemm((li, "qkv_t"), dqkv, pk["qkv_t"], residuals=(dln_mlp, *extra))

@@ -311,6 +311,15 @@ def test_attention_without_transposed_images(dev, B, H, S):
     if S > 1:
         for sl in (slice(0, d), slice(d, 2 * d)):
             assert rel(merged[:, sl], two_pass[:, sl]) < 6e-3
+    # BASELINE config[4]: the epilogues' OCP MX e4m3 copy of dqkv (operand of the qkv dgrad's MX GEMM) == mg_quantize_mx_fp8(dqkv) bit
+    # for bit, next to the bf16 output and on its own (no_out)
+    mx = ops.mx_empty(B * S, 3 * d, dev)
+    merged_b = ops.attn_bwd_rows(xf, dO, out, lse, merged_rot=(rot, sin_t, cos_t), mx_out=mx)
+    qref, sref = ops.quantize_mx_fp8(merged)
+    assert torch.equal(merged_b, merged) and torch.equal(mx[0], qref) and torch.equal(mx[1], sref)
+    mx2 = ops.mx_empty(B * S, 3 * d, dev)
+    assert ops.attn_bwd_rows(xf, dO, out, lse, merged_rot=(rot, sin_t, cos_t), mx_out=mx2, no_out=True) is None
+    assert torch.equal(mx2[0], qref) and torch.equal(mx2[1], sref)
 
 
 def test_rotary_merge_bwd(dev):

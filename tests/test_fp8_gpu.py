@@ -347,7 +347,7 @@ def test_gemm_mx_fp8_tile256(dev, layout, M, N, K):
     assert rel(b256.float(), (ad.double() @ wd.double().t() + bias.double()).float()) < 5e-3
 
 
-@pytest.mark.parametrize("B,H,S", [(1, 1, 1), (2, 2, 57), (1, 2, 300), (2, 1, 385), (1, 1, 1024)])
+@pytest.mark.parametrize("B,H,S", [(1, 1, 1), (2, 2, 57), (1, 2, 300), (2, 1, 385), (1, 1, 1024), (2, 16, 2048)])
 def test_fp8_attention_forward(dev, B, H, S):
     """BASELINE config[4] "fp8 MFMA path for GPT-J attention": mg_rotary_split_fp8 + mg_attn_prefill_fp8
     (v_mfma_scale_f32_32x32x64_f8f6f4, OCP MX e4m3 operands, fp32 softmax).
@@ -403,6 +403,13 @@ def test_fp8_attention_forward(dev, B, H, S):
     wide = torch.full((B * S, d + 136), float("nan"), dtype=BF16, device=dev)
     ops.attn_prefill_fp8(op, wide[:, :d])
     assert torch.equal(wide[:, :d], out)
+    # round 6: the epilogue's OCP MX e4m3 copy of the output (the operand of out_proj's MX GEMM) is mg_quantize_mx_fp8(out) bit
+    # for bit -- elements and scale bytes -- and asking for it does not change the bf16 output
+    mx = ops.mx_empty(B * S, d, dev)
+    out_b = torch.empty_like(out)
+    ops.attn_prefill_fp8(op, out_b, mx_out=mx)
+    qref, sref = ops.quantize_mx_fp8(out)
+    assert torch.equal(out_b, out) and torch.equal(mx[0], qref) and torch.equal(mx[1], sref)
 
 
 @pytest.mark.parametrize("producer", ["row", "mx"])

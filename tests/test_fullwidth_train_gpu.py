@@ -170,8 +170,8 @@ def test_gradients_four_blocks_deep_full_width_s2048(dev):
 _FP8_ORACLE_MEMO = {}
 
 
-@pytest.mark.parametrize("fp8_attn,fp8_mx", [(False, False), (True, False), (True, True)])
-def test_fp8_training_step_vs_oracle_on_dequantised_weights(dev, fp8_attn, fp8_mx):
+@pytest.mark.parametrize("fp8_attn,fp8_mx,fp8_adapters", [(False, False, False), (True, False, False), (True, True, False), (True, True, True)])
+def test_fp8_training_step_vs_oracle_on_dequantised_weights(dev, fp8_attn, fp8_mx, fp8_adapters):
     """BASELINE config[4], training side, at full width (d 4096, ff 16384, V 50258, S = 2048, one block, tiny trunk): the engine with
     eng.fp8 = True runs qkv / out_proj / fc_in / fc_out forward AND their dgrads on the fp8 MFMA (e4m3, per-row activation scales,
     per-output-channel weight scales).  Oracle: torch.autograd through the fp32 restatement evaluated on the DEQUANTISED e4m3
@@ -179,7 +179,7 @@ def test_fp8_training_step_vs_oracle_on_dequantised_weights(dev, fp8_attn, fp8_m
     of the ACTIVATIONS / incoming gradients to e4m3 and the separately quantised transposed weights of the dgrads; the stated
     bound is calibrated on the size of the effect that IS modelled: e_w = how far the e4m3 weight quantisation alone moves each
     gradient (oracle on dequantised vs oracle on unquantised weights).
-        per tensor   err(HIP fp8, oracle dequantised) <= 2.5 x e_w + 3e-2   (rel-L2)
+        per tensor   err(HIP fp8, oracle dequantised) <= 2.5 x e_w + 3e-2   (rel-L2; 3 x e_w with the adapter GEMMs in fp8 too)
         all tensors  cosine(HIP fp8, oracle dequantised) >= 0.99;  global err <= 1.5 x global e_w + 1e-2
         loss         within 5e-3 relative of the dequantised oracle's.
     Measured (MI355X, round 4): loss 11.6359 vs 11.6332 (unquantised oracle 11.6310); global error 0.115 where the weight
@@ -197,6 +197,9 @@ def test_fp8_training_step_vs_oracle_on_dequantised_weights(dev, fp8_attn, fp8_m
     eng = MagmaEngine(model)
     eng.fp8 = True
     eng.fp8_attn = fp8_attn       # round 5: QK^T / PV of the attention forward on the fp8 MFMA as well (the oracle does not model it either)
+    eng.fp8_adapters = fp8_adapters   # round 6 (BASELINE config[4] "... + adapter GEMMs"): the MLP adapter's down / up GEMMs and their dgrads on the
+                                      # fp8 MFMA, operands from the MX output copies of the producing epilogues (train_engine.__init__); the oracle
+                                      # keeps the (trainable) adapter weights and every activation exact -- the same bounds hold
     eng.fp8_mx = fp8_mx           # round 5: gelu(fc_in) and its gradient exist only as OCP MX e4m3, written by the GEMM epilogues; fc_out
                                   # and the fc_in dgrad multiply them by MX-quantised weights (whose dequantisation the oracle gets below)
     eng.train()
@@ -211,6 +214,7 @@ def test_fp8_training_step_vs_oracle_on_dequantised_weights(dev, fp8_attn, fp8_m
     out = eng(images.to(dev), caps.to(dev), dropout_mask=mask.to(dev))
     loss_hip = float(out.loss)
     eng.backward(out.loss)
+    assert bool(eng._ad8_cache) == fp8_adapters            # the fp8 adapter chain ran iff asked for
     packs = eng._fp8_packs
     assert {(0, "qkv"), (0, "out"), (0, "fc_in"), (0, "fc_out"), (0, "qkv_t"), (0, "out_t"), (0, "fc_in_t"), (0, "fc_out_t")} <= set(packs), sorted(packs)
     d = cfg.d_model
@@ -256,6 +260,12 @@ def test_fp8_training_step_vs_oracle_on_dequantised_weights(dev, fp8_attn, fp8_m
     name_of = {id(p): n for n, p in model.named_parameters()}
     seen, bad, rows = set(), [], []
     dot = nh = nr = dw = nu = 0.0
+    # per-tensor factor: 2.5 x e_w; with the adapter GEMMs in fp8 as well 3 x e_w -- two more quantised products (the adapter's
+    # dgrads, operands MX-quantised by the producing epilogues) sit on the gradient's way down, none of them modelled by the oracle.
+    # Measured (MI355X, round 6): worst tensor 0.250 against e_w 0.085 (2.6 x; the same BatchNorm gain deep in the trunk that is
+    # worst without: 0.19), loss 11.6479 vs 11.6340, global error 0.134 (weight quantisation alone 0.113), cosine 0.9911 -- the
+    # global bounds below are NOT widened.
+    k_tensor = 3.0 if fp8_adapters else 2.5
     for grp in eng.groups:
         for p in grp.params:
             n = name_of[id(p)]
@@ -266,7 +276,7 @@ def test_fp8_training_step_vs_oracle_on_dequantised_weights(dev, fp8_attn, fp8_m
             got, ref, unq = eng.grad_of(p).float().cpu().reshape(-1), g_deq[n].reshape(-1), g_unq[n].reshape(-1)
             e_hip, e_w = rel(got, ref), rel(g_cal[n].reshape(-1), unq)
             rows.append((e_hip - 2.5 * e_w, n, e_hip, e_w))
-            if e_hip > 2.5 * e_w + 3e-2:
+            if e_hip > k_tensor * e_w + 3e-2:
                 bad.append((n, e_hip, e_w))
             dot += float((got * ref).sum()); nh += float((got * got).sum()); nr += float((ref * ref).sum())
             dw += float(((g_cal[n].reshape(-1) - unq) ** 2).sum()); nu += float(((got - ref) ** 2).sum())
