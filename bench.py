@@ -604,6 +604,7 @@ def config1_leg(model, dev):
     import numpy as np
     import PIL.Image as I
     from magma_amd import ImageInput
+    model.eval()                 # the training leg ran before this one: back to the inference operands (BatchNorm folded, packed weights)
     rng = np.random.RandomState(3)
     arr = (rng.rand(224, 224, 3) * 255).astype(np.uint8)
     prompt = "Describe"          # 8 tokens under the byte-level stand-in tokenizer (no GPT-2 files offline); preprocess_inputs takes str / ImageInput only

@@ -1155,8 +1155,12 @@ def mx_empty(M: int, N: int, device):
     if Kp != N:
         q[:, N:].zero_()
     # scale bytes start at 127 (2^0), as the quantiser writes them for the zero blocks past N: the C8 epilogue only writes the
-    # blocks with n < N, and the consuming GEMM walks whole 128-element chunks -- a leftover 0xFF byte is NaN in E8M0
-    return q, torch.full((int(L.load().mg_mx_scale_bytes(M, N)),), 127, dtype=torch.uint8, device=device)
+    # blocks with n < N, and the consuming GEMM walks whole 128-element chunks -- a leftover 0xFF byte is NaN in E8M0.  When every
+    # byte WILL be written (whole 64-row groups, whole 128-column chunks: the training shapes) the fill launch is skipped.
+    nbytes = int(L.load().mg_mx_scale_bytes(M, N))
+    if M % 64 == 0 and Kp == N:
+        return q, torch.empty(nbytes, dtype=torch.uint8, device=device)
+    return q, torch.full((nbytes,), 127, dtype=torch.uint8, device=device)
 
 
 def quantize_mx_fp8(x: torch.Tensor):
@@ -1167,7 +1171,11 @@ def quantize_mx_fp8(x: torch.Tensor):
     M, K = x.shape
     ldq = ceil_to(K, 128)
     q = torch.empty(M, ldq, dtype=torch.uint8, device=x.device)
-    scales = torch.full((int(L.load().mg_mx_scale_bytes(M, K)),), 127, dtype=torch.uint8, device=x.device)
+    nbytes = int(L.load().mg_mx_scale_bytes(M, K))
+    if M % 64 == 0:      # whole 64-row groups: the kernel writes every scale byte (one per 32-column block of ldq, per row)
+        scales = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    else:
+        scales = torch.full((nbytes,), 127, dtype=torch.uint8, device=x.device)
     check(L.load().mg_quantize_mx_fp8(x.data_ptr(), x.stride(0), M, K, q.data_ptr(), ldq, scales.data_ptr(), _stream()),
           "mg_quantize_mx_fp8")
     return q, scales

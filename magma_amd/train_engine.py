@@ -1486,7 +1486,10 @@ class MagmaEngine:
         kw = {}
         if num_workers > 0:
             dataset = host_side_view(dataset)
-            kw = dict(num_workers=num_workers, persistent_workers=True, prefetch_factor=2,
+            # workers are SPAWNED, not forked: a fork of the training process carries the HIP runtime's and RCCL's state into a child
+            # that must not touch the GPU, and forking a process with tens of GB mapped took 20 x longer on some hosts than on others
+            # (the same loader test: 3 s and 70 s).  The dataset view, its transform and the collate function travel by pickle.
+            kw = dict(num_workers=num_workers, persistent_workers=True, prefetch_factor=2, multiprocessing_context="spawn",
                       pin_memory=bool(pin_memory) and torch.cuda.is_available())
         return DataLoader(dataset, batch_size=bs, sampler=sampler, shuffle=False,
                           collate_fn=collate_fn or partial(default_collate, seq_len=self.module.seq_len), **kw)

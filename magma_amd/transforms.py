@@ -95,16 +95,19 @@ def _device_pipeline(image, n_px, device):
     return ops.crop_normalize(img, top, left, n_px, CLIP_MEAN, CLIP_STD).unsqueeze(0)
 
 
-def clip_preprocess(n_px, use_pad=False, device=None):
-    """``device``: a GPU -> RGB images are resized / cropped / normalised on it (same bits as the host path);
-    other modes (palette, alpha, grey) and ``device=None`` use PIL on the host like the reference."""
-    mean = torch.tensor(CLIP_MEAN).view(3, 1, 1)
-    std = torch.tensor(CLIP_STD).view(3, 1, 1)
+class ClipPreprocess:
+    """The callable clip_preprocess returns (reference transforms.py:87-134).  A class, not a closure: DataLoader worker
+    processes are SPAWNED (train_engine.deepspeed_io), so the dataset and its transform travel by pickle."""
 
-    on_gpu = device is not None and torch.device(device).type == "cuda"
+    def __init__(self, n_px, use_pad=False, device=None):
+        self.n_px, self.use_pad, self.device = n_px, use_pad, device
+        self.on_gpu = device is not None and torch.device(device).type == "cuda"
+        # the same transform with the tensors left on the host (bit-identical pixels): what a DataLoader worker process runs
+        self.host = ClipPreprocess(n_px, use_pad, device=None) if self.on_gpu else self
 
-    def pad_img(im):
+    def pad_img(self, im):
         """reference transforms.py:87-108: long side -> n_px (LANCZOS, PIL's old ANTIALIAS), pasted centred on black."""
+        n_px = self.n_px
         old = im.size
         ratio = float(n_px) / max(old)
         new = tuple(int(x * ratio) for x in old)
@@ -113,21 +116,25 @@ def clip_preprocess(n_px, use_pad=False, device=None):
         canvas.paste(im, ((n_px - new[0]) // 2, (n_px - new[1]) // 2))
         return canvas
 
-    def fn(image):
-        if on_gpu and not use_pad and image.mode == "RGB" and min(image.size) >= 2:
-            return _device_pipeline(image, n_px, device)
+    def __call__(self, image):
+        n_px = self.n_px
+        if self.on_gpu and not self.use_pad and image.mode == "RGB" and min(image.size) >= 2:
+            return _device_pipeline(image, n_px, self.device)
         image = _resize_short_side(image, n_px)
-        image = (pad_img(image) if use_pad else _center_crop(image, n_px)).convert("RGB")
+        image = (self.pad_img(image) if self.use_pad else _center_crop(image, n_px)).convert("RGB")
         t = torch.from_numpy(np.asarray(image, dtype=np.uint8).copy()).permute(2, 0, 1).float() / 255.0
+        mean = torch.tensor(CLIP_MEAN).view(3, 1, 1)
+        std = torch.tensor(CLIP_STD).view(3, 1, 1)
         out = maybe_add_batch_dim((t - mean) / std)
         # one transform -> one device: grey / palette / alpha images take the PIL branch but must land where the RGB
         # ones do, or collate_fn's torch.cat over a mixed batch raises (reference dataset.py:155-160)
-        return out.to(device) if on_gpu else out
+        return out.to(self.device) if self.on_gpu else out
 
-    # the same transform with the tensors left on the host (bit-identical pixels): what a DataLoader worker process
-    # runs (train_engine.deepspeed_io with workers; a forked worker must not touch the GPU)
-    fn.host = clip_preprocess(n_px, use_pad, device=None) if on_gpu else fn
-    return fn
+
+def clip_preprocess(n_px, use_pad=False, device=None):
+    """``device``: a GPU -> RGB images are resized / cropped / normalised on it (same bits as the host path);
+    other modes (palette, alpha, grey) and ``device=None`` use PIL on the host like the reference."""
+    return ClipPreprocess(n_px, use_pad, device)
 
 
 def pad_to_size(x, size=256):
@@ -219,26 +226,31 @@ class ColorJitter:
         return img
 
 
-def base_transforms(image_size, use_extra_transforms=False, device=None):
+class BaseTransforms:
     """reference transforms.py:71-84: RGB -> RandCropResize -> RandomHorizontalFlip(0.5) [-> ColorJitter(0.1, 0.1, 0.1, 0.05)
-    with use_extra_transforms] -> ToTensor -> batch dim."""
-    jitter = ColorJitter(0.1, 0.1, 0.1, 0.05) if use_extra_transforms else None
-    crop = RandCropResize(image_size)
-    on_gpu = device is not None and torch.device(device).type == "cuda"
+    with use_extra_transforms] -> ToTensor -> batch dim.  A picklable class for the same reason as ClipPreprocess."""
 
-    def fn(img):
+    def __init__(self, image_size, use_extra_transforms=False, device=None):
+        self.jitter = ColorJitter(0.1, 0.1, 0.1, 0.05) if use_extra_transforms else None
+        self.crop = RandCropResize(image_size)
+        self.device = device
+        self.on_gpu = device is not None and torch.device(device).type == "cuda"
+        self.host = BaseTransforms(image_size, use_extra_transforms, device=None) if self.on_gpu else self
+
+    def __call__(self, img):
         img = img.convert("RGB") if img.mode != "RGB" else img
-        img = crop(img)
+        img = self.crop(img)
         if float(torch.rand(1)) < 0.5:
             img = img.transpose(PilImage.FLIP_LEFT_RIGHT)
-        if jitter is not None:
-            img = jitter(img)
+        if self.jitter is not None:
+            img = self.jitter(img)
         t = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).float() / 255.0
         t = maybe_add_batch_dim(t)
-        return t.to(device) if on_gpu else t
+        return t.to(self.device) if self.on_gpu else t
 
-    fn.host = base_transforms(image_size, use_extra_transforms, device=None) if on_gpu else fn
-    return fn
+
+def base_transforms(image_size, use_extra_transforms=False, device=None):
+    return BaseTransforms(image_size, use_extra_transforms, device)
 
 
 def get_transforms(image_size, encoder_name, input_resolution=None, use_extra_transforms=False, device=None):

@@ -214,6 +214,13 @@ def test_loader_workers_iterate_a_host_side_view(tmp_path):
     assert len(got) == len(ref) == 2
     for (gi, gc), (ri, rc) in zip(got, ref):
         assert gi.shape == (2, 3, 32, 32) and torch.equal(gi, ri) and torch.equal(gc, rc)
+    # the engine's loader SPAWNS its workers (train_engine.deepspeed_io: no fork of a process that holds HIP / RCCL state): the
+    # dataset view, its transform (a picklable class since round 6) and the collate function travel by pickle
+    real = torch.utils.data.Subset(ImgCptDataset(tmp_path, ByteTokenizer(64), clip_preprocess(32), seq_len=64), [4, 2, 0, 1])
+    spawned = [b for b in torch.utils.data.DataLoader(host_side_view(real), batch_size=2, num_workers=2, multiprocessing_context="spawn",
+                                                      collate_fn=partial(collate_fn, seq_len=64))]
+    for (gi, gc), (ri, rc) in zip(spawned, ref):
+        assert torch.equal(gi, ri) and torch.equal(gc, rc)
 
 
 def _write_dataset(root, n, modes=("RGB",)):
