@@ -437,7 +437,7 @@ int attn_bwd_launch(const mg_bf16* q, const mg_bf16* k, const mg_bf16* v, const 
   const int64_t rows = (int64_t)B * S * H;
   const dim3 grid((unsigned)(((S + 127) / 128) * B * H));
   const char* env_v = getenv("MAGMA_ATTN_BWD");        // read per call: tests and A/B scripts switch it in-process
-  const int variant = env_v ? atoi(env_v) : 4;
+  const int variant = env_v ? atoi(env_v) : 8;          // round 6: the tr-read kernels (attention_tr.hip) also behind this signature; qt / kt / dOt are then unused
   if (make_dOt && variant < 5)
     hipLaunchKernelGGL(attn_bwd_prep_t_kernel, dim3((S + 31) / 32, B * H), dim3(256), 0, s, dO, O, lse, D, (mg_bf16*)dOt, ld_t, B, H, S, ld_o);
   else
