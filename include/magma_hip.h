@@ -75,8 +75,12 @@ const char* mg_version(void);
  *      descriptor that embeds an epilogue changed size.
  *   5  round 6: added mg_rotary_qk_inplace_bf16 / mg_attn_fwd_rows_bf16 / mg_attn_bwd_rows_bf16 (attention without transposed operand
  *      images, q / k / v taken as strided rows -- straight from the fused qkv activation); mg_attn_prefill_fp8 gained
- *      out8 / ld_out8 / out8_scales (the MX e4m3 copy of its output, before the stream).                                             */
-#define MG_ABI_VERSION 5
+ *      out8 / ld_out8 / out8_scales (the MX e4m3 copy of its output, before the stream).
+ *   6  round 6: mg_epilogue.reserved0 became `accumulate` and the struct grew by `row_scale` (weight-gradient GEMMs add
+ *      row_scale[m] * (A W^T) straight into the fp32 gradient: no temporary, no second pass): every descriptor that embeds an
+ *      epilogue changed size.  Added mg_conv_weight_relayout_batch / mg_bn_fold_batch (one launch per step for all
+ *      convolutions of the image encoder) and mg_transpose_bn_param_grad_bf16.                                                                                            */
+#define MG_ABI_VERSION 6
 int32_t mg_abi_version(void);
 const char* mg_last_error(void);
 
@@ -118,7 +122,13 @@ typedef struct mg_epilogue {
   int64_t ldc8;
   uint8_t* c8_scales;
   int32_t c8_rgroups;
-  int32_t reserved0;
+  /* fp32 outputs only (out_f32): C[m*ldc+n] += v instead of = v -- the weight-gradient GEMMs accumulate into the gradient
+   * buffer in place (reference semantics: .grad += over micro-batches, magma/train_loop.py:22-33 through DeepSpeed).  ABI 6.  */
+  int32_t accumulate;
+  /* optional per-ROW factor of the accumulator, fp32 [M]: v = acc * row_scale[m] * scale[n] + bias[n] (the folded-BatchNorm scale
+   * of a convolution's weight gradient: dW[co][:] = scale[co] * g^T a).  Tile GEMMs only; mg_gemm_fp8 takes its activation row
+   * scale as an argument instead and refuses both.  ABI 6.                                                                     */
+  const float* row_scale;
 } mg_epilogue;
 
 /* K9/K11/K12/K13/K14/K18 (GPT-J + adapter GEMMs, prefill/training shapes),
@@ -507,6 +517,11 @@ int mg_scale_rows_acc_f32(float* dst, const float* src, int64_t ld_src, const fl
 int mg_add_gate_bf16(const mg_bf16* a, const mg_bf16* b, const mg_bf16* gate, mg_bf16* out, int64_t n, void* stream);
 int mg_bn_param_grad_f32(const mg_bf16* g, const mg_bf16* y, const mg_bf16* sub, const float* gamma,
                          const float* beta, float* dgamma, float* dbeta, int32_t M, int32_t C, void* stream);
+/* The same sums taken while g is transposed for the convolution's weight-gradient GEMM (out = g^T [C, ld_out], as mg_transpose_bf16;
+ * y / sub in g's layout): one pass over g instead of two, from a grid of 64x64 tiles (ABI 6).                                   */
+int mg_transpose_bn_param_grad_bf16(const mg_bf16* g, int64_t ld_in, mg_bf16* out, int64_t ld_out, int32_t R, int32_t C,
+                                    const mg_bf16* y, const mg_bf16* sub, const float* gamma, const float* beta,
+                                    float* dgamma, float* dbeta, void* stream);
 /* trainable conv weight [Cout][Cin][k][k] (k = 1, 3) -> row-major GEMM operand, rows zero padded to ldo:
  *   mode 0: out[co][tap*Cin + ci] = w[co][ci][ky][kx]                       (forward, implicit-im2col order)
  *   mode 1: out[ci][tap*Cout + co] = bf16(w[co][ci][k-1-ky][k-1-kx] * scale[co])   (dgrad: flipped taps, BN scale folded)
@@ -517,6 +532,28 @@ int mg_conv_weight_relayout_bf16(const mg_bf16* w, const float* scale, mg_bf16* 
  * scale = gamma / sqrt(var + eps), shift = beta - mean * scale; all fp32 [C].                                   */
 int mg_bn_fold_f32(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
                    float* scale, float* shift, int32_t C, void* stream);
+/* The two calls above for MANY convolutions / BatchNorms in one launch each (ABI 6): the training engine re-derives the GEMM
+ * operands of all 127 trunk convolutions (forward + dgrad layout) and the folded affine of their BatchNorms once per step --
+ * 2 launches instead of ~380.  `jobs`: DEVICE array (caller-owned, 8-byte aligned), sorted by first_block; job i covers the
+ * workgroups [first_block, first_block + ceil(rows * ldo / 256)) resp. [first_block, first_block + ceil(C / 256));
+ * total_blocks = the end of the last job.  Same arithmetic, element for element, as the single-job entry points.
+ * (reference: the convolutions / BatchNorms of magma/image_encoders.py:48-76's CLIP trunk, trained as in magma/magma.py:98-100) */
+typedef struct mg_relayout_job {
+  const mg_bf16* w;      /* [Cout][Cin][k][k] */
+  const float* scale;    /* mode 1: [Cout] or NULL */
+  mg_bf16* out;          /* rows x ldo */
+  int64_t ldo;
+  int32_t Cout, Cin, k, mode;
+  int64_t first_block;
+} mg_relayout_job;
+typedef struct mg_bn_fold_job {
+  const float* gamma; const float* beta; const float* mean; const float* var;
+  float* scale; float* shift;
+  float eps; int32_t C;
+  int64_t first_block;
+} mg_bn_fold_job;
+int mg_conv_weight_relayout_batch(const mg_relayout_job* jobs, int32_t njobs, int64_t total_blocks, void* stream);
+int mg_bn_fold_batch(const mg_bn_fold_job* jobs, int32_t njobs, int64_t total_blocks, void* stream);
 int mg_im2col_t_bf16(const mg_bf16* x, mg_bf16* out, int64_t ldo, int32_t B, int32_t H, int32_t W, int32_t Cin, void* stream);
 
 /* batch-statistics BatchNorm of the CLIP trunk in training (the reference's tower runs in train mode after its

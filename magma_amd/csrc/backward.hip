@@ -56,6 +56,73 @@ __global__ __launch_bounds__(256) void transpose_kernel(const mg_bf16* __restric
   }
 }
 
+// transpose + the parameter gradients of a frozen-statistics BatchNorm in ONE pass over g (the CLIP trunk's backward: g^T is the
+// operand of the convolution's weight gradient, and bn_param_grad_kernel read the same g a second time from a grid of a few
+// workgroups): out = g^T, dbeta[c] += sum_r g[r][c], dgamma[c] += sum_r g[r][c] * (y[r][c] - sub[r][c] - beta[c]) / gamma[c]
+// -- element arithmetic of bn_param_grad_kernel; the sums leave the workgroup as 2 x 64 fp32 atomics.
+__global__ __launch_bounds__(256) void transpose_bn_grad_kernel(const mg_bf16* __restrict__ in, int64_t ld_in, mg_bf16* __restrict__ out,
+                                                                int64_t ld_out, int R, int C, const mg_bf16* __restrict__ y,
+                                                                const mg_bf16* __restrict__ sub, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float* __restrict__ dgamma,
+                                                                float* __restrict__ dbeta) {
+  __shared__ mg_bf16 tile[64][64 + 2];
+  __shared__ float prod[64][64 + 1];
+  const int tid = threadIdx.x;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int ci = tid + it * 256;
+    const int r = ci >> 3, cc = (ci & 7) * 8;
+    u32x4 v = (u32x4){0u, 0u, 0u, 0u}, yv = v, sv = v;
+    float bt[8], ig[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { bt[j] = 0.f; ig[j] = 0.f; }
+    if (r0 + r < R && c0 + cc < C) {
+      const int64_t off = (int64_t)(r0 + r) * ld_in + c0 + cc;
+      v = *(const u32x4*)(in + off);
+      yv = *(const u32x4*)(y + off);
+      if (sub) sv = *(const u32x4*)(sub + off);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { bt[j] = beta[c0 + cc + j]; const float gm = gamma[c0 + cc + j]; ig[j] = gm != 0.f ? 1.f / gm : 0.f; }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      tile[r][cc + 2 * j] = (mg_bf16)(v[j] & 0xffffu);
+      tile[r][cc + 2 * j + 1] = (mg_bf16)(v[j] >> 16);
+      prod[r][cc + 2 * j] = bflo(v[j]) * (bflo(yv[j]) - bflo(sv[j]) - bt[2 * j]) * ig[2 * j];
+      prod[r][cc + 2 * j + 1] = bfhi(v[j]) * (bfhi(yv[j]) - bfhi(sv[j]) - bt[2 * j + 1]) * ig[2 * j + 1];
+    }
+  }
+  __syncthreads();
+  if (tid < 128) {       // rows beyond R were stored as zeros: no bounds in the sums.  Threads 0-63: dbeta, 64-127: dgamma
+    const int c = tid & 63;
+    if (c0 + c < C) {
+      float acc = 0.f;
+      if (tid < 64) {
+#pragma unroll 8
+        for (int r = 0; r < 64; ++r) acc += bf2f(tile[r][c]);
+        atomicAdd(dbeta + c0 + c, acc);
+      } else {
+#pragma unroll 8
+        for (int r = 0; r < 64; ++r) acc += prod[r][c];
+        atomicAdd(dgamma + c0 + c, acc);
+      }
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int ci = tid + it * 256;
+    const int c = ci >> 3, rr = (ci & 7) * 8;
+    if (c0 + c < C && r0 + rr < R) {
+      u32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        o[j] = (uint32_t)tile[rr + 2 * j][c] | ((uint32_t)tile[rr + 2 * j + 1][c] << 16);
+      *(u32x4*)(out + (int64_t)(c0 + c) * ld_out + r0 + rr) = o;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // head transpose: element (b, s, h, d) at src + b*sb + s*ss + h*sh + d  ->
 // dst[(((b*H + h)*(ld/32) + s/32)*256 + d)*32 + s%32]  (column-tiled transposed layout); positions in
@@ -634,6 +701,21 @@ extern "C" int mg_transpose_bf16(const mg_bf16* in, int64_t ld_in, int64_t bs_in
   return MG_OK;
 }
 
+// g [R, C] -> out = g^T [C, ld_out] (as mg_transpose_bf16) while accumulating the frozen-statistics BatchNorm parameter gradients of
+// mg_bn_param_grad_f32 (y, sub: the layout of g; sub may be NULL) -- one pass over g instead of two.
+extern "C" int mg_transpose_bn_param_grad_bf16(const mg_bf16* g, int64_t ld_in, mg_bf16* out, int64_t ld_out, int32_t R, int32_t C,
+                                               const mg_bf16* y, const mg_bf16* sub, const float* gamma, const float* beta,
+                                               float* dgamma, float* dbeta, void* stream) {
+  if (R <= 0 || C <= 0 || (C & 7) || ld_out < ((R + 7) & ~7)) MG_FAIL(MG_ERR_SHAPE, "mg_transpose_bn_param_grad_bf16: C%%8==0 and ld_out >= round_up(R,8) required");
+  if (!g || !out || !y || !gamma || !beta || !dgamma || !dbeta || !MG_ALIGNED16(g) || !MG_ALIGNED16(out) || !MG_ALIGNED16(y) || !MG_ALIGNED16(sub) ||
+      (ld_in & 7) || (ld_out & 7))
+    MG_FAIL(MG_ERR_ALIGN, "mg_transpose_bn_param_grad_bf16: null pointer or 16-byte alignment violated");
+  dim3 grid((C + 63) / 64, (R + 63) / 64, 1);
+  hipLaunchKernelGGL(transpose_bn_grad_kernel, grid, dim3(256), 0, (hipStream_t)stream, g, ld_in, out, ld_out, R, C, y, sub, gamma, beta, dgamma, dbeta);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
 // The same transpose (one matrix) that also ACCUMULATES the column sums of `in` into colsum[C] (fp32): d bias and the operand of d weight
 // of a Linear from one pass over its output gradient.
 extern "C" int mg_transpose_colsum_bf16(const mg_bf16* in, int64_t ld_in, mg_bf16* out, int64_t ld_out, int32_t R, int32_t C,
@@ -873,6 +955,63 @@ extern "C" int mg_conv_weight_relayout_bf16(const mg_bf16* w, const float* scale
   const int64_t n = (int64_t)(mode == 0 ? Cout : Cin) * ldo;
   hipLaunchKernelGGL(conv_weight_relayout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, scale, out, ldo,
                      Cout, Cin, k, mode);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
+// All the weight re-layouts of one training step in ONE launch (the 127 convolutions of the CLIP trunk x {forward operand, dgrad
+// operand}: 252 launches of ~7 us on 1-40 workgroups each before).  `jobs` is a device array sorted by first_block; a
+// workgroup finds its job by bisection over the (wave-uniform) block index, then does what conv_weight_relayout_kernel does.
+namespace {
+__global__ __launch_bounds__(256) void conv_weight_relayout_batch_kernel(const mg_relayout_job* __restrict__ jobs, int njobs) {
+  const int64_t b = blockIdx.x;
+  int lo = 0, hi = njobs - 1;
+  while (lo < hi) {                      // last job with first_block <= b
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].first_block <= b) lo = mid; else hi = mid - 1;
+  }
+  const mg_relayout_job j = jobs[lo];
+  const int k = j.k, taps = k * k;
+  const int rows = j.mode == 0 ? j.Cout : j.Cin, inner = j.mode == 0 ? j.Cin : j.Cout;
+  const int64_t idx = (b - j.first_block) * 256 + threadIdx.x;
+  if (idx >= (int64_t)rows * j.ldo) return;
+  const int r = (int)(idx / j.ldo), c = (int)(idx - (int64_t)r * j.ldo);
+  mg_bf16 v = 0;
+  if (c < taps * inner) {
+    const int tap = c / inner, i = c - tap * inner;
+    const int ky = tap / k, kx = tap - ky * k;
+    if (j.mode == 0) v = j.w[(((int64_t)r * j.Cin + i) * k + ky) * k + kx];
+    else v = f2bf(bf2f(j.w[(((int64_t)i * j.Cin + r) * k + (k - 1 - ky)) * k + (k - 1 - kx)]) * (j.scale ? j.scale[i] : 1.0f));
+  }
+  j.out[idx] = v;
+}
+
+__global__ __launch_bounds__(256) void bn_fold_batch_kernel(const mg_bn_fold_job* __restrict__ jobs, int njobs) {
+  const int64_t b = blockIdx.x;
+  int lo = 0, hi = njobs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].first_block <= b) lo = mid; else hi = mid - 1;
+  }
+  const mg_bn_fold_job j = jobs[lo];
+  const int c = (int)(b - j.first_block) * 256 + threadIdx.x;
+  if (c >= j.C) return;
+  const float s = j.gamma[c] / sqrtf(j.var[c] + j.eps);      // the arithmetic of bn_fold_kernel
+  j.scale[c] = s;
+  j.shift[c] = j.beta[c] - j.mean[c] * s;
+}
+}  // namespace
+
+extern "C" int mg_conv_weight_relayout_batch(const mg_relayout_job* jobs, int32_t njobs, int64_t total_blocks, void* stream) {
+  if (!jobs || njobs <= 0 || total_blocks <= 0 || total_blocks > 0x7fffffff) MG_FAIL(MG_ERR_SHAPE, "mg_conv_weight_relayout_batch: bad arguments");
+  hipLaunchKernelGGL(conv_weight_relayout_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, jobs, njobs);
+  MG_CHECK_LAUNCH();
+  return MG_OK;
+}
+
+extern "C" int mg_bn_fold_batch(const mg_bn_fold_job* jobs, int32_t njobs, int64_t total_blocks, void* stream) {
+  if (!jobs || njobs <= 0 || total_blocks <= 0 || total_blocks > 0x7fffffff) MG_FAIL(MG_ERR_SHAPE, "mg_bn_fold_batch: bad arguments");
+  hipLaunchKernelGGL(bn_fold_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, jobs, njobs);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }

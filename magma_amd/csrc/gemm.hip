@@ -841,7 +841,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
     if (n < p.N) epilogue_cols<W>(ep, n, p.N, c);
     // an epilogue without aux / residual operands walks its rows in a build of the loop that contains no global load
     // (interior bf16-output tiles only: W == 8 and FULL): nothing in it waits for the stores of the rows before
-    const bool loads = ep.aux_mode != MG_AUX_NONE || ep.res0 || ep.res1 || ep.res2;
+    const bool loads = ep.aux_mode != MG_AUX_NONE || ep.res0 || ep.res1 || ep.res2 || ep.accumulate;
     stage(std::integral_constant<int, 0>{});
     MG_STAMP(2);
     if (FULL && W == 8 && !loads) epilogue_rows_c<256, EPI256_ROWB, W, NT, FULL, false, Q8>(ep, c, smem, 128, 8, wave, lane, mb0, 128, nb, mlim, p.N, p.row_scale);
@@ -904,6 +904,8 @@ int check_epilogue(const mg_epilogue& ep, const char* who, bool tile_gemm = fals
   if (ep.aux_mode < 0 || ep.aux_mode > 4) MG_FAIL(MG_ERR_SHAPE, "%s: bad aux_mode", who);
   if (ep.aux_mode != MG_AUX_NONE && (!ep.aux || (ep.ldaux & 3) || !MG_ALIGNED16(ep.aux))) MG_FAIL(MG_ERR_ALIGN, "%s: aux operand must be 16-byte aligned with ldaux %% 4 == 0", who);
   if (ep.C2 && ((ep.ldc2 & 3) || !MG_ALIGNED16(ep.C2))) MG_FAIL(MG_ERR_ALIGN, "%s: C2 must be 16-byte aligned with ldc2 %% 4 == 0", who);
+  if (ep.accumulate && (!ep.out_f32 || ep.C8 || !ep.C)) MG_FAIL(MG_ERR_UNSUPPORTED, "%s: accumulate adds into an fp32 output (out_f32, no MX copy)", who);
+  if (ep.row_scale && (!tile_gemm || ((uintptr_t)ep.row_scale & 3))) MG_FAIL(MG_ERR_UNSUPPORTED, "%s: mg_epilogue.row_scale is an fp32 [M] vector of the tile GEMMs", who);
   return MG_OK;
 }
 
@@ -944,18 +946,20 @@ int launch_gemm256(GemmParams gp, hipStream_t s) {
   gp.group_m = group_m_256(gp.tiles_m, gp.tiles_n, gp.K);
   gp.a_kt = 64;
   const mg_epilogue real_ep = gp.ep;
+  const float* const real_row_scale = gp.row_scale;
   if (gp.splits > 1) {      // the kernel writes raw fp32 partial sums: slab `sp` = ws + sp * M * ldws (rows of ldws floats)
     mg_epilogue slab;
     memset(&slab, 0, sizeof(slab));
     slab.C = gp.ws; slab.ldc = gp.ldws; slab.out_f32 = 1;
     gp.ep = slab;
+    gp.row_scale = nullptr;   // the fix-up applies it, once
     gp.nt = 0;
   }
   hipLaunchKernelGGL((gemm256_kernel<WLAYOUT, LATE_LGKM, FP8, MFMA32, ABL, SPLITK, MX, Q8>), dim3(gp.tiles_m * gp.tiles_n * gp.splits), dim3(512), LDS, s, gp);
   MG_CHECK_LAUNCH();
   if (gp.splits > 1) {
     const int64_t quads = (int64_t)gp.M * ((gp.N + 3) >> 2);
-    hipLaunchKernelGGL(splitk_fixup_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, gp.ws, gp.splits, gp.M, gp.N, gp.ldws, real_ep, gp.row_scale);
+    hipLaunchKernelGGL(splitk_fixup_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, gp.ws, gp.splits, gp.M, gp.N, gp.ldws, real_ep, real_row_scale);
     MG_CHECK_LAUNCH();
   }
   return MG_OK;
@@ -995,7 +999,9 @@ int gemm_dispatch(const mg_gemm_desc* d, bool fp8, const float* row_scale, hipSt
   gp.zero = d->zero_page;
   gp.tiles_m = (d->M + BM - 1) / BM; gp.tiles_n = (d->N + BN - 1) / BN;
   gp.ep = d->ep;
-  gp.row_scale = row_scale;
+  if (row_scale && d->ep.row_scale) MG_FAIL(MG_ERR_UNSUPPORTED, "%s: the fp8 GEMMs take the row scale as their argument, not through mg_epilogue.row_scale", who);
+  if (mx && d->ep.row_scale) MG_FAIL(MG_ERR_UNSUPPORTED, "%s: MX operands carry their scales; mg_epilogue.row_scale is not applied", who);
+  gp.row_scale = row_scale ? row_scale : d->ep.row_scale;
   gp.mx_a = mx ? mx->a : nullptr; gp.mx_w = mx ? mx->w : nullptr; gp.rg_a = (d->M + 63) / 64; gp.rg_w = (d->N + 63) / 64;
   // outputs far larger than the caches are streamed out with non-temporal stores (measured -9 % on the
   // 256x256 kernel at K = 4096: the tile no longer evicts the operand panels from L2)

@@ -237,10 +237,11 @@ MG_DEV void epilogue_apply_impl(const mg_epilogue& ep, const EpiColsW<W>& c, int
     if (full) {
 #pragma unroll
       for (int g = 0; g < W; g += 4) {
-        const f32x4 w = {o[g], o[g + 1], o[g + 2], o[g + 3]};
+        f32x4 w = {o[g], o[g + 1], o[g + 2], o[g + 3]};
+        if (ep.accumulate) w += *(const f32x4*)(cp + g);       // weight gradients: += into the fp32 gradient buffer
         if (NT) __builtin_nontemporal_store(w, (f32x4*)(cp + g)); else *(f32x4*)(cp + g) = w;
       }
-    } else for (int r = 0; r < W; ++r) if (n + r < N) cp[r] = o[r];
+    } else for (int r = 0; r < W; ++r) if (n + r < N) cp[r] = ep.accumulate ? cp[r] + o[r] : o[r];
   } else {
     mg_bf16* cp = (mg_bf16*)ep.C + (int64_t)m * ep.ldc + n;
     if (full) store_bf16_row<W, NT, COH>(cp, o);
@@ -292,7 +293,10 @@ MG_DEV void epilogue_store4(const mg_epilogue& ep, int m, int n, f32x4 v, int N)
         for (int r = 0; r < 4; ++r) o[r] = o[r] > 0.f ? o[r] : 0.f;
       }
       if (ep.out_f32) {
-        *(f32x4*)((float*)ep.C + (int64_t)m * ep.ldc + n) = (f32x4){o[0], o[1], o[2], o[3]};
+        f32x4* cp = (f32x4*)((float*)ep.C + (int64_t)m * ep.ldc + n);
+        f32x4 w = {o[0], o[1], o[2], o[3]};
+        if (ep.accumulate) w += *cp;
+        *cp = w;
       } else {
         u32x2 w; w[0] = pack2bf(o[0], o[1]); w[1] = pack2bf(o[2], o[3]);
         *(u32x2*)((mg_bf16*)ep.C + (int64_t)m * ep.ldc + n) = w;
@@ -508,7 +512,8 @@ MG_DEV void epilogue_rows_c(const mg_epilogue& ep, const EpiColsW<W>& c, const c
             float* cp = (float*)ep.C + (int64_t)m[k] * ep.ldc + n;
 #pragma unroll
             for (int g = 0; g < W; g += 4) {
-              const f32x4 w = {o[k][g], o[k][g + 1], o[k][g + 2], o[k][g + 3]};
+              f32x4 w = {o[k][g], o[k][g + 1], o[k][g + 2], o[k][g + 3]};
+              if (LOADS && ep.accumulate) w += *(const f32x4*)(cp + g);     // (the callers count `accumulate` among the loads)
               if (NT) __builtin_nontemporal_store(w, (f32x4*)(cp + g)); else *(f32x4*)(cp + g) = w;
             }
           }
@@ -560,7 +565,7 @@ MG_DEV void epilogue_rows(const mg_epilogue& ep, const char* lds, int rows, int 
   EpiColsW<W> c;
   epilogue_cols<W>(ep, n, N, c);
   // no aux / residual operand and at most four iterations per lane: the build of the walk without global loads
-  const bool loads = ep.aux_mode != MG_AUX_NONE || ep.res0 || ep.res1 || ep.res2;
+  const bool loads = ep.aux_mode != MG_AUX_NONE || ep.res0 || ep.res1 || ep.res2 || ep.accumulate;
   if (!loads && rows <= 8 * nwaves * (64 / (NCOLS / W)))
     epilogue_rows_c<NCOLS, ROWB, W, NT, false, false>(ep, c, lds, rows, nwaves, wave, lane, m_base, hi_stride, n0, M, N, row_scale);
   else

@@ -19,7 +19,7 @@ MG_A_DENSE, MG_A_CONV3X3 = 0, 1
 MG_AUX_NONE, MG_AUX_RELU_GATE, MG_AUX_GELU_GRAD, MG_AUX_MUL, MG_AUX_QUICK_GELU_GRAD = 0, 1, 2, 3, 4
 
 
-ABI_VERSION = 5      # include/magma_hip.h MG_ABI_VERSION
+ABI_VERSION = 6      # include/magma_hip.h MG_ABI_VERSION
 
 
 class MagmaHipError(RuntimeError):
@@ -37,8 +37,19 @@ class Epilogue(C.Structure):
         ("aux", C.c_void_p), ("ldaux", C.c_int64),
         ("aux_after", C.c_int32), ("act_n0", C.c_int32),
         ("C2", C.c_void_p), ("ldc2", C.c_int64),
-        ("C8", C.c_void_p), ("ldc8", C.c_int64), ("c8_scales", C.c_void_p), ("c8_rgroups", C.c_int32), ("reserved0", C.c_int32),
+        ("C8", C.c_void_p), ("ldc8", C.c_int64), ("c8_scales", C.c_void_p), ("c8_rgroups", C.c_int32), ("accumulate", C.c_int32),
+        ("row_scale", C.c_void_p),
     ]
+
+
+class RelayoutJob(C.Structure):          # mg_relayout_job
+    _fields_ = [("w", C.c_void_p), ("scale", C.c_void_p), ("out", C.c_void_p), ("ldo", C.c_int64),
+                ("Cout", C.c_int32), ("Cin", C.c_int32), ("k", C.c_int32), ("mode", C.c_int32), ("first_block", C.c_int64)]
+
+
+class BnFoldJob(C.Structure):            # mg_bn_fold_job
+    _fields_ = [("gamma", C.c_void_p), ("beta", C.c_void_p), ("mean", C.c_void_p), ("var", C.c_void_p),
+                ("scale", C.c_void_p), ("shift", C.c_void_p), ("eps", C.c_float), ("C", C.c_int32), ("first_block", C.c_int64)]
 
 
 class GemmDesc(C.Structure):
@@ -139,6 +150,7 @@ SYMBOLS = {
     "mg_scale_rows_acc_f32": (C.c_int, [_vp, _vp, _i64, _vp, _i32, _i32, _vp]),
     "mg_add_gate_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
     "mg_bn_param_grad_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
+    "mg_transpose_bn_param_grad_bf16": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mg_im2col_t_bf16": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     "mg_sumsq_f32": (C.c_int, [_vp, _i64, _vp, _vp]),
     "mg_adamw_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _vp, _f32, _vp]),
@@ -156,6 +168,8 @@ SYMBOLS = {
     "mg_debug_mx_mfma": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "mg_conv_weight_relayout_bf16": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     "mg_bn_fold_f32": (C.c_int, [_vp, _vp, _vp, _vp, _f32, _vp, _vp, _i32, _vp]),
+    "mg_conv_weight_relayout_batch": (C.c_int, [_vp, _i32, _i64, _vp]),
+    "mg_bn_fold_batch": (C.c_int, [_vp, _i32, _i64, _vp]),
     "mg_resample_u8": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _i32, _vp]),
     "mg_crop_normalize_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, C.POINTER(C.c_float), C.POINTER(C.c_float), _vp, _vp]),
 }

@@ -166,10 +166,13 @@ def gemm(a: torch.Tensor, w: PackedLinear, out: Optional[torch.Tensor] = None, *
          residuals: Sequence[torch.Tensor] = (), act_after: int = MG_ACT_NONE, scale=None,
          use_bias: bool = True, out_dtype=BF16, layout: Optional[str] = None,
          conv: Optional[tuple] = None, aux=None, aux_mode: int = MG_AUX_NONE, aux_after: bool = False,
-         out2: Optional[torch.Tensor] = None, tile: int = 0, split_k: int = 0, act_n0: int = 0) -> torch.Tensor:
+         out2: Optional[torch.Tensor] = None, tile: int = 0, split_k: int = 0, act_n0: int = 0,
+         accumulate: bool = False, row_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[M,N] = epilogue(a[M,K] @ w^T).  ``act_n0``: ``act`` applies to output columns >= act_n0 only.  ``conv=(H, W, Cin)`` switches the A
     loader to implicit-im2col 3x3 over an NHWC image (a = [B*H*W, Cin]).
-    ``split_k``: 0 lets the library cut K when the grid would leave the chip idle, 1 never, n forces n."""
+    ``split_k``: 0 lets the library cut K when the grid would leave the chip idle, 1 never, n forces n.
+    ``accumulate`` (fp32 ``out`` only): out += ... instead of out = ...; ``row_scale`` fp32 [M]: per-row factor of the accumulator
+    (mg_epilogue.accumulate / .row_scale -- the weight-gradient GEMMs add into the gradient buffer in place)."""
     _need_gpu(a)
     assert a.dtype == BF16 and a.ndim == 2 and a.stride(1) == 1
     M = a.shape[0]
@@ -201,6 +204,13 @@ def gemm(a: torch.Tensor, w: PackedLinear, out: Optional[torch.Tensor] = None, *
     d.ep = _epilogue(out, w.N, w.bias if use_bias else None, scale, act, residuals, act_after, aux, aux_mode,
                      aux_after, out2)
     d.ep.act_n0 = act_n0
+    if accumulate:
+        assert out.dtype == torch.float32, "accumulate adds into an fp32 output"
+        d.ep.accumulate = 1
+    if row_scale is not None:
+        _need_gpu(row_scale)
+        assert row_scale.dtype == torch.float32 and row_scale.is_contiguous() and row_scale.numel() >= M
+        d.ep.row_scale = row_scale.data_ptr()
     check(L.load().mg_gemm_bf16(C.byref(d), _stream()), "mg_gemm_bf16")
     return out
 
@@ -939,6 +949,19 @@ def bn_param_grad(g, y, sub, gamma, beta, dgamma, dbeta):
                                         dgamma.data_ptr(), dbeta.data_ptr(), M, Cc, _stream()), "mg_bn_param_grad_f32")
 
 
+def transpose_bn_param_grad(g, y, sub, gamma, beta, dgamma, dbeta) -> torch.Tensor:
+    """g^T [C, round_up(M, 8)] (as ``transpose``) and, from the same pass over g, the frozen-statistics BatchNorm parameter gradients
+    that ``bn_param_grad`` accumulates."""
+    _need_gpu(g, y, sub, gamma, beta, dgamma, dbeta)
+    M, Cc = g.shape
+    assert g.dtype == BF16 and g.stride(1) == 1 and y.shape == g.shape and y.stride() == g.stride() and (sub is None or (sub.shape == g.shape and sub.stride() == g.stride()))
+    out = torch.empty(Cc, ceil_to(M, 8), dtype=BF16, device=g.device)
+    check(L.load().mg_transpose_bn_param_grad_bf16(g.data_ptr(), g.stride(0), out.data_ptr(), out.stride(0), M, Cc, y.data_ptr(), _p(sub),
+                                                   gamma.data_ptr(), beta.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), _stream()),
+          "mg_transpose_bn_param_grad_bf16")
+    return out
+
+
 def im2col_t(x_nhwc: torch.Tensor, B, H, W, Cin) -> torch.Tensor:
     """-> [Cin*9, round_up(M,8)] (row = ci*9 + tap, zero padded columns) for the 3x3 wgrad GEMM."""
     _need_gpu(x_nhwc)
@@ -1024,6 +1047,64 @@ def conv_weight_relayout(w: torch.Tensor, mode: int, scale: Optional[torch.Tenso
     check(L.load().mg_conv_weight_relayout_bf16(w.data_ptr(), _p(scale), out.data_ptr(), ldo, cout, cin, k, mode, _stream()),
           "mg_conv_weight_relayout_bf16")
     return out
+
+
+def _job_table(jobs, device) -> torch.Tensor:
+    """ctypes job structs -> device byte tensor (the DEVICE array the batched entry points read)."""
+    arr = (type(jobs[0]) * len(jobs))(*jobs)
+    return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+
+
+class ConvOperandPlan:
+    """GEMM operands of MANY trainable convolutions + the folded affine of their frozen-statistics BatchNorms, re-derived from the
+    current weights by TWO launches (mg_bn_fold_batch, then mg_conv_weight_relayout_batch) -- the training engine calls ``refresh``
+    once per forward instead of ~3 small launches per convolution.  ``units``: list of (weight bf16 [Cout,Cin,k,k] with k in (1, 3),
+    gamma, beta, mean, var fp32 [Cout], eps); weight / statistics storage must stay where it is (the tables hold raw pointers).
+    Per unit i afterwards: ``fwd[i]`` [Cout, ld] (mode 0), ``dgrad[i]`` [Cin, ld] (mode 1, BN scale folded), ``scale[i]``, ``shift[i]``."""
+
+    def __init__(self, units, device):
+        from .lib import BnFoldJob, RelayoutJob
+        self.keep = units
+        ctot = sum(u[0].shape[0] for u in units)
+        self._aff = torch.empty(2, ctot, dtype=torch.float32, device=device)
+        self.scale, self.shift, self.fwd, self.dgrad = [], [], [], []
+        sizes = []
+        for (w, *_rest) in units:
+            _need_gpu(w)
+            assert w.dtype == BF16 and w.ndim == 4 and w.is_contiguous() and w.shape[2] == w.shape[3] and w.shape[2] in (1, 3)
+            cout, cin, k, _ = w.shape
+            # (a 1x1 weight whose Cin is a whole number of 64-element K-tiles already IS its forward operand: no copy)
+            sizes.append((0 if (k == 1 and cin % 64 == 0) else cout * ceil_to(k * k * cin, 64), cin * ceil_to(k * k * cout, 64)))
+        self._ops = torch.empty(sum(a + b for a, b in sizes), dtype=BF16, device=device)
+        bn_jobs, rl_jobs, c0, o0, bb, rb = [], [], 0, 0, 0, 0
+        for (w, gamma, beta, mean, var, eps), (n0, n1) in zip(units, sizes):
+            cout, cin, k, _ = w.shape
+            for t in (gamma, beta, mean, var):
+                _need_gpu(t)
+                assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == cout
+            sc, sh = self._aff[0, c0:c0 + cout], self._aff[1, c0:c0 + cout]
+            c0 += cout
+            bn_jobs.append(BnFoldJob(gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), var.data_ptr(), sc.data_ptr(), sh.data_ptr(),
+                                     float(eps), cout, bb))
+            bb += (cout + 255) // 256
+            g = self._ops[o0 + n0:o0 + n0 + n1].view(cin, -1)
+            if n0:
+                f = self._ops[o0:o0 + n0].view(cout, -1)
+                rl_jobs.append(RelayoutJob(w.data_ptr(), None, f.data_ptr(), f.shape[1], cout, cin, k, 0, rb))
+                rb += (n0 + 255) // 256
+            else:
+                f = w.view(cout, cin)
+            o0 += n0 + n1
+            rl_jobs.append(RelayoutJob(w.data_ptr(), sc.data_ptr(), g.data_ptr(), g.shape[1], cout, cin, k, 1, rb))
+            rb += (n1 + 255) // 256
+            self.scale.append(sc); self.shift.append(sh); self.fwd.append(f); self.dgrad.append(g)
+        self._bn_tab, self._rl_tab = _job_table(bn_jobs, device), _job_table(rl_jobs, device)
+        self._nbn, self._bn_blocks, self._nrl, self._rl_blocks = len(bn_jobs), bb, len(rl_jobs), rb
+
+    def refresh(self):
+        lib = L.load()
+        check(lib.mg_bn_fold_batch(self._bn_tab.data_ptr(), self._nbn, self._bn_blocks, _stream()), "mg_bn_fold_batch")
+        check(lib.mg_conv_weight_relayout_batch(self._rl_tab.data_ptr(), self._nrl, self._rl_blocks, _stream()), "mg_conv_weight_relayout_batch")
 
 
 # ---- image preprocessing (reference magma/transforms.py:121-134) ------------------------------------------------

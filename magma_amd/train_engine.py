@@ -122,6 +122,11 @@ class LRScheduler:
         self.last_step = sd["last_step"]
 
 
+_CONV_PLAN = os.environ.get("MAGMA_CONV_PLAN", "1") != "0"               # A/B switch: 0 = one re-layout / BN-fold launch per convolution
+_BN_GRAD_FUSED = os.environ.get("MAGMA_BN_GRAD_FUSED", "1") != "0"       # A/B switch: 0 = bn_param_grad + transpose as two passes over g
+_WGRAD_INPLACE = os.environ.get("MAGMA_WGRAD_INPLACE", "1") != "0"     # A/B switch: 0 = fp32 temporary + scale_rows_acc pass
+
+
 def _t(x: torch.Tensor) -> RawWeight:
     """Transposed copy of a [R, C] activation/weight as a GEMM B operand [C, R]."""
     return RawWeight(ops.transpose(x))       # [C, round_up(R,8)], zero padded
@@ -178,6 +183,7 @@ class MagmaEngine:
         # eval_every-1 and inference); MAGMA_BN_BATCH_STATS=1 or train(bn_batch_stats=True) selects the later behaviour.
         self.bn_batch_stats = os.environ.get("MAGMA_BN_BATCH_STATS", "0") == "1"
         self._bn_dirty = False
+        self._plan = self._plan_live = None     # ops.ConvOperandPlan of the CLIP trunk (frozen-statistics mode), built on first use
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.gas = max(1, int(self.config.gradient_accumulation_steps))
         self.clip = float(self.config.gradient_clipping or 0.0)
@@ -770,9 +776,16 @@ class MagmaEngine:
 
     def _acc_wgrad(self, param, gT: RawWeight, xT: RawWeight, row_scale=None):
         """grad(param)[N,K] += gT[N,M] . xT[K,M]^T  (fp32), optional per-row scale."""
-        tmp = ops.gemm(gT.rm, xT, out_dtype=F32, layout="rm", use_bias=False)
         gview = self.grad_of(param).view(param.shape[0], -1)
-        ops.scale_rows_acc(gview, tmp[:, : gview.shape[1]], row_scale)
+        nk = gview.shape[1]
+        if _WGRAD_INPLACE and nk % 4 == 0 and gview.data_ptr() % 16 == 0 and xT.N >= nk:
+            # the GEMM's epilogue (or its split-K fix-up) adds row_scale[n] * (g^T x) into the fp32 gradient in place: no
+            # temporary, no second pass (mg_epilogue.accumulate / .row_scale, ABI 6)
+            xw = xT if xT.N == nk else RawWeight(xT.rm[:nk], K=xT.K)
+            ops.gemm(gT.rm, xw, out=gview, layout="rm", use_bias=False, accumulate=True, row_scale=row_scale)
+            return
+        tmp = ops.gemm(gT.rm, xT, out_dtype=F32, layout="rm", use_bias=False)
+        ops.scale_rows_acc(gview, tmp[:, : nk], row_scale)
 
     def _adapter_backward(self, mod, g, x_in, t, pre=None):
         """y = x_in + Wup act(Wdn [LN] x_in + bdn) + bup.  Given g = dL/dy accumulates the adapter's parameter gradients and
@@ -1257,21 +1270,49 @@ class MagmaEngine:
         scale, shift = ops.bn_fold(gamma, beta, st[0], st[1], bn.eps)
         return gamma, beta, scale, shift
 
+    def _conv_plan(self, enc):
+        """Frozen-statistics mode: the GEMM operands of every trunk convolution (forward and dgrad layout) and the folded affine of
+        its BatchNorm live in ONE buffer each and are re-derived from the current weights by two launches per forward
+        (ops.ConvOperandPlan) -- before: one re-layout per convolution and direction plus one fold per BatchNorm, ~380 launches."""
+        if self._plan is None:
+            units, idx = [], {}
+            pairs = [(enc.conv1, enc.bn1), (enc.conv2, enc.bn2), (enc.conv3, enc.bn3)]      # the pairs _encoder_forward walks
+            for li in range(1, 5):
+                for blk in getattr(enc, f"layer{li}"):
+                    pairs += [(blk.conv1, blk.bn1), (blk.conv2, blk.bn2), (blk.conv3, blk.bn3)]
+                    if blk.downsample is not None:
+                        pairs.append((blk.downsample[1], blk.downsample[2]))
+            for conv, bn in pairs:
+                st = self._bn_stats.get(id(bn))
+                if st is None:
+                    st = self._bn_stats[id(bn)] = (bn.running_mean.float().contiguous(), bn.running_var.float().contiguous())
+                idx[id(conv)] = len(units)
+                units.append((conv.weight.data, self.master_of(bn.weight), self.master_of(bn.bias), st[0], st[1], bn.eps))
+            self._plan = (ops.ConvOperandPlan(units, self.device), idx)
+        return self._plan
+
     def _unit_fwd(self, conv, bn, a, geom, relu, residual=None, kind=None):
         w = conv.weight.data
         cout, cin, kh, _ = w.shape
-        gamma, beta, scale, shift = self._bn_vectors(bn)
+        pi = None
+        if self._plan_live is not None:
+            plan, idx = self._plan_live
+            pi = idx.get(id(conv))
+        if pi is not None:
+            gamma, beta, scale, shift = self.master_of(bn.weight), self.master_of(bn.bias), plan.scale[pi], plan.shift[pi]
+        else:
+            gamma, beta, scale, shift = self._bn_vectors(bn)
         if kind == "stem":
             w2 = torch.zeros(cout, 64, dtype=BF16, device=w.device)
             w2[:, :27] = w.reshape(cout, 27)
             wop, convarg = RawWeight(w2, bias=shift, K=32), None
         elif kh == 1:
-            wop, convarg = RawWeight(ops.conv_weight_relayout(w, 0), bias=shift, K=cin), None
+            wop, convarg = RawWeight(plan.fwd[pi] if pi is not None else ops.conv_weight_relayout(w, 0), bias=shift, K=cin), None
         else:
-            wop = RawWeight(ops.conv_weight_relayout(w, 0), bias=shift, K=9 * cin)
+            wop = RawWeight(plan.fwd[pi] if pi is not None else ops.conv_weight_relayout(w, 0), bias=shift, K=9 * cin)
             convarg = (geom[1], geom[2], cin)
         rec = {"conv": conv, "bn": bn, "a": a, "geom": geom, "kind": kind or ("1x1" if kh == 1 else "3x3"),
-               "gamma": gamma, "beta": beta, "sub": residual}
+               "gamma": gamma, "beta": beta, "sub": residual, "dgrad_op": plan.dgrad[pi] if pi is not None else None}
         if self.bn_batch_stats:
             # batch statistics: raw conv output, per-channel sums, fold, normalise (+ residual, ReLU); the running
             # statistics (fp32 copies) are updated in place with nn.BatchNorm2d's momentum rule
@@ -1312,6 +1353,10 @@ class MagmaEngine:
         B, _, H, W = x.shape
         h, w = H // 2, W // 2
         units = []
+        self._plan_live = None
+        if _CONV_PLAN and not self.bn_batch_stats:      # batch statistics: the dgrad operand is unscaled and the affine comes from the batch
+            self._plan_live = self._conv_plan(enc)
+            self._plan_live[0].refresh()
         cols = ops.stem_im2col(x)
         y, r = self._unit_fwd(enc.conv1, enc.bn1, cols, (B, h, w), True, kind="stem"); units.append(r)
         y, r = self._unit_fwd(enc.conv2, enc.bn2, y, (B, h, w), True); units.append(r)
@@ -1360,9 +1405,13 @@ class MagmaEngine:
             self.grad_of(bn.weight).add_(dgamma)
             self.grad_of(bn.bias).add_(dbeta)
             g = ops.bn_bwd_dz(g, rec["z"], rec["mean"], rec["rstd"], rec["gamma"], dgamma, dbeta)
+            gT = _t(g)
+        elif _BN_GRAD_FUSED and g.is_contiguous() and rec["y"].is_contiguous() and (rec["sub"] is None or rec["sub"].is_contiguous()):
+            # g^T (the weight gradient's operand) and the BatchNorm parameter gradients from ONE pass over g
+            gT = RawWeight(ops.transpose_bn_param_grad(g, rec["y"], rec["sub"], rec["gamma"], rec["beta"], self.grad_of(bn.weight), self.grad_of(bn.bias)))
         else:
             ops.bn_param_grad(g, rec["y"], rec["sub"], rec["gamma"], rec["beta"], self.grad_of(bn.weight), self.grad_of(bn.bias))
-        gT = _t(g)
+            gT = _t(g)
         if rec["kind"] == "3x3":
             # im2col^T rows come in the weight's own (ci, ky, kx) order -> dW needs no re-layout
             self._acc_wgrad(conv.weight, gT, RawWeight(ops.im2col_t(a, Bq, hh, ww, cin)), row_scale=scale)
@@ -1373,11 +1422,14 @@ class MagmaEngine:
         aux_kw = {}
         if gate is not None:
             aux_kw = dict(aux=gate, aux_mode=ops.MG_AUX_RELU_GATE, aux_after=gate_after)
+        dg = rec.get("dgrad_op")       # made at the start of the forward by the batched re-layout (frozen statistics)
+        if dg is None:
+            dg = ops.conv_weight_relayout(w, 1, scale)
         if rec["kind"] == "3x3":
             # dX = conv3x3(g, W') with W'[ci][(ky,kx),co] = W[co][ci][2-ky][2-kx] * scale[co]
-            wop = RawWeight(ops.conv_weight_relayout(w, 1, scale), K=9 * cout)
+            wop = RawWeight(dg, K=9 * cout)
             return ops.gemm(g, wop, conv=(hh, ww, cout), layout="rm", use_bias=False, residuals=residuals, **aux_kw)
-        wop = RawWeight(ops.conv_weight_relayout(w, 1, scale), K=cout)     # [cin, cout] * scale[co]
+        wop = RawWeight(dg, K=cout)     # [cin, cout] * scale[co]
         return ops.gemm(g, wop, layout="rm", use_bias=False, residuals=residuals, **aux_kw)
 
     def _encoder_backward(self, et, g_out):
@@ -1527,6 +1579,7 @@ class MagmaEngine:
         sd = torch.load(path, map_location="cpu", weights_only=False)
         self.module.load_checkpoint_state(sd["module"])
         self._bn_stats = {}         # BatchNorm statistics may have changed
+        self._plan = self._plan_live = None
         for g in self.groups:       # parameters were re-pointed at the flat buffers; refresh masters from the loaded values
             for p, o in zip(g.params, g.offsets):
                 g.master[o:o + p.numel()].copy_(p.data.reshape(-1).float())

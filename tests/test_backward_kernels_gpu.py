@@ -373,6 +373,12 @@ def test_conv_backward_helpers(dev):
         ops.bn_param_grad(g2, y2, s2, gm, bt, dg2, db2)
         yy = y2.float() - (s2.float() if with_sub else 0)
         assert rel(db2, g2.float().sum(0)) < 1e-4 and rel(dg2, (g2.float() * (yy - bt) / gm).sum(0)) < 1e-4, (M2, C2)
+        # the same sums taken while g is transposed for the weight-gradient GEMM (one pass over g): the transpose bit for bit, the
+        # sums accumulated ON TOP of what the buffers hold
+        dg3, db3 = torch.full((C2,), 3.0, device=dev), torch.full((C2,), -2.0, device=dev)
+        gt = ops.transpose_bn_param_grad(g2, y2, s2, gm, bt, dg3, db3)
+        assert torch.equal(gt, ops.transpose(g2))
+        assert rel(db3 + 2.0, g2.float().sum(0)) < 1e-4 and rel(dg3 - 3.0, (g2.float() * (yy - bt) / gm).sum(0)) < 1e-4, (M2, C2)
 
 
 def test_adamw_and_clip(dev):

@@ -685,7 +685,8 @@ def test_ctypes_structs_have_the_layout_of_the_header(tmp_path):
     import subprocess
     from magma_amd import lib as L
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    structs = {"mg_epilogue": L.Epilogue, "mg_gemm_desc": L.GemmDesc, "mg_skinny_desc": L.SkinnyDesc}
+    structs = {"mg_epilogue": L.Epilogue, "mg_gemm_desc": L.GemmDesc, "mg_skinny_desc": L.SkinnyDesc,
+               "mg_relayout_job": L.RelayoutJob, "mg_bn_fold_job": L.BnFoldJob}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "magma_hip.h"', 'int main(void) {']
     for cname, cls in structs.items():
         lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')

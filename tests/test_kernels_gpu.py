@@ -572,6 +572,42 @@ def test_gemm256_split_k(dev, M, N, K, split):
         assert float((out - o128).abs().max()) <= 2e-3 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("M,N,K,tile,split", [
+    (96, 264, 1568, 0, 1),          # 128x128 kernel, un-split, ragged M / N (a late CLIP stage's weight gradient)
+    (96, 264, 1568, 0, 0),          # ... cut along K by the automatic policy: the fix-up accumulates
+    (300, 204, 2048, 128, 3),       # N % 8 != 0: the 4-column epilogue walk
+    (512, 1056, 4096, 256, 1),      # 256x256 kernel, un-split
+    (4096, 1024, 32768, 0, 0),      # the adapters' weight gradient: split 256x256 form + fix-up
+])
+def test_gemm_accumulates_into_fp32_output_with_row_scale(dev, M, N, K, tile, split):
+    """mg_epilogue.accumulate / .row_scale (ABI 6): C (fp32) += row_scale[m] * (A W^T) in place -- what the weight-gradient GEMMs of
+    the training engine do to the gradient buffer (reference: .grad accumulation over micro-batches, train_loop.py:22-33).  Every
+    kernel form: both tile kernels, un-split and split-K (fix-up); columns past N untouched; a bf16 output refuses."""
+    from magma_amd import ops
+    a = rnd(M, K, dev=dev, seed=700).to(BF16)
+    w = rnd(N, K, dev=dev, seed=701, scale=0.05).to(BF16)
+    rs = rnd(M, dev=dev, seed=702).abs() + 0.5
+    lin = ops.PackedLinear(w, tiled=True, rowmajor=True)
+    prod = a.float() @ w.float().t()
+    ld = ops.ceil_to(N, 4) + 4
+    for layout in ("rm", "ft"):
+        for use_rs in (False, True):
+            buf = rnd(M, ld, dev=dev, seed=703).contiguous()
+            before = buf.clone()
+            ops.gemm(a, lin, out=buf[:, :N], layout=layout, use_bias=False, tile=tile, split_k=split, accumulate=True,
+                     row_scale=rs if use_rs else None)
+            ref = before[:, :N] + (prod * rs[:, None] if use_rs else prod)
+            assert_close(buf[:, :N], ref, 2e-5, f"accumulate {layout} row_scale={use_rs}")
+            assert torch.equal(buf[:, N:], before[:, N:]), "wrote past N"
+            # twice = the product added twice (no hidden state in the workspace)
+            ops.gemm(a, lin, out=buf[:, :N], layout=layout, use_bias=False, tile=tile, split_k=split, accumulate=True,
+                     row_scale=rs if use_rs else None)
+            assert_close(buf[:, :N], before[:, :N] + 2 * (prod * rs[:, None] if use_rs else prod), 2e-5, "second accumulation")
+    with pytest.raises(Exception, match="accumulate"):
+        d_out = torch.zeros(M, ops.ceil_to(N, 8), dtype=BF16, device=dev)
+        ops.gemm(a, lin, out=d_out[:, :N], use_bias=False, accumulate=True)
+
+
 @pytest.mark.parametrize("M,N,ld", [(300, 520, 528), (2048, 1024, 1024)])
 def test_gelu_erf_passes(dev, M, N, ld):
     """torch.nn.GELU() (erf) and g * gelu'(pre) as stand-alone passes (adapters built with activation=nn.GELU, reference
