@@ -958,25 +958,38 @@ __global__ __launch_bounds__(256) void rotary_qk_inplace_kernel(mg_bf16* __restr
   }
 }
 
-// ld2[b,h,s] = {-16 lse, -rowsum(dO o O)}: the two per-query statistics of the backward (attention_bwd.hip: attn_bwd_prep_kernel),
-// one wave per (b, s, h) row of 256; O rows may sit in a wider buffer
+// ld2[b,h,s] = {-16 lse, -rowsum(dO o O)}: the two per-query statistics of the backward (attention_bwd.hip: attn_bwd_prep_kernel).
+// A half-wave per (b, s, h) row of 256 (16 bytes per lane), four rows per half-wave in flight: 8 rows = 4 KiB of dO and of O per
+// wave (the one-row-per-wave form with 8-byte loads streamed its 537 MB at 3.8 TB/s); O rows may sit in a wider buffer.
 __global__ __launch_bounds__(256) void attn_bwd_stats_kernel(const mg_bf16* __restrict__ dO, const mg_bf16* __restrict__ O,
                                                              const float* __restrict__ lse, float* __restrict__ ld2,
                                                              int B, int H, int S, int64_t ld_o) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t row = (int64_t)blockIdx.x * 4 + wave;   // over B*S*H, (b,s,h) order = memory order of [M, H*256]
-  if (row >= (int64_t)B * S * H) return;
-  const u32x2 a = *(const u32x2*)(dO + row * DH + lane * 4);
-  const u32x2 o = *(const u32x2*)(O + (row / H) * ld_o + (row % H) * DH + lane * 4);
-  float s = bflo(a[0]) * bflo(o[0]) + bfhi(a[0]) * bfhi(o[0]) + bflo(a[1]) * bflo(o[1]) + bfhi(a[1]) * bfhi(o[1]);
-  s = wave_sum(s);
-  if (lane == 0) {
-    const int h = (int)(row % H);
-    const int64_t bs = row / H;
-    const int sidx = (int)(bs % S), b = (int)(bs / S);
-    const int64_t i = ((int64_t)b * H + h) * S + sidx;
-    ld2[i * 2] = -16.0f * lse[i];
-    ld2[i * 2 + 1] = -s;
+  const int l32 = lane & 31, half = lane >> 5;
+  const int64_t rows = (int64_t)B * S * H;
+  const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * 8 + half;   // rows row0 + 2 j, (b,s,h) order = memory order of [M, H*256]
+  u32x4 a[4], o[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int64_t row = min(row0 + 2 * j, rows - 1);
+    a[j] = *(const u32x4*)(dO + row * DH + l32 * 8);
+    o[j] = *(const u32x4*)(O + (row / H) * ld_o + (row % H) * DH + l32 * 8);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) s += bflo(a[j][w]) * bflo(o[j][w]) + bfhi(a[j][w]) * bfhi(o[j][w]);
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);     // within the half-wave
+    const int64_t row = row0 + 2 * j;
+    if (l32 == 0 && row < rows) {
+      const int h = (int)(row % H);
+      const int64_t bs = row / H;
+      const int sidx = (int)(bs % S), b = (int)(bs / S);
+      const int64_t i = ((int64_t)b * H + h) * S + sidx;
+      *(mg_f32x2*)(ld2 + i * 2) = (mg_f32x2){-16.0f * lse[i], -s};
+    }
   }
 }
 
@@ -1092,7 +1105,7 @@ extern "C" int mg_attn_bwd_rows_bf16(const mg_bf16* q, const mg_bf16* k, const m
   }
   hipStream_t s = (hipStream_t)stream;
   const int64_t rows = (int64_t)B * S * H;
-  hipLaunchKernelGGL(attn_bwd_stats_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, dO, O, lse, D, B, H, S, ld_o);
+  hipLaunchKernelGGL(attn_bwd_stats_kernel, dim3((unsigned)((rows + 31) / 32)), dim3(256), 0, s, dO, O, lse, D, B, H, S, ld_o);
   const AttnRows x{q, k, v, stride_b, stride_h, (int)ld_row};
   if (int rc = attn_bwd_dq32_tr_launch(x, dO, D, gq, B, H, S, 4, s, who)) return rc;
   return attn_bwd_dkdv32_tr_launch(x, dO, D, gk, gv, B, H, S, 3, s, who);

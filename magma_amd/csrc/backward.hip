@@ -586,11 +586,31 @@ __global__ __launch_bounds__(256) void bn_bwd_dz_kernel(const mg_bf16* __restric
 MG_DEV float grad_ld(const float* g, int64_t i) { return g[i]; }
 MG_DEV float grad_ld(const mg_bf16* g, int64_t i) { return bf2f(g[i]); }
 
-template <typename G>
+// (VEC: 16 bytes per lane and load -- 4 fp32 / 8 bf16 gradients --, two loads in flight per thread; the 4-byte form streamed at 2 TB/s)
+MG_DEV float sumsq16(const float* g, int64_t q) { const f32x4 v = ((const f32x4*)g)[q]; return v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]; }
+MG_DEV float sumsq16(const mg_bf16* g, int64_t q) {
+  const u32x4 v = ((const u32x4*)g)[q];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { const float a = bflo(v[j]), b = bfhi(v[j]); s += a * a + b * b; }
+  return s;
+}
+template <typename G, bool VEC = false>
 __global__ __launch_bounds__(256) void sumsq_kernel(const G* __restrict__ g, int64_t n, float* __restrict__ out) {
   __shared__ float red[4];
   float s = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) { const float v = grad_ld(g, i); s += v * v; }
+  if constexpr (VEC) {
+    constexpr int E = 16 / (int)sizeof(G);
+    const int64_t nq = n / E, stride = (int64_t)gridDim.x * 256;
+    float s1 = 0.f;
+    int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (; q + stride < nq; q += 2 * stride) { s += sumsq16(g, q); s1 += sumsq16(g, q + stride); }
+    if (q < nq) s += sumsq16(g, q);
+    s += s1;
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n - nq * E)) { const float v = grad_ld(g, nq * E + threadIdx.x); s += v * v; }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) { const float v = grad_ld(g, i); s += v * v; }
+  }
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
@@ -599,7 +619,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const G* __restrict__ g, int
 
 // p (fp32 master), m, v, g (gradient SUM over micro-steps and ranks; grad_scale = 1 / (gas * world) turns it into the
 // mean); writes the bf16 model copy.  clip = min(1, max_norm / (sqrt(*norm_sq) + 1e-6)).
-template <typename G>
+template <typename G, bool VEC = false>
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
                                                     const G* __restrict__ g, mg_bf16* __restrict__ p_bf16,
                                                     int64_t n, float lr, float beta1, float beta2, float eps,
@@ -610,14 +630,34 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
     const float nrm = sqrtf(*norm_sq) * grad_scale;
     clip = grad_scale * fminf(1.0f, max_norm / (nrm + 1e-6f));
   }
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const float gi = grad_ld(g, i) * clip;
-    float pi = p[i];
+  auto update = [&](float graw, float& pi, float& mi, float& vi) {      // ONE element: the arithmetic of both forms below
+    const float gi = graw * clip;
     pi -= lr * wd * pi;                                  // decoupled weight decay (torch.optim.AdamW)
-    const float mi = beta1 * m[i] + (1.f - beta1) * gi;
-    const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
-    m[i] = mi; v[i] = vi;
+    mi = beta1 * mi + (1.f - beta1) * gi;
+    vi = beta2 * vi + (1.f - beta2) * gi * gi;
     pi -= lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
+  };
+  int64_t i0 = 0;
+  if constexpr (VEC) {
+    // four elements per thread and iteration as 16-byte accesses (alone both forms stream at 4.7 TB/s: profiles/r06_adamw_forms.jsonl)
+    const int64_t nq = n >> 2;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < nq; q += (int64_t)gridDim.x * 256) {
+      f32x4 pv = ((const f32x4*)p)[q], mv = ((const f32x4*)m)[q], vv = ((const f32x4*)v)[q];
+      float gr[4];
+      if constexpr (sizeof(G) == 4) { const f32x4 gv = ((const f32x4*)g)[q]; gr[0] = gv[0]; gr[1] = gv[1]; gr[2] = gv[2]; gr[3] = gv[3]; }
+      else { const u32x2 gv = ((const u32x2*)g)[q]; gr[0] = bflo(gv[0]); gr[1] = bfhi(gv[0]); gr[2] = bflo(gv[1]); gr[3] = bfhi(gv[1]); }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { float pj = pv[j], mj = mv[j], vj = vv[j]; update(gr[j], pj, mj, vj); pv[j] = pj; mv[j] = mj; vv[j] = vj; }
+      ((f32x4*)m)[q] = mv; ((f32x4*)v)[q] = vv; ((f32x4*)p)[q] = pv;
+      if (p_bf16) { u32x2 o; o[0] = pack2bf(pv[0], pv[1]); o[1] = pack2bf(pv[2], pv[3]); ((u32x2*)p_bf16)[q] = o; }
+    }
+    i0 = nq << 2;
+    if (blockIdx.x != 0) return;                          // the (< 4 element) tail: first workgroup
+  }
+  for (int64_t i = i0 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float pi = p[i], mi = m[i], vi = v[i];
+    update(grad_ld(g, i), pi, mi, vi);
+    m[i] = mi; v[i] = vi;
     p[i] = pi;
     if (p_bf16) p_bf16[i] = f2bf(pi);
   }
@@ -846,14 +886,20 @@ extern "C" int mg_im2col_t_bf16(const mg_bf16* x, mg_bf16* out, int64_t ldo, int
 
 extern "C" int mg_sumsq_f32(const float* g, int64_t n, float* out, void* stream) {
   if (n <= 0 || !g || !out) MG_FAIL(MG_ERR_SHAPE, "mg_sumsq_f32: bad arguments");
-  hipLaunchKernelGGL(sumsq_kernel<float>, dim3(grid_for(n) > 1024 ? 1024 : grid_for(n)), dim3(256), 0, (hipStream_t)stream, g, n, out);
+  if (MG_ALIGNED16(g) && n >= 4096)
+    hipLaunchKernelGGL((sumsq_kernel<float, true>), dim3(grid_for(n / 4) > 2048 ? 2048 : grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, g, n, out);
+  else
+    hipLaunchKernelGGL(sumsq_kernel<float>, dim3(grid_for(n) > 1024 ? 1024 : grid_for(n)), dim3(256), 0, (hipStream_t)stream, g, n, out);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }
 
 extern "C" int mg_sumsq_bf16(const mg_bf16* g, int64_t n, float* out, void* stream) {
   if (n <= 0 || !g || !out) MG_FAIL(MG_ERR_SHAPE, "mg_sumsq_bf16: bad arguments");
-  hipLaunchKernelGGL(sumsq_kernel<mg_bf16>, dim3(grid_for(n) > 1024 ? 1024 : grid_for(n)), dim3(256), 0, (hipStream_t)stream, g, n, out);
+  if (MG_ALIGNED16(g) && n >= 4096)
+    hipLaunchKernelGGL((sumsq_kernel<mg_bf16, true>), dim3(grid_for(n / 8) > 2048 ? 2048 : grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, g, n, out);
+  else
+    hipLaunchKernelGGL(sumsq_kernel<mg_bf16>, dim3(grid_for(n) > 1024 ? 1024 : grid_for(n)), dim3(256), 0, (hipStream_t)stream, g, n, out);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }
@@ -873,7 +919,11 @@ int adamw_launch(float* p, float* m, float* v, const G* g, mg_bf16* p_bf16, int6
                  void* stream, const char* who) {
   if (n <= 0 || step <= 0 || !p || !m || !v || !g) MG_FAIL(MG_ERR_SHAPE, "%s: bad arguments", who);
   const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
-  hipLaunchKernelGGL(adamw_kernel<G>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, m, v, g, p_bf16, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, max_norm, norm_sq, grad_scale);
+  const bool vec = MG_ALIGNED16(p) && MG_ALIGNED16(m) && MG_ALIGNED16(v) && !((uintptr_t)g & (4 * sizeof(G) - 1)) && !((uintptr_t)p_bf16 & 7u) && n >= 1024;
+  if (vec)
+    hipLaunchKernelGGL((adamw_kernel<G, true>), dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, p, m, v, g, p_bf16, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, max_norm, norm_sq, grad_scale);
+  else
+    hipLaunchKernelGGL(adamw_kernel<G>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, m, v, g, p_bf16, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, max_norm, norm_sq, grad_scale);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }

@@ -1405,6 +1405,8 @@ class MagmaEngine:
             self.grad_of(bn.weight).add_(dgamma)
             self.grad_of(bn.bias).add_(dbeta)
             g = ops.bn_bwd_dz(g, rec["z"], rec["mean"], rec["rstd"], rec["gamma"], dgamma, dbeta)
+        # the unit's parameter gradients: BatchNorm affine (frozen statistics) + convolution weight
+        if rec["batch"]:
             gT = _t(g)
         elif _BN_GRAD_FUSED and g.is_contiguous() and rec["y"].is_contiguous() and (rec["sub"] is None or rec["sub"].is_contiguous()):
             # g^T (the weight gradient's operand) and the BatchNorm parameter gradients from ONE pass over g
