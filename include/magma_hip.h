@@ -79,7 +79,8 @@ const char* mg_version(void);
  *   6  round 6: mg_epilogue.reserved0 became `accumulate` and the struct grew by `row_scale` (weight-gradient GEMMs add
  *      row_scale[m] * (A W^T) straight into the fp32 gradient: no temporary, no second pass): every descriptor that embeds an
  *      epilogue changed size.  Added mg_conv_weight_relayout_batch / mg_bn_fold_batch (one launch per step for all
- *      convolutions of the image encoder) and mg_transpose_bn_param_grad_bf16.                                                                                            */
+ *      convolutions of the image encoder) and mg_transpose_bn_param_grad_bf16; mg_rotary_split_fp8 gained `inplace` (before the stream):
+ *      the rotated q / k also written back into the fused qkv activation, replacing a mg_rotary_qk_inplace_bf16 pass.                                                                                            */
 #define MG_ABI_VERSION 6
 int32_t mg_abi_version(void);
 const char* mg_last_error(void);
@@ -600,7 +601,7 @@ int mg_adamw_gbf16_f32(float* p, float* m, float* v, const mg_bf16* g, mg_bf16* 
 int32_t mg_attn_fp8_scale_stride(int32_t S);
 int mg_rotary_split_fp8(const mg_bf16* qkv, int32_t B, int32_t S, int32_t H, int32_t rot_dim, const float* sin_t,
                         const float* cos_t, mg_bf16* q, mg_bf16* k, mg_bf16* v, mg_bf16* qt, mg_bf16* kt, int32_t ld_t,
-                        uint8_t* q8, uint8_t* k8, uint8_t* v8t, uint8_t* eq, uint8_t* ek, uint8_t* sv8, void* stream);
+                        uint8_t* q8, uint8_t* k8, uint8_t* v8t, uint8_t* eq, uint8_t* ek, uint8_t* sv8, int32_t inplace, void* stream);
 int mg_attn_prefill_fp8(const uint8_t* q8, const uint8_t* k8, const uint8_t* v8t, const uint8_t* eq, const uint8_t* ek,
                         const uint8_t* sv8, mg_bf16* out, int64_t ld_out, float* lse, int32_t B, int32_t H, int32_t S,
                         uint8_t* out8, int64_t ld_out8, uint8_t* out8_scales, void* stream);

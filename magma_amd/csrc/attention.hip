@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void rotary_split_fp8_kernel(
     const mg_bf16* __restrict__ qkv, int B, int S, int H, int rot_dim, const float* __restrict__ sin_t, const float* __restrict__ cos_t,
     mg_bf16* __restrict__ q_out, mg_bf16* __restrict__ k_out, mg_bf16* __restrict__ v_out, mg_bf16* __restrict__ qt, mg_bf16* __restrict__ kt,
     int ld_t, uint8_t* __restrict__ q8, uint8_t* __restrict__ k8, uint8_t* __restrict__ v8t, uint8_t* __restrict__ eq, uint8_t* __restrict__ ek,
-    uint8_t* __restrict__ sv8, int Sp) {
+    uint8_t* __restrict__ sv8, int Sp, int inplace) {
   __shared__ __attribute__((aligned(16))) mg_bf16 tile[3 * 32 * DH];        // rotated q, k rows (transposes) and v rows
   const int tid = threadIdx.x;
   const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
@@ -175,6 +175,10 @@ __global__ __launch_bounds__(256) void rotary_split_fp8_kernel(
           qv[pi] = pack2bf(q0 * cs - q1 * sn, q1 * cs + q0 * sn);
           kv[pi] = pack2bf(k0 * cs - k1 * sn, k1 * cs + k0 * sn);
         }
+      }
+      if (inplace && d0 < rot_dim) {      // the rotated q / k sections back into the fused activation (each lane rewrites the 16 bytes it read):
+        *(u32x4*)const_cast<mg_bf16*>(base) = qv;                 // the bf16 backward reads q, k, v as rows of that buffer
+        *(u32x4*)const_cast<mg_bf16*>(base + dmodel) = kv;
       }
       if (q_out) {                        // (NULL: forward only -- nobody reads the bf16 copies)
         *(u32x4*)(q_out + ((int64_t)bh * S + s) * DH + d0) = qv;
@@ -500,11 +504,12 @@ extern "C" int mg_rotary_split_train_bf16(const mg_bf16* qkv, int32_t B, int32_t
 // training form for the fp8 attention forward: everything mg_rotary_split_train_bf16 writes except V^T, plus the OCP MX e4m3 copies
 // (rotary_split_fp8_kernel): q8 / k8 [B,H,S,256] with one E8M0 per token in eq / ek [B,H,Sp] (bytes; Sp = mg_attn_fp8_scale_stride(S)),
 // v8t [B,H,ceil(S/64),256,64] with one E8M0 per (d, 32 keys) in sv8 [B,H,ceil(S/64),512].  qt / kt may be NULL (no backward), and
-// so may q / k / v together (forward only: just the e4m3 operands).
+// so may q / k / v together (forward only: just the e4m3 operands).  inplace != 0: the rotated q / k are also written back into
+// qkv (what mg_rotary_qk_inplace_bf16 does, without its pass): the bf16 attention backward reads rows of that buffer.
 extern "C" int32_t mg_attn_fp8_scale_stride(int32_t S) { return ((S + 63) / 64) * 64 + 256; }
 extern "C" int mg_rotary_split_fp8(const mg_bf16* qkv, int32_t B, int32_t S, int32_t H, int32_t rot_dim, const float* sin_t,
                                    const float* cos_t, mg_bf16* q, mg_bf16* k, mg_bf16* v, mg_bf16* qt, mg_bf16* kt, int32_t ld_t,
-                                   uint8_t* q8, uint8_t* k8, uint8_t* v8t, uint8_t* eq, uint8_t* ek, uint8_t* sv8, void* stream) {
+                                   uint8_t* q8, uint8_t* k8, uint8_t* v8t, uint8_t* eq, uint8_t* ek, uint8_t* sv8, int32_t inplace, void* stream) {
   if (B <= 0 || S <= 0 || H <= 0) MG_FAIL(MG_ERR_SHAPE, "mg_rotary_split_fp8: B,S,H must be positive");
   if (rot_dim < 0 || rot_dim > DH || (rot_dim & 7)) MG_FAIL(MG_ERR_SHAPE, "mg_rotary_split_fp8: rot_dim must be a multiple of 8 in [0,256]");
   if (!qkv || !q8 || !k8 || !v8t || !eq || !ek || !sv8 || (rot_dim && (!sin_t || !cos_t)) || (!qt != !kt) || (!q != !k) || (!q != !v) || (qt && !q))
@@ -515,7 +520,7 @@ extern "C" int mg_rotary_split_fp8(const mg_bf16* qkv, int32_t B, int32_t S, int
   if (qt && ((ld_t & 31) || ld_t < ((S + 31) & ~31))) MG_FAIL(MG_ERR_SHAPE, "mg_rotary_split_fp8: ld_t must be a multiple of 32 and >= S");
   dim3 grid(((S + 63) / 64) * 2, B * H);      // both 32-key halves of every 64-key V^T tile
   hipLaunchKernelGGL(rotary_split_fp8_kernel, grid, dim3(256), 0, (hipStream_t)stream, qkv, B, S, H, rot_dim, sin_t, cos_t, q, k, v, qt, kt,
-                     ld_t, q8, k8, v8t, eq, ek, sv8, mg_attn_fp8_scale_stride(S));
+                     ld_t, q8, k8, v8t, eq, ek, sv8, mg_attn_fp8_scale_stride(S), inplace);
   MG_CHECK_LAUNCH();
   return MG_OK;
 }

@@ -97,7 +97,7 @@ SYMBOLS = {
     "mg_comm_broadcast": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
     "mg_comm_destroy": (C.c_int, [_vp]),
     "mg_attn_fp8_scale_stride": (_i32, [_i32]),
-    "mg_rotary_split_fp8": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mg_rotary_split_fp8": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "mg_attn_prefill_fp8": (C.c_int, [_vp] * 7 + [_i64, _vp, _i32, _i32, _i32, _vp, _i64, _vp, _vp]),
     "mg_stream_create_cu_mask": (C.c_int, [C.POINTER(C.c_void_p), _i32]),
     "mg_stream_destroy": (C.c_int, [_vp]),

@@ -421,16 +421,17 @@ class AttnFP8Operands:
         return q, k, v
 
 
-def rotary_split_fp8(qkv, B, S, H, rot_dim, sin_t, cos_t, q=None, k=None, v=None, qt=None, kt=None) -> AttnFP8Operands:
+def rotary_split_fp8(qkv, B, S, H, rot_dim, sin_t, cos_t, q=None, k=None, v=None, qt=None, kt=None, inplace: bool = False) -> AttnFP8Operands:
     """rotary_split_train without V^T + the OCP MX e4m3 operands of the fp8 attention forward (-> AttnFP8Operands).
-    q / k / v (and qt / kt) None: forward only, just the e4m3 operands."""
+    q / k / v (and qt / kt) None: forward only, just the e4m3 operands.  ``inplace``: the rotated q / k are also written back into
+    ``qkv`` (rotary_qk_inplace's result from this pass)."""
     _need_gpu(qkv)
     assert qkv.is_contiguous() and qkv.shape == (B * S, 3 * H * 256)
     op = AttnFP8Operands(B, H, S, qkv.device)
     check(L.load().mg_rotary_split_fp8(qkv.data_ptr(), B, S, H, rot_dim, sin_t.data_ptr(), cos_t.data_ptr(), _p(q), _p(k),
                                        _p(v), _p(qt), _p(kt), (qt.shape[2] * 32) if qt is not None else 0,
                                        op.q8.data_ptr(), op.k8.data_ptr(), op.v8t.data_ptr(), op.eq.data_ptr(), op.ek.data_ptr(),
-                                       op.sv8.data_ptr(), _stream()), "mg_rotary_split_fp8")
+                                       op.sv8.data_ptr(), int(bool(inplace)), _stream()), "mg_rotary_split_fp8")
     return op
 
 

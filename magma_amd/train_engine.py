@@ -641,10 +641,9 @@ class MagmaEngine:
             qkv = self._fgemm((li, "qkv"), ln, ly.qkv, lnq)
             a8 = rows = None
             if self.fp8 and self.fp8_attn:
-                # e4m3 copies of q, k, v^T for the fp8 forward, made from the qkv buffer AFTER the in-place rotary (rot_dim 0: the
-                # split pass only quantises); the bf16 backward reads q, k, v as rows of that same buffer -- no bf16 copies
-                ops.rotary_qk_inplace(qkv, B, S, H, eng.rot, eng.sin_t, eng.cos_t)
-                a8 = ops.rotary_split_fp8(qkv, B, S, H, 0, eng.sin_t, eng.cos_t)
+                # e4m3 copies of q, k, v^T for the fp8 forward; the same pass writes the rotated q / k back into the qkv buffer (the
+                # arithmetic of rotary_qk_inplace): the bf16 backward reads q, k, v as rows of that buffer -- no bf16 copies
+                a8 = ops.rotary_split_fp8(qkv, B, S, H, eng.rot, eng.sin_t, eng.cos_t, inplace=True)
                 rows = ops.AttnRows.of_qkv(qkv, B, S, H)
             elif os.environ.get("MAGMA_ATTN_TR", "1") == "0":
                 # A/B switch only (tools/gpu_r06_step_ab.sh): the round-5 path -- split pass with three transposes, kernels with

@@ -377,6 +377,14 @@ def test_fp8_attention_forward(dev, B, H, S):
     op = ops.rotary_split_fp8(qkv, B, S, H, rot, sin_t, cos_t, q1, k1, v1, qt1, kt1)
     for a, b_, name in ((q1, q0, "q"), (k1, k0, "k"), (v1, v0, "v"), (qt1, qt0, "qt"), (kt1, kt0, "kt")):
         assert torch.equal(a, b_), name
+    # inplace=True (the fp8 training forward): the same e4m3 operands, and qkv afterwards is what mg_rotary_qk_inplace_bf16 leaves
+    qkv_a, qkv_b = qkv.clone(), qkv.clone()
+    op_ip = ops.rotary_split_fp8(qkv_a, B, S, H, rot, sin_t, cos_t, inplace=True)
+    ops.rotary_qk_inplace(qkv_b, B, S, H, rot, sin_t, cos_t)
+    assert torch.equal(qkv_a, qkv_b)
+    for name in ("q8", "k8", "v8t", "sv8"):
+        assert torch.equal(getattr(op_ip, name), getattr(op, name)), name
+    assert torch.equal(op_ip.eq[:, :, :S], op.eq[:, :, :S]) and torch.equal(op_ip.ek[:, :, :S], op.ek[:, :, :S])
     qd, kd, vd = op.dequant()
     for deq, src, name in ((qd, q0, "q8"), (kd, k0, "k8"), (vd, v0, "v8")):
         err = (deq - src.float()).abs()
