@@ -415,6 +415,37 @@ def test_conv_weight_relayout(dev, cout, cin, k):
     assert d.shape[1] % 64 == 0 and torch.equal(d[:, : k * k * cout], ref_d) and bool((d[:, k * k * cout:] == 0).all())
 
 
+def test_conv_operand_plan_matches_the_single_calls(dev):
+    """mg_conv_weight_relayout_batch / mg_bn_fold_batch (ops.ConvOperandPlan: every convolution of the CLIP trunk re-derived by two
+    launches per step) == mg_conv_weight_relayout_bf16 / mg_bn_fold_f32 per convolution, bit for bit -- 1x1 and 3x3, ragged
+    channel counts, a 1x1 whose Cin is a multiple of 64 (no forward copy: the weight is its own operand); refresh() after the
+    weights changed in place picks the new values up."""
+    from magma_amd import ops
+    shapes = [(24, 16, 3), (96, 48, 3), (40, 72, 1), (128, 64, 1), (384, 384, 3), (8, 8, 1), (3072, 768, 1)]
+    units = []
+    for i, (cout, cin, k) in enumerate(shapes):
+        w = rnd(cout, cin, k, k, dev=dev, seed=600 + i, scale=0.1).to(BF16).contiguous()
+        gamma, beta = rnd(cout, dev=dev, seed=620 + i) + 2, rnd(cout, dev=dev, seed=640 + i)
+        mean, var = rnd(cout, dev=dev, seed=660 + i), rnd(cout, dev=dev, seed=680 + i).abs() + 0.1
+        units.append((w, gamma.contiguous(), beta.contiguous(), mean.contiguous(), var.contiguous(), 1e-5 * (i + 1)))
+    plan = ops.ConvOperandPlan(units, dev)
+    for rnd_no in range(2):
+        plan.refresh()
+        for i, (w, gamma, beta, mean, var, eps) in enumerate(units):
+            sc, sh = ops.bn_fold(gamma, beta, mean, var, eps)
+            assert torch.equal(plan.scale[i], sc) and torch.equal(plan.shift[i], sh), i
+            cout, cin, k, _ = w.shape
+            f = ops.conv_weight_relayout(w, 0)
+            if k == 1 and cin % 64 == 0:
+                assert plan.fwd[i].data_ptr() == w.data_ptr() and torch.equal(plan.fwd[i], f[:, :cin])
+            else:
+                assert torch.equal(plan.fwd[i], f), i
+            assert torch.equal(plan.dgrad[i], ops.conv_weight_relayout(w, 1, sc)), i
+        for (w, gamma, *_r) in units:          # an optimizer step: same storage, new values
+            w.mul_(1.5)
+            gamma.add_(0.25)
+
+
 @pytest.mark.parametrize("R,C", [(4096, 1024), (1000, 520), (77, 64)])
 def test_transpose_colsum(dev, R, C):
     """transpose + column sums in one pass == transpose and colsum separately (bias gradient and weight-gradient operand of a Linear)."""
