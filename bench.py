@@ -237,16 +237,27 @@ def pmc_traffic_per_launch(shapes):
     return tot / len(shapes), os.path.relpath(path, ROOT)
 
 
-def train_flops_per_image(model, res, S, c=1.0):
+def train_flops_per_image(model, res, S, c=1.0, bottom_rows=0):
     """SURVEY 8d, 'no recompute' policy: T = 2G + 3A + W + 3E per image.  c = 1: full-S^2 attention FLOPs, as the
-    reference computes them; c = 0.5: the causal tiles the flash kernels actually execute."""
+    reference computes them; c = 0.5: the causal tiles the flash kernels actually execute.  ``bottom_rows`` = P > 0 (executed
+    count only): the bottom block of the frozen LM forms its input gradient for the P prefix rows only -- the dgrads through
+    qkv / fc_in / fc_out of that block run on P of S rows, its dQ on the first ceil(P / 128) query blocks and its dK / dV on the
+    first key blocks (train_engine._lm_backward)."""
     L, d, ff, V = model.lm.config.num_layers, model.lm.config.hidden_size, model.lm.config.intermediate_size, model.lm.config.vocab_size
     r = sum(ad.N for ad in (model.lm.engine.layers[0].mlp_adapter or ())[:1]) + sum(ad.N for ad in (model.lm.engine.layers[0].attn_adapter or ())[:1])
     G = S * (L * (8 * d * d + 4 * d * ff + 4 * d * r))            # block GEMMs fwd (head runs on target rows only)
     A = 4 * L * d * S * S * c                                      # attention fwd
     Wg = 4 * S * L * d * r                                         # adapter wgrad
     E = 47.72e9 * (res / 224.0) ** 2                               # CLIP trunk fwd per image
-    return 2 * G + 3 * A + Wg + 3 * E
+    skipped = 0.0
+    if bottom_rows:
+        nb, n = (S + 127) // 128, (bottom_rows + 127) // 128
+        f = n / nb
+        skipped = (S - bottom_rows) * (6 * d * d + 4 * d * ff)     # three dgrad GEMMs of block 0 on the rows that are not formed
+        # attention backward of block 0 (2 x its forward): dK / dV of the first n key blocks (every later query: f (2 - f) of the
+        # causal tiles, ~0.6 of the backward's products), dQ of the first n query blocks (f^2, ~0.4)
+        skipped += 2 * (4 * d * S * S * c) * (1.0 - (0.6 * f * (2 - f) + 0.4 * f * f))
+    return 2 * G + 3 * A + Wg + 3 * E - skipped
 
 
 def _forward_fp8(model, images, caps, mode, sync, dtf, f_fwd, scaling="row"):
@@ -372,7 +383,7 @@ def bench_train(model, args, rank, world, dev):
             dt = float(t)
         key = "truncated" if trunc else "full_S2048"
         fl = train_flops_per_image(model, args.res, S) * B
-        fl_exec = train_flops_per_image(model, args.res, S, c=0.5) * B
+        fl_exec = train_flops_per_image(model, args.res, S, c=0.5, bottom_rows=getattr(eng, "bottom_prefix_rows", 0)) * B
         out[key] = {"images_per_s": world * B / dt, "ms_per_step": dt * 1e3, "loss": float(loss),
                     "algorithmic_tflops_per_gpu": None if trunc else fl / dt / 1e12,
                     "mfma_frac_of_2.5PF": None if trunc else fl / dt / 2.5e15,
@@ -402,7 +413,8 @@ def bench_train(model, args, rank, world, dev):
             out["full_S2048_fp8"] = {"error": repr(e)[:300]}
         finally:
             eng.fp8 = False
-    out["policy"] = "no recompute; bf16; adapters+CLIP trunk+prefix trainable; clip 1.0 + AdamW in the timed region"
+    out["policy"] = ("no recompute; bf16; adapters+CLIP trunk+prefix trainable; clip 1.0 + AdamW in the timed region; the bottom LM block forms its "
+                     "input gradient for the image-prefix rows only (nothing else below it is trainable: every parameter gradient unchanged)")
     out["per_gpu_batch"], out["seq_len"] = B, S
     n_train = sum(g.n for g in eng.groups)
     backend = None
@@ -577,7 +589,7 @@ def variant_v2(args, dev):
         fl = train_flops_per_image(model, args.res, S) * B
         out["train_full_S2048"] = {"images_per_s": B / dt, "ms_per_step": dt * 1e3, "loss": float(loss), "spread": spread,
                                    "mfma_frac_of_2.5PF": fl / dt / 2.5e15,
-                                   "mfma_frac_executed": train_flops_per_image(model, args.res, S, c=0.5) * B / dt / 2.5e15}
+                                   "mfma_frac_executed": train_flops_per_image(model, args.res, S, c=0.5, bottom_rows=getattr(eng, "bottom_prefix_rows", 0)) * B / dt / 2.5e15}
     return out
 
 

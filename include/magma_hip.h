@@ -80,7 +80,8 @@ const char* mg_version(void);
  *      row_scale[m] * (A W^T) straight into the fp32 gradient: no temporary, no second pass): every descriptor that embeds an
  *      epilogue changed size.  Added mg_conv_weight_relayout_batch / mg_bn_fold_batch (one launch per step for all
  *      convolutions of the image encoder) and mg_transpose_bn_param_grad_bf16; mg_rotary_split_fp8 gained `inplace` (before the stream):
- *      the rotated q / k also written back into the fused qkv activation, replacing a mg_rotary_qk_inplace_bf16 pass.                                                                                            */
+ *      the rotated q / k also written back into the fused qkv activation, replacing a mg_rotary_qk_inplace_bf16 pass; mg_attn_bwd_rows_bf16
+ *      gained `first_rows` (before the stream): only the gradients of the first positions (the bottom block of a frozen LM).                                                                                            */
 #define MG_ABI_VERSION 6
 int32_t mg_abi_version(void);
 const char* mg_last_error(void);
@@ -503,7 +504,7 @@ int mg_attn_fwd_rows_bf16(const mg_bf16* q, const mg_bf16* k, const mg_bf16* v, 
 int mg_attn_bwd_rows_bf16(const mg_bf16* q, const mg_bf16* k, const mg_bf16* v, int64_t ld_row, int64_t stride_b,
                           int64_t stride_h, const mg_bf16* dO, const mg_bf16* O, int64_t ld_o, const float* lse, float* D,
                           mg_bf16* dq, mg_bf16* dk, mg_bf16* dv, mg_bf16* dqkv, int32_t rot_dim, const float* sin_t,
-                          const float* cos_t, int32_t B, int32_t H, int32_t S, uint8_t* dqkv8, uint8_t* dqkv8_scales, void* stream);
+                          const float* cos_t, int32_t B, int32_t H, int32_t S, uint8_t* dqkv8, uint8_t* dqkv8_scales, int32_t first_rows, void* stream);
 
 /* CLIP trunk backward helpers */
 int mg_avgpool2_bwd_nhwc_bf16(const mg_bf16* dy, const mg_bf16* gate, mg_bf16* dx, int32_t B, int32_t H, int32_t W, int32_t C, void* stream);

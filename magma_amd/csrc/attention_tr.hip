@@ -120,12 +120,12 @@ constexpr int TRKV_EPILOGUE = 4 * 32 * EP_ROW;     // the ring becomes the four 
 // NST stages of (Q rows | dO rows | statistics); the tile t + NST - 1 is in flight while tile t is multiplied.
 template <int NST>
 __global__ __launch_bounds__(256) void attn_bwd_dkdv32_tr_kernel(
-    const AttnRows x, const mg_bf16* __restrict__ dO, const float* __restrict__ ld2, const GradOut gk, const GradOut gv, int B, int H, int S) {
+    const AttnRows x, const mg_bf16* __restrict__ dO, const float* __restrict__ ld2, const GradOut gk, const GradOut gv, int B, int H, int S,
+    int nblk) {       // nblk: key blocks of 128 per (b, h) this launch covers -- ceil(S / 128), or fewer (first_rows: only the first keys' gradients)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hi = lane >> 5;
-  const int nblk = (S + 127) >> 7;
   const int wg = xcd_contiguous_index(blockIdx.x, gridDim.x);
   const int bh = wg / nblk, b = bh / H, h = bh - b * H;
   const int k0 = (wg - bh * nblk) * 128;       // earliest key blocks (most query tiles) first
@@ -437,12 +437,12 @@ constexpr int TRQ_STAGE = 2 * ROW_TILE;            // K rows | V rows
 // with ds_read_b64_tr_b16: 8 LDS-DMA pieces per tile step instead of 12, no K^T operand.
 template <int NST>
 __global__ __launch_bounds__(256) void attn_bwd_dq32_tr_kernel(
-    const AttnRows x, const mg_bf16* __restrict__ dO, const float* __restrict__ ld2, const GradOut gq, int B, int H, int S) {
+    const AttnRows x, const mg_bf16* __restrict__ dO, const float* __restrict__ ld2, const GradOut gq, int B, int H, int S,
+    int nblk) {       // nblk: query blocks of 128 per (b, h) this launch covers (the FIRST ones; see attn_bwd_dkdv32_tr_kernel)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hi = lane >> 5;
-  const int nblk = (S + 127) >> 7;
   const int wg = xcd_contiguous_index(blockIdx.x, gridDim.x);
   const int bh = wg / nblk, b = bh / H, h = bh - b * H;
   const int qt0 = (nblk - 1 - (wg - bh * nblk)) * 128;            // longest (latest) query blocks first
@@ -996,32 +996,34 @@ __global__ __launch_bounds__(256) void attn_bwd_stats_kernel(const mg_bf16* __re
 }  // namespace
 
 int attn_bwd_dkdv32_tr_launch(const AttnRows& x, const mg_bf16* dO, const float* ld2,
-                              const GradOut& gk, const GradOut& gv, int B, int H, int S, int stages, hipStream_t s, const char* who) {
-  const dim3 grid((unsigned)(((S + 127) / 128) * B * H));
+                              const GradOut& gk, const GradOut& gv, int B, int H, int S, int stages, hipStream_t s, const char* who, int nrun) {
+  const int nblk = nrun > 0 ? std::min(nrun, (S + 127) / 128) : (S + 127) / 128;
+  const dim3 grid((unsigned)(nblk * B * H));
   if (stages == 3) {
     const int lds = 3 * TRKV_STAGE > TRKV_EPILOGUE ? 3 * TRKV_STAGE : TRKV_EPILOGUE;
     if (int rc = mg_allow_dynamic_lds((const void*)attn_bwd_dkdv32_tr_kernel<3>, lds, who)) return rc;
-    hipLaunchKernelGGL(attn_bwd_dkdv32_tr_kernel<3>, grid, dim3(256), lds, s, x, dO, ld2, gk, gv, B, H, S);
+    hipLaunchKernelGGL(attn_bwd_dkdv32_tr_kernel<3>, grid, dim3(256), lds, s, x, dO, ld2, gk, gv, B, H, S, nblk);
   } else {
     const int lds = 2 * TRKV_STAGE > TRKV_EPILOGUE ? 2 * TRKV_STAGE : TRKV_EPILOGUE;
     if (int rc = mg_allow_dynamic_lds((const void*)attn_bwd_dkdv32_tr_kernel<2>, lds, who)) return rc;
-    hipLaunchKernelGGL(attn_bwd_dkdv32_tr_kernel<2>, grid, dim3(256), lds, s, x, dO, ld2, gk, gv, B, H, S);
+    hipLaunchKernelGGL(attn_bwd_dkdv32_tr_kernel<2>, grid, dim3(256), lds, s, x, dO, ld2, gk, gv, B, H, S, nblk);
   }
   MG_CHECK_LAUNCH();
   return MG_OK;
 }
 
 int attn_bwd_dq32_tr_launch(const AttnRows& x, const mg_bf16* dO, const float* ld2,
-                            const GradOut& gq, int B, int H, int S, int stages, hipStream_t s, const char* who) {
-  const dim3 grid((unsigned)(((S + 127) / 128) * B * H));
+                            const GradOut& gq, int B, int H, int S, int stages, hipStream_t s, const char* who, int nrun) {
+  const int nblk = nrun > 0 ? std::min(nrun, (S + 127) / 128) : (S + 127) / 128;
+  const dim3 grid((unsigned)(nblk * B * H));
   if (stages == 4) {
     const int lds = 4 * TRQ_STAGE;
     if (int rc = mg_allow_dynamic_lds((const void*)attn_bwd_dq32_tr_kernel<4>, lds, who)) return rc;
-    hipLaunchKernelGGL(attn_bwd_dq32_tr_kernel<4>, grid, dim3(256), lds, s, x, dO, ld2, gq, B, H, S);
+    hipLaunchKernelGGL(attn_bwd_dq32_tr_kernel<4>, grid, dim3(256), lds, s, x, dO, ld2, gq, B, H, S, nblk);
   } else {
     const int lds = 3 * TRQ_STAGE;
     if (int rc = mg_allow_dynamic_lds((const void*)attn_bwd_dq32_tr_kernel<3>, lds, who)) return rc;
-    hipLaunchKernelGGL(attn_bwd_dq32_tr_kernel<3>, grid, dim3(256), lds, s, x, dO, ld2, gq, B, H, S);
+    hipLaunchKernelGGL(attn_bwd_dq32_tr_kernel<3>, grid, dim3(256), lds, s, x, dO, ld2, gq, B, H, S, nblk);
   }
   MG_CHECK_LAUNCH();
   return MG_OK;
@@ -1082,8 +1084,9 @@ extern "C" int mg_attn_bwd_rows_bf16(const mg_bf16* q, const mg_bf16* k, const m
                                      int64_t stride_h, const mg_bf16* dO, const mg_bf16* O, int64_t ld_o, const float* lse, float* D,
                                      mg_bf16* dq, mg_bf16* dk, mg_bf16* dv, mg_bf16* dqkv, int32_t rot_dim, const float* sin_t,
                                      const float* cos_t, int32_t B, int32_t H, int32_t S, uint8_t* dqkv8, uint8_t* dqkv8_scales,
-                                     void* stream) {
+                                     int32_t first_rows, void* stream) {
   const char* who = "mg_attn_bwd_rows_bf16";
+  if (first_rows < 0) MG_FAIL(MG_ERR_SHAPE, "%s: first_rows must be >= 0", who);
   if (int rc = check_rows(who, q, k, v, ld_row, stride_b, stride_h, B, H, S)) return rc;
   if (!dO || !O || !lse || !D) MG_FAIL(MG_ERR_SHAPE, "%s: null pointer", who);
   if (!MG_ALIGNED16(dO) || !MG_ALIGNED16(O)) MG_FAIL(MG_ERR_ALIGN, "%s: dO and O must be 16-byte aligned", who);
@@ -1107,6 +1110,10 @@ extern "C" int mg_attn_bwd_rows_bf16(const mg_bf16* q, const mg_bf16* k, const m
   const int64_t rows = (int64_t)B * S * H;
   hipLaunchKernelGGL(attn_bwd_stats_kernel, dim3((unsigned)((rows + 31) / 32)), dim3(256), 0, s, dO, O, lse, D, B, H, S, ld_o);
   const AttnRows x{q, k, v, stride_b, stride_h, (int)ld_row};
-  if (int rc = attn_bwd_dq32_tr_launch(x, dO, D, gq, B, H, S, 4, s, who)) return rc;
-  return attn_bwd_dkdv32_tr_launch(x, dO, D, gk, gv, B, H, S, 3, s, who);
+  // first_rows > 0: only the gradients of positions < first_rows are wanted (the bottom block of a frozen LM: nothing but the image
+  // prefix receives a gradient below it) -- the first ceil(first_rows / 128) query blocks of dQ and key blocks of dK / dV run (whole
+  // blocks are written); every statistic and every later query still takes part in dK / dV
+  const int nrun = first_rows > 0 ? (first_rows + 127) / 128 : 0;
+  if (int rc = attn_bwd_dq32_tr_launch(x, dO, D, gq, B, H, S, 4, s, who, nrun)) return rc;
+  return attn_bwd_dkdv32_tr_launch(x, dO, D, gk, gv, B, H, S, 3, s, who, nrun);
 }

@@ -47,8 +47,8 @@ struct AttnRows {
   int ld;
 };
 int attn_bwd_dkdv32_tr_launch(const AttnRows& x, const mg_bf16* dO, const float* ld2,
-                              const GradOut& gk, const GradOut& gv, int B, int H, int S, int stages, hipStream_t s, const char* who);
+                              const GradOut& gk, const GradOut& gv, int B, int H, int S, int stages, hipStream_t s, const char* who, int nrun = 0);
 int attn_bwd_dq32_tr_launch(const AttnRows& x, const mg_bf16* dO, const float* ld2,
-                            const GradOut& gq, int B, int H, int S, int stages, hipStream_t s, const char* who);
+                            const GradOut& gq, int B, int H, int S, int stages, hipStream_t s, const char* who, int nrun = 0);
 int attn_fwd32_tr_launch(const AttnRows& x, mg_bf16* out, int64_t ld_out, float* lse, int B, int H, int S, float defer, hipStream_t s,
                          const char* who);

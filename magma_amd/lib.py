@@ -143,7 +143,7 @@ SYMBOLS = {
     "mg_rotary_qk_inplace_bf16": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "mg_attn_fwd_rows_bf16": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _vp]),
     "mg_attn_bwd_rows_bf16": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp,
-                                        _i32, _i32, _i32, _vp, _vp, _vp]),
+                                        _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
     "mg_avgpool2_bwd_nhwc_bf16": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mg_mul_bf16": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "mg_gelu_erf_bf16": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _vp]),

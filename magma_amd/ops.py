@@ -882,11 +882,12 @@ def attn_fwd_rows(x: AttnRows, out, lse: Optional[torch.Tensor] = None):
     return out
 
 
-def attn_bwd_rows(x: AttnRows, dO, O, lse, merged_rot=None, mx_out=None, no_out: bool = False):
+def attn_bwd_rows(x: AttnRows, dO, O, lse, merged_rot=None, mx_out=None, no_out: bool = False, first_rows: int = 0):
     """Attention backward without transposed operands.  merged_rot None -> (dq, dk, dv) [B,H,S,256]; merged_rot = (rot_dim, sin_t,
     cos_t) -> dqkv [B*S, 3 H 256], the gradient of the fused qkv projection (inverse rotary applied).  Merged form only:
     ``mx_out`` = (q, scales) from mx_empty(B*S, 3 H 256) -> the epilogue also writes the OCP MX e4m3 copy of dqkv; with ``no_out``
-    only that copy (returns None)."""
+    only that copy (returns None).  ``first_rows`` > 0: only the gradients of the positions < first_rows of every sequence are
+    wanted (rounded up to whole 128-position blocks; the other rows of the outputs stay unwritten)."""
     _need_gpu(dO)
     assert O.ndim == 2 and O.stride(1) == 1 and dO.is_contiguous()
     B, H, S, dev = x.B, x.H, x.S, dO.device
@@ -895,7 +896,7 @@ def attn_bwd_rows(x: AttnRows, dO, O, lse, merged_rot=None, mx_out=None, no_out:
         dq, dk, dv = (torch.empty(B, H, S, 256, dtype=BF16, device=dev) for _ in range(3))
         check(L.load().mg_attn_bwd_rows_bf16(x.q, x.k, x.v, x.ld_row, x.stride_b, x.stride_h, dO.data_ptr(), O.data_ptr(), O.stride(0),
                                              lse.data_ptr(), D.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), None, 0, None, None,
-                                             B, H, S, None, None, _stream()), "mg_attn_bwd_rows_bf16")
+                                             B, H, S, None, None, int(first_rows), _stream()), "mg_attn_bwd_rows_bf16")
         return dq, dk, dv
     rot_dim, sin_t, cos_t = merged_rot
     q8, sc8 = mx_out if mx_out is not None else (None, None)
@@ -906,7 +907,7 @@ def attn_bwd_rows(x: AttnRows, dO, O, lse, merged_rot=None, mx_out=None, no_out:
     dqkv = None if no_out else torch.empty(B * S, 3 * H * 256, dtype=BF16, device=dev)
     check(L.load().mg_attn_bwd_rows_bf16(x.q, x.k, x.v, x.ld_row, x.stride_b, x.stride_h, dO.data_ptr(), O.data_ptr(), O.stride(0),
                                          lse.data_ptr(), D.data_ptr(), None, None, None, _p(dqkv), rot_dim, sin_t.data_ptr(),
-                                         cos_t.data_ptr(), B, H, S, _p(q8), _p(sc8), _stream()), "mg_attn_bwd_rows_bf16")
+                                         cos_t.data_ptr(), B, H, S, _p(q8), _p(sc8), int(first_rows), _stream()), "mg_attn_bwd_rows_bf16")
     return dqkv
 
 

@@ -123,6 +123,7 @@ class LRScheduler:
 
 
 _CONV_PLAN = os.environ.get("MAGMA_CONV_PLAN", "1") != "0"               # A/B switch: 0 = one re-layout / BN-fold launch per convolution
+_BOTTOM_PREFIX_ONLY = os.environ.get("MAGMA_BOTTOM_PREFIX_ONLY", "1") != "0"   # A/B switch: 0 = the bottom block's input gradient on all B*S rows
 _BN_GRAD_FUSED = os.environ.get("MAGMA_BN_GRAD_FUSED", "1") != "0"       # A/B switch: 0 = bn_param_grad + transpose as two passes over g
 _WGRAD_INPLACE = os.environ.get("MAGMA_WGRAD_INPLACE", "1") != "0"     # A/B switch: 0 = fp32 temporary + scale_rows_acc pass
 
@@ -184,6 +185,7 @@ class MagmaEngine:
         self.bn_batch_stats = os.environ.get("MAGMA_BN_BATCH_STATS", "0") == "1"
         self._bn_dirty = False
         self._plan = self._plan_live = None     # ops.ConvOperandPlan of the CLIP trunk (frozen-statistics mode), built on first use
+        self.bottom_prefix_rows = 0             # P when the last backward formed the bottom block's input gradient for the prefix rows only
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.gas = max(1, int(self.config.gradient_accumulation_steps))
         self.clip = float(self.config.gradient_clipping or 0.0)
@@ -763,7 +765,10 @@ class MagmaEngine:
         del scale_note
         d_emb = self._lm_backward(tape)
         B, S, P = tape["B"], tape["S"], tape["P"]
-        d_prefix = d_emb.view(B, S, -1)[:, :P].contiguous()
+        if isinstance(d_emb, tuple):      # the bottom block formed the gradient of the prefix rows only
+            d_prefix = d_emb[1].view(B, P, -1)
+        else:
+            d_prefix = d_emb.view(B, S, -1)[:, :P].contiguous()
         if self.lm_trainable:       # word embedding rows of the caption tokens (positions P .. S-1)
             wte = self.module.lm.transformer.wte.weight
             ids = tape["caption_ids"][:, : S - P].reshape(-1)
@@ -874,6 +879,16 @@ class MagmaEngine:
             if tape.get("block_fn") is not None:       # per-block recompute: rebuild this block's activations from its input
                 _, sv = tape["block_fn"](li, ly, blk, sv["x"])
                 tape["layers"][li] = None
+            # The BOTTOM block of a frozen LM: below it only the image prefix (positions < P of every sequence) receives a gradient
+            # -- the word embeddings are frozen (reference magma.py:98-100 trains adapters + image prefix) --, so the three dgrads
+            # into ln_1 (fc_out^T, fc_in^T, qkv^T), dQ and the LayerNorm backward are needed for B*P of the B*S rows only, and dK / dV
+            # for the first P keys.  Every parameter gradient is what it was (the adapter branch runs on all rows).
+            bottom = (_BOTTOM_PREFIX_ONLY and li == 0 and not self.lm_trainable and 0 < tape["P"] < S and sv.get("rows") is not None
+                      and ly.mlp_par is None and ly.attn_par is None)
+            P = tape["P"]
+            take = (lambda t_: t_.view(B, S, -1)[:, :P].reshape(B * P, -1)) if bottom else (lambda t_: t_)
+            if li == 0:
+                self.bottom_prefix_rows = P if bottom else 0      # (bench.py: executed-FLOP accounting)
             # ---- MLP branch ----
             par = ly.mlp_par is not None or ly.attn_par is not None
             ln = ops.layernorm(sv["x"], ly.ln_g, ly.ln_b, eng.eps) if par else None   # the parallel adapters' input, recomputed
@@ -883,7 +898,7 @@ class MagmaEngine:
                 dt, dn_t = self._par_adapter_backward(blk.mlp, g, ln, sv["t"], sv.get("t_pre"))
                 extra.append(self._adapter_dx(blk.mlp, dt, dn_t, ln))
                 dm = g
-            elif self._ad8_ok(ly, blk.mlp[1]):
+            elif self._ad8_ok(ly, blk.mlp[1]) and not bottom:
                 mod, p8 = blk.mlp[1], self._ad8(li, blk.mlp[1])
                 gq = ops.quantize_rows_fp8(g)          # also the operand of the out_proj dgrad below (no attention adapter: da = g)
                 self._acc_wgrad(mod.up.weight, RawWeight(ops.transpose_colsum(g, self.grad_of(mod.up.bias))), _t(sv["t"]))
@@ -899,8 +914,8 @@ class MagmaEngine:
                 dm = self._adapter_dx(blk.mlp[1], dt, dn_t, sv["m"], res=g)
             else:
                 dm = g
-            dhpre = self._fgemm((li, "fc_out_t"), dm, pk["fc_out_t"], aux=sv["hpre"], aux_mode=ops.MG_AUX_GELU_GRAD,
-                                mx_out=self.fp8 and self.fp8_mx)
+            dhpre = self._fgemm((li, "fc_out_t"), take(dm), pk["fc_out_t"], aux=take(sv["hpre"]), aux_mode=ops.MG_AUX_GELU_GRAD,
+                                mx_out=self.fp8 and self.fp8_mx and not bottom)
             dln_mlp = self._fgemm((li, "fc_in_t"), dhpre, pk["fc_in_t"])
             if self.lm_trainable:
                 a_mod, mlp_mod = ly._src
@@ -925,6 +940,9 @@ class MagmaEngine:
             if sv["rows"] is None:      # MAGMA_ATTN_TR=0 (A/B only)
                 q, k, v, qt, kt = sv["old"]
                 dqkv = ops.attn_bwd_merged(q, k, v, qt, kt, dctx, sv["ctx"], sv["lse"], B, H, S, eng.rot, eng.sin_t, eng.cos_t)
+            elif bottom:
+                # dQ of the first ceil(P / 128) query blocks, dK / dV of the first key blocks (mg_attn_bwd_rows_bf16 first_rows)
+                dqkv = take(ops.attn_bwd_rows(sv["rows"], dctx, sv["ctx"], sv["lse"], merged_rot=(eng.rot, eng.sin_t, eng.cos_t), first_rows=P))
             elif self.fp8 and self.fp8_mx and (3 * H * 256) % 256 == 0:
                 # fp8_mx: the gradient of the fused qkv projection leaves the attention backward's epilogues ONLY as the OCP MX e4m3
                 # operand of the qkv dgrad (the LM is frozen in fp8 mode: nothing else reads dqkv) -- no bf16 dqkv, no quantisation pass
@@ -941,7 +959,9 @@ class MagmaEngine:
                     self._acc_wgrad(prj.weight, RawWeight(dqkvT[i3 * dd:(i3 + 1) * dd]), lnT)
                 g = self._ln_bwd(blk.ln_1, dln, sv["x"], res=g)
             else:
-                g = ops.layernorm_bwd(dln, sv["x"], ly.ln_g, eng.eps, res=g)
+                g = ops.layernorm_bwd(dln, take(sv["x"]), ly.ln_g, eng.eps, res=take(g))
+                if bottom:
+                    g = ("prefix", g)     # [B * P, d]: the gradient of the image prefix; the other rows were never formed
             tape["layers"][li] = None     # free this layer's activations
             self._reduce_params_async([p for p in blk.parameters() if p.requires_grad])
         return g

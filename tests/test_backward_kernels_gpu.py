@@ -320,6 +320,16 @@ def test_attention_without_transposed_images(dev, B, H, S):
     mx2 = ops.mx_empty(B * S, 3 * d, dev)
     assert ops.attn_bwd_rows(xf, dO, out, lse, merged_rot=(rot, sin_t, cos_t), mx_out=mx2, no_out=True) is None
     assert torch.equal(mx2[0], qref) and torch.equal(mx2[1], sref)
+    # first_rows (the bottom block of a frozen LM: only the first positions' gradients are wanted): the first ceil(P / 128) query /
+    # key blocks carry the same bits as the full launch -- dK / dV of those keys still sum over EVERY later query
+    for P in (1, 49, 144, 200):
+        if P >= S:
+            continue
+        n = min(S, (P + 127) // 128 * 128)
+        for a, b_ in zip(ops.attn_bwd_rows(x, dO, out, lse, first_rows=P), (dq, dk, dv)):
+            assert torch.equal(a[:, :, :n], b_[:, :, :n]), P
+        part = ops.attn_bwd_rows(xf, dO, out, lse, merged_rot=(rot, sin_t, cos_t), first_rows=P)
+        assert torch.equal(part.view(B, S, 3 * d)[:, :n], merged.view(B, S, 3 * d)[:, :n]), P
 
 
 def test_rotary_merge_bwd(dev):
