@@ -498,3 +498,59 @@ def test_out_proj_and_adapter_up_as_one_gemm(dev):
             bad.append((n, e_c, e_p, e_bf, rel(g_c[n], g_p[n])))
     assert not bad, bad[:6]
     assert abs(loss_c - loss_p) <= 2e-3 * abs(loss_ref), (loss_c, loss_p)
+
+
+def test_bottom_block_forms_its_input_gradient_for_the_prefix_rows_only(dev, monkeypatch):
+    """Below the bottom LM block only the image prefix is trainable (the LM incl. its word embeddings is frozen: reference
+    magma.py:98-100), so the engine forms that block's input gradient for the B*P prefix rows only (dgrads through fc_out /
+    fc_in / qkv, LayerNorm backward, dQ of the first query blocks, dK / dV of the first key blocks:
+    train_engine._lm_backward, mg_attn_bwd_rows_bf16 first_rows).  Checked: the path IS taken; every LM-side parameter
+    gradient (adapters of all blocks) is BIT-IDENTICAL to the all-rows form -- they never depended on the skipped rows --; the
+    image-prefix / trunk gradients agree to GEMM-shape rounding and satisfy the oracle criterion in both forms."""
+    from magma_amd import train_engine
+    from magma_amd.testing import build_reduced_magma
+    from magma_amd.train_engine import MagmaEngine
+    from oracle.model import OracleConfig, init_params
+    cfg = OracleConfig.tiny(mlp_adapter_hidden=128, attn_adapter_hidden=0, n_positions=128)
+    params = init_params(cfg, seed=29)
+    for k in params:
+        if ".adapter." in k:
+            params[k] = params[k] * 20
+    g = torch.Generator().manual_seed(7)
+    B, P = 2, 4
+    images = torch.randn(B, 3, 64, 64, generator=g)
+    caps = torch.full((B, 128), cfg.eos_token, dtype=torch.int64)
+    caps[0, :27] = torch.randint(0, 1000, (27,), generator=g)
+    caps[1, :13] = torch.randint(0, 1000, (13,), generator=g)
+    mask = (torch.rand(B, P, cfg.d_model, generator=g) < 0.9).float() / 0.9
+    loss_ref, g_ref = oracle_grads(cfg, params, images, caps, mask, torch.float32)
+    loss_bf, g_bf = oracle_grads(cfg, params, images, caps, mask, torch.bfloat16)
+
+    def run(on):
+        monkeypatch.setattr(train_engine, "_BOTTOM_PREFIX_ONLY", on)
+        model = build_reduced_magma(dev, mlp_factor=4, attn_factor=None, n_positions=128)
+        model.load_checkpoint_state(params)
+        model.config.gradient_accumulation_steps = 1
+        eng = MagmaEngine(model)
+        eng.train()
+        out = eng(images.to(dev), caps.to(dev), dropout_mask=mask.to(dev))
+        eng.backward(out.loss)
+        name_of = {id(p): n for n, p in model.named_parameters()}
+        grads = {}
+        for grp in eng.groups:
+            for p in grp.params:
+                n = name_of[id(p)]
+                grads["lm." + n if n.startswith("transformer.") else n] = eng.grad_of(p).float().cpu().clone()
+        return grads, eng.bottom_prefix_rows
+
+    g_on, rows_on = run(True)
+    g_off, rows_off = run(False)
+    assert rows_on == P and rows_off == 0, (rows_on, rows_off)
+    bad = []
+    for n, ref in g_ref.items():
+        if ".adapter." in n:
+            assert torch.equal(g_on[n], g_off[n]), n
+        e_on, e_off, e_bf = rel(g_on[n], ref), rel(g_off[n], ref), rel(g_bf[n], ref)
+        if e_on > 2 * e_bf + 1e-2 or e_off > 2 * e_bf + 1e-2 or rel(g_on[n], g_off[n]) > 2 * e_bf + 1e-2:
+            bad.append((n, e_on, e_off, e_bf, rel(g_on[n], g_off[n])))
+    assert not bad, bad[:6]
