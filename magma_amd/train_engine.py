@@ -894,6 +894,7 @@ class MagmaEngine:
             ln = ops.layernorm(sv["x"], ly.ln_g, ly.ln_b, eng.eps) if par else None   # the parallel adapters' input, recomputed
             extra = []                                                                 # dL/d ln through the parallel adapters
             gq = None                                                                  # row-quantised g, shared by its consumers
+            dm_taken = False                                                           # bottom block: dm already holds the prefix rows only
             if ly.mlp_adapter is not None and ly.mlp_par is not None:
                 dt, dn_t = self._par_adapter_backward(blk.mlp, g, ln, sv["t"], sv.get("t_pre"))
                 extra.append(self._adapter_dx(blk.mlp, dt, dn_t, ln))
@@ -911,10 +912,15 @@ class MagmaEngine:
                 dm = ("mx", *dm_mx)                    # dL/dm exists only as the MX operand of the fc_out dgrad
             elif ly.mlp_adapter is not None:
                 dt, dn_t = self._adapter_backward(blk.mlp[1], g, sv["m"], sv["t"], sv.get("t_pre"))
-                dm = self._adapter_dx(blk.mlp[1], dt, dn_t, sv["m"], res=g)
+                if bottom and blk.mlp[1].ln is None:
+                    # dL/dm feeds nothing but the (prefix-rows-only) fc_out dgrad: the same rows suffice here
+                    dm = self._adapter_dx(blk.mlp[1], take(dt), dn_t, None, res=take(g))
+                    dm_taken = True
+                else:
+                    dm = self._adapter_dx(blk.mlp[1], dt, dn_t, sv["m"], res=g)
             else:
                 dm = g
-            dhpre = self._fgemm((li, "fc_out_t"), take(dm), pk["fc_out_t"], aux=take(sv["hpre"]), aux_mode=ops.MG_AUX_GELU_GRAD,
+            dhpre = self._fgemm((li, "fc_out_t"), dm if dm_taken else take(dm), pk["fc_out_t"], aux=take(sv["hpre"]), aux_mode=ops.MG_AUX_GELU_GRAD,
                                 mx_out=self.fp8 and self.fp8_mx and not bottom)
             dln_mlp = self._fgemm((li, "fc_in_t"), dhpre, pk["fc_in_t"])
             if self.lm_trainable:
